@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: edges/sec of one full-batch GAT train step (forward + loss + backward + optimizer
+step) on an ogbn-arxiv-shaped synthetic graph (BASELINE.json config 2), plus the HBM roofline of the
+dominant kernel (the CSR/CSC SpMM of the 3x250 GAT aggregation) and a CPU baseline timed in the same run.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `value` = preprocessed edges of the whole graph / wall time per step
+(max over ranks), inputs resident in HBM.  For N > 1 the same graph is 1-D vertex-partitioned over the
+ranks with a halo all-to-all per layer on RCCL ("scaling": "strong").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+# reference command for config 2 (src/no-sampling/run.py:1011-1013):
+#   run.py --optimizer=rmsprop --lr=0.002 --loss=loge --labels --mask-rate=0.5 --model=gat --linear
+#          --n-heads=3 --n-hidden=250 --dropout=0.75 --input-drop=0.25 --attn-drop=0.1
+CFG = dict(n_layers=3, n_heads=3, n_hidden=250, norm="batch", dropout=0.75, input_drop=0.25, attn_drop=0.1,
+           edge_drop=0.0, non_interactive_attn=False, use_symmetric_norm=False, linear=True, residual=False)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="arxiv", choices=["arxiv", "cora", "products", "reddit"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; reported in config)")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def spmm_alg_bytes(n, e, H, D, weighted):
+    """compulsory bytes of one SpMM pass, int32 indices."""
+    return 4 * (2 * n * H * D + e + (n + 1) + (e * H if weighted else 0))
+
+
+def cpu_baseline(ds_cpu, n_classes, steps):
+    """The oracle's C restatement of DGL's CPU kernels (oracle/c_ops.py) driving the same 3-layer GAT step
+    (forward + loge loss + backward; dropout omitted) on the host cores of this box."""
+    from oracle import c_ops
+    from oracle import ref_models as RM
+    torch.set_num_threads(os.cpu_count())
+    s, d, n, feat, labels, train_idx = ds_cpu
+    g = c_ops.CGraph(s, d, n)
+    from bot_amd import nn as bnn
+    torch.manual_seed(0)
+    model = bnn.GAT(dim_node=feat.shape[1] + n_classes, dim_edge=0, dim_output=n_classes, activation=F.relu, **CFG)
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone())
+          for k, v in model.state_dict().items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    mask = torch.rand(train_idx.shape) < 0.5
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        x = RM.add_labels(feat, labels, train_idx[mask], n_classes)
+        pred = RM.gat_forward(g, x, sd, n_layers=CFG["n_layers"], n_heads=CFG["n_heads"], n_hidden=CFG["n_hidden"],
+                              n_classes=n_classes, norm="batch", linear=True, training=True)
+        loss = RM.compute_loss(pred[train_idx[~mask]], labels[train_idx[~mask]], "loge")
+        torch.autograd.grad(loss, params)
+        times.append(time.perf_counter() - t0)
+    t = min(times[1:])  # first step is the warm-up
+    return {"value": s.numel() / t, "unit": "edges/s", "cores": int(c_ops.num_threads()), "kind": "port",
+            "sample": f"{steps} full train steps (fwd+loss+bwd, no dropout) of the same graph after 1 warm-up; best step "
+                      f"{t:.3f} s; OpenMP C restatement of DGL's CPU SpMM/SDDMM/edge_softmax + torch CPU GEMMs"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import bot_amd
+    from bot_amd import _C, synth, train
+    from bot_amd import nn as bnn
+
+    ds = synth.make_dataset(args.workload, device="cpu", seed=0, scale=args.scale)
+    n, C = ds.graph.number_of_nodes(), ds.n_classes
+    E = ds.graph.number_of_edges()
+    src_cpu, dst_cpu = ds.graph.edges()
+    torch.manual_seed(0)
+    model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **CFG).to(dev)
+    opt = torch.optim.RMSprop(model.parameters(), lr=0.002)
+
+    if world == 1:
+        g = ds.graph.to(dev)
+        g.create_formats_()
+        feat, labels = ds.feat.to(dev), ds.labels.to(dev)
+        tr, va, te = ds.train_idx.to(dev), ds.val_idx.to(dev), ds.test_idx.to(dev)
+
+        def step():
+            return train.train_step(model, g, feat, labels, tr, va, te, opt, use_labels=True, mask_rate=0.5, loss="loge",
+                                    n_classes=C)
+        barrier = lambda: None
+    else:
+        from bot_amd import dist as bdist
+        part = bdist.partition_dataset(ds, rank, world, dev)
+        model = bdist.wrap_model(model)
+
+        def step():
+            return bdist.train_step(model, part, opt, use_labels=True, mask_rate=0.5, loss="loge", n_classes=C)
+        barrier = torch.distributed.barrier
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly K steps between barrier + synchronize
+    _C.PROFILE = prof = []
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    _C.PROFILE = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel: weighted SpMM of the hidden layers (H=3, D=250), forward (CSC sweep)
+    # and transposed backward (CSR sweep) launches alike; HIP events recorded around each launch on the launch stream.
+    H, D = CFG["n_heads"], CFG["n_hidden"]
+    durs = [e0.elapsed_time(e1) * 1e-3 for (name, key, e0, e1) in prof if name == "spmm" and key == (H, D, True)]
+    roof = None
+    if durs:
+        n_loc = durs and (part.n_owned if world > 1 else n)
+        e_loc = part.n_edges if world > 1 else E
+        alg = spmm_alg_bytes(n_loc, e_loc, H, D, True)
+        avg = sum(durs) / len(durs)
+        ach = alg / avg / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "spmm_traffic.json")
+        if world == 1 and args.scale == 1.0 and os.path.exists(tf):
+            traffic = json.load(open(tf)).get("bytes_per_launch")
+        roof = {"bound": "hbm", "kernel": "bot::spmm_kernel<2,64,2,true> (u_mul_e_sum H=3 D=250, fwd + transposed bwd)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg * 1e3, 4),
+                "launches_timed": len(durs)}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_baseline != "off":
+        cpu = cpu_baseline((src_cpu, dst_cpu, n, ds.feat, ds.labels, ds.train_idx), C, args.cpu_steps)
+
+    if rank == 0:
+        out = {
+            "metric": "edges/sec full-batch GAT fwd+bwd on ogbn-arxiv; achieved HBM GB/s vs peak",
+            "value": E / (ms * 1e-3), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"S-{args.workload}: power-law graph N={n} E={E} (raw {ds.raw_edges}), F={ds.feat.shape[1]}, "
+                                   f"C={C}; GAT 3 layers x 3 heads x 250, --labels --loss=loge --linear --norm=batch, "
+                                   f"dropout 0.75/0.25/0.1, RMSprop step included",
+                       "scale": args.scale, "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,268 @@
+"""ctypes binding of libbot_gnn.so (include/bot_gnn.h) — the only compute backend of bot_amd.
+
+There is no CPU or pure-PyTorch fallback: if the shared library is missing the import fails, and
+every wrapper refuses non-HIP tensors.  Tensors cross the boundary as raw device pointers plus
+sizes/strides; launches go to torch's current HIP stream and are not synchronised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbot_gnn.so")
+ABI_VERSION = 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the gfx950 kernels first "
+        "(`make -C bot_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+        "bot_amd has no CPU / PyTorch fallback."
+    )
+_lib = ctypes.CDLL(LIB_PATH)
+
+_P = c_void_p
+_SIGS = {
+    "bot_abi_version": (ctypes.c_int, []),
+    "bot_last_error": (c_char_p, []),
+    "bot_row_plan_default_chunk": (c_int32, [c_int64]),
+    "bot_row_plan_size_host": (ctypes.c_int, [_P, c_int64, c_int32, _P, _P, _P]),
+    "bot_row_plan_fill_host": (ctypes.c_int, [_P, c_int64, c_int32, _P, _P, _P]),
+    "bot_degrees_i64": (ctypes.c_int, [_P, c_int64, _P, _P]),
+    "bot_spmm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
+    "bot_spmm_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
+                                    c_int32, c_int32, _P, c_int64, c_int64, _P, _P]),
+    "bot_sddmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                         c_int32, c_int32, _P, _P, c_int32, _P]),
+    "bot_sddmm_u_add_v_f32": (ctypes.c_int, [_P, _P, c_int64, _P, _P, c_int32, _P, _P]),
+    "bot_gat_attn_fwd_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, _P, c_float,
+                                            c_int32, _P, _P, _P]),
+    "bot_gat_attn_bwd_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_int32,
+                                            _P, _P, _P, _P, _P, _P, _P]),
+    "bot_segment_sum_f32": (ctypes.c_int, [_P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, c_int32, _P, _P]),
+    "bot_gather_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
+    "bot_scatter_add_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(_lib, _name)  # AttributeError here = header and library disagree
+    _fn.restype, _fn.argtypes = _res, _args
+EXPORTED = tuple(_SIGS)
+
+if _lib.bot_abi_version() != ABI_VERSION:
+    raise ImportError(f"libbot_gnn.so ABI {_lib.bot_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+
+
+class BotKernelError(RuntimeError):
+    pass
+
+
+# bench.py sets this to a list to time individual launches with HIP events recorded on the launch stream
+# (torch's current stream); entries are (kernel family, shape key, start event, end event).
+PROFILE = None
+
+
+def _timed(name, key, launch):
+    if PROFILE is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = launch()
+    e1.record()
+    PROFILE.append((name, key, e0, e1))
+    return rc
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise BotKernelError(f"{what} failed (rc={rc}): {_lib.bot_last_error().decode()}")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise BotKernelError(
+                "bot_amd kernels run on MI355X only: got a CPU tensor and there is no CPU fallback "
+                "(move the graph and features to the GPU)")
+
+
+def _f32(t, name):
+    if t is not None and t.dtype != torch.float32:
+        raise BotKernelError(f"{name} must be float32, got {t.dtype}")
+    return t
+
+
+def _i32(t, name):
+    if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+        raise BotKernelError(f"{name} must be contiguous int32")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ host plan
+def default_chunk(nnz: int) -> int:
+    return int(_lib.bot_row_plan_default_chunk(int(nnz)))
+
+
+def row_plan(indptr_cpu: torch.Tensor, chunk: int):
+    """Host-side work plan for one compressed direction (include/bot_gnn.h "Row plan").
+
+    indptr_cpu: CPU int32 [n_rows+1].  Returns CPU int32 tensors (items [n_items,4], long_rows, long_ptr)."""
+    assert indptr_cpu.device.type == "cpu" and indptr_cpu.dtype == torch.int32 and indptr_cpu.is_contiguous()
+    n_rows = indptr_cpu.numel() - 1
+    n_items, n_long, n_slots = c_int64(), c_int64(), c_int64()
+    _check(_lib.bot_row_plan_size_host(indptr_cpu.data_ptr(), n_rows, chunk, ctypes.addressof(n_items),
+                                       ctypes.addressof(n_long), ctypes.addressof(n_slots)), "row_plan_size")
+    items = torch.empty((n_items.value, 4), dtype=torch.int32)
+    long_rows = torch.empty((n_long.value,), dtype=torch.int32)
+    long_ptr = torch.empty((n_long.value + 1,), dtype=torch.int32)
+    _check(_lib.bot_row_plan_fill_host(indptr_cpu.data_ptr(), n_rows, chunk, items.data_ptr(), _ptr(long_rows) if n_long.value else None,
+                                       long_ptr.data_ptr()), "row_plan_fill")
+    return items, long_rows, long_ptr, int(n_slots.value)
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+# `d` is a bot_amd.graph.Direction: indptr/indices (int32, device), items/long_rows/long_ptr, sizes.
+
+def degrees(d) -> torch.Tensor:
+    _dev(d.indptr)
+    out = torch.empty(d.n_rows, dtype=torch.int64, device=d.indptr.device)
+    _check(_lib.bot_degrees_i64(d.indptr.data_ptr(), d.n_rows, out.data_ptr(), _stream()), "degrees")
+    return out
+
+
+def _slab(x, name):
+    """[n,H,D] float32 view with unit inner stride -> (tensor, ld, hs)."""
+    _f32(x, name)
+    if x.dim() != 3:
+        raise BotKernelError(f"{name} must be [n,H,D]")
+    if x.stride(2) != 1 and x.shape[2] != 1:
+        x = x.contiguous()
+    if x.shape[1] == 1:
+        return x, x.stride(0), max(x.shape[2], 1)
+    return x, x.stride(0), x.stride(1)
+
+
+def spmm(d, x, w=None, wperm=None, out=None):
+    """out[r,h,:] = sum_k w[wperm[k],h] * x[indices[k],h,:]   (w None: plain sum).  x: [n_src,H,D]."""
+    _dev(x, w, d.indptr)
+    x, ldx, hsx = _slab(x, "x")
+    H, D = x.shape[1], x.shape[2]
+    if w is not None:
+        _f32(w, "w")
+        w = w.contiguous()
+        if w.dim() != 2 or w.shape[1] != H:
+            raise BotKernelError(f"w must be [nnz,{H}], got {tuple(w.shape)}")
+    if out is None:
+        out = torch.empty((d.n_rows, H, D), dtype=torch.float32, device=x.device)
+    out_, ldo, hso = _slab(out, "out")
+    assert out_ is out
+    partial = None
+    if d.n_long:
+        partial = torch.empty(int(_lib.bot_spmm_workspace_floats(d.n_slots, H, D)), dtype=torch.float32, device=x.device)
+    _check(_timed("spmm", (H, D, w is not None), lambda: _lib.bot_spmm_f32(
+        d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
+        _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, _ptr(w), _ptr(_i32(wperm, "wperm")), H, D, out.data_ptr(), ldo, hso,
+        _ptr(partial), _stream())), "spmm")
+    return out
+
+
+def sddmm_dot(d, x, y, operm=None, out=None):
+    """out[operm[k],h] = <x[indices[k],h,:], y[r,h,:]> for every position k of every row r.  -> [nnz,H]"""
+    _dev(x, y, d.indptr)
+    x, ldx, hsx = _slab(x, "x")
+    y, ldy, hsy = _slab(y, "y")
+    H, D = x.shape[1], x.shape[2]
+    if out is None:
+        out = torch.empty((d.nnz, H), dtype=torch.float32, device=x.device)
+    _check(_timed("sddmm_dot", (H, D), lambda: _lib.bot_sddmm_dot_f32(
+        d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, x.data_ptr(), ldx, hsx,
+        y.data_ptr(), ldy, hsy, H, D, out.data_ptr(), _ptr(_i32(operm, "operm")), 0, _stream())), "sddmm_dot")
+    return out
+
+
+def u_add_v(src, dst, x, y=None):
+    """out[e,:] = x[src[e],:] (+ y[dst[e],:]).  x, y: [n,W] float32; src/dst: int32 [E]."""
+    _dev(x, y, src)
+    x = _f32(x, "x").contiguous()
+    y = None if y is None else _f32(y, "y").contiguous()
+    E, W = src.numel(), x.shape[1]
+    out = torch.empty((E, W), dtype=torch.float32, device=x.device)
+    _check(_lib.bot_sddmm_u_add_v_f32(_i32(src, "src").data_ptr(), _ptr(_i32(dst, "dst")), E, x.data_ptr(), _ptr(y), W,
+                                      out.data_ptr(), _stream()), "u_add_v")
+    return out
+
+
+def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm):
+    """Fused logits + leaky-ReLU + per-row softmax.  el/er: [n,H]; ee: [nnz,H] via eperm; -> a [nnz,H]."""
+    _dev(el, er, ee, d.indptr)
+    el = None if el is None else _f32(el, "el").contiguous()
+    er = None if er is None else _f32(er, "er").contiguous()
+    ee = None if ee is None else _f32(ee, "ee").contiguous()
+    if keep is not None and (keep.dtype != torch.uint8 or not keep.is_contiguous()):
+        raise BotKernelError("keep must be contiguous uint8")
+    a = torch.empty((d.nnz, H), dtype=torch.float32, device=d.indptr.device)
+    _check(_lib.bot_gat_attn_fwd_f32(d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, _ptr(d.long_rows), d.n_long,
+                                     d.chunk, _ptr(el), _ptr(er), _ptr(ee), _ptr(_i32(eperm, "eperm")), _ptr(keep),
+                                     float(slope), H, a.data_ptr(), _ptr(_i32(aperm, "aperm")), _stream()), "gat_attn_fwd")
+    return a
+
+
+def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der):
+    """Backward of gat_attn_fwd -> (dz [nnz,H] at zperm, der [n_rows,H] or None)."""
+    _dev(a, da, d.indptr)
+    el = None if el is None else _f32(el, "el").contiguous()
+    er = None if er is None else _f32(er, "er").contiguous()
+    ee = None if ee is None else _f32(ee, "ee").contiguous()
+    a = _f32(a, "a").contiguous()
+    da = _f32(da, "da").contiguous()
+    dz = torch.empty((d.nnz, H), dtype=torch.float32, device=a.device)
+    der = torch.empty((d.n_rows, H), dtype=torch.float32, device=a.device) if want_der else None
+    _check(_lib.bot_gat_attn_bwd_f32(d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, _ptr(d.long_rows), d.n_long,
+                                     d.chunk, _ptr(el), _ptr(er), _ptr(ee), _ptr(_i32(eperm, "eperm")), float(slope), H,
+                                     a.data_ptr(), da.data_ptr(), _ptr(_i32(aperm, "aperm")), dz.data_ptr(),
+                                     _ptr(_i32(zperm, "zperm")), _ptr(der), _stream()), "gat_attn_bwd")
+    return dz, der
+
+
+def segment_sum(d, vals, perm=None):
+    """out[r,:] = sum_k vals[perm[k],:].  vals: [nnz,W] -> [n_rows,W]"""
+    _dev(vals, d.indptr)
+    vals = _f32(vals, "vals").contiguous()
+    W = vals.shape[1]
+    out = torch.empty((d.n_rows, W), dtype=torch.float32, device=vals.device)
+    _check(_lib.bot_segment_sum_f32(d.indptr.data_ptr(), d.n_rows, d.nnz, _ptr(d.long_rows), d.n_long, d.chunk, vals.data_ptr(),
+                                    _ptr(_i32(perm, "perm")), W, out.data_ptr(), _stream()), "segment_sum")
+    return out
+
+
+def gather_rows(x, rows):
+    """out[i,:] = x[rows[i],:]   x: [n,F] float32 (row stride allowed), rows: int32."""
+    _dev(x, rows)
+    _f32(x, "x")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    out = torch.empty((rows.numel(), x.shape[1]), dtype=torch.float32, device=x.device)
+    _check(_lib.bot_gather_rows_f32(x.data_ptr(), x.stride(0), _i32(rows, "rows").data_ptr(), rows.numel(), x.shape[1],
+                                    out.data_ptr(), out.stride(0), _stream()), "gather_rows")
+    return out
+
+
+def scatter_add_rows(x, rows, vals):
+    """x[rows[i],:] += vals[i,:] in place; rows sorted-unique int32."""
+    _dev(x, rows, vals)
+    _f32(x, "x"), _f32(vals, "vals")
+    assert x.stride(1) == 1
+    vals = vals.contiguous()
+    _check(_lib.bot_scatter_add_rows_f32(x.data_ptr(), x.stride(0), _i32(rows, "rows").data_ptr(), rows.numel(), x.shape[1],
+                                         vals.data_ptr(), vals.stride(0), _stream()), "scatter_add_rows")
+    return x

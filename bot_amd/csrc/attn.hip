@@ -1,0 +1,353 @@
+// Edge-sized (nnz*H) kernels for gfx950: attention logits + leaky-ReLU + per-destination softmax
+// (forward and backward) and the segment sum of edge values.
+//
+// These sweep 4*H bytes per edge instead of 4*H*D, so they are two orders of magnitude lighter
+// than the SpMM/SDDMM gathers; the node-side operands el/er ([n,H], 2 MB at ogbn-arxiv) stay
+// resident in the 4 MiB XCD L2.  Lanes run ACROSS THE EDGES of a row: a 16-lane group per short
+// row (4 rows per wavefront; mean in-degree of the target graphs is ~15), one 256-thread workgroup
+// per long row (rows above the row plan's chunk), both through the same per-row routine.  Softmax is
+// the online (running max / running sum) form: two passes over the row, not three; heads are held
+// in registers HT at a time.  No atomics; fixed reduction order.
+//
+// HBM roofline: forward 4*[2*nnz*H + nnz + (n+1) + n*H*k] bytes, backward 4*[3*nnz*H + nnz + (n+1)].
+#include "common.h"
+
+namespace bot {
+
+constexpr int kRowLanes = 16;
+
+template <int LANES>
+struct GroupCtx {
+    static constexpr int kStride = LANES;
+    int lane;
+    __device__ __forceinline__ float sum(float v) const { return group_sum<LANES>(v); }
+    __device__ __forceinline__ float max(float v) const { return group_max<LANES>(v); }
+};
+
+struct BlockCtx {
+    static constexpr int kStride = kBlock;
+    int lane;    // thread id in the workgroup
+    float* lds;  // kBlock / 64 floats
+    __device__ __forceinline__ float sum(float v) const {
+        v = group_sum<64>(v);
+        __syncthreads();
+        if ((lane & 63) == 0) lds[lane >> 6] = v;
+        __syncthreads();
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < kBlock / 64; ++i) s += lds[i];
+        return s;
+    }
+    __device__ __forceinline__ float max(float v) const {
+        v = group_max<64>(v);
+        __syncthreads();
+        if ((lane & 63) == 0) lds[lane >> 6] = v;
+        __syncthreads();
+        float s = lds[0];
+#pragma unroll
+        for (int i = 1; i < kBlock / 64; ++i) s = fmaxf(s, lds[i]);
+        return s;
+    }
+};
+
+struct AttnArgs {
+    const int32_t* indptr;
+    const int32_t* indices;
+    int64_t n_rows;
+    const int32_t* long_rows;
+    int32_t chunk;
+    const float* el;
+    const float* er;
+    const float* ee;
+    const int32_t* eperm;
+    const uint8_t* keep;
+    float slope;
+    int32_t H, h0;
+    // forward: a (out).  backward: a, da (in), dz, der (out)
+    float* a;
+    const float* da;
+    const int32_t* aperm;
+    float* dz;
+    const int32_t* zperm;
+    float* der;
+};
+
+template <int HT>
+__device__ __forceinline__ void edge_logits(const AttnArgs& p, int src, int ep, const float (&erv)[HT], float (&e)[HT],
+                                            float (&z)[HT]) {
+#pragma unroll
+    for (int j = 0; j < HT; ++j) {
+        float v = erv[j];
+        if (p.el) v += p.el[(int64_t)src * p.H + p.h0 + j];
+        if (p.ee) v += p.ee[(int64_t)ep * p.H + p.h0 + j];
+        z[j] = v;
+        e[j] = v > 0.f ? v : v * p.slope;
+    }
+}
+
+template <int HT, class Ctx>
+__device__ __forceinline__ void attn_fwd_row(const AttnArgs& p, const Ctx& ctx, int row, int beg, int end) {
+    const float NEG_INF = -__builtin_inff();
+    float erv[HT], m[HT], s[HT];
+#pragma unroll
+    for (int j = 0; j < HT; ++j) {
+        erv[j] = p.er ? p.er[(int64_t)row * p.H + p.h0 + j] : 0.f;
+        m[j] = NEG_INF;
+        s[j] = 0.f;
+    }
+    for (int k = beg + ctx.lane; k < end; k += Ctx::kStride) {
+        const int src = p.indices ? p.indices[k] : 0;
+        const int ep = p.eperm ? p.eperm[k] : k;
+        if (p.keep && p.keep[ep] == 0) continue;
+        float e[HT], z[HT];
+        edge_logits<HT>(p, src, ep, erv, e, z);
+#pragma unroll
+        for (int j = 0; j < HT; ++j) {
+            const float mn = fmaxf(m[j], e[j]);
+            s[j] = s[j] * expf(m[j] - mn) + expf(e[j] - mn);  // m = -inf on first use: s = 0 * 0 + 1
+            m[j] = mn;
+        }
+    }
+    float M[HT], inv[HT];
+#pragma unroll
+    for (int j = 0; j < HT; ++j) {
+        M[j] = ctx.max(m[j]);
+        const float mine = m[j] > NEG_INF ? s[j] * expf(m[j] - M[j]) : 0.f;
+        const float S = ctx.sum(mine);
+        inv[j] = S > 0.f ? 1.f / S : 0.f;
+    }
+    for (int k = beg + ctx.lane; k < end; k += Ctx::kStride) {
+        const int src = p.indices ? p.indices[k] : 0;
+        const int ep = p.eperm ? p.eperm[k] : k;
+        const bool kept = !(p.keep && p.keep[ep] == 0);
+        float e[HT], z[HT];
+        edge_logits<HT>(p, src, ep, erv, e, z);
+        const int64_t o = (int64_t)(p.aperm ? p.aperm[k] : k) * p.H + p.h0;
+#pragma unroll
+        for (int j = 0; j < HT; ++j) p.a[o + j] = kept ? expf(e[j] - M[j]) * inv[j] : 0.f;
+    }
+}
+
+template <int HT, class Ctx>
+__device__ __forceinline__ void attn_bwd_row(const AttnArgs& p, const Ctx& ctx, int row, int beg, int end) {
+    float erv[HT], t[HT], dacc[HT];
+#pragma unroll
+    for (int j = 0; j < HT; ++j) {
+        erv[j] = p.er ? p.er[(int64_t)row * p.H + p.h0 + j] : 0.f;
+        t[j] = 0.f;
+        dacc[j] = 0.f;
+    }
+    for (int k = beg + ctx.lane; k < end; k += Ctx::kStride) {
+        const int64_t o = (int64_t)(p.aperm ? p.aperm[k] : k) * p.H + p.h0;
+#pragma unroll
+        for (int j = 0; j < HT; ++j) t[j] = fmaf(p.a[o + j], p.da[o + j], t[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < HT; ++j) t[j] = ctx.sum(t[j]);
+    const bool need_z = p.slope != 1.f;
+    for (int k = beg + ctx.lane; k < end; k += Ctx::kStride) {
+        const int64_t o = (int64_t)(p.aperm ? p.aperm[k] : k) * p.H + p.h0;
+        float e[HT], z[HT];
+        if (need_z) {
+            const int src = p.indices ? p.indices[k] : 0;
+            const int ep = p.eperm ? p.eperm[k] : k;
+            edge_logits<HT>(p, src, ep, erv, e, z);
+        }
+        const int64_t oz = (int64_t)(p.zperm ? p.zperm[k] : k) * p.H + p.h0;
+#pragma unroll
+        for (int j = 0; j < HT; ++j) {
+            float g = p.a[o + j] * (p.da[o + j] - t[j]);
+            if (need_z && !(z[j] > 0.f)) g *= p.slope;
+            p.dz[oz + j] = g;
+            dacc[j] += g;
+        }
+    }
+    if (p.der) {
+#pragma unroll
+        for (int j = 0; j < HT; ++j) {
+            const float d = ctx.sum(dacc[j]);
+            if (ctx.lane == 0) p.der[(int64_t)row * p.H + p.h0 + j] = d;
+        }
+    }
+}
+
+template <int HT, bool BWD>
+__global__ __launch_bounds__(kBlock) void attn_short_kernel(AttnArgs p) {
+    const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kRowLanes;
+    if (row >= p.n_rows) return;
+    const int beg = p.indptr[row], end = p.indptr[row + 1];
+    if (end - beg > p.chunk) return;  // the workgroup-per-row kernel owns it
+    GroupCtx<kRowLanes> ctx{(int)(threadIdx.x % kRowLanes)};
+    if constexpr (BWD) attn_bwd_row<HT>(p, ctx, (int)row, beg, end);
+    else attn_fwd_row<HT>(p, ctx, (int)row, beg, end);
+}
+
+template <int HT, bool BWD>
+__global__ __launch_bounds__(kBlock) void attn_long_kernel(AttnArgs p) {
+    __shared__ float lds[kBlock / 64];
+    const int row = p.long_rows[blockIdx.x];
+    const int beg = p.indptr[row], end = p.indptr[row + 1];
+    BlockCtx ctx{(int)threadIdx.x, lds};
+    if constexpr (BWD) attn_bwd_row<HT>(p, ctx, row, beg, end);
+    else attn_fwd_row<HT>(p, ctx, row, beg, end);
+}
+
+template <bool BWD>
+static int launch_attn(AttnArgs p, int64_t n_long, hipStream_t st) {
+    const int64_t blocks = (p.n_rows * kRowLanes + kBlock - 1) / kBlock;
+    for (int h0 = 0; h0 < p.H;) {  // heads in register tiles of up to 4
+        const int ht = p.H - h0 >= 4 ? 4 : p.H - h0;
+        p.h0 = h0;
+#define BOT_LAUNCH_ATTN(HT)                                                                                             \
+    do {                                                                                                                \
+        hipLaunchKernelGGL((attn_short_kernel<HT, BWD>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);                \
+        if (n_long > 0) hipLaunchKernelGGL((attn_long_kernel<HT, BWD>), dim3((unsigned)n_long), dim3(kBlock), 0, st, p); \
+    } while (0)
+        if (ht == 4) BOT_LAUNCH_ATTN(4);
+        else if (ht == 3) BOT_LAUNCH_ATTN(3);
+        else if (ht == 2) BOT_LAUNCH_ATTN(2);
+        else BOT_LAUNCH_ATTN(1);
+#undef BOT_LAUNCH_ATTN
+        h0 += ht;
+    }
+    return hip_status(BWD ? "gat_attn_bwd launch" : "gat_attn_fwd launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// segment sum: out[r,:] = sum_k vals[perm[k],:]
+// ---------------------------------------------------------------------------------------------
+struct SegArgs {
+    const int32_t* indptr;
+    int64_t n_rows;
+    const int32_t* long_rows;
+    int32_t chunk;
+    const float* vals;
+    const int32_t* perm;
+    int32_t W, w0;
+    float* out;
+};
+
+template <int WT, class Ctx>
+__device__ __forceinline__ void seg_row(const SegArgs& p, const Ctx& ctx, int row, int beg, int end) {
+    float acc[WT];
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[j] = 0.f;
+    for (int k = beg + ctx.lane; k < end; k += Ctx::kStride) {
+        const int64_t o = (int64_t)(p.perm ? p.perm[k] : k) * p.W + p.w0;
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[j] += p.vals[o + j];
+    }
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+        const float s = ctx.sum(acc[j]);
+        if (ctx.lane == 0) p.out[(int64_t)row * p.W + p.w0 + j] = s;
+    }
+}
+
+template <int WT>
+__global__ __launch_bounds__(kBlock) void seg_short_kernel(SegArgs p) {
+    const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kRowLanes;
+    if (row >= p.n_rows) return;
+    const int beg = p.indptr[row], end = p.indptr[row + 1];
+    if (end - beg > p.chunk) return;
+    GroupCtx<kRowLanes> ctx{(int)(threadIdx.x % kRowLanes)};
+    seg_row<WT>(p, ctx, (int)row, beg, end);
+}
+
+template <int WT>
+__global__ __launch_bounds__(kBlock) void seg_long_kernel(SegArgs p) {
+    __shared__ float lds[kBlock / 64];
+    const int row = p.long_rows[blockIdx.x];
+    BlockCtx ctx{(int)threadIdx.x, lds};
+    seg_row<WT>(p, ctx, row, p.indptr[row], p.indptr[row + 1]);
+}
+
+__global__ __launch_bounds__(kBlock) void degrees_kernel(const int32_t* indptr, int64_t n_rows, int64_t* deg) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r < n_rows) deg[r] = (int64_t)indptr[r + 1] - (int64_t)indptr[r];
+}
+
+static int attn_check(const char* who, const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                      const int32_t* long_rows, int64_t n_long, int32_t chunk, const float* el, int32_t H) {
+    BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_long >= 0, BOT_E_RANGE, "%s: negative size", who);
+    BOT_REQUIRE(nnz < INT32_MAX && n_rows < INT32_MAX, BOT_E_RANGE, "%s: int32 index range exceeded", who);
+    BOT_REQUIRE(H >= 1 && chunk >= 1, BOT_E_RANGE, "%s: H=%d chunk=%d", who, H, chunk);
+    BOT_REQUIRE(indptr != nullptr, BOT_E_NULL, "%s: indptr is NULL", who);
+    BOT_REQUIRE(n_long == 0 || long_rows, BOT_E_NULL, "%s: long_rows is NULL", who);
+    BOT_REQUIRE(el == nullptr || indices != nullptr || nnz == 0, BOT_E_NULL, "%s: el given without indices", who);
+    return 0;
+}
+
+}  // namespace bot
+
+extern "C" {
+
+int bot_gat_attn_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                         const int32_t* long_rows, int64_t n_long, int32_t chunk, const float* el, const float* er,
+                         const float* ee, const int32_t* eperm, const uint8_t* keep, float slope, int32_t H, float* a,
+                         const int32_t* aperm, bot_stream_t stream) {
+    using namespace bot;
+    if (int rc = attn_check("gat_attn_fwd", indptr, indices, n_rows, nnz, long_rows, n_long, chunk, el, H)) return rc;
+    if (n_rows == 0 || nnz == 0) return 0;
+    BOT_REQUIRE(a != nullptr, BOT_E_NULL, "gat_attn_fwd: a is NULL");
+    BOT_REQUIRE(el || er || ee, BOT_E_NULL, "gat_attn_fwd: no logit source (el, er, ee all NULL)");
+    AttnArgs p{indptr, indices, n_rows, long_rows, chunk, el, er, ee, eperm, keep, slope, H, 0, a, nullptr, aperm, nullptr,
+               nullptr, nullptr};
+    return launch_attn<false>(p, n_long, (hipStream_t)stream);
+}
+
+int bot_gat_attn_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                         const int32_t* long_rows, int64_t n_long, int32_t chunk, const float* el, const float* er,
+                         const float* ee, const int32_t* eperm, float slope, int32_t H, const float* a, const float* da,
+                         const int32_t* aperm, float* dz, const int32_t* zperm, float* der, bot_stream_t stream) {
+    using namespace bot;
+    if (int rc = attn_check("gat_attn_bwd", indptr, indices, n_rows, nnz, long_rows, n_long, chunk, el, H)) return rc;
+    if (n_rows == 0) return 0;
+    BOT_REQUIRE(nnz == 0 || (a && da && dz), BOT_E_NULL, "gat_attn_bwd: a/da/dz is NULL");
+    BOT_REQUIRE(slope == 1.f || el || er || ee, BOT_E_NULL, "gat_attn_bwd: slope != 1 needs el/er/ee to recompute the sign");
+    AttnArgs p{indptr, indices, n_rows, long_rows, chunk, el, er, ee, eperm, nullptr, slope, H, 0, const_cast<float*>(a), da,
+               aperm, dz, zperm, der};
+    return launch_attn<true>(p, n_long, (hipStream_t)stream);
+}
+
+int bot_segment_sum_f32(const int32_t* indptr, int64_t n_rows, int64_t nnz, const int32_t* long_rows, int64_t n_long,
+                        int32_t chunk, const float* vals, const int32_t* perm, int32_t W, float* out,
+                        bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_long >= 0, BOT_E_RANGE, "segment_sum: negative size");
+    BOT_REQUIRE(W >= 1 && chunk >= 1, BOT_E_RANGE, "segment_sum: W=%d chunk=%d", W, chunk);
+    if (n_rows == 0) return 0;
+    BOT_REQUIRE(indptr && out && (nnz == 0 || vals), BOT_E_NULL, "segment_sum: NULL pointer");
+    BOT_REQUIRE(n_long == 0 || long_rows, BOT_E_NULL, "segment_sum: long_rows is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    SegArgs p{indptr, n_rows, long_rows, chunk, vals, perm, W, 0, out};
+    const int64_t blocks = (n_rows * kRowLanes + kBlock - 1) / kBlock;
+    for (int w0 = 0; w0 < W;) {
+        const int wt = W - w0 >= 4 ? 4 : W - w0;
+        p.w0 = w0;
+#define BOT_LAUNCH_SEG(WT)                                                                                    \
+    do {                                                                                                      \
+        hipLaunchKernelGGL((seg_short_kernel<WT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);            \
+        if (n_long > 0) hipLaunchKernelGGL((seg_long_kernel<WT>), dim3((unsigned)n_long), dim3(kBlock), 0, st, p); \
+    } while (0)
+        if (wt == 4) BOT_LAUNCH_SEG(4);
+        else if (wt == 3) BOT_LAUNCH_SEG(3);
+        else if (wt == 2) BOT_LAUNCH_SEG(2);
+        else BOT_LAUNCH_SEG(1);
+#undef BOT_LAUNCH_SEG
+        w0 += wt;
+    }
+    return hip_status("segment_sum launch");
+}
+
+int bot_degrees_i64(const int32_t* indptr, int64_t n_rows, int64_t* deg, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n_rows >= 0, BOT_E_RANGE, "degrees: n_rows=%lld", (long long)n_rows);
+    if (n_rows == 0) return 0;
+    BOT_REQUIRE(indptr && deg, BOT_E_NULL, "degrees: NULL pointer");
+    hipLaunchKernelGGL(degrees_kernel, dim3((unsigned)((n_rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       indptr, n_rows, deg);
+    return hip_status("degrees launch");
+}
+
+}  // extern "C"

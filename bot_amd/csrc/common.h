@@ -1,0 +1,100 @@
+// Shared helpers for the gfx950 kernels behind include/bot_gnn.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/bot_gnn.h"
+
+namespace bot {
+
+void set_error(const char* fmt, ...);
+
+inline int hip_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+#define BOT_REQUIRE(cond, code, ...)    \
+    do {                                \
+        if (!(cond)) {                  \
+            bot::set_error(__VA_ARGS__); \
+            return (code);              \
+        }                               \
+    } while (0)
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+constexpr int kBlock = 256;   // 4 wave64 per workgroup
+constexpr int kWave = 64;
+
+// ---- vector types -------------------------------------------------------------------------
+template <int VEC> struct Vec;
+template <> struct Vec<1> { using type = float; };
+template <> struct Vec<2> { using type = float2; };
+template <> struct Vec<4> { using type = float4; };
+
+template <int VEC>
+__device__ __forceinline__ void vload(float (&r)[VEC], const float* p) {
+    using T = typename Vec<VEC>::type;
+    T v = *reinterpret_cast<const T*>(p);
+    if constexpr (VEC == 1) { r[0] = v; }
+    if constexpr (VEC == 2) { r[0] = v.x; r[1] = v.y; }
+    if constexpr (VEC == 4) { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+}
+
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const float (&r)[VEC]) {
+    using T = typename Vec<VEC>::type;
+    T v;
+    if constexpr (VEC == 1) { v = r[0]; }
+    if constexpr (VEC == 2) { v.x = r[0]; v.y = r[1]; }
+    if constexpr (VEC == 4) { v.x = r[0]; v.y = r[1]; v.z = r[2]; v.w = r[3]; }
+    *reinterpret_cast<T*>(p) = v;
+}
+
+// Broadcast lane `j` of a LANES-wide group.  For full-wave groups the source lane is wave-uniform,
+// so v_readlane puts the value in an SGPR and the dependent address math stays scalar.
+template <int LANES>
+__device__ __forceinline__ int group_bcast(int v, int j) {
+    if constexpr (LANES == 64) return __builtin_amdgcn_readlane(v, j);
+    else return __shfl(v, j, LANES);
+}
+template <int LANES>
+__device__ __forceinline__ float group_bcast(float v, int j) {
+    return __int_as_float(group_bcast<LANES>(__float_as_int(v), j));
+}
+
+template <int LANES>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int m = LANES / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, LANES);
+    return v;
+}
+template <int LANES>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int m = LANES / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, LANES));
+    return v;
+}
+
+// Vector width usable for a feature slab: every stride and base must keep VEC*4-byte alignment.
+inline int pick_vec(int32_t D, std::initializer_list<int64_t> strides, std::initializer_list<const void*> ptrs) {
+    for (int v : {4, 2}) {
+        bool ok = (D % v) == 0;
+        for (int64_t s : strides) ok = ok && (s % v) == 0;
+        for (const void* p : ptrs) ok = ok && (p == nullptr || aligned(p, 4 * v));
+        if (ok) return v;
+    }
+    return 1;
+}
+
+// Workgroup -> XCD note: blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).
+// The kernels below order their work head-major so that one head's source slab (N*D*4 bytes,
+// 169 MB at ogbn-arxiv H=3 D=250) is what is live in the 256 MiB Infinity Cache at a time.
+
+}  // namespace bot

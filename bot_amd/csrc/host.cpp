@@ -1,0 +1,96 @@
+// Host-side pieces of libbot_gnn.so: error reporting, ABI version, row plan (integer work only).
+#include <stdarg.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace bot {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace bot
+
+extern "C" {
+
+int bot_abi_version(void) { return BOT_ABI_VERSION; }
+const char* bot_last_error(void) { return bot::g_err; }
+
+int32_t bot_row_plan_default_chunk(int64_t nnz) {
+    // cdna_hip_programming.md Appendix B "Scatter / gather": split lists longer than a quarter of one
+    // wavefront's share of the rows; 256 CUs x 16 waves in flight.
+    int64_t share = nnz / (256 * 16) / 4;
+    int32_t c = 64;
+    while (c * 2 <= share && c < 512) c *= 2;
+    return c;
+}
+
+static int plan_check(const int32_t* indptr, int64_t n_rows, int32_t chunk) {
+    BOT_REQUIRE(indptr != nullptr, BOT_E_NULL, "row plan: indptr_host is NULL");
+    BOT_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, BOT_E_RANGE, "row plan: n_rows=%lld out of range", (long long)n_rows);
+    BOT_REQUIRE(chunk >= 1, BOT_E_RANGE, "row plan: chunk=%d must be >= 1", chunk);
+    for (int64_t r = 0; r < n_rows; ++r)
+        BOT_REQUIRE(indptr[r + 1] >= indptr[r], BOT_E_PLAN, "row plan: indptr not monotone at row %lld", (long long)r);
+    return 0;
+}
+
+int bot_row_plan_size_host(const int32_t* indptr, int64_t n_rows, int32_t chunk, int64_t* n_items, int64_t* n_long,
+                           int64_t* n_slots) {
+    if (int rc = plan_check(indptr, n_rows, chunk)) return rc;
+    BOT_REQUIRE(n_items && n_long && n_slots, BOT_E_NULL, "row plan: output pointer is NULL");
+    int64_t items = 0, longs = 0, slots = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        int64_t deg = (int64_t)indptr[r + 1] - indptr[r];
+        if (deg > chunk) {
+            int64_t c = (deg + chunk - 1) / chunk;
+            items += c, slots += c, longs += 1;
+        } else {
+            items += 1;
+        }
+    }
+    *n_items = items, *n_long = longs, *n_slots = slots;
+    return 0;
+}
+
+int bot_row_plan_fill_host(const int32_t* indptr, int64_t n_rows, int32_t chunk, int32_t* items, int32_t* long_rows,
+                           int32_t* long_ptr) {
+    if (int rc = plan_check(indptr, n_rows, chunk)) return rc;
+    BOT_REQUIRE(items && long_ptr, BOT_E_NULL, "row plan: output pointer is NULL");
+    // 1. long rows, in row order; their chunks come first (every chunk but the last is full-size).
+    int64_t it = 0, nl = 0, slot = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        int32_t beg = indptr[r], end = indptr[r + 1];
+        if ((int64_t)end - beg <= chunk) continue;
+        BOT_REQUIRE(long_rows != nullptr, BOT_E_NULL, "row plan: long_rows_host is NULL but long rows exist");
+        long_rows[nl] = (int32_t)r;
+        long_ptr[nl] = (int32_t)slot;
+        for (int32_t b = beg; b < end; b += chunk) {
+            int32_t* q = items + 4 * it++;
+            q[0] = (int32_t)r, q[1] = b, q[2] = std::min<int64_t>((int64_t)b + chunk, end), q[3] = (int32_t)slot++;
+        }
+        ++nl;
+    }
+    long_ptr[nl] = (int32_t)slot;
+    // 2. whole rows, longest first (counting sort on the degree, stable in the row id) so that the
+    //    groups sharing a wavefront have similar trip counts and heavy items start early.
+    std::vector<int64_t> start(chunk + 2, 0);
+    for (int64_t r = 0; r < n_rows; ++r) {
+        int64_t deg = (int64_t)indptr[r + 1] - indptr[r];
+        if (deg <= chunk) start[chunk - deg + 1] += 1;  // bucket 0 = degree `chunk`
+    }
+    for (int32_t b = 0; b <= chunk; ++b) start[b + 1] += start[b];
+    for (int64_t r = 0; r < n_rows; ++r) {
+        int64_t deg = (int64_t)indptr[r + 1] - indptr[r];
+        if (deg > chunk) continue;
+        int32_t* q = items + 4 * (it + start[chunk - deg]++);
+        q[0] = (int32_t)r, q[1] = indptr[r], q[2] = indptr[r + 1], q[3] = -1;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,213 @@
+// CSR/CSC SpMM for gfx950: out[r,h,:] = sum_k w[k,h] * x[indices[k],h,:].
+//
+// Shape of the kernel (MI355X_MICROARCH.md "Indexed rows", cdna_hip_programming.md Appendix B
+// "Scatter / gather"): one LANES-wide lane group per (work item, head, feature tile); lanes run
+// across the feature dimension with 4/8/16-byte loads so every neighbour row is one coalesced
+// segment; the neighbour ids (and weights) of a row are fetched LANES at a time with one coalesced
+// load, then broadcast lane by lane (v_readlane -> SGPR base address for full-wave groups), four
+// neighbour rows in flight per group; the per-destination sum stays in registers in neighbour
+// order and is stored once with plain stores — no atomics, bitwise reproducible.  Long rows are
+// split by the row plan into chunk-sized items whose partial sums are added in slot order by
+// spmm_combine_kernel.  Work is ordered head-major (see common.h).
+//
+// HBM roofline: algorithmic bytes per launch = 4*[2*n*H*D + nnz + (n+1) + (w? nnz*H : 0)].
+#include "common.h"
+
+namespace bot {
+
+struct SpmmArgs {
+    const int32_t* indices;
+    const int4* items;
+    int64_t n_items;
+    const float* x;
+    int64_t ldx, hsx;
+    const float* w;
+    const int32_t* wperm;
+    int32_t H, D, n_tiles;
+    float* out;
+    int64_t ldo, hso;
+    float* partial;
+    int64_t ldp;
+};
+
+template <int VEC, int LANES, int NCHUNK, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs a) {
+    constexpr int TILE = VEC * LANES * NCHUNK;
+    constexpr int U = 4;
+    const int lane = threadIdx.x % LANES;
+    const int64_t gid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+    if (gid >= a.n_items * a.H * a.n_tiles) return;  // whole groups leave together
+    const int64_t ht = gid / a.n_items;
+    const int64_t item = gid - ht * a.n_items;
+    int head = (int)(ht / a.n_tiles);
+    int tile = (int)(ht - (int64_t)head * a.n_tiles);
+    const int4 it = a.items[item];
+    int row = it.x, beg = it.y, end = it.z, slot = it.w;
+    if constexpr (LANES == 64) {  // wave-uniform: keep them in SGPRs
+        row = __builtin_amdgcn_readfirstlane(row);
+        beg = __builtin_amdgcn_readfirstlane(beg);
+        end = __builtin_amdgcn_readfirstlane(end);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        head = __builtin_amdgcn_readfirstlane(head);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+    }
+    const int doff = tile * TILE;
+    const int dcount = min(TILE, a.D - doff);
+    const float* xb = a.x + (int64_t)head * a.hsx + doff;
+
+    int off[NCHUNK];
+    bool act[NCHUNK];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int e = (c * LANES + lane) * VEC;
+        act[c] = e < dcount;
+        off[c] = act[c] ? e : 0;  // idle lanes re-read element 0: always in bounds, never stored
+    }
+    float acc[NCHUNK][VEC];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) acc[c][t] = 0.f;
+
+    for (int k0 = beg; k0 < end; k0 += LANES) {
+        const int k = k0 + lane;
+        int idx = 0;
+        float wv = 0.f;
+        if (k < end) {
+            idx = a.indices[k];
+            if constexpr (WEIGHTED) {
+                const int wp = a.wperm ? a.wperm[k] : k;
+                wv = a.w[(int64_t)wp * a.H + head];
+            }
+        }
+        const int cnt = min(LANES, end - k0);
+        int i = 0;
+        for (; i + U <= cnt; i += U) {
+            float v[U][NCHUNK][VEC];
+            float ww[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = group_bcast<LANES>(idx, i + u);
+                if constexpr (WEIGHTED) ww[u] = group_bcast<LANES>(wv, i + u);
+                const float* p = xb + (int64_t)s * a.ldx;
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], p + off[c]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                    for (int t = 0; t < VEC; ++t) {
+                        if constexpr (WEIGHTED) acc[c][t] = fmaf(ww[u], v[u][c][t], acc[c][t]);
+                        else acc[c][t] += v[u][c][t];
+                    }
+        }
+        for (; i < cnt; ++i) {
+            const int s = group_bcast<LANES>(idx, i);
+            float w1 = 1.f;
+            if constexpr (WEIGHTED) w1 = group_bcast<LANES>(wv, i);
+            const float* p = xb + (int64_t)s * a.ldx;
+            float v[NCHUNK][VEC];
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[c], p + off[c]);
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) {
+                    if constexpr (WEIGHTED) acc[c][t] = fmaf(w1, v[c][t], acc[c][t]);
+                    else acc[c][t] += v[c][t];
+                }
+        }
+    }
+
+    float* ob = slot < 0 ? a.out + (int64_t)row * a.ldo + (int64_t)head * a.hso + doff
+                         : a.partial + (int64_t)slot * a.ldp + (int64_t)head * a.D + doff;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+        if (act[c]) vstore<VEC>(ob + off[c], acc[c]);
+}
+
+// out[row,h,d] = partial[first slot] + ... + partial[last slot], in slot order.
+__global__ __launch_bounds__(kBlock) void spmm_combine_kernel(const int32_t* long_rows, const int32_t* long_ptr,
+                                                             int64_t n_long, int32_t H, int32_t D, const float* partial,
+                                                             int64_t ldp, float* out, int64_t ldo, int64_t hso) {
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t hd = (int64_t)H * D;
+    if (gid >= n_long * hd) return;
+    const int64_t i = gid / hd;
+    const int e = (int)(gid - i * hd);
+    const int h = e / D, d = e - h * D;
+    float s = 0.f;
+    for (int p = long_ptr[i]; p < long_ptr[i + 1]; ++p) s += partial[(int64_t)p * ldp + e];
+    out[(int64_t)long_rows[i] * ldo + (int64_t)h * hso + d] = s;
+}
+
+template <int VEC, int LANES, int NCHUNK>
+static void launch_spmm(const SpmmArgs& a, hipStream_t st) {
+    const int64_t groups = a.n_items * a.H * a.n_tiles;
+    const int64_t blocks = (groups * LANES + kBlock - 1) / kBlock;
+    if (blocks == 0) return;
+    if (a.w) hipLaunchKernelGGL((spmm_kernel<VEC, LANES, NCHUNK, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((spmm_kernel<VEC, LANES, NCHUNK, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+}
+
+template <int VEC>
+static void dispatch_spmm(SpmmArgs& a, hipStream_t st) {
+    const int L = (a.D + VEC - 1) / VEC;  // lanes needed for one head slab
+    a.n_tiles = 1;
+    if (L <= 8) launch_spmm<VEC, 8, 1>(a, st);
+    else if (L <= 16) launch_spmm<VEC, 16, 1>(a, st);
+    else if (L <= 32) launch_spmm<VEC, 32, 1>(a, st);
+    else if (L <= 64) launch_spmm<VEC, 64, 1>(a, st);
+    else if (L <= 128) launch_spmm<VEC, 64, 2>(a, st);
+    else if (L <= 192) launch_spmm<VEC, 64, 3>(a, st);
+    else {
+        a.n_tiles = (L + 255) / 256;
+        launch_spmm<VEC, 64, 4>(a, st);
+    }
+}
+
+}  // namespace bot
+
+extern "C" {
+
+int64_t bot_spmm_workspace_floats(int64_t n_slots, int32_t H, int32_t D) { return n_slots * (int64_t)H * D; }
+
+int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz, const int32_t* items,
+                 int64_t n_items, const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, const float* x,
+                 int64_t ldx, int64_t hsx, const float* w, const int32_t* wperm, int32_t H, int32_t D, float* out,
+                 int64_t ldo, int64_t hso, float* partial, bot_stream_t stream) {
+    using namespace bot;
+    (void)indptr;
+    BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_items >= 0 && n_long >= 0, BOT_E_RANGE, "spmm: negative size");
+    BOT_REQUIRE(nnz < INT32_MAX && n_rows < INT32_MAX, BOT_E_RANGE, "spmm: int32 index range exceeded");
+    BOT_REQUIRE(H >= 1 && D >= 1, BOT_E_RANGE, "spmm: H=%d D=%d must be >= 1", H, D);
+    if (n_rows == 0) return 0;
+    BOT_REQUIRE(items && x && out, BOT_E_NULL, "spmm: items/x/out is NULL");
+    BOT_REQUIRE(nnz == 0 || indices, BOT_E_NULL, "spmm: indices is NULL");
+    BOT_REQUIRE(n_items >= n_rows - n_long, BOT_E_PLAN, "spmm: plan has %lld items for %lld rows", (long long)n_items,
+                (long long)n_rows);
+    BOT_REQUIRE(n_long == 0 || (long_rows && long_ptr && partial), BOT_E_NULL, "spmm: long rows need long_rows/long_ptr/partial");
+    BOT_REQUIRE(ldx >= (int64_t)(H - 1) * hsx + D && ldo >= (int64_t)(H - 1) * hso + D && hsx >= D && hso >= D, BOT_E_RANGE,
+                "spmm: strides smaller than the slab (ldx=%lld hsx=%lld ldo=%lld hso=%lld H=%d D=%d)", (long long)ldx,
+                (long long)hsx, (long long)ldo, (long long)hso, H, D);
+    BOT_REQUIRE(aligned(x, 4) && aligned(out, 4) && aligned(items, 16), BOT_E_ALIGN, "spmm: misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    SpmmArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, hsx, w, wperm, H, D, 1, out, ldo, hso, partial,
+               (int64_t)H * D};
+    const int vec = pick_vec(D, {ldx, hsx, ldo, hso}, {x, out, partial});
+    if (vec == 4) dispatch_spmm<4>(a, st);
+    else if (vec == 2) dispatch_spmm<2>(a, st);
+    else dispatch_spmm<1>(a, st);
+    if (int rc = hip_status("spmm launch")) return rc;
+    if (n_long > 0) {
+        const int64_t n = n_long * H * D;
+        hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows,
+                           long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso);
+        if (int rc = hip_status("spmm combine launch")) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

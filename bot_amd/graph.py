@@ -1,0 +1,264 @@
+"""Graph object for full-batch message passing on one MI355X.
+
+Mirrors the closed slice of the `dgl 0.5.*` graph surface that the reference layers touch
+(reference src/no-sampling/models.py:333-388, 476-551; run.py:138-146) so the
+reference's layer code runs on it unchanged, and holds the device-side structures the HIP kernels
+consume: both compressed directions (in-edges by destination = "csc", out-edges by source = "csr"),
+int32, each stable in edge id, with the position->edge-id permutations and the row plans.
+"""
+from __future__ import annotations
+
+import contextlib
+from dataclasses import dataclass
+
+import torch
+
+from . import _C
+
+
+@dataclass
+class Direction:
+    """One compressed direction + its row plan (include/bot_gnn.h "Row plan")."""
+    indptr: torch.Tensor     # int32 [n_rows+1]
+    indices: torch.Tensor    # int32 [nnz]  neighbour node of each position
+    eid: torch.Tensor        # int32 [nnz]  position -> edge id
+    items: torch.Tensor      # int32 [n_items,4]
+    long_rows: torch.Tensor | None
+    long_ptr: torch.Tensor | None
+    n_rows: int
+    nnz: int
+    n_items: int
+    n_long: int
+    n_slots: int
+    chunk: int
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device)
+        return Direction(mv(self.indptr), mv(self.indices), mv(self.eid), mv(self.items), mv(self.long_rows),
+                         mv(self.long_ptr), self.n_rows, self.nnz, self.n_items, self.n_long, self.n_slots, self.chunk)
+
+
+def build_direction(rows: torch.Tensor, cols: torch.Tensor, n_rows: int, chunk: int | None = None) -> Direction:
+    """Compress the COO list (edge e: row rows[e], neighbour cols[e]) by row, stable in edge id.
+
+    Integer work done with torch on whatever device the edge list lives on; the row plan is host-side C.
+    """
+    dev = rows.device
+    nnz = int(rows.numel())
+    if nnz >= 2 ** 31 - 1 or n_rows >= 2 ** 31 - 1:
+        raise ValueError("bot_amd uses int32 indices: graph too large")
+    eid = torch.argsort(rows, stable=True)
+    counts = torch.bincount(rows, minlength=n_rows)
+    indptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(counts, 0)
+    indptr32 = indptr.to(torch.int32)
+    if chunk is None:
+        chunk = _C.default_chunk(nnz)
+    items, long_rows, long_ptr, n_slots = _C.row_plan(indptr32.cpu().contiguous(), chunk)
+    n_long = int(long_rows.numel())
+    return Direction(indptr32.contiguous(), cols[eid].to(torch.int32).contiguous(), eid.to(torch.int32).contiguous(),
+                     items.to(dev), long_rows.to(dev) if n_long else None, long_ptr.to(dev) if n_long else None,
+                     int(n_rows), nnz, int(items.shape[0]), n_long, n_slots, int(chunk))
+
+
+class _Frame(dict):
+    """Feature dict (`graph.ndata` / `graph.edata`)."""
+
+
+class Graph:
+    """Homogeneous graph over nodes 0..N-1 with edges in edge-id order (edge e: src[e] -> dst[e])."""
+
+    is_block = False  # models.py:494 / ogbn-proteins/models.py:94 — full-graph branch only
+
+    def __init__(self, src, dst, num_nodes: int, *, chunk: int | None = None, _share=None):
+        src = torch.as_tensor(src).to(torch.int64)
+        dst = torch.as_tensor(dst).to(torch.int64)
+        if src.shape != dst.shape or src.dim() != 1:
+            raise ValueError("src and dst must be 1-D tensors of equal length")
+        if src.numel() and (int(torch.max(src.max(), dst.max())) >= num_nodes or int(torch.min(src.min(), dst.min())) < 0):
+            raise ValueError("node id out of range")
+        self._src, self._dst, self._n = src, dst, int(num_nodes)
+        self._chunk = chunk
+        self._csc = self._csr = self._csr2csc = self._csc2csr = None
+        self._src32 = self._dst32 = None
+        self.ndata, self.edata = _Frame(), _Frame()
+
+    # ---------------------------------------------------------------- dgl-like queries
+    @property
+    def device(self):
+        return self._src.device
+
+    @property
+    def srcdata(self):
+        return self.ndata
+
+    @property
+    def dstdata(self):
+        return self.ndata
+
+    def number_of_nodes(self):
+        return self._n
+
+    num_nodes = number_of_nodes
+
+    def number_of_src_nodes(self):
+        return self._n
+
+    def number_of_dst_nodes(self):
+        return self._n
+
+    def number_of_edges(self):
+        return int(self._src.numel())
+
+    num_edges = number_of_edges
+
+    def edges(self):
+        return self._src, self._dst
+
+    def in_degrees(self):
+        """int64 [N] — models.py:335,388,478,551.  Computed by the HIP degree kernel from the CSC row pointer."""
+        return _C.degrees(self.csc)
+
+    def out_degrees(self):
+        """int64 [N] — models.py:352,501; ogbn-proteins/gat.py:64."""
+        return _C.degrees(self.csr)
+
+    @contextlib.contextmanager
+    def local_scope(self):
+        """models.py:333,476 — feature writes inside the scope do not leak out."""
+        nd, ed = _Frame(self.ndata), _Frame(self.edata)
+        try:
+            yield
+        finally:
+            self.ndata, self.edata = nd, ed
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        g = Graph(self._src.to(device), self._dst.to(device), self._n, chunk=self._chunk)
+        for name in ("_csc", "_csr", "_csr2csc", "_csc2csr", "_src32", "_dst32"):
+            v = getattr(self, name)
+            setattr(g, name, None if v is None else v.to(device))
+        g.ndata = _Frame({k: v.to(device) for k, v in self.ndata.items()})
+        g.edata = _Frame({k: v.to(device) for k, v in self.edata.items()})
+        return g
+
+    def create_formats_(self):
+        """run.py:146 — materialise both compressed directions now."""
+        _ = self.csc, self.csr, self.csr2csc
+        return None
+
+    # ---------------------------------------------------------------- transforms (run.py:138-143); integer, bit-exact
+    def remove_self_loop(self):
+        keep = self._src != self._dst
+        g = Graph(self._src[keep], self._dst[keep], self._n, chunk=self._chunk)
+        g.ndata = _Frame(self.ndata)
+        return g
+
+    def add_self_loop(self):
+        loops = torch.arange(self._n, dtype=torch.int64, device=self.device)
+        g = Graph(torch.cat([self._src, loops]), torch.cat([self._dst, loops]), self._n, chunk=self._chunk)
+        g.ndata = _Frame(self.ndata)
+        return g
+
+    # ---------------------------------------------------------------- device structures
+    @property
+    def csc(self) -> Direction:
+        """In-edges grouped by destination: rows = dst, indices = src."""
+        if self._csc is None:
+            self._csc = build_direction(self._dst, self._src, self._n, self._chunk)
+        return self._csc
+
+    @property
+    def csr(self) -> Direction:
+        """Out-edges grouped by source: rows = src, indices = dst."""
+        if self._csr is None:
+            self._csr = build_direction(self._src, self._dst, self._n, self._chunk)
+        return self._csr
+
+    def _inverse(self, perm):
+        inv = torch.empty_like(perm)
+        inv[perm.long()] = torch.arange(perm.numel(), dtype=perm.dtype, device=perm.device)
+        return inv
+
+    @property
+    def csr2csc(self) -> torch.Tensor:
+        """int32 [E]: CSC position of the edge that sits at CSR position k."""
+        if self._csr2csc is None:
+            self._csr2csc = self._inverse(self.csc.eid)[self.csr.eid.long()].contiguous()
+        return self._csr2csc
+
+    @property
+    def src32(self):
+        if self._src32 is None:
+            self._src32 = self._src.to(torch.int32).contiguous()
+        return self._src32
+
+    @property
+    def dst32(self):
+        if self._dst32 is None:
+            self._dst32 = self._dst.to(torch.int32).contiguous()
+        return self._dst32
+
+    # ---------------------------------------------------------------- message passing (dgl.function builders)
+    def apply_edges(self, msg):
+        """models.py:523,525 — `fn.u_add_v` / `fn.copy_u` into edata."""
+        from . import ops
+        if msg.kind == "copy_u":
+            self.edata[msg.out] = ops.copy_u(self, self.ndata[msg.a])
+        elif msg.kind == "u_add_v":
+            self.edata[msg.out] = ops.u_add_v(self, self.ndata[msg.a], self.ndata[msg.b])
+        else:
+            raise NotImplementedError(f"apply_edges({msg.kind})")
+
+    def update_all(self, msg, reduce):
+        """models.py:374,381,547; ogbn-proteins/gat.py:58 — (copy_u | u_mul_e | copy_e) + sum."""
+        from . import ops
+        if reduce.kind != "sum" or reduce.msg != msg.out:
+            raise NotImplementedError("only fn.sum over the message field is supported")
+        if msg.kind == "copy_u":
+            out = ops.copy_u_sum(self, self.ndata[msg.a])
+        elif msg.kind == "u_mul_e":
+            out = ops.u_mul_e_sum(self, self.ndata[msg.a], self.edata[msg.b])
+        elif msg.kind == "copy_e":
+            out = ops.copy_e_sum(self, self.edata[msg.a])
+        else:
+            raise NotImplementedError(f"update_all({msg.kind})")
+        self.ndata[reduce.out] = out
+
+
+def graph(edges, num_nodes=None) -> Graph:
+    """`dgl.graph((src, dst))` (models.py:187)."""
+    src, dst = (torch.as_tensor(x).to(torch.int64) for x in edges)
+    if num_nodes is None:
+        num_nodes = int(torch.max(src.max(), dst.max())) + 1 if src.numel() else 0
+    return Graph(src, dst, num_nodes)
+
+
+def to_bidirected(g: Graph) -> Graph:
+    """`dgl.to_bidirected(graph)` — run.py:138.  Adds every reverse edge, then collapses duplicate
+    (src, dst) pairs; the result is ordered by (src, dst).  Node/edge features are dropped (the
+    reference re-attaches `feat` itself, run.py:137-139).  Integer work, bit-exact vs the oracle."""
+    n = g.number_of_nodes()
+    key = torch.unique(torch.cat([g._src * n + g._dst, g._dst * n + g._src]))
+    return Graph(torch.div(key, n, rounding_mode="floor"), key % n, n, chunk=g._chunk)
+
+
+def add_self_loop(g: Graph) -> Graph:
+    return g.add_self_loop()
+
+
+def remove_self_loop(g: Graph) -> Graph:
+    return g.remove_self_loop()
+
+
+def preprocess(g: Graph) -> Graph:
+    """The graph half of `preprocess(graph)` — run.py:133-148."""
+    feat = g.ndata.get("feat")
+    g = to_bidirected(g)
+    if feat is not None:
+        g.ndata["feat"] = feat
+    g = g.remove_self_loop().add_self_loop()
+    g.create_formats_()
+    return g

@@ -1,0 +1,197 @@
+"""Differentiable sparse operators over a `bot_amd.Graph`, each backed by hand-written gfx950 kernels
+through the C ABI (include/bot_gnn.h).  They replace the `dgl.ops` calls the reference makes
+(SURVEY §2.1): copy_u_sum, u_mul_e_sum, copy_e_sum, copy_u, u_add_v, edge_softmax (+ `eids`), and add
+the fused attention op the layers use (`gat_attention`: logits + leaky-ReLU + softmax in one sweep).
+
+Edge tensors cross this API in edge-id order, like DGL's.  `gat_attention` / `u_mul_e_sum` also accept
+`order="csc"`: the attention weights then stay in destination-major position order between the two
+ops (no permutation gathers); the layers in `bot_amd.nn` use that form.
+
+Backward formulas (hand-derived; checked against autograd of the oracle's forward definitions):
+  copy_u_sum      dx = copy_u_sum on the reversed graph (CSR sweep)
+  u_mul_e_sum     dx[u] = sum_{e: u->v} a_e * dout[v]  (CSR sweep, weights through csr2csc);
+                  da_e  = <x[u], dout[v]>              (SDDMM dot, CSC sweep)
+  gat_attention   t_v = sum a*da;  de = a*(da - t_v);  dz = de * leaky'(z);
+                  d_er[v] = sum_in dz;  d_el[u] = sum_out dz;  d_ee = dz
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _C
+
+__all__ = ["copy_u_sum", "u_mul_e_sum", "copy_e_sum", "copy_u", "u_add_v", "edge_softmax", "gat_attention"]
+
+
+def _as3(x):
+    """[n], [n,F] or [n,H,D] -> [n,H,D] view."""
+    if x.dim() == 1:
+        return x.view(-1, 1, 1)
+    if x.dim() == 2:
+        return x.unsqueeze(1)
+    if x.dim() == 3:
+        return x
+    return x.reshape(x.shape[0], 1, -1)
+
+
+def _edge2(a, H=None):
+    """[E,H,1] / [E,H] / [E] -> [E,H]."""
+    return a.reshape(a.shape[0], -1)
+
+
+class _CopyUSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, x):
+        ctx.g, ctx.shape = g, x.shape
+        return _C.spmm(g.csc, _as3(x)).view((g.number_of_dst_nodes(),) + tuple(x.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.g
+        return None, _C.spmm(g.csr, _as3(dout.contiguous())).view(ctx.shape)
+
+
+def copy_u_sum(g, x):
+    """`update_all(fn.copy_src('h','m'), fn.sum('m','h'))` — models.py:374,381."""
+    return _CopyUSum.apply(g, x)
+
+
+class _UMulESum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, x, a, order):
+        x3, a2 = _as3(x), _edge2(a)
+        ctx.g, ctx.order, ctx.xshape, ctx.ashape = g, order, x.shape, a.shape
+        ctx.save_for_backward(x3, a2)
+        wperm = g.csc.eid if order == "eid" else None
+        return _C.spmm(g.csc, x3, a2, wperm).view((g.number_of_dst_nodes(),) + tuple(x.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.g
+        x3, a2 = ctx.saved_tensors
+        d3 = _as3(dout.contiguous())
+        dx = da = None
+        if ctx.needs_input_grad[1]:
+            wperm = g.csr.eid if ctx.order == "eid" else g.csr2csc
+            dx = _C.spmm(g.csr, d3, a2, wperm).view(ctx.xshape)
+        if ctx.needs_input_grad[2]:
+            operm = g.csc.eid if ctx.order == "eid" else None
+            da = _C.sddmm_dot(g.csc, x3, d3, operm).view(ctx.ashape)
+        return None, dx, da, None
+
+
+def u_mul_e_sum(g, x, a, order="eid"):
+    """`update_all(fn.u_mul_e('ft','a','m'), fn.sum('m','ft'))` — models.py:547.
+    x: [N,H,D]; a: [E,H,1] (or [E,H]) in edge-id order, or in CSC position order with order="csc"."""
+    return _UMulESum.apply(g, x, a, order)
+
+
+class _CopyESum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, w):
+        ctx.g, ctx.shape = g, w.shape
+        return _C.segment_sum(g.csc, _edge2(w), g.csc.eid).view((g.number_of_dst_nodes(),) + tuple(w.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.g
+        return None, _C.u_add_v(g.dst32, None, dout.reshape(dout.shape[0], -1).contiguous()).view(ctx.shape)
+
+
+def copy_e_sum(g, w):
+    """`update_all(fn.copy_e('feat','m'), fn.sum('m','feat'))` — ogbn-proteins/gat.py:58."""
+    return _CopyESum.apply(g, w)
+
+
+class _UAddV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, x, y):
+        ctx.g, ctx.xshape = g, x.shape
+        ctx.has_y = y is not None
+        ctx.yshape = y.shape if ctx.has_y else None
+        x2 = x.reshape(x.shape[0], -1)
+        y2 = None if y is None else y.reshape(y.shape[0], -1)
+        return _C.u_add_v(g.src32, g.dst32 if ctx.has_y else None, x2, y2).view((g.number_of_edges(),) + tuple(x.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, de):
+        g = ctx.g
+        de2 = de.reshape(de.shape[0], -1).contiguous()
+        dx = _C.segment_sum(g.csr, de2, g.csr.eid).view(ctx.xshape) if ctx.needs_input_grad[1] else None
+        dy = _C.segment_sum(g.csc, de2, g.csc.eid).view(ctx.yshape) if ctx.has_y and ctx.needs_input_grad[2] else None
+        return None, dx, dy
+
+
+def copy_u(g, x):
+    """`apply_edges(fn.copy_u('el','e'))` — models.py:525."""
+    return _UAddV.apply(g, x, None)
+
+
+def u_add_v(g, x, y):
+    """`apply_edges(fn.u_add_v('el','er','e'))` — models.py:523."""
+    return _UAddV.apply(g, x, y)
+
+
+class _GatAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, el, er, ee, keep, slope, order):
+        csc = g.csc
+        H = (el if el is not None else ee).reshape((el if el is not None else ee).shape[0], -1).shape[1]
+        el2 = None if el is None else el.reshape(-1, H)
+        er2 = None if er is None else er.reshape(-1, H)
+        ee2 = None if ee is None else ee.reshape(-1, H)
+        aperm = csc.eid if order == "eid" else None
+        eperm = csc.eid if (ee is not None or keep is not None) else None
+        a = _C.gat_attn_fwd(csc, el2, er2, ee2, eperm, keep, slope, H, aperm)
+        ctx.g, ctx.slope, ctx.order, ctx.H = g, slope, order, H
+        ctx.shapes = tuple(None if t is None else t.shape for t in (el, er, ee))
+        ctx.save_for_backward(el2, er2, ee2, a)
+        return a.view(-1, H, 1)
+
+    @staticmethod
+    def backward(ctx, da):
+        g, H = ctx.g, ctx.H
+        csc, csr = g.csc, g.csr
+        el2, er2, ee2, a = ctx.saved_tensors
+        aperm = csc.eid if ctx.order == "eid" else None
+        eperm = csc.eid if ee2 is not None else None
+        # dz is written in edge-id order when something edge-indexed consumes it, else CSC position order
+        z_eid = ee2 is not None
+        dz, der = _C.gat_attn_bwd(csc, el2, er2, ee2, eperm, ctx.slope, H, a, da.reshape(-1, H), aperm,
+                                  csc.eid if z_eid else None, er2 is not None)
+        d_el = d_er = d_ee = None
+        if el2 is not None and ctx.needs_input_grad[1]:
+            d_el = _C.segment_sum(csr, dz, csr.eid if z_eid else g.csr2csc).view(ctx.shapes[0])
+        if er2 is not None and ctx.needs_input_grad[2]:
+            d_er = der.view(ctx.shapes[1])
+        if ee2 is not None and ctx.needs_input_grad[3]:
+            d_ee = dz.view(ctx.shapes[2])
+        return None, d_el, d_er, d_ee, None, None, None
+
+
+def gat_attention(g, el=None, er=None, ee=None, *, keep=None, negative_slope=0.2, order="eid"):
+    """Attention weights of one GAT layer in a single sweep over the in-edges (models.py:517-544):
+
+        z_e = el[src] (+ er[dst]) (+ ee_e);  a = softmax over in-edges of leaky_relu(z, negative_slope)
+
+    el, er: [N,H,1]; ee: [E,H,1] in edge-id order; keep: optional uint8 [E] in edge-id order — edges
+    with keep == 0 are excluded from the softmax and get a == 0 (the edge-drop branch, models.py:528-539).
+    Returns a [E,H,1] in edge-id order (order="eid") or CSC position order (order="csc")."""
+    return _GatAttention.apply(g, el, er, ee, keep, float(negative_slope), order)
+
+
+def edge_softmax(graph, logits, eids=None, norm_by="dst"):
+    """`dgl.ops.edge_softmax(graph, logits, eids=ALL)` — models.py:544 and, with `eids`, :537.
+
+    With `eids`, `logits` holds values for those edges only and the softmax runs over the
+    edge-induced subgraph that keeps all nodes; the result has the shape and order of `logits`."""
+    if norm_by != "dst":
+        raise NotImplementedError("edge_softmax: only norm_by='dst' is on the reference's path")
+    if eids is None or not torch.is_tensor(eids):
+        return gat_attention(graph, None, None, logits, negative_slope=1.0, order="eid").view(logits.shape)
+    E = graph.number_of_edges()
+    full = logits.new_zeros((E,) + tuple(logits.shape[1:])).index_copy(0, eids, logits)
+    keep = torch.zeros(E, dtype=torch.uint8, device=logits.device)
+    keep[eids] = 1
+    a = gat_attention(graph, None, None, full, keep=keep, negative_slope=1.0, order="eid")
+    return a.view(full.shape)[eids]

@@ -1,0 +1,181 @@
+/*
+ * bot_gnn.h — C ABI of libbot_gnn.so: gfx950 (MI355X) message-passing kernels for full-batch
+ * GAT / GCN forward + backward.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one `dgl 0.5.*` operator that the
+ * reference (AiRyunn/BoT) invokes from its layer code; the citation next to each function is the
+ * reference call site (paths relative to the reference repository root).  The reference's own FFI
+ * for this path is DGL's Python->C++ operator registry (`dgl.ops.gspmm / gsddmm / edge_softmax`,
+ * reached through `graph.update_all`, `graph.apply_edges`, `dgl.ops.edge_softmax`); the host-side
+ * binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers unless the name ends in `_host`.  The caller allocates and
+ *    owns every buffer (inputs, outputs, workspace); the library never allocates, frees, copies,
+ *    synchronises or keeps a pointer past the call — every launch function is hipGraph-capturable.
+ *  - Work is enqueued on `stream` (a hipStream_t passed as void*) and NOT synchronised.
+ *  - Return value: 0 = ok, < 0 = invalid argument (BOT_E_*), > 0 = a hipError_t from the launch.
+ *    `bot_last_error()` returns a thread-local description of the last non-zero return.
+ *  - A graph direction is given in compressed-row form: `indptr[n_rows+1]`, `indices[nnz]`.
+ *    For the forward pass rows are DESTINATION nodes and indices are the SOURCE of every in-edge
+ *    (CSC of the adjacency); for the transposed pass rows are sources and indices destinations.
+ *    Within a row, positions are in ascending edge-id order.  Index type is int32.
+ *  - "position order" = the order of `indices`; `perm[k]` maps position k to a row of an
+ *    edge-indexed array (the edge id, or the position in the other direction).  NULL = identity.
+ *  - Node features are fp32, laid out [n, H, D] with explicit strides in floats: `ld*` between
+ *    nodes, `hs*` between heads (so padded layouts are allowed).  Edge arrays are [nnz, H] dense.
+ *  - No float atomics anywhere: identical inputs give bitwise identical outputs run to run.
+ */
+#ifndef BOT_GNN_H
+#define BOT_GNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BOT_ABI_VERSION 1
+
+#define BOT_E_NULL (-1)     /* required pointer is NULL                 */
+#define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
+#define BOT_E_ALIGN (-3)    /* pointer not 4-byte aligned               */
+#define BOT_E_PLAN (-4)     /* inconsistent row plan                    */
+
+typedef void* bot_stream_t; /* hipStream_t */
+
+int bot_abi_version(void);
+const char* bot_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row plan (host side, pure integer work; built once per graph direction).
+ *
+ * Splits rows longer than `chunk` neighbours into chunks so that no wavefront owns more than
+ * `chunk` gathers (power-law tails), and lists those long rows.  A work item is 4 x int32:
+ * {row, begin, end, slot}; slot < 0: the item owns the whole row and writes the result directly;
+ * slot >= 0: the item writes a partial sum into workspace slot `slot`, and the long row's partials
+ * [long_ptr[i], long_ptr[i+1]) are added in slot order afterwards (deterministic).
+ * Items are emitted longest-first so heavy items start early.
+ * ------------------------------------------------------------------------------------------- */
+int bot_row_plan_size_host(const int32_t* indptr_host, int64_t n_rows, int32_t chunk,
+                           int64_t* n_items, int64_t* n_long, int64_t* n_slots);
+int bot_row_plan_fill_host(const int32_t* indptr_host, int64_t n_rows, int32_t chunk,
+                           int32_t* items_host /* [n_items*4] */, int32_t* long_rows_host /* [n_long] */,
+                           int32_t* long_ptr_host /* [n_long+1] */);
+/* chunk size recommended for a graph with nnz edges (a quarter of one wavefront's share). */
+int32_t bot_row_plan_default_chunk(int64_t nnz);
+
+/* ---------------------------------------------------------------------------------------------
+ * Degrees.  Replaces graph.in_degrees() / graph.out_degrees()
+ * (src/no-sampling/models.py:335,352,388,478,501,551; src/ogbn-proteins/gat.py:64).
+ * deg[r] = indptr[r+1] - indptr[r], int64, bit-exact.
+ * ------------------------------------------------------------------------------------------- */
+int bot_degrees_i64(const int32_t* indptr, int64_t n_rows, int64_t* deg, bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SpMM.  Replaces update_all(fn.copy_src/copy_u, fn.sum)   — copy_u_sum  (models.py:374,381)
+ *        and      update_all(fn.u_mul_e, fn.sum)            — u_mul_e_sum (models.py:547,
+ *        src/ogbn-proteins/models.py:146, src/ogbn-products/models.py:147), and serves as their
+ *        backward on the transposed direction.
+ *
+ *   out[r,h,:] = sum_{k in row r} w[wperm[k],h] * x[indices[k],h,:]       (w == NULL: weight 1)
+ *
+ * `partial` is caller-provided workspace of bot_spmm_workspace_floats(...) floats (may be NULL when
+ * the plan has no long rows).
+ * ------------------------------------------------------------------------------------------- */
+int64_t bot_spmm_workspace_floats(int64_t n_slots, int32_t H, int32_t D);
+int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                 const int32_t* items, int64_t n_items,
+                 const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long,
+                 const float* x, int64_t ldx, int64_t hsx,
+                 const float* w, const int32_t* wperm,
+                 int32_t H, int32_t D,
+                 float* out, int64_t ldo, int64_t hso,
+                 float* partial, bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SDDMM dot.  The backward of u_mul_e_sum with respect to the edge weights (models.py:547):
+ *
+ *   out[operm[k], h] = < x[indices[k],h,:] , y[r,h,:] >        for every position k of every row r
+ *
+ * `accumulate` != 0 adds into `out` (used to tile D > the per-launch limit of 1024 floats).
+ * ------------------------------------------------------------------------------------------- */
+int bot_sddmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                      const int32_t* items, int64_t n_items,
+                      const float* x, int64_t ldx, int64_t hsx,
+                      const float* y, int64_t ldy, int64_t hsy,
+                      int32_t H, int32_t D,
+                      float* out, const int32_t* operm, int32_t accumulate, bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SDDMM copy_u / u_add_v.  Replaces apply_edges(fn.copy_u) / apply_edges(fn.u_add_v)
+ * (models.py:525 / :523; proteins models.py:127 / :125) on the COO list in edge-id order:
+ *
+ *   out[e, :] = x[src[e], :] (+ y[dst[e], :] when y != NULL)          width W floats per node
+ * ------------------------------------------------------------------------------------------- */
+int bot_sddmm_u_add_v_f32(const int32_t* src, const int32_t* dst, int64_t n_edges,
+                          const float* x, const float* y, int32_t W, float* out, bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention logits + leaky-ReLU + per-destination softmax in one sweep (models.py:517-544):
+ *
+ *   z[k,h] = el[indices[k],h] (+ er[r,h]) (+ ee[eperm[k],h])        el, er: [n,H]; ee: [nnz,H]
+ *   a[k,h] = softmax over the positions k of row r of leaky_relu(z[k,h], slope)
+ *
+ * `keep` (uint8, indexed through eperm like ee; may be NULL) restates the edge-drop branch
+ * models.py:528-539: positions with keep == 0 are left out of the softmax and get a = 0.
+ * With el == er == NULL, slope == 1 this is dgl.ops.edge_softmax(graph, ee) (models.py:544) on
+ * logits given in edge-id order.  `a` is written at aperm[k] (NULL: position order).
+ * `long_rows` (rows longer than the plan's chunk) are handled by one workgroup each.
+ * ------------------------------------------------------------------------------------------- */
+int bot_gat_attn_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                         const int32_t* long_rows, int64_t n_long, int32_t chunk,
+                         const float* el, const float* er, const float* ee, const int32_t* eperm,
+                         const uint8_t* keep, float slope, int32_t H,
+                         float* a, const int32_t* aperm, bot_stream_t stream);
+
+/* Backward of the above.  Given a (forward output) and da (gradient w.r.t. a), both addressed
+ * through aperm like the forward output:
+ *
+ *   t[r,h]   = sum_k a*da ;  de = a*(da - t) ;  dz = de * (z > 0 ? 1 : slope)
+ *   dz[k,h]  written at zperm[k] (NULL: position order) — it is the gradient of ee, and the edge
+ *            values whose per-source sum is the gradient of el (bot_segment_sum_f32 on the other
+ *            direction);
+ *   der[r,h] = sum_k dz[k,h]       (written when der != NULL)
+ *
+ * With el == er == NULL, slope == 1 this is the backward of dgl.ops.edge_softmax.
+ */
+int bot_gat_attn_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                         const int32_t* long_rows, int64_t n_long, int32_t chunk,
+                         const float* el, const float* er, const float* ee, const int32_t* eperm,
+                         float slope, int32_t H,
+                         const float* a, const float* da, const int32_t* aperm,
+                         float* dz, const int32_t* zperm, float* der, bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Segment sum of edge values.  Replaces update_all(fn.copy_e, fn.sum) — copy_e_sum
+ * (src/ogbn-proteins/gat.py:58) — and serves the backward of copy_u / u_add_v (models.py:523,525):
+ *
+ *   out[r, :] = sum_{k in row r} vals[perm[k], :]                      width W floats per edge
+ * ------------------------------------------------------------------------------------------- */
+int bot_segment_sum_f32(const int32_t* indptr, int64_t n_rows, int64_t nnz,
+                        const int32_t* long_rows, int64_t n_long, int32_t chunk,
+                        const float* vals, const int32_t* perm, int32_t W,
+                        float* out, bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row gather / scatter-add used by the 1-D vertex-partitioned mode to pack halo rows for the RCCL
+ * all-to-all and to fold received halo gradients back into owned rows (no reference counterpart:
+ * the reference is single-device).  `rows` must be sorted-unique for the add form.
+ *   gather:      out[i,:] = x[rows[i],:]
+ *   scatter_add: x[rows[i],:] += vals[i,:]
+ * ------------------------------------------------------------------------------------------- */
+int bot_gather_rows_f32(const float* x, int64_t ldx, const int32_t* rows, int64_t n_sel, int32_t F,
+                        float* out, int64_t ldo, bot_stream_t stream);
+int bot_scatter_add_rows_f32(float* x, int64_t ldx, const int32_t* rows, int64_t n_sel, int32_t F,
+                             const float* vals, int64_t ldv, bot_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOT_GNN_H */

@@ -31,6 +31,45 @@ class CooGraph:
         return int(self.src.numel())
 
 
+def _is_c(g):
+    return type(g).__name__ == "CGraph"  # oracle/c_ops.py: same semantics on the C restatement (timed CPU baseline)
+
+
+def _copy_u_sum(g, x):
+    if _is_c(g):
+        from . import c_ops
+        return c_ops.copy_u_sum(g, x)
+    return R.copy_u_sum(g.src, g.dst, g.num_nodes, x)
+
+
+def _u_mul_e_sum(g, x, a):
+    if _is_c(g):
+        from . import c_ops
+        return c_ops.u_mul_e_sum(g, x, a)
+    return R.u_mul_e_sum(g.src, g.dst, g.num_nodes, x, a)
+
+
+def _u_add_v(g, x, y):
+    if _is_c(g):
+        from . import c_ops
+        return c_ops.u_add_v(g, x, y)
+    return R.copy_u(g.src, x) if y is None else R.u_add_v(g.src, g.dst, x, y)
+
+
+def _edge_softmax(g, e, keep_eids=None):
+    """All-edges softmax, or (models.py:534-539) zeros scattered with the softmax over the kept edges."""
+    if _is_c(g):
+        from . import c_ops
+        keep = None
+        if keep_eids is not None:
+            keep = torch.zeros(g.num_edges, dtype=torch.uint8)
+            keep[keep_eids] = 1
+        return c_ops.edge_softmax(g, e, keep)
+    if keep_eids is None:
+        return R.edge_softmax(g.dst, g.num_nodes, e)
+    return torch.zeros_like(e).index_put((keep_eids,), R.edge_softmax(g.dst, g.num_nodes, e[keep_eids], keep_eids))
+
+
 class ZeroInDegreeError(Exception):
     """Counterpart of the DGLError / `assert False` raised at models.py:334-346 and :477-479."""
 
@@ -54,7 +93,7 @@ def graphconv_forward(g: CooGraph, feat, weight, bias, norm="both", activation=N
     w_first = weight is not None and weight.shape[0] > weight.shape[1]  # :368 in_feats > out_feats
     if w_first:  # :368-376
         h = torch.matmul(h, weight)
-    rst = R.copy_u_sum(g.src, g.dst, g.num_nodes, h)  # :374 / :381
+    rst = _copy_u_sum(g, h)  # :374 / :381
     if not w_first and weight is not None:  # :384-385
         rst = torch.matmul(rst, weight)
     if norm == "both":  # :387-395
@@ -85,16 +124,12 @@ def gatconv_forward(g: CooGraph, feat, fc_weight, attn_l, attn_r=None, res_fc_we
     el = (ft * attn_l).sum(dim=-1).unsqueeze(-1)  # :517
     if attn_r is not None:  # :520-523
         er = (ft_dst * attn_r).sum(dim=-1).unsqueeze(-1)
-        e = R.u_add_v(g.src, g.dst, el, er)
+        e = _u_add_v(g, el, er)
     else:  # :525
-        e = R.copy_u(g.src, el)
+        e = _u_add_v(g, el, None)
     e = F.leaky_relu(e, negative_slope)  # :526
-    if keep_eids is not None:  # :528-539
-        a = torch.zeros_like(e)
-        a = a.index_put((keep_eids,), R.edge_softmax(g.dst, n, e[keep_eids], keep_eids))
-    else:  # :544
-        a = R.edge_softmax(g.dst, n, e)
-    rst = R.u_mul_e_sum(g.src, g.dst, n, ft, a)  # :547-548
+    a = _edge_softmax(g, e, keep_eids)  # :528-539 (edge drop) / :544
+    rst = _u_mul_e_sum(g, ft, a)  # :547-548
     if use_symmetric_norm:  # :550-555  (+0.5)
         rst = rst * _deg_pow(R.in_degrees(g.dst, n), 0.5, rst)
     if res_fc_weight is not None:  # :558-560
@@ -170,17 +205,14 @@ def proteins_gatconv_forward(g: CooGraph, feat_src, sd: dict, prefix: str, *, n_
     a_src = F.linear(feat_src, p("attn_src_fc.weight")).view(-1, n_heads, 1)  # :108
     if f"{prefix}attn_dst_fc.weight" in sd:  # :122-125
         a_dst = F.linear(feat_src, p("attn_dst_fc.weight")).view(-1, n_heads, 1)
-        e = R.u_add_v(g.src, g.dst, a_src, a_dst)
+        e = _u_add_v(g, a_src, a_dst)
     else:  # :127
-        e = R.copy_u(g.src, a_src)
+        e = _u_add_v(g, a_src, None)
     if feat_edge is not None:  # :130-133
         e = e + F.linear(feat_edge, p("attn_edge_fc.weight")).view(-1, n_heads, 1)
     e = F.leaky_relu(e, negative_slope)  # :134
-    if keep_eids is not None:  # :136-141
-        a = torch.zeros_like(e).index_put((keep_eids,), R.edge_softmax(g.dst, n, e[keep_eids], keep_eids))
-    else:  # :143
-        a = R.edge_softmax(g.dst, n, e)
-    rst = R.u_mul_e_sum(g.src, g.dst, n, ft, a)  # :146-148
+    a = _edge_softmax(g, e, keep_eids)  # :136-141 (edge drop) / :143
+    rst = _u_mul_e_sum(g, ft, a)  # :146-148
     rst = rst + res  # :159-160
     if activation is not None:
         rst = activation(rst)

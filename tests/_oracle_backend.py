@@ -1,0 +1,113 @@
+"""CPU stand-in for `bot_amd._C` kernel wrappers, for the `-m "not gpu"` suite ONLY.
+
+The product has no CPU path.  To exercise the host logic above the C ABI (autograd wrappers,
+permutation plumbing, layer modules, partitioned mode) in a container without a GPU, tests
+monkeypatch the tensor-level wrappers of `bot_amd._C` with these functions, which restate the
+contract written in include/bot_gnn.h with plain torch ops on CPU tensors.  GPU tests never install
+this; they call the real kernels through the same wrappers.
+"""
+import torch
+
+from oracle import ref_ops as R
+
+
+def _rows(d):
+    deg = (d.indptr[1:] - d.indptr[:-1]).long()
+    return torch.repeat_interleave(torch.arange(d.n_rows), deg)
+
+
+def _perm(p, n):
+    return torch.arange(n) if p is None else p.long()
+
+
+def degrees(d):
+    return (d.indptr[1:] - d.indptr[:-1]).to(torch.int64)
+
+
+def spmm(d, x, w=None, wperm=None, out=None):
+    xs = x[d.indices.long()]
+    if w is not None:
+        xs = xs * w[_perm(wperm, d.nnz)].unsqueeze(-1)
+    res = torch.zeros((d.n_rows,) + tuple(x.shape[1:]), dtype=x.dtype).index_add(0, _rows(d), xs)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def sddmm_dot(d, x, y, operm=None, out=None):
+    val = (x[d.indices.long()] * y[_rows(d)]).sum(-1)
+    res = torch.empty_like(val)
+    res[_perm(operm, d.nnz)] = val
+    return res
+
+
+def u_add_v(src, dst, x, y=None):
+    out = x[src.long()]
+    if y is not None:
+        out = out + y[dst.long()]
+    return out
+
+
+def _logits(d, el, er, ee, eperm, slope, H):
+    z = torch.zeros(d.nnz, H)
+    if el is not None:
+        z = z + el[d.indices.long()]
+    if er is not None:
+        z = z + er[_rows(d)]
+    if ee is not None:
+        z = z + ee[_perm(eperm, d.nnz)]
+    return z, torch.where(z > 0, z, z * slope)
+
+
+def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm):
+    z, e = _logits(d, el, er, ee, eperm, slope, H)
+    rows = _rows(d)
+    a = torch.zeros_like(e)
+    if keep is not None:
+        kept = keep[_perm(eperm, d.nnz)].bool()
+        pos = torch.nonzero(kept).squeeze(1)
+        a[pos] = R.edge_softmax(rows, d.n_rows, e[pos], pos)
+    else:
+        a = R.edge_softmax(rows, d.n_rows, e)
+    out = torch.empty_like(a)
+    out[_perm(aperm, d.nnz)] = a
+    return out
+
+
+def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der):
+    rows = _rows(d)
+    ap = _perm(aperm, d.nnz)
+    a_, da_ = a[ap], da[ap]
+    t = torch.zeros(d.n_rows, H).index_add(0, rows, a_ * da_)
+    de = a_ * (da_ - t[rows])
+    if slope != 1.0:
+        z, _ = _logits(d, el, er, ee, eperm, slope, H)
+        de = torch.where(z > 0, de, de * slope)
+    dz = torch.empty_like(de)
+    dz[_perm(zperm, d.nnz)] = de
+    der = torch.zeros(d.n_rows, H).index_add(0, rows, de) if want_der else None
+    return dz, der
+
+
+def segment_sum(d, vals, perm=None):
+    return torch.zeros(d.n_rows, vals.shape[1]).index_add(0, _rows(d), vals[_perm(perm, d.nnz)])
+
+
+def gather_rows(x, rows):
+    return x[rows.long()].clone()
+
+
+def scatter_add_rows(x, rows, vals):
+    x[rows.long()] += vals
+    return x
+
+
+NAMES = ["degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+         "scatter_add_rows"]
+
+
+def install(monkeypatch):
+    from bot_amd import _C
+    for n in NAMES:
+        monkeypatch.setattr(_C, n, globals()[n])

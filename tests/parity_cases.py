@@ -1,0 +1,267 @@
+"""Parity checks shared by the CPU suite (host logic over the emulated backend) and the GPU suite
+(real HIP kernels): bot_amd ops / layers / stacks against the golden vectors generated from the
+reference's own modules, and against the oracle on seeded inputs.
+
+Tolerances: integers bit-exact; fp32 forward within 1e-4 absolute of the reference (BASELINE.json
+"logits within 1e-4"), gradients within 1e-4 relative to the largest gradient entry.
+"""
+import ast
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import bot_amd
+from bot_amd import nn as bnn
+from bot_amd import ops
+from oracle import ref_models as RM
+from oracle import ref_ops as R
+
+FWD_ATOL = 1e-4
+GRAD_RTOL = 1e-4
+
+
+def fwd_close(a, b, atol=FWD_ATOL):
+    a = a.detach().cpu().double().numpy()
+    b = np.asarray(b, dtype=np.float64)
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=atol)
+
+
+def grad_close(a, b, rtol=GRAD_RTOL):
+    a = a.detach().cpu().double().numpy()
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    np.testing.assert_allclose(a, b, rtol=rtol * 10, atol=rtol * scale)
+
+
+def leaf(t, device="cpu"):
+    """Fresh leaf tensor on `device` (never aliases `t`, also when device is the CPU)."""
+    return t.detach().clone().to(device).requires_grad_()
+
+
+def make_graph(golden, name, device):
+    s, d, n = golden.graph(name)
+    return bot_amd.Graph(s, d, n).to(device)
+
+
+def load_params(module, case, device, prefix="p."):
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in case.sub(prefix).items()}
+    missing, unexpected = module.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return module.to(device)
+
+
+# ---------------------------------------------------------------------------------------------- integer work
+def check_graph_structures(golden, device):
+    for name in ("doc_loop", "g64", "g300"):
+        s, d, n = golden.graph(name)
+        g = bot_amd.Graph(s, d, n).to(device)
+        f = golden.file("graphs")
+        assert np.array_equal(g.in_degrees().cpu().numpy(), f[f"{name}.in_deg"])
+        assert np.array_equal(g.out_degrees().cpu().numpy(), f[f"{name}.out_deg"])
+        assert g.in_degrees().dtype == torch.int64
+        ip, idx, eid = R.build_csc(s, d, n)
+        assert torch.equal(g.csc.indptr.cpu().long(), ip) and torch.equal(g.csc.indices.cpu().long(), idx)
+        assert torch.equal(g.csc.eid.cpu().long(), eid)
+        ip, idx, eid = R.build_csr(s, d, n)
+        assert torch.equal(g.csr.indptr.cpu().long(), ip) and torch.equal(g.csr.indices.cpu().long(), idx)
+        assert torch.equal(g.csr.eid.cpu().long(), eid)
+        # csr2csc: the edge at CSR position k sits at CSC position csr2csc[k]
+        assert torch.equal(g.csc.eid.cpu()[g.csr2csc.cpu().long()], g.csr.eid.cpu())
+
+
+def check_preprocess(golden, device):
+    for name in ("g64", "g300"):
+        rs, rd, n = golden.graph(name + "_raw")
+        g = bot_amd.preprocess(bot_amd.Graph(rs, rd, n).to(device))
+        es, ed, _ = golden.graph(name)
+        s, d = g.edges()
+        assert torch.equal(s.cpu(), es) and torch.equal(d.cpu(), ed)  # edge ids bit-exact, self-loops last
+
+
+# ---------------------------------------------------------------------------------------------- single ops vs oracle
+def check_ops_against_oracle(golden, device, gname="g300", seed=0):
+    s, d, n = golden.graph(gname)
+    g = bot_amd.Graph(s, d, n, chunk=8).to(device)  # small chunk: long-row splitting is exercised
+    E = s.numel()
+    gen = torch.Generator().manual_seed(seed)
+    for (H, D) in ((1, 16), (3, 5), (2, 250), (1, 40), (3, 7), (1, 300), (5, 4)):
+        x = torch.randn(n, H, D, generator=gen)
+        a = torch.rand(E, H, 1, generator=gen)
+        gout = torch.randn(n, H, D, generator=gen)
+        # --- copy_u_sum
+        xo = leaf(x)
+        ref = R.copy_u_sum(s, d, n, xo)
+        (ref * gout).sum().backward()
+        xt = leaf(x, device)
+        out = ops.copy_u_sum(g, xt)
+        (out * gout.to(device)).sum().backward()
+        fwd_close(out, ref.detach().numpy(), 2e-5)
+        grad_close(xt.grad, xo.grad.numpy())
+        # --- u_mul_e_sum, edge-id order
+        xo, ao = leaf(x), leaf(a)
+        ref = R.u_mul_e_sum(s, d, n, xo, ao)
+        (ref * gout).sum().backward()
+        xt, at = leaf(x, device), leaf(a, device)
+        out = ops.u_mul_e_sum(g, xt, at)
+        (out * gout.to(device)).sum().backward()
+        fwd_close(out, ref.detach().numpy(), 2e-5)
+        grad_close(xt.grad, xo.grad.numpy())
+        grad_close(at.grad, ao.grad.numpy())
+    for H in (1, 3, 6):
+        el = torch.randn(n, H, 1, generator=gen)
+        er = torch.randn(n, H, 1, generator=gen)
+        e = torch.randn(E, H, 1, generator=gen) * 3
+        ga = torch.randn(E, H, 1, generator=gen)
+        # --- copy_u / u_add_v
+        for use_v in (False, True):
+            lo, ro = leaf(el), leaf(er)
+            ref = R.u_add_v(s, d, lo, ro) if use_v else R.copy_u(s, lo)
+            (ref * ga).sum().backward()
+            lt, rt = leaf(el, device), leaf(er, device)
+            out = ops.u_add_v(g, lt, rt) if use_v else ops.copy_u(g, lt)
+            (out * ga.to(device)).sum().backward()
+            fwd_close(out, ref.detach().numpy(), 1e-6)
+            grad_close(lt.grad, lo.grad.numpy())
+            if use_v:
+                grad_close(rt.grad, ro.grad.numpy())
+        # --- edge_softmax, all edges and the eids form
+        eo = leaf(e)
+        ref = R.edge_softmax(d, n, eo)
+        (ref * ga).sum().backward()
+        et = leaf(e, device)
+        out = ops.edge_softmax(g, et)
+        (out * ga.to(device)).sum().backward()
+        fwd_close(out, ref.detach().numpy(), 1e-6)
+        grad_close(et.grad, eo.grad.numpy())
+        eids = torch.randperm(E, generator=gen)[E // 3:]
+        eo = leaf(e[eids])
+        ref = R.edge_softmax(d, n, eo, eids)
+        (ref * ga[eids]).sum().backward()
+        et = leaf(e[eids], device)
+        out = ops.edge_softmax(g, et, eids=eids.to(device))
+        (out * ga[eids].to(device)).sum().backward()
+        fwd_close(out, ref.detach().numpy(), 1e-6)
+        grad_close(et.grad, eo.grad.numpy())
+        # --- copy_e_sum (ogbn-proteins/gat.py:58)
+        w = torch.rand(E, 8, generator=gen)
+        wo = leaf(w)
+        ref = R.copy_e_sum(d, n, wo)
+        gn = torch.randn(n, 8, generator=gen)
+        (ref * gn).sum().backward()
+        wt = leaf(w, device)
+        out = ops.copy_e_sum(g, wt)
+        (out * gn.to(device)).sum().backward()
+        fwd_close(out, ref.detach().numpy(), 2e-5)
+        grad_close(wt.grad, wo.grad.numpy())
+
+
+# ---------------------------------------------------------------------------------------------- layers vs golden
+def check_graphconv_golden(golden, device):
+    for c in golden.cases("graphconv"):
+        gname, norm, fin, fout, dt = (str(x) for x in c["meta"])
+        if dt != "float32":
+            continue
+        g = make_graph(golden, gname, device)
+        conv = load_params(bnn.GraphConv(int(fin), int(fout), norm=norm), c, device)
+        feat = leaf(c.t("feat"), device)
+        rst = conv(g, feat)
+        fwd_close(rst, c["rst"])
+        (rst * c.t("gout").to(device)).sum().backward()
+        grad_close(feat.grad, c["dfeat"])
+        grad_close(conv.weight.grad, c["g.weight"])
+        grad_close(conv.bias.grad, c["g.bias"])
+
+
+def check_gatconv_golden(golden, device):
+    n_drop = 0
+    for c in golden.cases("gatconv"):
+        gname, symm, attn_r, linear, H, D, fin, edge_drop, dt = (str(x) for x in c["meta"])
+        if dt != "float32":
+            continue
+        g = make_graph(golden, gname, device)
+        conv = bnn.GATConv(int(fin), int(D), num_heads=int(H), edge_drop=float(edge_drop), linear=bool(int(linear)),
+                           use_symmetric_norm=bool(int(symm)), non_interactive_attn=bool(int(attn_r)))
+        conv = load_params(conv, c, device)
+        keep = None
+        if "keep_eids" in c:
+            keep = torch.zeros(g.number_of_edges(), dtype=torch.uint8)
+            keep[c.t("keep_eids")] = 1
+            keep = keep.to(device)
+            n_drop += 1
+        feat = leaf(c.t("feat"), device)
+        rst = conv(g, feat, keep=keep)
+        fwd_close(rst, c["rst"])
+        (rst * c.t("gout").to(device)).sum().backward()
+        grad_close(feat.grad, c["dfeat"])
+        for k, p in conv.named_parameters():
+            grad_close(p.grad, c[f"g.{k}"])
+    assert n_drop >= 2
+
+
+def _reference_style_gatconv(g, conv, feat):
+    """The reference's own op sequence (models.py:517-548) on the dgl-like surface: apply_edges,
+    edge_softmax in edge-id order, update_all."""
+    from bot_amd import function as fn
+    H, D = conv._num_heads, conv._out_feats
+    with g.local_scope():
+        ft = conv.fc(feat).view(-1, H, D)
+        el = (ft * conv.attn_l).sum(dim=-1).unsqueeze(-1)
+        g.srcdata.update({"ft": ft, "el": el})
+        if conv.attn_r is not None:
+            g.dstdata.update({"er": (ft * conv.attn_r).sum(dim=-1).unsqueeze(-1)})
+            g.apply_edges(fn.u_add_v("el", "er", "e"))
+        else:
+            g.apply_edges(fn.copy_u("el", "e"))
+        e = conv.leaky_relu(g.edata.pop("e"))
+        g.edata["a"] = bot_amd.edge_softmax(g, e)
+        g.update_all(fn.u_mul_e("ft", "a", "m"), fn.sum("m", "ft"))
+        rst = g.dstdata["ft"]
+        if conv.res_fc is not None:
+            rst = rst + conv.res_fc(feat).view(feat.shape[0], -1, D)
+        return rst
+
+
+def check_dgl_surface_matches_fused(golden, device):
+    """update_all / apply_edges / edge_softmax (edge-id order) give the same layer as the fused CSC-order path."""
+    n_checked = 0
+    for c in golden.cases("gatconv"):
+        gname, symm, attn_r, linear, H, D, fin, edge_drop, dt = (str(x) for x in c["meta"])
+        if dt != "float32" or symm == "1" or float(edge_drop) > 0:
+            continue
+        g = make_graph(golden, gname, device)
+        conv = load_params(bnn.GATConv(int(fin), int(D), num_heads=int(H), linear=bool(int(linear)),
+                                       non_interactive_attn=bool(int(attn_r))), c, device)
+        feat = leaf(c.t("feat"), device)
+        rst = _reference_style_gatconv(g, conv, feat)
+        fwd_close(rst, c["rst"])
+        (rst * c.t("gout").to(device)).sum().backward()
+        grad_close(feat.grad, c["dfeat"])
+        for k, p in conv.named_parameters():
+            grad_close(p.grad, c[f"g.{k}"])
+        assert "ft" not in g.ndata and "a" not in g.edata  # local_scope restored
+        n_checked += 1
+    assert n_checked >= 4
+
+
+def build_stack(kind, cfg, fin=11, C=5):
+    if kind == "gcn":
+        return bnn.GCN(in_feats=fin, n_classes=C, activation=F.relu, **cfg)
+    return bnn.GAT(dim_node=fin, dim_edge=0, dim_output=C, activation=F.relu, **cfg)
+
+
+def check_stacks_golden(golden, device):
+    for c in golden.cases("stacks"):
+        gname, kind, training, cfg = (str(x) for x in c["meta"])
+        cfg = ast.literal_eval(cfg)
+        g = make_graph(golden, gname, device)
+        model = load_params(build_stack(kind, cfg), c, device)
+        assert sum(p.numel() for p in model.parameters()) == int(c["n_params"])
+        model.train(bool(int(training)))
+        feat = leaf(c.t("feat"), device)
+        logits = model(g, feat)
+        fwd_close(logits, c["logits"])
+        (logits * c.t("gout").to(device)).sum().backward()
+        grad_close(feat.grad, c["dfeat"], 3e-4)
+        for k, p in model.named_parameters():
+            grad_close(p.grad, c[f"g.{k}"], 3e-4)
