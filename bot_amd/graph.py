@@ -66,19 +66,27 @@ class _Frame(dict):
 
 
 class Graph:
-    """Homogeneous graph over nodes 0..N-1 with edges in edge-id order (edge e: src[e] -> dst[e])."""
+    """Graph over nodes 0..N-1 with edges in edge-id order (edge e: src[e] -> dst[e]).
 
-    is_block = False  # models.py:494 / ogbn-proteins/models.py:94 — full-graph branch only
+    With `num_dst_nodes < num_nodes` it is a *block* in DGL's sense (models.py:493-496): destinations
+    are the first `num_dst_nodes` source nodes.  The 1-D vertex-partitioned mode uses exactly that
+    shape — owned vertices first, halo sources appended (bot_amd/dist.py) — and may attach a `halo`
+    plan that extends owned node features with the remote rows (`Graph.extend`)."""
 
-    def __init__(self, src, dst, num_nodes: int, *, chunk: int | None = None, _share=None):
+    def __init__(self, src, dst, num_nodes: int, *, num_dst_nodes: int | None = None, chunk: int | None = None):
         src = torch.as_tensor(src).to(torch.int64)
         dst = torch.as_tensor(dst).to(torch.int64)
         if src.shape != dst.shape or src.dim() != 1:
             raise ValueError("src and dst must be 1-D tensors of equal length")
-        if src.numel() and (int(torch.max(src.max(), dst.max())) >= num_nodes or int(torch.min(src.min(), dst.min())) < 0):
+        n_dst = int(num_nodes if num_dst_nodes is None else num_dst_nodes)
+        if n_dst > num_nodes:
+            raise ValueError("num_dst_nodes exceeds num_nodes")
+        if src.numel() and (int(src.max()) >= num_nodes or int(dst.max()) >= n_dst or int(torch.min(src.min(), dst.min())) < 0):
             raise ValueError("node id out of range")
-        self._src, self._dst, self._n = src, dst, int(num_nodes)
+        self._src, self._dst, self._n, self._n_dst = src, dst, int(num_nodes), n_dst
         self._chunk = chunk
+        self.halo = None                 # bot_amd.dist.HaloPlan in partitioned mode
+        self.global_out_degrees = None   # int64 [num_dst_nodes]: out-degrees in the WHOLE graph (partitioned mode)
         self._csc = self._csr = self._csr2csc = self._csc2csr = None
         self._src32 = self._dst32 = None
         self.ndata, self.edata = _Frame(), _Frame()
@@ -87,6 +95,19 @@ class Graph:
     @property
     def device(self):
         return self._src.device
+
+    @property
+    def is_block(self):
+        return self._n_dst != self._n
+
+    def extend(self, x_dst):
+        """Owned/destination node features -> source node features.  Identity on a full graph; in
+        partitioned mode appends the halo rows fetched from their owners (RCCL all-to-all)."""
+        if self.halo is not None:
+            return self.halo.extend(x_dst)
+        if self.is_block:
+            raise ValueError("a block without a halo plan needs source features supplied by the caller")
+        return x_dst
 
     @property
     def srcdata(self):
@@ -105,7 +126,7 @@ class Graph:
         return self._n
 
     def number_of_dst_nodes(self):
-        return self._n
+        return self._n_dst
 
     def number_of_edges(self):
         return int(self._src.numel())
@@ -136,8 +157,8 @@ class Graph:
         device = torch.device(device)
         if device == self.device:
             return self
-        g = Graph(self._src.to(device), self._dst.to(device), self._n, chunk=self._chunk)
-        for name in ("_csc", "_csr", "_csr2csc", "_csc2csr", "_src32", "_dst32"):
+        g = Graph(self._src.to(device), self._dst.to(device), self._n, num_dst_nodes=self._n_dst, chunk=self._chunk)
+        for name in ("_csc", "_csr", "_csr2csc", "_csc2csr", "_src32", "_dst32", "global_out_degrees", "halo"):
             v = getattr(self, name)
             setattr(g, name, None if v is None else v.to(device))
         g.ndata = _Frame({k: v.to(device) for k, v in self.ndata.items()})
@@ -151,12 +172,14 @@ class Graph:
 
     # ---------------------------------------------------------------- transforms (run.py:138-143); integer, bit-exact
     def remove_self_loop(self):
+        assert not self.is_block, "graph transforms apply to whole graphs"
         keep = self._src != self._dst
         g = Graph(self._src[keep], self._dst[keep], self._n, chunk=self._chunk)
         g.ndata = _Frame(self.ndata)
         return g
 
     def add_self_loop(self):
+        assert not self.is_block, "graph transforms apply to whole graphs"
         loops = torch.arange(self._n, dtype=torch.int64, device=self.device)
         g = Graph(torch.cat([self._src, loops]), torch.cat([self._dst, loops]), self._n, chunk=self._chunk)
         g.ndata = _Frame(self.ndata)
@@ -167,7 +190,7 @@ class Graph:
     def csc(self) -> Direction:
         """In-edges grouped by destination: rows = dst, indices = src."""
         if self._csc is None:
-            self._csc = build_direction(self._dst, self._src, self._n, self._chunk)
+            self._csc = build_direction(self._dst, self._src, self._n_dst, self._chunk)
         return self._csc
 
     @property

@@ -43,7 +43,10 @@ def degree_norm(graph, which: str, power: float) -> torch.Tensor:
     c = _graph_cache(graph)
     key = (which, power)
     if key not in c:
-        deg = graph.out_degrees() if which == "out" else graph.in_degrees()
+        if which == "out":  # degrees of the nodes whose features the caller holds (owned nodes in partitioned mode)
+            deg = graph.global_out_degrees if graph.global_out_degrees is not None else graph.out_degrees()
+        else:
+            deg = graph.in_degrees()
         d = deg.float().clamp(min=1)
         c[key] = 1.0 / d if power == -1.0 else torch.pow(d, power)
     return c[key]
@@ -129,12 +132,14 @@ class GraphConv(nn.Module):
         h = feat
         if self._norm == "both":
             h = h * _bcast(degree_norm(graph, "out", -0.5), h)
+        # graph.extend: identity on one GPU; in partitioned mode the halo rows arrive here, after the
+        # narrowing GEMM when there is one (so the narrower tensor is what crosses xGMI)
         if self._in_feats > self._out_feats:
             if w is not None:
                 h = torch.matmul(h, w)
-            rst = ops.copy_u_sum(graph, h)
+            rst = ops.copy_u_sum(graph, graph.extend(h))
         else:
-            rst = ops.copy_u_sum(graph, h)
+            rst = ops.copy_u_sum(graph, graph.extend(h))
             if w is not None:
                 rst = torch.matmul(rst, w)
         if self._norm == "both":
@@ -224,6 +229,7 @@ class GATConv(nn.Module):
         ft_dst = ft
         if self._use_symmetric_norm:
             ft = ft * _bcast(degree_norm(graph, "out", -0.5), ft)
+        ft = graph.extend(ft)  # identity on one GPU; appends the halo rows in partitioned mode
         el = (ft * self.attn_l).sum(dim=-1, keepdim=True)
         er = (ft_dst * self.attn_r).sum(dim=-1, keepdim=True) if self.attn_r is not None else None
         if keep is None and self.training and self.edge_drop > 0:

@@ -19,8 +19,8 @@ def add_labels(feat, labels, idx, n_classes):
     return torch.cat([feat, onehot], dim=-1)
 
 
-def compute_loss(x, labels, loss="logit"):
-    """run.py:229-237 — cross entropy, optionally reshaped by loge (log(eps + CE) - log eps) or savage."""
+def per_node_loss(x, labels, loss="logit"):
+    """The per-node term of run.py:229-236: cross entropy, optionally reshaped by loge or savage."""
     y = F.cross_entropy(x, labels[:, 0], reduction="none")
     if loss == "loge":
         y = torch.log(EPSILON + y) - math.log(EPSILON)
@@ -28,7 +28,12 @@ def compute_loss(x, labels, loss="logit"):
         y = (1 - torch.exp(-y)) ** 2
     elif loss != "logit":
         raise ValueError(f"unknown loss {loss!r}")
-    return torch.mean(y)
+    return y
+
+
+def compute_loss(x, labels, loss="logit"):
+    """run.py:229-237 — mean over the nodes of the (reshaped) cross entropy."""
+    return torch.mean(per_node_loss(x, labels, loss))
 
 
 def adjust_learning_rate(optimizer, lr, epoch):

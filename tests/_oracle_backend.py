@@ -111,3 +111,10 @@ def install(monkeypatch):
     from bot_amd import _C
     for n in NAMES:
         monkeypatch.setattr(_C, n, globals()[n])
+
+
+def install_direct():
+    """For spawned worker processes of the multi-process tests (no pytest monkeypatch there)."""
+    from bot_amd import _C
+    for n in NAMES:
+        setattr(_C, n, globals()[n])
