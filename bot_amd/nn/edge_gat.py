@@ -1,0 +1,146 @@
+"""GAT with edge features — the layer of src/ogbn-proteins/models.py:19-168 (identical in
+src/ogbn-products/models.py:20-167) and the two stacks built from it, on the full graph
+(the `not isinstance(g, list)` branch, ogbn-proteins/models.py:231-234): attention scores come from
+linear maps of the INPUT features (`attn_src_fc`, `attn_dst_fc`) plus `attn_edge_fc` of the edge
+embedding; the destination branch `dst_fc` (with bias) is the residual.
+
+The edge term enters the fused attention kernel as a per-edge logit in edge-id order
+(`bot_amd.ops.gat_attention(..., ee=...)`), so no [E,H] intermediate beyond it is materialised.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from . import _bcast, _pair, degree_norm, has_zero_in_degree
+
+__all__ = ["GATConv", "ProteinsGAT", "ProductsGAT"]
+
+
+class GATConv(nn.Module):
+    def __init__(self, node_feats, edge_feats, out_feats, n_heads=1, attn_drop=0.0, edge_drop=0.0, negative_slope=0.2,
+                 residual=True, activation=None, use_attn_dst=True, allow_zero_in_degree=True, use_symmetric_norm=False):
+        super().__init__()
+        self._n_heads = n_heads
+        self._in_src_feats, self._in_dst_feats = _pair(node_feats)
+        self._out_feats = out_feats
+        self._allow_zero_in_degree = allow_zero_in_degree
+        self._use_symmetric_norm = use_symmetric_norm
+        self.src_fc = nn.Linear(self._in_src_feats, out_feats * n_heads, bias=False)
+        if residual:
+            self.dst_fc = nn.Linear(self._in_src_feats, out_feats * n_heads)
+            self.bias = None
+        else:  # the reference's `nn.Parameter(int)` here cannot run; give it the evident meaning
+            self.dst_fc = None
+            self.bias = nn.Parameter(torch.zeros(out_feats * n_heads))
+        self.attn_src_fc = nn.Linear(self._in_src_feats, n_heads, bias=False)
+        self.attn_dst_fc = nn.Linear(self._in_src_feats, n_heads, bias=False) if use_attn_dst else None
+        self.attn_edge_fc = nn.Linear(edge_feats, n_heads, bias=False) if edge_feats > 0 else None
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.edge_drop = edge_drop
+        self.leaky_relu = nn.LeakyReLU(negative_slope, inplace=True)
+        self.activation = activation
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        for lin in (self.src_fc, self.dst_fc, self.attn_src_fc, self.attn_dst_fc, self.attn_edge_fc):
+            if lin is not None:
+                nn.init.xavier_normal_(lin.weight, gain=gain)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def set_allow_zero_in_degree(self, set_value):
+        self._allow_zero_in_degree = set_value
+
+    def forward(self, graph, feat_src, feat_edge=None, keep=None):
+        if not self._allow_zero_in_degree:
+            assert not has_zero_in_degree(graph), "0-in-degree nodes (ogbn-proteins/models.py:89-91)"
+        H, D = self._n_heads, self._out_feats
+        feat_dst = feat_src
+        if self._use_symmetric_norm:
+            feat_src = feat_src * _bcast(degree_norm(graph, "out", -0.5), feat_src)
+        ft = graph.extend(self.src_fc(feat_src).view(-1, H, D))
+        attn_src = graph.extend(self.attn_src_fc(feat_src).view(-1, H, 1))
+        attn_dst = self.attn_dst_fc(feat_dst).view(-1, H, 1) if self.attn_dst_fc is not None else None
+        ee = self.attn_edge_fc(feat_edge).view(-1, H, 1) if feat_edge is not None else None
+        if keep is None and self.training and self.edge_drop > 0:
+            E = graph.number_of_edges()
+            keep = torch.zeros(E, dtype=torch.uint8, device=graph.device)
+            keep[torch.randperm(E, device=graph.device)[int(E * self.edge_drop):]] = 1
+        a = ops.gat_attention(graph, attn_src, attn_dst, ee, keep=keep, negative_slope=self.leaky_relu.negative_slope,
+                              order="csc")
+        rst = ops.u_mul_e_sum(graph, ft, self.attn_drop(a), order="csc")
+        if self._use_symmetric_norm:
+            rst = rst * _bcast(degree_norm(graph, "in", 0.5), rst)
+        if self.dst_fc is not None:
+            rst = rst + self.dst_fc(feat_dst).view(-1, H, D)
+        else:
+            rst = rst + self.bias.view(1, H, D)
+        if self.activation is not None:
+            rst = self.activation(rst, inplace=True)
+        return rst
+
+
+class _EdgeGAT(nn.Module):
+    """Shared body of the proteins / products stacks (ogbn-proteins/models.py:171-264, ogbn-products/models.py:170-265)."""
+
+    def __init__(self, node_feats, edge_feats, n_classes, n_layers, n_heads, n_hidden, edge_emb, activation, dropout,
+                 input_drop, attn_drop, edge_drop, use_attn_dst, allow_zero_in_degree, first_in):
+        super().__init__()
+        self.n_layers, self.n_heads, self.n_hidden, self.n_classes = n_layers, n_heads, n_hidden, n_classes
+        self.convs, self.norms = nn.ModuleList(), nn.ModuleList()
+        self.node_encoder = nn.Linear(node_feats, n_hidden)
+        self.edge_encoder = nn.ModuleList() if edge_emb > 0 else None
+        for i in range(n_layers):
+            if self.edge_encoder is not None:
+                self.edge_encoder.append(nn.Linear(edge_feats, edge_emb))
+            self.convs.append(GATConv(n_heads * n_hidden if i > 0 else first_in, edge_emb, n_hidden, n_heads=n_heads,
+                                      attn_drop=attn_drop, edge_drop=edge_drop, use_attn_dst=use_attn_dst,
+                                      allow_zero_in_degree=allow_zero_in_degree, use_symmetric_norm=False))
+            self.norms.append(nn.BatchNorm1d(n_heads * n_hidden))
+        self.pred_linear = nn.Linear(n_heads * n_hidden, n_classes)
+        self.input_drop, self.dropout = nn.Dropout(input_drop), nn.Dropout(dropout)
+        self.activation = activation
+
+    def _body(self, g, h, residual):
+        h = self.input_drop(h)
+        h_last = None
+        efeat = g.edata.get("feat") if self.edge_encoder is not None else None
+        for i in range(self.n_layers):
+            emb = F.relu(self.edge_encoder[i](efeat), inplace=True) if efeat is not None else None
+            h = self.convs[i](g, h, emb).flatten(1, -1)
+            if residual and h_last is not None:
+                h = h + h_last[: h.shape[0], :]
+            h_last = h
+            h = self.dropout(self.activation(self.norms[i](h), inplace=True))
+        return self.pred_linear(h)
+
+
+class ProteinsGAT(_EdgeGAT):
+    """`GAT` of src/ogbn-proteins/models.py:171-264: node encoder + ReLU first, inter-layer residual always on."""
+
+    def __init__(self, node_feats, edge_feats, n_classes, n_layers, n_heads, n_hidden, edge_emb, activation, dropout,
+                 input_drop, attn_drop, edge_drop, use_attn_dst=True, allow_zero_in_degree=False):
+        super().__init__(node_feats, edge_feats, n_classes, n_layers, n_heads, n_hidden, edge_emb, activation, dropout,
+                         input_drop, attn_drop, edge_drop, use_attn_dst, allow_zero_in_degree, first_in=n_hidden)
+
+    def forward(self, g):
+        h = F.relu(self.node_encoder(g.srcdata["feat"]), inplace=True)
+        return self._body(g, h, residual=True)
+
+
+class ProductsGAT(_EdgeGAT):
+    """`GAT` of src/ogbn-products/models.py:170-265: `node_encoder` is constructed but not applied (:198, :237-239
+    absent), the inter-layer residual is a flag."""
+
+    def __init__(self, node_feats, edge_feats, n_classes, n_layers, n_heads, n_hidden, edge_emb, activation, dropout,
+                 input_drop, attn_drop, edge_drop, use_attn_dst=True, allow_zero_in_degree=False, residual=False):
+        super().__init__(node_feats, edge_feats, n_classes, n_layers, n_heads, n_hidden, edge_emb, activation, dropout,
+                         input_drop, attn_drop, edge_drop, use_attn_dst, allow_zero_in_degree, first_in=node_feats)
+        self.residual = residual
+
+    def forward(self, g, inference=False):
+        return self._body(g, g.srcdata["feat"], residual=self.residual)

@@ -58,7 +58,7 @@ def powerlaw_edges(n, e_raw, seed, gamma=2.0):
 
 
 def t2n(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()  # copy: later in-place updates (optimizer step, BN running stats) must not leak in
 
 
 def sd2n(prefix, sd):

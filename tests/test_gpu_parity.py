@@ -167,3 +167,15 @@ def test_block_graphs_reproduce_full_graph(golden):
         dr[p.lo:p.hi] += re.grad
         assert torch.equal(p.graph.in_degrees().cpu(), g.in_degrees().cpu()[p.lo:p.hi])
     assert torch.allclose(dx, xf.grad, atol=1e-4) and torch.allclose(dl, lf.grad, atol=1e-4) and torch.allclose(dr, rf.grad, atol=1e-4)
+
+
+def test_proteins_golden(golden):
+    PC.check_proteins_golden(golden, DEV)
+
+
+def test_copy_e_sum_preprocess(golden):
+    PC.check_copy_e_sum_preprocess(golden, DEV)
+
+
+def test_train_step_golden(golden):
+    PC.check_train_step_golden(golden, DEV)

@@ -84,3 +84,15 @@ def test_empty_and_isolated(cpu_backend):
     assert g.in_degrees().tolist() == [0] * 5
     out = bot_amd.ops.copy_u_sum(g, torch.randn(5, 3))
     assert torch.all(out == 0)
+
+
+def test_proteins_golden(golden, cpu_backend):
+    PC.check_proteins_golden(golden, "cpu")
+
+
+def test_copy_e_sum_preprocess(golden, cpu_backend):
+    PC.check_copy_e_sum_preprocess(golden, "cpu")
+
+
+def test_train_step_golden(golden, cpu_backend):
+    PC.check_train_step_golden(golden, "cpu")
