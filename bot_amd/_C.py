@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int32, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int32, c_int64, c_uint64, c_void_p
 
 import torch
 
@@ -45,6 +45,13 @@ _SIGS = {
     "bot_segment_sum_f32": (ctypes.c_int, [_P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, c_int32, _P, _P]),
     "bot_gather_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
     "bot_scatter_add_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
+    "bot_bn_workspace_floats": (c_int64, [c_int32]),
+    "bot_colstats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
+    "bot_bn_act_fwd_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, c_int64, _P]),
+    "bot_bn_act_bwd_reduce_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
+                                                 c_uint64, _P, _P, _P, _P]),
+    "bot_bn_act_bwd_apply_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
+                                                c_uint64, _P, _P, c_double, _P, c_int64, _P]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(_lib, _name)  # AttributeError here = header and library disagree
@@ -266,3 +273,66 @@ def scatter_add_rows(x, rows, vals):
     _check(_lib.bot_scatter_add_rows_f32(x.data_ptr(), x.stride(0), _i32(rows, "rows").data_ptr(), rows.numel(), x.shape[1],
                                          vals.data_ptr(), vals.stride(0), _stream()), "scatter_add_rows")
     return x
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm + ReLU + dropout
+def _mat(x, name):
+    _f32(x, name)
+    if x.dim() != 2:
+        raise BotKernelError(f"{name} must be [n,F]")
+    return x if x.stride(1) == 1 else x.contiguous()
+
+
+def _bn_ws(F, device):
+    return torch.empty(int(_lib.bot_bn_workspace_floats(F)), dtype=torch.float32, device=device)
+
+
+def colstats(x):
+    """Per-column mean and M2 = sum (x - mean)^2 of x [n,F] -> (mean [F], m2 [F])."""
+    _dev(x)
+    x = _mat(x, "x")
+    n, F = x.shape
+    mean = torch.empty(F, dtype=torch.float32, device=x.device)
+    m2 = torch.empty(F, dtype=torch.float32, device=x.device)
+    _check(_lib.bot_colstats_f32(x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), m2.data_ptr(), _bn_ws(F, x.device).data_ptr(),
+                                 _stream()), "colstats")
+    return mean, m2
+
+
+def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed):
+    """y = dropout_p(relu?((x - mean) * invstd * weight + bias)); Philox mask from `seed`."""
+    _dev(x, mean, invstd)
+    x = _mat(x, "x")
+    n, F = x.shape
+    y = torch.empty((n, F), dtype=torch.float32, device=x.device)
+    _check(_timed("bn_act_fwd", (F,), lambda: _lib.bot_bn_act_fwd_f32(
+        x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p),
+        int(seed), y.data_ptr(), y.stride(0), _stream())), "bn_act_fwd")
+    return y
+
+
+def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed):
+    """Column sums (sum_g, sum_gx) of the masked upstream gradient and of g * xhat."""
+    _dev(dy, x)
+    dy, x = _mat(dy, "dy"), _mat(x, "x")
+    n, F = x.shape
+    sg = torch.empty(F, dtype=torch.float32, device=x.device)
+    sgx = torch.empty(F, dtype=torch.float32, device=x.device)
+    _check(_lib.bot_bn_act_bwd_reduce_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, F, mean.data_ptr(),
+                                          invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p), int(seed),
+                                          sg.data_ptr(), sgx.data_ptr(), _bn_ws(F, x.device).data_ptr(), _stream()),
+           "bn_act_bwd_reduce")
+    return sg, sgx
+
+
+def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count):
+    """dx of the fused BatchNorm+ReLU+dropout; sum_g/sum_gx None = statistics were constants (eval mode)."""
+    _dev(dy, x)
+    dy, x = _mat(dy, "dy"), _mat(x, "x")
+    n, F = x.shape
+    dx = torch.empty((n, F), dtype=torch.float32, device=x.device)
+    _check(_lib.bot_bn_act_bwd_apply_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, F, mean.data_ptr(),
+                                         invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p), int(seed),
+                                         _ptr(sum_g), _ptr(sum_gx), float(total_count), dx.data_ptr(), dx.stride(0), _stream()),
+           "bn_act_bwd_apply")
+    return dx

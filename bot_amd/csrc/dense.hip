@@ -1,0 +1,344 @@
+// Node-axis BatchNorm + ReLU + dropout, fused (gfx950).  SURVEY §8 row f1: the epilogue of every hidden
+// layer of the reference stacks (src/no-sampling/models.py:636-639, :726-731) is
+//     h = BatchNorm1d(h) over ALL nodes;  h = relu(h);  h = dropout(h)
+// on a [N, H*D] tensor (508 MB at BASELINE config 2).  Done with stock elementwise kernels that is ~10 HBM
+// round trips per layer per step; here it is 2 reads + 1 write forward and 3 reads + 1 write backward:
+//
+//   colstats      : per-column mean and M2 = sum (x-mean)^2, two-stage (partials per row block, then a
+//                   fixed-order combine in double) — no atomics, bitwise reproducible.
+//   bn_act_fwd    : y = drop(relu((x-mean)*invstd*w + b)); the dropout keep-mask is a counter-based
+//                   Philox4x32-10 stream keyed by (seed, element group), so the backward regenerates it and
+//                   nothing but x is saved.
+//   bn_act_bwd_red: column sums of g and g*xhat, g = dy * keep/(1-p) * [bn > 0]   (same two-stage shape)
+//   bn_act_bwd_app: dx = w*invstd*(g - sum_g/n - xhat*sum_gx/n)
+//
+// The split at the column statistics is deliberate: in the vertex-partitioned mode the (mean, M2, count) triples
+// and the (sum_g, sum_gx) pairs are what gets all-reduced between the two kernels.
+// HBM roofline: algorithmic bytes = 4*n*F * {1 (stats), 2 (fwd), 2 (bwd reduce), 3 (bwd apply)}.
+#include "common.h"
+
+namespace bot {
+
+constexpr int kTX = 64;   // lanes across columns (x VEC floats each)
+constexpr int kTY = 4;    // rows per block iteration
+constexpr int kRowBlocks = 256;
+
+struct Philox {
+    // Philox4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0,k1)
+    static __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+    }
+    static __device__ __forceinline__ void gen(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            round(c, k0, k1);
+            k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = c[i];
+    }
+};
+
+// keep/(1-p) factors for the VEC elements of element-group `grp`
+template <int VEC>
+__device__ __forceinline__ void drop_factors(uint64_t seed, uint64_t grp, float p, float scale, float (&f)[VEC]) {
+    uint32_t r[4];
+    Philox::gen(seed, grp, r);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) f[t] = ((r[t] >> 8) * (1.0f / 16777216.0f)) >= p ? scale : 0.f;
+}
+
+struct BnArgs {
+    const float* x;
+    int64_t ldx;
+    int64_t n;
+    int32_t F;
+    const float* mean;
+    const float* invstd;
+    const float* w;
+    const float* b;
+    int32_t relu;
+    float p;
+    uint64_t seed;
+    // fwd
+    float* y;
+    int64_t ldy;
+    // bwd
+    const float* dy;
+    int64_t lddy;
+    const float* sum_g;
+    const float* sum_gx;
+    float inv_count;
+    float* dx;
+    int64_t lddx;
+    float* part;  // [kRowBlocks][2][F]
+};
+
+// part[rb][0][c] = sum_{rows of block rb} (x - pivot_c),  part[rb][1][c] = sum (x - pivot_c)^2,  pivot = x[0,c]
+template <int VEC>
+__global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float* x, int64_t ldx, int64_t n, int32_t F, float* part) {
+    __shared__ float lds[2][kTY][kTX * VEC];
+    const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
+    const int c = (blockIdx.x * kTX + tx) * VEC;
+    float s[VEC], q[VEC], piv[VEC];
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) s[t] = q[t] = 0.f;
+    if (c < F) {
+        vload<VEC>(piv, x + c);
+        for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < n; r += (int64_t)gridDim.y * kTY) {
+            float v[VEC];
+            vload<VEC>(v, x + r * ldx + c);
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                const float d = v[t] - piv[t];
+                s[t] += d;
+                q[t] = fmaf(d, d, q[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) lds[0][ty][tx * VEC + t] = s[t], lds[1][ty][tx * VEC + t] = q[t];
+    __syncthreads();
+    if (ty == 0 && c < F) {
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int j = 0; j < kTY; ++j) a += lds[0][j][tx * VEC + t], b += lds[1][j][tx * VEC + t];
+            part[((int64_t)blockIdx.y * 2 + 0) * F + c + t] = a;
+            part[((int64_t)blockIdx.y * 2 + 1) * F + c + t] = b;
+        }
+    }
+}
+
+// mean[c] = pivot + S/n ; m2[c] = Q - S^2/n      (fixed order, double)
+__global__ __launch_bounds__(kBlock) void colstats_final_kernel(const float* x, int64_t n, int32_t F, const float* part, int nblk,
+                                                               float* mean, float* m2) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= F) return;
+    double S = 0.0, Q = 0.0;
+    for (int b = 0; b < nblk; ++b) S += (double)part[((int64_t)b * 2 + 0) * F + c], Q += (double)part[((int64_t)b * 2 + 1) * F + c];
+    mean[c] = (float)((double)x[c] + S / (double)n);
+    m2[c] = (float)fmax(Q - S * S / (double)n, 0.0);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
+    const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
+    const int c = (blockIdx.x * kTX + tx) * VEC;
+    if (c >= a.F) return;
+    float mu[VEC], sc[VEC], sh[VEC];
+    vload<VEC>(mu, a.mean + c);
+    vload<VEC>(sc, a.invstd + c);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+        sc[t] *= a.w ? a.w[c + t] : 1.f;
+        sh[t] = a.b ? a.b[c + t] : 0.f;
+    }
+    const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+    const int64_t ngrp = (a.F + VEC - 1) / VEC;
+    for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < a.n; r += (int64_t)gridDim.y * kTY) {
+        float v[VEC], f[VEC];
+        vload<VEC>(v, a.x + r * a.ldx + c);
+        if (a.p > 0.f) drop_factors<VEC>(a.seed, (uint64_t)(r * ngrp + c / VEC), a.p, scale, f);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+            float o = fmaf(v[t] - mu[t], sc[t], sh[t]);
+            if (a.relu) o = fmaxf(o, 0.f);
+            if (a.p > 0.f) o *= f[t];
+            v[t] = o;
+        }
+        vstore<VEC>(a.y + r * a.ldy + c, v);
+    }
+}
+
+// g = dy * keep/(1-p) * [bn > 0];  partial column sums of g and g*xhat
+template <int VEC>
+__global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_reduce_kernel(BnArgs a) {
+    __shared__ float lds[2][kTY][kTX * VEC];
+    const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
+    const int c = (blockIdx.x * kTX + tx) * VEC;
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) s[t] = q[t] = 0.f;
+    if (c < a.F) {
+        float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+        vload<VEC>(mu, a.mean + c);
+        vload<VEC>(is, a.invstd + c);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+            sc[t] = a.w ? a.w[c + t] : 1.f;
+            sh[t] = a.b ? a.b[c + t] : 0.f;
+        }
+        const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+        const int64_t ngrp = (a.F + VEC - 1) / VEC;
+        for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < a.n; r += (int64_t)gridDim.y * kTY) {
+            float v[VEC], g[VEC], f[VEC];
+            vload<VEC>(v, a.x + r * a.ldx + c);
+            vload<VEC>(g, a.dy + r * a.lddy + c);
+            if (a.p > 0.f) drop_factors<VEC>(a.seed, (uint64_t)(r * ngrp + c / VEC), a.p, scale, f);
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                const float xh = (v[t] - mu[t]) * is[t];
+                float gg = g[t];
+                if (a.p > 0.f) gg *= f[t];
+                if (a.relu && !(fmaf(xh, sc[t], sh[t]) > 0.f)) gg = 0.f;
+                s[t] += gg;
+                q[t] = fmaf(gg, xh, q[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) lds[0][ty][tx * VEC + t] = s[t], lds[1][ty][tx * VEC + t] = q[t];
+    __syncthreads();
+    if (ty == 0 && c < a.F) {
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+            float u = 0.f, w = 0.f;
+#pragma unroll
+            for (int j = 0; j < kTY; ++j) u += lds[0][j][tx * VEC + t], w += lds[1][j][tx * VEC + t];
+            a.part[((int64_t)blockIdx.y * 2 + 0) * a.F + c + t] = u;
+            a.part[((int64_t)blockIdx.y * 2 + 1) * a.F + c + t] = w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void pair_final_kernel(int32_t F, const float* part, int nblk, float* s0, float* s1) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= F) return;
+    double A = 0.0, B = 0.0;
+    for (int b = 0; b < nblk; ++b) A += (double)part[((int64_t)b * 2 + 0) * F + c], B += (double)part[((int64_t)b * 2 + 1) * F + c];
+    s0[c] = (float)A;
+    s1[c] = (float)B;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
+    const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
+    const int c = (blockIdx.x * kTX + tx) * VEC;
+    if (c >= a.F) return;
+    float mu[VEC], is[VEC], sc[VEC], sh[VEC], mg[VEC], mgx[VEC];
+    vload<VEC>(mu, a.mean + c);
+    vload<VEC>(is, a.invstd + c);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+        sc[t] = a.w ? a.w[c + t] : 1.f;
+        sh[t] = a.b ? a.b[c + t] : 0.f;
+        mg[t] = a.sum_g ? a.sum_g[c + t] * a.inv_count : 0.f;     // NULL sums: eval mode (running statistics are constants)
+        mgx[t] = a.sum_gx ? a.sum_gx[c + t] * a.inv_count : 0.f;
+    }
+    const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+    const int64_t ngrp = (a.F + VEC - 1) / VEC;
+    for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < a.n; r += (int64_t)gridDim.y * kTY) {
+        float v[VEC], g[VEC], f[VEC];
+        vload<VEC>(v, a.x + r * a.ldx + c);
+        vload<VEC>(g, a.dy + r * a.lddy + c);
+        if (a.p > 0.f) drop_factors<VEC>(a.seed, (uint64_t)(r * ngrp + c / VEC), a.p, scale, f);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+            const float xh = (v[t] - mu[t]) * is[t];
+            float gg = g[t];
+            if (a.p > 0.f) gg *= f[t];
+            if (a.relu && !(fmaf(xh, sc[t], sh[t]) > 0.f)) gg = 0.f;
+            v[t] = sc[t] * is[t] * (gg - mg[t] - xh * mgx[t]);
+        }
+        vstore<VEC>(a.dx + r * a.lddx + c, v);
+    }
+}
+
+static dim3 bn_grid(int32_t F, int vec, int64_t n) {
+    const int64_t rb = (n + kTY - 1) / kTY;
+    return dim3((unsigned)((F + kTX * vec - 1) / (kTX * vec)), (unsigned)(rb < kRowBlocks ? (rb > 0 ? rb : 1) : kRowBlocks));
+}
+
+}  // namespace bot
+
+extern "C" {
+
+int64_t bot_bn_workspace_floats(int32_t F) { return (int64_t)bot::kRowBlocks * 2 * F; }
+
+int bot_colstats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* mean, float* m2, float* workspace,
+                     bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 1 && F >= 1 && ldx >= F, BOT_E_RANGE, "colstats: n=%lld F=%d ldx=%lld", (long long)n, F, (long long)ldx);
+    BOT_REQUIRE(x && mean && m2 && workspace, BOT_E_NULL, "colstats: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = pick_vec(F, {ldx}, {x});
+    const dim3 grid = bn_grid(F, vec, n);
+    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
+    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
+    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
+    hipLaunchKernelGGL(colstats_final_kernel, dim3((F + kBlock - 1) / kBlock), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
+                       mean, m2);
+    return hip_status("colstats launch");
+}
+
+int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
+                       const float* weight, const float* bias, int32_t relu, float p, uint64_t seed, float* y, int64_t ldy,
+                       bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && ldy >= F, BOT_E_RANGE, "bn_act_fwd: n=%lld F=%d", (long long)n, F);
+    BOT_REQUIRE(p >= 0.f && p < 1.f, BOT_E_RANGE, "bn_act_fwd: dropout p=%f must be in [0,1)", (double)p);
+    if (n == 0) return 0;
+    BOT_REQUIRE(x && mean && invstd && y, BOT_E_NULL, "bn_act_fwd: NULL pointer");
+    BnArgs a{};
+    a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
+    a.seed = seed, a.y = y, a.ldy = ldy;
+    const int vec = pick_vec(F, {ldx, ldy}, {x, y, mean, invstd});
+    const dim3 grid = bn_grid(F, vec, n);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec == 4) hipLaunchKernelGGL((bn_act_fwd_kernel<4>), grid, dim3(kTX * kTY), 0, st, a);
+    else if (vec == 2) hipLaunchKernelGGL((bn_act_fwd_kernel<2>), grid, dim3(kTX * kTY), 0, st, a);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<1>), grid, dim3(kTX * kTY), 0, st, a);
+    return hip_status("bn_act_fwd launch");
+}
+
+int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
+                              const float* mean, const float* invstd, const float* weight, const float* bias, int32_t relu,
+                              float p, uint64_t seed, float* sum_g, float* sum_gx, float* workspace, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 1 && F >= 1 && ldx >= F && lddy >= F, BOT_E_RANGE, "bn_act_bwd_reduce: n=%lld F=%d", (long long)n, F);
+    BOT_REQUIRE(dy && x && mean && invstd && sum_g && sum_gx && workspace, BOT_E_NULL, "bn_act_bwd_reduce: NULL pointer");
+    BnArgs a{};
+    a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
+    a.seed = seed, a.dy = dy, a.lddy = lddy, a.part = workspace;
+    const int vec = pick_vec(F, {ldx, lddy}, {x, dy, mean, invstd});
+    const dim3 grid = bn_grid(F, vec, n);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec == 4) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<4>), grid, dim3(kTX * kTY), 0, st, a);
+    else if (vec == 2) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<2>), grid, dim3(kTX * kTY), 0, st, a);
+    else hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<1>), grid, dim3(kTX * kTY), 0, st, a);
+    hipLaunchKernelGGL(pair_final_kernel, dim3((F + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F, workspace, (int)grid.y, sum_g,
+                       sum_gx);
+    return hip_status("bn_act_bwd_reduce launch");
+}
+
+int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
+                             const float* mean, const float* invstd, const float* weight, const float* bias, int32_t relu,
+                             float p, uint64_t seed, const float* sum_g, const float* sum_gx, double total_count, float* dx,
+                             int64_t lddx, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && lddy >= F && lddx >= F, BOT_E_RANGE, "bn_act_bwd_apply: n=%lld F=%d", (long long)n, F);
+    if (n == 0) return 0;
+    BOT_REQUIRE(dy && x && mean && invstd && dx, BOT_E_NULL, "bn_act_bwd_apply: NULL pointer");
+    BOT_REQUIRE((sum_g == nullptr) == (sum_gx == nullptr), BOT_E_NULL, "bn_act_bwd_apply: sum_g and sum_gx go together");
+    BOT_REQUIRE(sum_g == nullptr || total_count >= 1.0, BOT_E_RANGE, "bn_act_bwd_apply: total_count=%f", total_count);
+    BnArgs a{};
+    a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
+    a.seed = seed, a.dy = dy, a.lddy = lddy, a.sum_g = sum_g, a.sum_gx = sum_gx, a.inv_count = sum_g ? (float)(1.0 / total_count) : 0.f;
+    a.dx = dx, a.lddx = lddx;
+    const int vec = pick_vec(F, {ldx, lddy, lddx}, {x, dy, dx, mean, invstd, sum_g, sum_gx});
+    const dim3 grid = bn_grid(F, vec, n);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec == 4) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<4>), grid, dim3(kTX * kTY), 0, st, a);
+    else if (vec == 2) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<2>), grid, dim3(kTX * kTY), 0, st, a);
+    else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<1>), grid, dim3(kTX * kTY), 0, st, a);
+    return hip_status("bn_act_bwd_apply launch");
+}
+
+}  // extern "C"

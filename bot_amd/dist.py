@@ -194,6 +194,7 @@ class SyncBatchNorm1d(nn.BatchNorm1d):
     Device-agnostic (plain torch ops + differentiable all-reduce), so the gloo tests cover it."""
 
     group = None
+    _bot_sync = True  # bot_amd.ops.bn_relu_dropout: all-reduce the column statistics across ranks
 
     def forward(self, x):
         if not self.training or not (dist.is_available() and dist.is_initialized()):

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 from ..errors import DGLError
@@ -50,6 +51,14 @@ def degree_norm(graph, which: str, power: float) -> torch.Tensor:
         d = deg.float().clamp(min=1)
         c[key] = 1.0 / d if power == -1.0 else torch.pow(d, power)
     return c[key]
+
+
+def _epilogue(h, norm, activation, dropout, training):
+    """`dropout(activation(norm(h)))` — models.py:636-639 / :726-731.  BatchNorm1d + ReLU (+ dropout) run as the
+    fused HIP epilogue (2 reads + 1 write instead of ~10 round trips); other activations take the stock ops."""
+    if isinstance(norm, nn.BatchNorm1d) and activation in (F.relu, torch.relu) and h.dim() == 2:
+        return ops.bn_relu_dropout(h, norm, relu=True, p=dropout.p, training=training)
+    return dropout(activation(norm(h)))
 
 
 def _bcast(norm, like):
@@ -225,13 +234,20 @@ class GATConv(nn.Module):
             raise NotImplementedError("bipartite (block) inputs belong to the sampled scripts, outside the full-batch path")
         H, D = self._num_heads, self._out_feats
         h = self.feat_drop(feat)
-        ft = self.fc(h).view(-1, H, D)
-        ft_dst = ft
+        W = self.fc.weight
+        ft = F.linear(h, W).view(-1, H, D)
+        # Attention scores without a pass over ft:  el[n,h] = <ft[n,h,:], attn_l[h,:]> = h[n,:] . (W_h^T attn_l[h])
+        # (models.py:517, :521 — same value up to fp32 summation order; saves three 508 MB round trips per layer
+        # forward and as many backward).  attn_r sees the projection BEFORE the symmetric scaling (models.py:498).
+        Wh = W.view(H, D, -1)
+        el = F.linear(h, (Wh * self.attn_l.view(H, D, 1)).sum(1))
+        er = F.linear(h, (Wh * self.attn_r.view(H, D, 1)).sum(1)).unsqueeze(-1) if self.attn_r is not None else None
         if self._use_symmetric_norm:
-            ft = ft * _bcast(degree_norm(graph, "out", -0.5), ft)
+            norm = degree_norm(graph, "out", -0.5)
+            ft = ft * _bcast(norm, ft)
+            el = el * norm.unsqueeze(-1)
         ft = graph.extend(ft)  # identity on one GPU; appends the halo rows in partitioned mode
-        el = (ft * self.attn_l).sum(dim=-1, keepdim=True)
-        er = (ft_dst * self.attn_r).sum(dim=-1, keepdim=True) if self.attn_r is not None else None
+        el = graph.extend(el).unsqueeze(-1)
         if keep is None and self.training and self.edge_drop > 0:
             keep = self._kept_edges(graph)
         a = ops.gat_attention(graph, el, er, keep=keep, negative_slope=self.leaky_relu.negative_slope, order="csc")
@@ -239,8 +255,8 @@ class GATConv(nn.Module):
         rst = ops.u_mul_e_sum(graph, ft, a, order="csc")
         if self._use_symmetric_norm:
             rst = rst * _bcast(degree_norm(graph, "in", 0.5), rst)
-        if self.res_fc is not None:
-            rst = rst + self.res_fc(h).view(h.shape[0], -1, D)
+        if self.res_fc is not None:  # residual folded into the GEMM epilogue (beta = 1)
+            rst = torch.addmm(rst.reshape(rst.shape[0], H * D), h, self.res_fc.weight.t()).view(-1, H, D)
         if self._activation is not None:
             rst = self._activation(rst)
         return rst
@@ -281,8 +297,9 @@ class GCN(nn.Module):
                     h = h + h_last
                 h_last = h
                 if len(self.norms):
-                    h = self.norms[i](h)
-                h = self.dropout(self.activation(h))
+                    h = _epilogue(h, self.norms[i], self.activation, self.dropout, self.training)
+                else:
+                    h = self.dropout(self.activation(h))
         return h
 
 
@@ -325,6 +342,8 @@ class GAT(nn.Module):
                     h = h + h_last
                 h_last = h
                 h = h.flatten(1)
-                h = self.norms[i](h) if len(self.norms) else self.biases[i](h)
-                h = self.dropout(self.activation(h))
+                if len(self.norms):
+                    h = _epilogue(h, self.norms[i], self.activation, self.dropout, self.training)
+                else:
+                    h = self.dropout(self.activation(self.biases[i](h)))
         return self.biases[-1](h.mean(1))

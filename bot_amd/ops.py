@@ -195,3 +195,78 @@ def edge_softmax(graph, logits, eids=None, norm_by="dst"):
     keep[eids] = 1
     a = gat_attention(graph, None, None, full, keep=keep, negative_slope=1.0, order="eid")
     return a.view(full.shape)[eids]
+
+
+# ------------------------------------------------------------------------------------------------ fused hidden-layer epilogue
+def _dist_group(bn):
+    """(do_sync, group) — global statistics when `bn` is a bot_amd.dist.SyncBatchNorm1d and a process group is up."""
+    import torch.distributed as dist
+    if getattr(bn, "_bot_sync", False) and dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.group) > 1:
+        return True, bn.group
+    return False, None
+
+
+class _BNActDrop(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, relu, p, bn_training):
+        import torch.distributed as dist
+        n, F = x.shape
+        sync, group = _dist_group(bn)
+        total = float(n)
+        if bn_training:
+            mean, m2 = _C.colstats(x)
+            if sync:  # Chan et al. pairwise combination of (count, mean, M2) across ranks, via two small all-reduces
+                pack = torch.cat([mean * n, mean.new_tensor([float(n)])])
+                dist.all_reduce(pack, group=group)
+                total = float(pack[-1].item())
+                gmean = pack[:-1] / total
+                m2 = m2 + n * (mean - gmean) ** 2
+                dist.all_reduce(m2, group=group)
+                mean = gmean
+            var = m2 / total
+            invstd = torch.rsqrt(var + bn.eps)
+            if bn.track_running_stats:
+                with torch.no_grad():
+                    mom = 0.1 if bn.momentum is None else bn.momentum
+                    bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(m2 / max(total - 1.0, 1.0), alpha=mom)
+                    bn.num_batches_tracked += 1
+        else:
+            mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+        seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
+        y = _C.bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed)
+        ctx.save_for_backward(x, mean, invstd, weight, bias)
+        ctx.cfg = (relu, p, seed, bn_training, sync, group, total)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        x, mean, invstd, weight, bias = ctx.saved_tensors
+        relu, p, seed, bn_training, sync, group, total = ctx.cfg
+        dy = dy.contiguous()
+        sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed)
+        dw = sgx if weight is not None and ctx.needs_input_grad[1] else None  # local sums: ranks' parameter grads are
+        db = sg if bias is not None and ctx.needs_input_grad[2] else None     # summed later with all the others
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if bn_training:
+                if sync:
+                    both = torch.stack([sg, sgx])
+                    dist.all_reduce(both, group=group)
+                    sg, sgx = both[0].contiguous(), both[1].contiguous()
+                dx = _C.bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sg, sgx, total)
+            else:
+                dx = _C.bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, None, None, total)
+        return dx, dw, db, None, None, None, None
+
+
+def bn_relu_dropout(x, bn, *, relu=True, p=0.0, training=False):
+    """`dropout(relu(bn(x)))` over the node axis in 2 reads + 1 write (models.py:636-639, :726-731).
+
+    `bn` is the layer's nn.BatchNorm1d (its parameters, running statistics and train/eval state are used and
+    updated exactly as nn.BatchNorm1d would); `p` is the dropout rate, applied when `training`."""
+    w = bn.weight if bn.affine else None
+    b = bn.bias if bn.affine else None
+    bn_training = bn.training or not bn.track_running_stats
+    return _BNActDrop.apply(x, w, b, bn, bool(relu), float(p) if training else 0.0, bn_training)

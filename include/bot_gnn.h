@@ -175,6 +175,38 @@ int bot_gather_rows_f32(const float* x, int64_t ldx, const int32_t* rows, int64_
 int bot_scatter_add_rows_f32(float* x, int64_t ldx, const int32_t* rows, int64_t n_sel, int32_t F,
                              const float* vals, int64_t ldv, bot_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Hidden-layer epilogue: BatchNorm over the node axis + ReLU + dropout, fused.
+ * Replaces `h = self.norms[i](h); h = self.activation(h); h = self.dropout(h)`
+ * (src/no-sampling/models.py:636-639 and :726-731; nn.BatchNorm1d over ALL nodes, :609 / :698).
+ *
+ *   colstats      mean[c] = mean_r x[r,c];  m2[c] = sum_r (x[r,c]-mean[c])^2     (two-stage, fixed order)
+ *   bn_act_fwd    y = drop_p( relu?( (x-mean)*invstd*weight + bias ) )
+ *   bwd_reduce    g = dy * keep/(1-p) * [bn > 0];  sum_g[c] = sum_r g;  sum_gx[c] = sum_r g*xhat
+ *   bwd_apply     dx = weight*invstd*( g - sum_g/count - xhat*sum_gx/count )
+ *                 (sum_g == sum_gx == NULL: statistics were constants (eval mode): dx = weight*invstd*g)
+ *
+ * The dropout mask is a counter-based Philox4x32-10 stream keyed by (seed, element group): forward and
+ * backward regenerate it from `seed`, nothing is stored.  p == 0 disables dropout.  `weight`/`bias` may be
+ * NULL.  `workspace` holds bot_bn_workspace_floats(F) floats.  In the vertex-partitioned mode the caller
+ * all-reduces (mean, m2, count) and (sum_g, sum_gx) between the two halves; `total_count` is the global
+ * row count.  The grad of weight is sum_gx, of bias sum_g.
+ * ------------------------------------------------------------------------------------------- */
+int64_t bot_bn_workspace_floats(int32_t F);
+int bot_colstats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* mean, float* m2, float* workspace,
+                     bot_stream_t stream);
+int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
+                       const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
+                       float* y, int64_t ldy, bot_stream_t stream);
+int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
+                              const float* mean, const float* invstd, const float* weight, const float* bias,
+                              int32_t relu, float p, uint64_t seed, float* sum_g, float* sum_gx, float* workspace,
+                              bot_stream_t stream);
+int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
+                             const float* mean, const float* invstd, const float* weight, const float* bias,
+                             int32_t relu, float p, uint64_t seed, const float* sum_g, const float* sum_gx,
+                             double total_count, float* dx, int64_t lddx, bot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

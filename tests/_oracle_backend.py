@@ -103,7 +103,39 @@ def scatter_add_rows(x, rows, vals):
     return x
 
 
-NAMES = ["degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+def colstats(x):
+    mean = x.mean(0)
+    return mean, ((x - mean) ** 2).sum(0)
+
+
+def _bn_gate(x, mean, invstd, weight, bias, relu, p):
+    assert p == 0.0, "the CPU emulation has no Philox stream: dropout parity is checked on the GPU only"
+    xh = (x - mean) * invstd
+    o = xh * (weight if weight is not None else 1.0) + (bias if bias is not None else 0.0)
+    return xh, o
+
+
+def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed):
+    _, o = _bn_gate(x, mean, invstd, weight, bias, relu, p)
+    return torch.relu(o) if relu else o
+
+
+def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed):
+    xh, o = _bn_gate(x, mean, invstd, weight, bias, relu, p)
+    g = torch.where(o > 0, dy, torch.zeros_like(dy)) if relu else dy
+    return g.sum(0), (g * xh).sum(0)
+
+
+def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count):
+    xh, o = _bn_gate(x, mean, invstd, weight, bias, relu, p)
+    g = torch.where(o > 0, dy, torch.zeros_like(dy)) if relu else dy
+    w = weight if weight is not None else 1.0
+    if sum_g is None:
+        return w * invstd * g
+    return w * invstd * (g - sum_g / total_count - xh * sum_gx / total_count)
+
+
+NAMES = ["colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -179,3 +179,66 @@ def test_copy_e_sum_preprocess(golden):
 
 def test_train_step_golden(golden):
     PC.check_train_step_golden(golden, DEV)
+
+
+@pytest.mark.parametrize("F", [750, 256, 41])
+def test_fused_bn_relu_dropout_matches_torch(F):
+    """BatchNorm1d (batch statistics over the node axis) + ReLU, fused, against torch's own modules: output,
+    input/affine gradients, running statistics; training and eval mode; also on a strided (row-padded) input."""
+    n = 5000
+    gen = torch.Generator().manual_seed(F)
+    x0 = (torch.randn(n, F, generator=gen) * 1.7 + 0.4).to(DEV)
+    gy = torch.randn(n, F, generator=gen).to(DEV)
+    for training in (True, False):
+        for strided in (False, True):
+            ref_bn, bn = torch.nn.BatchNorm1d(F).to(DEV), torch.nn.BatchNorm1d(F).to(DEV)
+            with torch.no_grad():
+                for m in (ref_bn, bn):
+                    m.weight.copy_(torch.linspace(0.5, 1.5, F))
+                    m.bias.copy_(torch.linspace(-0.3, 0.3, F))
+                    m.running_mean.fill_(0.1)
+                    m.running_var.fill_(1.3)
+            ref_bn.train(training), bn.train(training)
+            xr = x0.clone().requires_grad_()
+            if strided:
+                buf = torch.zeros(n, F + 6, device=DEV)
+                buf[:, :F] = x0
+                xt = buf[:, :F].detach().requires_grad_()
+            else:
+                xt = x0.clone().requires_grad_()
+            ref = torch.relu(ref_bn(xr))
+            out = ops.bn_relu_dropout(xt, bn, relu=True, p=0.5, training=False)  # dropout off: comparable
+            assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5)
+            (ref * gy).sum().backward()
+            (out * gy).sum().backward()
+            assert torch.allclose(xt.grad, xr.grad, atol=2e-5, rtol=1e-4)
+            assert torch.allclose(bn.weight.grad, ref_bn.weight.grad, rtol=1e-4, atol=1e-3)
+            assert torch.allclose(bn.bias.grad, ref_bn.bias.grad, rtol=1e-4, atol=1e-3)
+            assert torch.allclose(bn.running_mean, ref_bn.running_mean, atol=1e-6)
+            assert torch.allclose(bn.running_var, ref_bn.running_var, rtol=1e-5)
+            assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+
+
+def test_fused_dropout_mask_consistency():
+    """Dropout inside the fused epilogue: keep rate ~ 1-p, kept entries scaled by 1/(1-p), and the backward
+    regenerates exactly the forward mask (no mask is stored)."""
+    n, F, p = 20000, 750, 0.75
+    x = torch.randn(n, F, device=DEV).requires_grad_()
+    bn = torch.nn.BatchNorm1d(F).to(DEV).train()
+    y = ops.bn_relu_dropout(x, bn, relu=True, p=p, training=True)
+    with torch.no_grad():
+        base = torch.relu(torch.nn.functional.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.0, bn.eps))
+    pos = base > 1e-3
+    kept = (y != 0) & pos
+    rate = kept.sum().item() / pos.sum().item()
+    assert abs(rate - (1 - p)) < 5e-3, rate
+    assert torch.allclose(y[kept], base[kept] / (1 - p), rtol=1e-4, atol=1e-5)
+    factor = torch.where(kept, torch.full_like(y, 1 / (1 - p)), torch.zeros_like(y))  # the mask the forward used
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = x.detach().clone().requires_grad_()
+    ref = torch.relu(torch.nn.functional.batch_norm(xr, None, None, bn.weight, bn.bias, True, 0.0, bn.eps)) * factor
+    ref.backward(gy)
+    assert torch.allclose(x.grad, xr.grad, atol=5e-5, rtol=1e-3)
+    y2 = ops.bn_relu_dropout(x.detach(), bn, relu=True, p=p, training=True)
+    assert not torch.equal(y2 != 0, y != 0)  # a fresh seed per call
