@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; reported in config)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--force-partitioned", action="store_true",
+                    help="run the 1-D partitioned code path even with one rank (exercises the RCCL plumbing on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -57,7 +59,11 @@ def cpu_baseline(ds_cpu, n_classes, steps):
     (forward + loge loss + backward; dropout omitted) on the host cores of this box."""
     from oracle import c_ops
     from oracle import ref_models as RM
-    torch.set_num_threads(os.cpu_count())
+    # 32 threads: measured best on the 256-thread host of the GPU box (tools/exp_cpu_threads.py, 1/4-scale step:
+    # 8/16/32/64/128/256 threads -> 1.56/1.21/1.07/1.53/2.90/19.5 s); more threads only add contention.
+    threads = min(os.cpu_count(), 32)
+    torch.set_num_threads(threads)
+    c_ops.set_num_threads(threads)
     s, d, n, feat, labels, train_idx = ds_cpu
     g = c_ops.CGraph(s, d, n)
     from bot_amd import nn as bnn
@@ -91,9 +97,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    partitioned = world > 1 or args.force_partitioned
+    if partitioned:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import bot_amd
     from bot_amd import _C, synth, train
@@ -107,7 +116,7 @@ def main():
     model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **CFG).to(dev)
     opt = torch.optim.RMSprop(model.parameters(), lr=0.002)
 
-    if world == 1:
+    if not partitioned:
         g = ds.graph.to(dev)
         g.create_formats_()
         feat, labels = ds.feat.to(dev), ds.labels.to(dev)
@@ -139,7 +148,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     _C.PROFILE = None
-    if world > 1:
+    if partitioned:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -151,8 +160,8 @@ def main():
     durs = [e0.elapsed_time(e1) * 1e-3 for (name, key, e0, e1) in prof if name == "spmm" and key == (H, D, True)]
     roof = None
     if durs:
-        n_loc = durs and (part.n_owned if world > 1 else n)
-        e_loc = part.n_edges if world > 1 else E
+        n_loc = part.n_owned if partitioned else n
+        e_loc = part.n_edges if partitioned else E
         alg = spmm_alg_bytes(n_loc, e_loc, H, D, True)
         avg = sum(durs) / len(durs)
         ach = alg / avg / 1e9
@@ -182,7 +191,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if partitioned:
         torch.distributed.destroy_process_group()
 
 

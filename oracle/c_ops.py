@@ -45,6 +45,12 @@ def num_threads():
     return int(lib().oracle_num_threads())
 
 
+def set_num_threads(n: int):
+    """Thread count of the OpenMP kernels (torch's own pool is set with torch.set_num_threads)."""
+    lib().oracle_set_num_threads.argtypes = [ctypes.c_int]
+    lib().oracle_set_num_threads(int(n))
+
+
 class CGraph:
     """COO + both compressed directions with int64 ids (DGL's default idtype), built once."""
 

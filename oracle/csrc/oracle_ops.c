@@ -20,6 +20,14 @@
 #include <omp.h>
 #endif
 
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -228,7 +228,7 @@ def test_fused_dropout_mask_consistency():
     y = ops.bn_relu_dropout(x, bn, relu=True, p=p, training=True)
     with torch.no_grad():
         base = torch.relu(torch.nn.functional.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.0, bn.eps))
-    pos = base > 1e-3
+    pos = base > 0
     kept = (y != 0) & pos
     rate = kept.sum().item() / pos.sum().item()
     assert abs(rate - (1 - p)) < 5e-3, rate
@@ -239,6 +239,6 @@ def test_fused_dropout_mask_consistency():
     xr = x.detach().clone().requires_grad_()
     ref = torch.relu(torch.nn.functional.batch_norm(xr, None, None, bn.weight, bn.bias, True, 0.0, bn.eps)) * factor
     ref.backward(gy)
-    assert torch.allclose(x.grad, xr.grad, atol=5e-5, rtol=1e-3)
+    assert torch.allclose(x.grad, xr.grad, atol=1e-4, rtol=1e-3)
     y2 = ops.bn_relu_dropout(x.detach(), bn, relu=True, p=p, training=True)
     assert not torch.equal(y2 != 0, y != 0)  # a fresh seed per call
