@@ -35,6 +35,8 @@ _SIGS = {
     "bot_spmm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "bot_spmm_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                     c_int32, c_int32, _P, c_int64, c_int64, _P, _P]),
+    "bot_spmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
+                                        _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P]),
     "bot_sddmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                          c_int32, c_int32, _P, _P, c_int32, _P]),
     "bot_sddmm_u_add_v_f32": (ctypes.c_int, [_P, _P, c_int64, _P, _P, c_int32, _P, _P]),
@@ -181,6 +183,31 @@ def spmm(d, x, w=None, wperm=None, out=None):
         _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, _ptr(w), _ptr(_i32(wperm, "wperm")), H, D, out.data_ptr(), ldo, hso,
         _ptr(partial), _stream())), "spmm")
     return out
+
+
+def spmm_dot_max_d(x):
+    """Largest D the fused spmm_dot launch covers for this slab's alignment."""
+    return 1024 if (x.shape[2] % 4 == 0 and x.stride(0) % 4 == 0) else (512 if x.shape[2] % 2 == 0 and x.stride(0) % 2 == 0 else 256)
+
+
+def spmm_dot(d, x, w, wperm, y):
+    """Fused backward of u_mul_e_sum on direction `d`:  out[r,h,:] = sum_k w[wperm[k],h] x[indices[k],h,:]  and
+    dot[wperm[k],h] = <y[r,h,:], x[indices[k],h,:]>.  Returns (out [n_rows,H,D], dot [nnz,H])."""
+    _dev(x, w, y, d.indptr)
+    x, ldx, hsx = _slab(x, "x")
+    y, ldy, hsy = _slab(y, "y")
+    H, D = x.shape[1], x.shape[2]
+    w = _f32(w, "w").contiguous()
+    out = torch.empty((d.n_rows, H, D), dtype=torch.float32, device=x.device)
+    dot = torch.empty((d.nnz, H), dtype=torch.float32, device=x.device)
+    partial = None
+    if d.n_long:
+        partial = torch.empty(int(_lib.bot_spmm_workspace_floats(d.n_slots, H, D)), dtype=torch.float32, device=x.device)
+    _check(_timed("spmm_dot", (H, D), lambda: _lib.bot_spmm_dot_f32(
+        d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
+        _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, w.data_ptr(), _ptr(_i32(wperm, "wperm")), y.data_ptr(), ldy, hsy,
+        H, D, out.data_ptr(), out.stride(0), out.stride(1) if H > 1 else D, dot.data_ptr(), _ptr(partial), _stream())), "spmm_dot")
+    return out, dot
 
 
 def sddmm_dot(d, x, y, operm=None, out=None):

@@ -28,7 +28,113 @@ struct SpmmArgs {
     int64_t ldo, hso;
     float* partial;
     int64_t ldp;
+    // fused transposed-SpMM + SDDMM-dot (backward of u_mul_e_sum): row-local slab y and the per-edge dot output
+    const float* y;
+    int64_t ldy, hsy;
+    float* dot_out;
 };
+
+// Reduce 4 values per lane across a LANES-wide group; on return lane l holds the total of value number l % 4.
+template <int LANES>
+__device__ __forceinline__ float transpose_reduce4(float (&p)[4], int lane) {
+    const bool h2 = lane & 2;
+    float r[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = h2 ? p[i + 2] : p[i];
+        const float send = h2 ? p[i] : p[i + 2];
+        r[i] = keep + __shfl_xor(send, 2, LANES);
+    }
+    const bool h1 = lane & 1;
+    float s = (h1 ? r[1] : r[0]) + __shfl_xor(h1 ? r[0] : r[1], 1, LANES);
+#pragma unroll
+    for (int m = 4; m < LANES; m <<= 1) s += __shfl_xor(s, m, LANES);
+    return s;
+}
+
+// Backward of u_mul_e_sum in ONE sweep over the out-edges (CSR direction) — each gathered row dx[v,h,:] is used twice:
+//   out[u,h,:]           = sum_k w[wperm[k],h] * x[indices[k],h,:]        (d ft: transposed SpMM)
+//   dot_out[wperm[k],h]  = < y[u,h,:] , x[indices[k],h,:] >               (d a : SDDMM dot)
+// so the layer's backward needs one E*H*D gather instead of two.  Same decomposition as spmm_kernel; D must fit one
+// launch tile (n_tiles == 1), the dot is reduced 4 neighbours at a time with the transposing butterfly.
+template <int VEC, int LANES, int NCHUNK>
+__global__ __launch_bounds__(kBlock) void spmm_dot_kernel(SpmmArgs a) {
+    constexpr int U = 4;
+    const int lane = threadIdx.x % LANES;
+    const int64_t gid = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+    if (gid >= a.n_items * a.H) return;
+    int head = (int)(gid / a.n_items);
+    const int64_t item = gid - (int64_t)head * a.n_items;
+    const int4 it = a.items[item];
+    int row = it.x, beg = it.y, end = it.z, slot = it.w;
+    if constexpr (LANES == 64) {
+        row = __builtin_amdgcn_readfirstlane(row);
+        beg = __builtin_amdgcn_readfirstlane(beg);
+        end = __builtin_amdgcn_readfirstlane(end);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        head = __builtin_amdgcn_readfirstlane(head);
+    }
+    const float* xb = a.x + (int64_t)head * a.hsx;
+    const float* yb = a.y + (int64_t)row * a.ldy + (int64_t)head * a.hsy;
+    int off[NCHUNK];
+    bool act[NCHUNK];
+    float acc[NCHUNK][VEC], yv[NCHUNK][VEC];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int e = (c * LANES + lane) * VEC;
+        act[c] = e < a.D;
+        off[c] = act[c] ? e : 0;
+        vload<VEC>(yv[c], yb + off[c]);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+            acc[c][t] = 0.f;
+            if (!act[c]) yv[c][t] = 0.f;
+        }
+    }
+    for (int k0 = beg; k0 < end; k0 += LANES) {
+        const int k = k0 + lane;
+        int idx = 0, wp = 0;
+        float wv = 0.f;
+        if (k < end) {
+            idx = a.indices[k];
+            wp = a.wperm ? a.wperm[k] : k;
+            wv = a.w[(int64_t)wp * a.H + head];
+        }
+        const int cnt = min(LANES, end - k0);
+        for (int i = 0; i < cnt; i += U) {
+            float v[U][NCHUNK][VEC], ww[U], p[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = min(i + u, cnt - 1);  // past the end: re-read a valid neighbour with weight 0, result not stored
+                const int s = group_bcast<LANES>(idx, j);
+                ww[u] = i + u < cnt ? group_bcast<LANES>(wv, j) : 0.f;
+                const float* px = xb + (int64_t)s * a.ldx;
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + off[c]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                    for (int t = 0; t < VEC; ++t) {
+                        acc[c][t] = fmaf(ww[u], v[u][c][t], acc[c][t]);
+                        d = fmaf(v[u][c][t], yv[c][t], d);
+                    }
+                p[u] = d;
+            }
+            const float tot = transpose_reduce4<LANES>(p, lane);
+            const int mywp = __shfl(wp, i + (lane & 3), LANES);  // position whose dot this lane now holds
+            if (lane < U && i + lane < cnt) a.dot_out[(int64_t)mywp * a.H + head] = tot;
+        }
+    }
+    float* ob = slot < 0 ? a.out + (int64_t)row * a.ldo + (int64_t)head * a.hso
+                         : a.partial + (int64_t)slot * a.ldp + (int64_t)head * a.D;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+        if (act[c]) vstore<VEC>(ob + off[c], acc[c]);
+}
 
 template <int VEC, int LANES, int NCHUNK, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs a) {
@@ -152,6 +258,26 @@ static void launch_spmm(const SpmmArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL((spmm_kernel<VEC, LANES, NCHUNK, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
 }
 
+template <int VEC, int LANES, int NCHUNK>
+static void launch_spmm_dot(const SpmmArgs& a, hipStream_t st) {
+    const int64_t groups = a.n_items * a.H;
+    const int64_t blocks = (groups * LANES + kBlock - 1) / kBlock;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL((spmm_dot_kernel<VEC, LANES, NCHUNK>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+}
+
+template <int VEC>
+static void dispatch_spmm_dot(SpmmArgs& a, hipStream_t st) {
+    const int L = (a.D + VEC - 1) / VEC;
+    if (L <= 8) launch_spmm_dot<VEC, 8, 1>(a, st);
+    else if (L <= 16) launch_spmm_dot<VEC, 16, 1>(a, st);
+    else if (L <= 32) launch_spmm_dot<VEC, 32, 1>(a, st);
+    else if (L <= 64) launch_spmm_dot<VEC, 64, 1>(a, st);
+    else if (L <= 128) launch_spmm_dot<VEC, 64, 2>(a, st);
+    else if (L <= 192) launch_spmm_dot<VEC, 64, 3>(a, st);
+    else launch_spmm_dot<VEC, 64, 4>(a, st);
+}
+
 template <int VEC>
 static void dispatch_spmm(SpmmArgs& a, hipStream_t st) {
     const int L = (a.D + VEC - 1) / VEC;  // lanes needed for one head slab
@@ -195,7 +321,7 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
     BOT_REQUIRE(aligned(x, 4) && aligned(out, 4) && aligned(items, 16), BOT_E_ALIGN, "spmm: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     SpmmArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, hsx, w, wperm, H, D, 1, out, ldo, hso, partial,
-               (int64_t)H * D};
+               (int64_t)H * D, nullptr, 0, 0, nullptr};
     const int vec = pick_vec(D, {ldx, hsx, ldo, hso}, {x, out, partial});
     if (vec == 4) dispatch_spmm<4>(a, st);
     else if (vec == 2) dispatch_spmm<2>(a, st);
@@ -206,6 +332,40 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
         hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows,
                            long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso);
         if (int rc = hip_status("spmm combine launch")) return rc;
+    }
+    return 0;
+}
+
+int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz, const int32_t* items,
+                     int64_t n_items, const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, const float* x,
+                     int64_t ldx, int64_t hsx, const float* w, const int32_t* wperm, const float* y, int64_t ldy, int64_t hsy,
+                     int32_t H, int32_t D, float* out, int64_t ldo, int64_t hso, float* dot_out, float* partial,
+                     bot_stream_t stream) {
+    using namespace bot;
+    (void)indptr;
+    BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_items >= 0 && n_long >= 0, BOT_E_RANGE, "spmm_dot: negative size");
+    BOT_REQUIRE(nnz < INT32_MAX && n_rows < INT32_MAX, BOT_E_RANGE, "spmm_dot: int32 index range exceeded");
+    BOT_REQUIRE(H >= 1 && D >= 1, BOT_E_RANGE, "spmm_dot: H=%d D=%d must be >= 1", H, D);
+    if (n_rows == 0) return 0;
+    BOT_REQUIRE(items && x && out && y && (nnz == 0 || (indices && w && dot_out)), BOT_E_NULL, "spmm_dot: NULL pointer");
+    BOT_REQUIRE(n_long == 0 || (long_rows && long_ptr && partial), BOT_E_NULL, "spmm_dot: long rows need long_rows/long_ptr/partial");
+    BOT_REQUIRE(hsx >= D && hso >= D && hsy >= D && ldx >= (int64_t)(H - 1) * hsx + D && ldo >= (int64_t)(H - 1) * hso + D &&
+                    ldy >= (int64_t)(H - 1) * hsy + D, BOT_E_RANGE, "spmm_dot: strides smaller than the slab");
+    hipStream_t st = (hipStream_t)stream;
+    SpmmArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, hsx, w, wperm, H, D, 1, out, ldo, hso, partial,
+               (int64_t)H * D, y, ldy, hsy, dot_out};
+    const int vec = pick_vec(D, {ldx, hsx, ldo, hso, ldy, hsy}, {x, out, partial, y});
+    BOT_REQUIRE(D <= vec * 256, BOT_E_RANGE, "spmm_dot: D=%d exceeds the %d floats one launch tile covers (use bot_spmm_f32 + bot_sddmm_dot_f32)",
+                D, vec * 256);
+    if (vec == 4) dispatch_spmm_dot<4>(a, st);
+    else if (vec == 2) dispatch_spmm_dot<2>(a, st);
+    else dispatch_spmm_dot<1>(a, st);
+    if (int rc = hip_status("spmm_dot launch")) return rc;
+    if (n_long > 0) {
+        const int64_t n = n_long * H * D;
+        hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows,
+                           long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso);
+        if (int rc = hip_status("spmm_dot combine launch")) return rc;
     }
     return 0;
 }

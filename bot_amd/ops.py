@@ -71,6 +71,11 @@ class _UMulESum(torch.autograd.Function):
         x3, a2 = ctx.saved_tensors
         d3 = _as3(dout.contiguous())
         dx = da = None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and x3.shape[2] <= _C.spmm_dot_max_d(d3):
+            # one sweep over the out-edges yields both gradients: each gathered dout row is used twice
+            wperm = g.csr.eid if ctx.order == "eid" else g.csr2csc
+            dx, da = _C.spmm_dot(g.csr, d3, a2, wperm, x3)
+            return None, dx.view(ctx.xshape), da.view(ctx.ashape), None
         if ctx.needs_input_grad[1]:
             wperm = g.csr.eid if ctx.order == "eid" else g.csr2csc
             dx = _C.spmm(g.csr, d3, a2, wperm).view(ctx.xshape)

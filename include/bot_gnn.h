@@ -94,6 +94,26 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
                  float* partial, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused backward of u_mul_e_sum (models.py:547) in ONE sweep over the transposed direction (rows = sources u,
+ * indices = destinations v): every gathered row x[v,h,:] (the upstream gradient) is used twice,
+ *
+ *   out[u,h,:]          = sum_{k in row u} w[wperm[k],h] * x[indices[k],h,:]      (gradient of the node features)
+ *   dot_out[wperm[k],h] = < y[u,h,:] , x[indices[k],h,:] >                        (gradient of the edge weights)
+ *
+ * so a GAT layer's backward needs one E*H*D gather instead of the two of bot_spmm_f32 + bot_sddmm_dot_f32.
+ * y is the layer's forward input slab (row-local).  D <= 1024 (16-byte aligned slabs) / 512 / 256.
+ * ------------------------------------------------------------------------------------------- */
+int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                     const int32_t* items, int64_t n_items,
+                     const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long,
+                     const float* x, int64_t ldx, int64_t hsx,
+                     const float* w, const int32_t* wperm,
+                     const float* y, int64_t ldy, int64_t hsy,
+                     int32_t H, int32_t D,
+                     float* out, int64_t ldo, int64_t hso,
+                     float* dot_out, float* partial, bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * SDDMM dot.  The backward of u_mul_e_sum with respect to the edge weights (models.py:547):
  *
  *   out[operm[k], h] = < x[indices[k],h,:] , y[r,h,:] >        for every position k of every row r

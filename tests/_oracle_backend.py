@@ -35,6 +35,18 @@ def spmm(d, x, w=None, wperm=None, out=None):
     return res
 
 
+def spmm_dot_max_d(x):
+    return 1024
+
+
+def spmm_dot(d, x, w, wperm, y):
+    out = spmm(d, x, w, wperm)
+    val = (x[d.indices.long()] * y[_rows(d)]).sum(-1)
+    dot = torch.empty_like(val)
+    dot[_perm(wperm, d.nnz)] = val
+    return out, dot
+
+
 def sddmm_dot(d, x, y, operm=None, out=None):
     val = (x[d.indices.long()] * y[_rows(d)]).sum(-1)
     res = torch.empty_like(val)
@@ -135,7 +147,7 @@ def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, su
     return w * invstd * (g - sum_g / total_count - xh * sum_gx / total_count)
 
 
-NAMES = ["colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -242,3 +242,28 @@ def test_fused_dropout_mask_consistency():
     assert torch.allclose(x.grad, xr.grad, atol=1e-4, rtol=1e-3)
     y2 = ops.bn_relu_dropout(x.detach(), bn, relu=True, p=p, training=True)
     assert not torch.equal(y2 != 0, y != 0)  # a fresh seed per call
+
+
+def test_sddmm_dot_and_fused_backward_direct(golden):
+    """The standalone SDDMM-dot kernel and the fused spmm_dot kernel against plain torch indexing."""
+    s, d, n = golden.graph("g300")
+    g = bot_amd.Graph(s, d, n, chunk=8).to(DEV)
+    E = s.numel()
+    gen = torch.Generator().manual_seed(6)
+    for H, D in ((3, 250), (1, 40), (2, 7), (1, 1100)):
+        x = torch.randn(n, H, D, generator=gen).to(DEV)
+        y = torch.randn(n, H, D, generator=gen).to(DEV)
+        a = torch.rand(E, H, generator=gen).to(DEV)
+        csc, csr = g.csc, g.csr
+        rows = torch.repeat_interleave(torch.arange(n, device=DEV), (csc.indptr[1:] - csc.indptr[:-1]).long())
+        ref = (x[csc.indices.long()] * y[rows]).sum(-1)
+        assert torch.allclose(_C.sddmm_dot(csc, x, y), ref, atol=1e-3 * D ** 0.5, rtol=1e-4)
+        if D <= _C.spmm_dot_max_d(x):
+            out, dot = _C.spmm_dot(csr, x, a, g.csr2csc, y)
+            rows_r = torch.repeat_interleave(torch.arange(n, device=DEV), (csr.indptr[1:] - csr.indptr[:-1]).long())
+            w = a[g.csr2csc.long()]
+            ref_out = torch.zeros(n, H, D, device=DEV).index_add_(0, rows_r, x[csr.indices.long()] * w.unsqueeze(-1))
+            ref_dot = torch.empty(E, H, device=DEV)
+            ref_dot[g.csr2csc.long()] = (x[csr.indices.long()] * y[rows_r]).sum(-1)
+            assert torch.allclose(out, ref_out, atol=1e-4, rtol=1e-4)
+            assert torch.allclose(dot, ref_dot, atol=1e-3 * D ** 0.5, rtol=1e-4)

@@ -74,6 +74,9 @@ def main():
         if not only or "copy" in only:
             ms, _ = timeit(lambda: _C.spmm(g.csc, x, None, None, out=out), args.iters)
             report(f"spmm copy_u_sum H={H} D={D}", ms, alg_0, gat)
+        if (not only or "fused" in only) and D <= _C.spmm_dot_max_d(x):
+            ms, _ = timeit(lambda: _C.spmm_dot(g.csr, x, a, g.csr2csc, y), args.iters)
+            report(f"spmm_dot fused bwd (CSR) H={H} D={D}", ms, 4 * (3 * n * F + E + n + 1 + 2 * E * H), gat + 4 * (n * F + 2 * E * H))
         if not only or "sddmm" in only:
             ms, _ = timeit(lambda: _C.sddmm_dot(g.csc, x, y), args.iters)
             report(f"sddmm_dot H={H} D={D}", ms, 4 * (2 * n * F + E + E * H), 4 * (E * F + n * F + E + E * H))
