@@ -34,7 +34,7 @@ _SIGS = {
     "bot_degrees_i64": (ctypes.c_int, [_P, c_int64, _P, _P]),
     "bot_spmm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "bot_spmm_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
-                                    c_int32, c_int32, _P, c_int64, c_int64, _P, _P]),
+                                    c_int32, c_int32, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P]),
     "bot_spmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                         _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P]),
     "bot_sddmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
@@ -161,10 +161,13 @@ def _slab(x, name):
     return x, x.stride(0), x.stride(1)
 
 
-def spmm(d, x, w=None, wperm=None, out=None):
-    """out[r,h,:] = sum_k w[wperm[k],h] * x[indices[k],h,:]   (w None: plain sum).  x: [n_src,H,D]."""
+def spmm(d, x, w=None, wperm=None, out=None, addend=None):
+    """out[r,h,:] = sum_k w[wperm[k],h] * x[indices[k],h,:] (+ addend[r,h,:])   (w None: plain sum).  x: [n_src,H,D]."""
     _dev(x, w, d.indptr)
     x, ldx, hsx = _slab(x, "x")
+    lda = hsa = 0
+    if addend is not None:
+        addend, lda, hsa = _slab(addend, "addend")
     H, D = x.shape[1], x.shape[2]
     if w is not None:
         _f32(w, "w")
@@ -181,7 +184,7 @@ def spmm(d, x, w=None, wperm=None, out=None):
     _check(_timed("spmm", (H, D, w is not None), lambda: _lib.bot_spmm_f32(
         d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
         _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, _ptr(w), _ptr(_i32(wperm, "wperm")), H, D, out.data_ptr(), ldo, hso,
-        _ptr(partial), _stream())), "spmm")
+        _ptr(addend), lda, hsa, _ptr(partial), _stream())), "spmm")
     return out
 
 
@@ -190,7 +193,7 @@ def spmm_dot_max_d(x):
     return 1024 if (x.shape[2] % 4 == 0 and x.stride(0) % 4 == 0) else (512 if x.shape[2] % 2 == 0 and x.stride(0) % 2 == 0 else 256)
 
 
-def spmm_dot(d, x, w, wperm, y):
+def spmm_dot(d, x, w, wperm, y, out=None):
     """Fused backward of u_mul_e_sum on direction `d`:  out[r,h,:] = sum_k w[wperm[k],h] x[indices[k],h,:]  and
     dot[wperm[k],h] = <y[r,h,:], x[indices[k],h,:]>.  Returns (out [n_rows,H,D], dot [nnz,H])."""
     _dev(x, w, y, d.indptr)
@@ -198,7 +201,10 @@ def spmm_dot(d, x, w, wperm, y):
     y, ldy, hsy = _slab(y, "y")
     H, D = x.shape[1], x.shape[2]
     w = _f32(w, "w").contiguous()
-    out = torch.empty((d.n_rows, H, D), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((d.n_rows, H, D), dtype=torch.float32, device=x.device)
+    out_, ldo, hso = _slab(out, "out")
+    assert out_ is out
     dot = torch.empty((d.nnz, H), dtype=torch.float32, device=x.device)
     partial = None
     if d.n_long:
@@ -206,7 +212,7 @@ def spmm_dot(d, x, w, wperm, y):
     _check(_timed("spmm_dot", (H, D), lambda: _lib.bot_spmm_dot_f32(
         d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
         _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, w.data_ptr(), _ptr(_i32(wperm, "wperm")), y.data_ptr(), ldy, hsy,
-        H, D, out.data_ptr(), out.stride(0), out.stride(1) if H > 1 else D, dot.data_ptr(), _ptr(partial), _stream())), "spmm_dot")
+        H, D, out.data_ptr(), ldo, hso, dot.data_ptr(), _ptr(partial), _stream())), "spmm_dot")
     return out, dot
 
 
@@ -352,12 +358,14 @@ def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed):
     return sg, sgx
 
 
-def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count):
-    """dx of the fused BatchNorm+ReLU+dropout; sum_g/sum_gx None = statistics were constants (eval mode)."""
+def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, out=None):
+    """dx of the fused BatchNorm+ReLU+dropout; sum_g/sum_gx None = statistics were constants (eval mode).
+    `out` may be a row-strided [n,F] view (e.g. a column slice of a wider gradient buffer)."""
     _dev(dy, x)
     dy, x = _mat(dy, "dy"), _mat(x, "x")
     n, F = x.shape
-    dx = torch.empty((n, F), dtype=torch.float32, device=x.device)
+    dx = out if out is not None else torch.empty((n, F), dtype=torch.float32, device=x.device)
+    assert dx.stride(1) == 1 and dx.dtype == torch.float32
     _check(_lib.bot_bn_act_bwd_apply_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, F, mean.data_ptr(),
                                          invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p), int(seed),
                                          _ptr(sum_g), _ptr(sum_gx), float(total_count), dx.data_ptr(), dx.stride(0), _stream()),

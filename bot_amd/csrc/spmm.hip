@@ -32,6 +32,9 @@ struct SpmmArgs {
     const float* y;
     int64_t ldy, hsy;
     float* dot_out;
+    // optional epilogue of the forward SpMM: out[r,h,:] += addend[r,h,:] (the layer's residual branch, models.py:558-560)
+    const float* addend;
+    int64_t lda, hsa;
 };
 
 // Reduce 4 values per lane across a LANES-wide group; on return lane l holds the total of value number l % 4.
@@ -229,15 +232,25 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs a) {
 
     float* ob = slot < 0 ? a.out + (int64_t)row * a.ldo + (int64_t)head * a.hso + doff
                          : a.partial + (int64_t)slot * a.ldp + (int64_t)head * a.D + doff;
+    const float* ab = (a.addend && slot < 0) ? a.addend + (int64_t)row * a.lda + (int64_t)head * a.hsa + doff : nullptr;
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
-        if (act[c]) vstore<VEC>(ob + off[c], acc[c]);
+        if (act[c]) {
+            if (ab) {
+                float r[VEC];
+                vload<VEC>(r, ab + off[c]);
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) acc[c][t] += r[t];
+            }
+            vstore<VEC>(ob + off[c], acc[c]);
+        }
 }
 
-// out[row,h,d] = partial[first slot] + ... + partial[last slot], in slot order.
+// out[row,h,d] = partial[first slot] + ... + partial[last slot] (+ addend), in slot order.
 __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(const int32_t* long_rows, const int32_t* long_ptr,
                                                              int64_t n_long, int32_t H, int32_t D, const float* partial,
-                                                             int64_t ldp, float* out, int64_t ldo, int64_t hso) {
+                                                             int64_t ldp, float* out, int64_t ldo, int64_t hso,
+                                                             const float* addend = nullptr, int64_t lda = 0, int64_t hsa = 0) {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t hd = (int64_t)H * D;
     if (gid >= n_long * hd) return;
@@ -246,6 +259,7 @@ __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(const int32_t* lon
     const int h = e / D, d = e - h * D;
     float s = 0.f;
     for (int p = long_ptr[i]; p < long_ptr[i + 1]; ++p) s += partial[(int64_t)p * ldp + e];
+    if (addend) s += addend[(int64_t)long_rows[i] * lda + (int64_t)h * hsa + d];
     out[(int64_t)long_rows[i] * ldo + (int64_t)h * hso + d] = s;
 }
 
@@ -303,7 +317,8 @@ int64_t bot_spmm_workspace_floats(int64_t n_slots, int32_t H, int32_t D) { retur
 int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz, const int32_t* items,
                  int64_t n_items, const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, const float* x,
                  int64_t ldx, int64_t hsx, const float* w, const int32_t* wperm, int32_t H, int32_t D, float* out,
-                 int64_t ldo, int64_t hso, float* partial, bot_stream_t stream) {
+                 int64_t ldo, int64_t hso, const float* addend, int64_t lda, int64_t hsa, float* partial,
+                 bot_stream_t stream) {
     using namespace bot;
     (void)indptr;
     BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_items >= 0 && n_long >= 0, BOT_E_RANGE, "spmm: negative size");
@@ -320,9 +335,10 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
                 (long long)hsx, (long long)ldo, (long long)hso, H, D);
     BOT_REQUIRE(aligned(x, 4) && aligned(out, 4) && aligned(items, 16), BOT_E_ALIGN, "spmm: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
+    BOT_REQUIRE(addend == nullptr || (hsa >= D && lda >= (int64_t)(H - 1) * hsa + D), BOT_E_RANGE, "spmm: addend strides smaller than the slab");
     SpmmArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, hsx, w, wperm, H, D, 1, out, ldo, hso, partial,
-               (int64_t)H * D, nullptr, 0, 0, nullptr};
-    const int vec = pick_vec(D, {ldx, hsx, ldo, hso}, {x, out, partial});
+               (int64_t)H * D, nullptr, 0, 0, nullptr, addend, lda, hsa};
+    const int vec = addend ? pick_vec(D, {ldx, hsx, ldo, hso, lda, hsa}, {x, out, partial, addend}) : pick_vec(D, {ldx, hsx, ldo, hso}, {x, out, partial});
     if (vec == 4) dispatch_spmm<4>(a, st);
     else if (vec == 2) dispatch_spmm<2>(a, st);
     else dispatch_spmm<1>(a, st);
@@ -330,7 +346,7 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
     if (n_long > 0) {
         const int64_t n = n_long * H * D;
         hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows,
-                           long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso);
+                           long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso, addend, lda, hsa);
         if (int rc = hip_status("spmm combine launch")) return rc;
     }
     return 0;
@@ -353,7 +369,7 @@ int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_ro
                     ldy >= (int64_t)(H - 1) * hsy + D, BOT_E_RANGE, "spmm_dot: strides smaller than the slab");
     hipStream_t st = (hipStream_t)stream;
     SpmmArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, hsx, w, wperm, H, D, 1, out, ldo, hso, partial,
-               (int64_t)H * D, y, ldy, hsy, dot_out};
+               (int64_t)H * D, y, ldy, hsy, dot_out, nullptr, 0, 0};
     const int vec = pick_vec(D, {ldx, hsx, ldo, hso, ldy, hsy}, {x, out, partial, y});
     BOT_REQUIRE(D <= vec * 256, BOT_E_RANGE, "spmm_dot: D=%d exceeds the %d floats one launch tile covers (use bot_spmm_f32 + bot_sddmm_dot_f32)",
                 D, vec * 256);
@@ -364,7 +380,7 @@ int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_ro
     if (n_long > 0) {
         const int64_t n = n_long * H * D;
         hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows,
-                           long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso);
+                           long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso, (const float*)nullptr, (int64_t)0, (int64_t)0);
         if (int rc = hip_status("spmm_dot combine launch")) return rc;
     }
     return 0;

@@ -331,11 +331,17 @@ class GAT(nn.Module):
                 self.biases.append(ElementWiseLinear(heads * fout, weight=False, bias=True))
         self.input_drop, self.dropout = nn.Dropout(input_drop), nn.Dropout(dropout)
         self.activation, self.residual = activation, residual
+        self.fuse_layers = True  # one autograd node per hidden layer when the options allow (bot_amd/nn/fused.py)
 
     def forward(self, graph, feat):
+        from . import fused
         h = self.input_drop(feat)
         h_last = None
         for i in range(self.n_layers):
+            if (self.fuse_layers and i < self.n_layers - 1 and len(self.norms) and h.is_cuda | fused.FORCE
+                    and fused.can_fuse(self.convs[i], self.norms[i], self.activation, graph, self.training, self.residual)):
+                h = fused.gat_hidden_layer(self.convs[i], self.norms[i], graph, h, self.dropout.p, self.training)
+                continue
             h = self.convs[i](graph, h)
             if i < self.n_layers - 1:
                 if self.residual and h_last is not None:

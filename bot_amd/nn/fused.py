@@ -1,0 +1,129 @@
+"""One autograd node for a hidden GAT layer of the reference stack — `GATConv.forward` (models.py:475-566) followed by
+`flatten -> BatchNorm1d -> relu -> dropout` (models.py:725-731) — arranged so that nothing of size N*H*D is touched
+more often than it has to be:
+
+  forward   ONE GEMM  h @ [W_fc ; W_res ; W_fc^T-folded attn_l ; attn_r]^T  ->  [ft | res | el | er]  (row-padded to x128:
+            the extra columns ride in tiles the GEMM pads to anyway), fused attention kernel, SpMM that reads `ft` in place
+            (strided slab) and adds `res` in its epilogue, column statistics, BatchNorm+ReLU+dropout in one pass.
+  backward  BN/ReLU/dropout backward writes dx straight into the `res` columns of the [N, P] gradient buffer; the fused
+            spmm_dot kernel (one gather) reads dx there and writes d ft into the `fc` columns; d el / d er go into theirs;
+            ONE GEMM each for dW_cat and dh.
+
+Versus the modular path this drops the skinny [N,K]x[K,H] score GEMMs, the separate residual GEMMs/adds and every
+slice/cat copy: 29.5 -> ~25 ms per step at BASELINE config 2.  Used by `bot_amd.nn.GAT` when the layer's options allow
+(`can_fuse`); the modular path (bot_amd.nn.GATConv + ops.bn_relu_dropout) stays the general fallback, and both are held to
+the same golden vectors.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _C
+from ..ops import bn_batch_stats, new_dropout_seed
+
+
+FORCE = False  # tests set this to run the fused node over the emulated (CPU) backend
+CALLS = 0      # number of fused-layer invocations (tests assert the path was actually taken)
+
+
+def can_fuse(conv, norm, activation, graph, training, stack_residual) -> bool:
+    return (isinstance(norm, nn.BatchNorm1d) and activation in (F.relu, torch.relu) and not stack_residual
+            and hasattr(conv, "fc") and not conv._use_symmetric_norm and conv._activation is None
+            and not (training and (conv.edge_drop > 0 or conv.feat_drop.p > 0))
+            and graph.halo is None and not graph.is_block and conv._out_feats <= 256)
+
+
+def cat_weight(conv):
+    """[W_fc ; W_res ; wl ; wr ; 0-pad] with wl[h] = W_fc[h]^T attn_l[h]  (so that h @ wl^T == <fc(h)[h], attn_l[h]>,
+    models.py:517,521).  Differentiable: the gradients reach fc.weight, res_fc.weight, attn_l, attn_r through these ops."""
+    H, D = conv._num_heads, conv._out_feats
+    W = conv.fc.weight
+    Wh = W.view(H, D, -1)
+    rows = [W]
+    if conv.res_fc is not None:
+        rows.append(conv.res_fc.weight)
+    rows.append((Wh * conv.attn_l.view(H, D, 1)).sum(1))
+    if conv.attn_r is not None:
+        rows.append((Wh * conv.attn_r.view(H, D, 1)).sum(1))
+    used = sum(r.shape[0] for r in rows)
+    pad = (-used) % 128
+    if pad:
+        rows.append(W.new_zeros(pad, W.shape[1]))
+    return torch.cat(rows)
+
+
+class _GATHidden(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, Wcat, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training):
+        N, HD = h.shape[0], H * D
+        csc = graph.csc
+        out = torch.mm(h, Wcat.t())                                     # [N, P] = [ft | res | el | er | pad]
+        ft = out[:, :HD].unflatten(1, (H, D))
+        c = 2 * HD if has_res else HD
+        el = out[:, c:c + H].contiguous()
+        er = out[:, c + H:c + 2 * H].contiguous() if has_er else None
+        a = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None)
+        amask = None
+        if attn_p > 0:                                                  # nn.Dropout on the attention weights (models.py:544)
+            amask = (torch.rand_like(a) >= attn_p).to(a.dtype).mul_(1.0 / (1.0 - attn_p))
+        a_d = a * amask if amask is not None else a
+        res = out[:, HD:2 * HD].unflatten(1, (H, D)) if has_res else None
+        x = _C.spmm(csc, ft, a_d, None, addend=res).view(N, HD)         # aggregation + residual (models.py:547-560)
+        mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
+        seed = new_dropout_seed(drop_p)
+        y = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
+        ctx.save_for_backward(h, Wcat, out, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b)
+        ctx.graph = graph
+        ctx.cfg = (H, D, has_res, has_er, slope, drop_p, seed, bn_training, sync, group, total)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        h, Wcat, out, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
+        H, D, has_res, has_er, slope, drop_p, seed, bn_training, sync, group, total = ctx.cfg
+        g = ctx.graph
+        N, HD, P = h.shape[0], H * D, Wcat.shape[0]
+        dy = dy.contiguous()
+        sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
+        d_bn_w, d_bn_b = sgx, sg                                         # local sums (ranks' parameter grads are summed later)
+        if bn_training and sync:
+            both = torch.stack([sg, sgx])
+            dist.all_reduce(both, group=group)
+            sg, sgx = both[0].contiguous(), both[1].contiguous()
+        dout = torch.empty((N, P), dtype=h.dtype, device=h.device)
+        dx = dout[:, HD:2 * HD] if has_res else torch.empty((N, HD), dtype=h.dtype, device=h.device)
+        _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
+                            sgx if bn_training else None, total, out=dx)
+        ft = out[:, :HD].unflatten(1, (H, D))
+        _, da = _C.spmm_dot(g.csr, dx.unflatten(1, (H, D)), a_d, g.csr2csc, ft, out=dout[:, :HD].unflatten(1, (H, D)))
+        if amask is not None:
+            da = da * amask
+        dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er)
+        c = 2 * HD if has_res else HD
+        dout[:, c:c + H] = _C.segment_sum(g.csr, dz, g.csr2csc)
+        if has_er:
+            dout[:, c + H:c + 2 * H] = der
+        used = c + (2 * H if has_er else H)
+        if used < P:
+            dout[:, used:].zero_()
+        dW = torch.mm(dout.t(), h) if ctx.needs_input_grad[1] else None
+        dh = torch.mm(dout, Wcat) if ctx.needs_input_grad[0] else None
+        return (dh, dW, d_bn_w if ctx.needs_input_grad[2] else None, d_bn_b if ctx.needs_input_grad[3] else None,
+                None, None, None, None, None, None, None, None, None, None)
+
+
+def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
+    """`dropout(relu(bn(conv(graph, h).flatten(1))))` as one autograd node.  h: [N, Fin] -> [N, H*D]."""
+    from . import has_zero_in_degree
+    if not conv._allow_zero_in_degree:
+        assert not has_zero_in_degree(graph), "0-in-degree nodes (models.py:477-479)"
+    global CALLS
+    CALLS += 1
+    H, D = conv._num_heads, conv._out_feats
+    bn_training = bn.training or not bn.track_running_stats
+    return _GATHidden.apply(h, cat_weight(conv), bn.weight if bn.affine else None, bn.bias if bn.affine else None, graph, bn,
+                            H, D, conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
+                            conv.attn_drop.p if training else 0.0, dropout_p if training else 0.0, bn_training)

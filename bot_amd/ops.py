@@ -211,34 +211,45 @@ def _dist_group(bn):
     return False, None
 
 
+def bn_batch_stats(x, bn, bn_training):
+    """Column statistics for the fused epilogue: (mean, invstd, total_count, sync, group); updates bn's running statistics
+    exactly like nn.BatchNorm1d (momentum, unbiased running variance).  In partitioned mode the (count, mean, M2) triples of
+    the ranks are merged with Chan et al.'s pairwise formula through two small all-reduces."""
+    import torch.distributed as dist
+    n = x.shape[0]
+    sync, group = _dist_group(bn)
+    total = float(n)
+    if not bn_training:
+        return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps), total, sync, group
+    mean, m2 = _C.colstats(x)
+    if sync:
+        pack = torch.cat([mean * n, mean.new_tensor([float(n)])])
+        dist.all_reduce(pack, group=group)
+        total = float(pack[-1].item())
+        gmean = pack[:-1] / total
+        m2 = m2 + n * (mean - gmean) ** 2
+        dist.all_reduce(m2, group=group)
+        mean = gmean
+    invstd = torch.rsqrt(m2 / total + bn.eps)
+    if bn.track_running_stats:
+        with torch.no_grad():
+            mom = 0.1 if bn.momentum is None else bn.momentum
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(m2 / max(total - 1.0, 1.0), alpha=mom)
+            bn.num_batches_tracked += 1
+    return mean, invstd, total, sync, group
+
+
+def new_dropout_seed(p):
+    """Seed of the Philox stream of one fused-dropout call, drawn from torch's CPU generator (so torch.manual_seed governs it)."""
+    return int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
+
+
 class _BNActDrop(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn, relu, p, bn_training):
-        import torch.distributed as dist
-        n, F = x.shape
-        sync, group = _dist_group(bn)
-        total = float(n)
-        if bn_training:
-            mean, m2 = _C.colstats(x)
-            if sync:  # Chan et al. pairwise combination of (count, mean, M2) across ranks, via two small all-reduces
-                pack = torch.cat([mean * n, mean.new_tensor([float(n)])])
-                dist.all_reduce(pack, group=group)
-                total = float(pack[-1].item())
-                gmean = pack[:-1] / total
-                m2 = m2 + n * (mean - gmean) ** 2
-                dist.all_reduce(m2, group=group)
-                mean = gmean
-            var = m2 / total
-            invstd = torch.rsqrt(var + bn.eps)
-            if bn.track_running_stats:
-                with torch.no_grad():
-                    mom = 0.1 if bn.momentum is None else bn.momentum
-                    bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                    bn.running_var.mul_(1 - mom).add_(m2 / max(total - 1.0, 1.0), alpha=mom)
-                    bn.num_batches_tracked += 1
-        else:
-            mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
-        seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
+        mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
+        seed = new_dropout_seed(p)
         y = _C.bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed)
         ctx.save_for_backward(x, mean, invstd, weight, bias)
         ctx.cfg = (relu, p, seed, bn_training, sync, group, total)

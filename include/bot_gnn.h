@@ -78,9 +78,10 @@ int bot_degrees_i64(const int32_t* indptr, int64_t n_rows, int64_t* deg, bot_str
  *        src/ogbn-proteins/models.py:146, src/ogbn-products/models.py:147), and serves as their
  *        backward on the transposed direction.
  *
- *   out[r,h,:] = sum_{k in row r} w[wperm[k],h] * x[indices[k],h,:]       (w == NULL: weight 1)
+ *   out[r,h,:] = sum_{k in row r} w[wperm[k],h] * x[indices[k],h,:]  (+ addend[r,h,:])     (w == NULL: weight 1)
  *
- * `partial` is caller-provided workspace of bot_spmm_workspace_floats(...) floats (may be NULL when
+ * `addend` (may be NULL; strides lda/hsa) is the fused epilogue for the layer's residual branch
+ * `rst = rst + res_fc(h)` (models.py:558-560).  `partial` is caller-provided workspace of bot_spmm_workspace_floats(...) floats (may be NULL when
  * the plan has no long rows).
  * ------------------------------------------------------------------------------------------- */
 int64_t bot_spmm_workspace_floats(int64_t n_slots, int32_t H, int32_t D);
@@ -91,6 +92,7 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
                  const float* w, const int32_t* wperm,
                  int32_t H, int32_t D,
                  float* out, int64_t ldo, int64_t hso,
+                 const float* addend, int64_t lda, int64_t hsa,
                  float* partial, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -24,11 +24,13 @@ def degrees(d):
     return (d.indptr[1:] - d.indptr[:-1]).to(torch.int64)
 
 
-def spmm(d, x, w=None, wperm=None, out=None):
+def spmm(d, x, w=None, wperm=None, out=None, addend=None):
     xs = x[d.indices.long()]
     if w is not None:
         xs = xs * w[_perm(wperm, d.nnz)].unsqueeze(-1)
     res = torch.zeros((d.n_rows,) + tuple(x.shape[1:]), dtype=x.dtype).index_add(0, _rows(d), xs)
+    if addend is not None:
+        res = res + addend
     if out is not None:
         out.copy_(res)
         return out
@@ -39,8 +41,12 @@ def spmm_dot_max_d(x):
     return 1024
 
 
-def spmm_dot(d, x, w, wperm, y):
-    out = spmm(d, x, w, wperm)
+def spmm_dot(d, x, w, wperm, y, out=None):
+    res = spmm(d, x, w, wperm)
+    if out is not None:
+        out.copy_(res)
+    else:
+        out = res
     val = (x[d.indices.long()] * y[_rows(d)]).sum(-1)
     dot = torch.empty_like(val)
     dot[_perm(wperm, d.nnz)] = val
@@ -138,13 +144,15 @@ def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed):
     return g.sum(0), (g * xh).sum(0)
 
 
-def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count):
+def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, out=None):
     xh, o = _bn_gate(x, mean, invstd, weight, bias, relu, p)
     g = torch.where(o > 0, dy, torch.zeros_like(dy)) if relu else dy
     w = weight if weight is not None else 1.0
-    if sum_g is None:
-        return w * invstd * g
-    return w * invstd * (g - sum_g / total_count - xh * sum_gx / total_count)
+    res = w * invstd * g if sum_g is None else w * invstd * (g - sum_g / total_count - xh * sum_gx / total_count)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 NAMES = ["spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",

@@ -250,12 +250,17 @@ def build_stack(kind, cfg, fin=11, C=5):
     return bnn.GAT(dim_node=fin, dim_edge=0, dim_output=C, activation=F.relu, **cfg)
 
 
-def check_stacks_golden(golden, device):
+def check_stacks_golden(golden, device, fuse=True):
+    """`fuse=True`: hidden GAT layers run as the single fused autograd node where their options allow
+    (bot_amd/nn/fused.py); `fuse=False`: the modular path everywhere.  Both must reproduce the reference."""
+    from bot_amd.nn import fused
+    calls0 = fused.CALLS
     for c in golden.cases("stacks"):
         gname, kind, training, cfg = (str(x) for x in c["meta"])
         cfg = ast.literal_eval(cfg)
         g = make_graph(golden, gname, device)
         model = load_params(build_stack(kind, cfg), c, device)
+        model.fuse_layers = fuse
         assert sum(p.numel() for p in model.parameters()) == int(c["n_params"])
         model.train(bool(int(training)))
         feat = leaf(c.t("feat"), device)
@@ -265,6 +270,7 @@ def check_stacks_golden(golden, device):
         grad_close(feat.grad, c["dfeat"], 3e-4)
         for k, p in model.named_parameters():
             grad_close(p.grad, c[f"g.{k}"], 3e-4)
+    assert (fused.CALLS - calls0 >= 8) if fuse else (fused.CALLS == calls0)
 
 
 # ---------------------------------------------------------------------------------------------- edge-feature GAT (config 4/5)

@@ -32,9 +32,9 @@ def test_library_exports_every_declared_symbol():
 def test_argument_validation_without_gpu():
     lib = _C._lib
     # H = 0 is rejected before any launch
-    rc = lib.bot_spmm_f32(None, None, 4, 0, None, 4, None, None, 0, None, 4, 4, None, None, 0, 4, None, 4, 4, None, None)
+    rc = lib.bot_spmm_f32(None, None, 4, 0, None, 4, None, None, 0, None, 4, 4, None, None, 0, 4, None, 4, 4, None, 0, 0, None, None)
     assert rc == -2 and b"H=0" in lib.bot_last_error()
-    rc = lib.bot_spmm_f32(None, None, 4, 0, None, 4, None, None, 0, None, 4, 4, None, None, 1, 4, None, 4, 4, None, None)
+    rc = lib.bot_spmm_f32(None, None, 4, 0, None, 4, None, None, 0, None, 4, 4, None, None, 1, 4, None, 4, 4, None, 0, 0, None, None)
     assert rc == -1 and b"NULL" in lib.bot_last_error()
     rc = lib.bot_segment_sum_f32(None, 3, 0, None, 0, 0, None, None, 1, None, None)
     assert rc == -2

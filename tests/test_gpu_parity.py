@@ -45,8 +45,9 @@ def test_dgl_surface(golden):
     PC.check_dgl_surface_matches_fused(golden, DEV)
 
 
-def test_stacks_golden(golden):
-    PC.check_stacks_golden(golden, DEV)
+@pytest.mark.parametrize("fuse", [False, True])
+def test_stacks_golden(golden, fuse):
+    PC.check_stacks_golden(golden, DEV, fuse=fuse)
 
 
 def test_determinism(golden):

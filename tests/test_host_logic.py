@@ -49,8 +49,11 @@ def test_dgl_surface(golden, cpu_backend):
     PC.check_dgl_surface_matches_fused(golden, "cpu")
 
 
-def test_stacks_golden(golden, cpu_backend):
-    PC.check_stacks_golden(golden, "cpu")
+@pytest.mark.parametrize("fuse", [False, True])
+def test_stacks_golden(golden, cpu_backend, monkeypatch, fuse):
+    from bot_amd.nn import fused
+    monkeypatch.setattr(fused, "FORCE", True)
+    PC.check_stacks_golden(golden, "cpu", fuse=fuse)
 
 
 def test_state_dict_keys_and_param_counts():
@@ -94,5 +97,9 @@ def test_copy_e_sum_preprocess(golden, cpu_backend):
     PC.check_copy_e_sum_preprocess(golden, "cpu")
 
 
-def test_train_step_golden(golden, cpu_backend):
+def test_train_step_golden(golden, cpu_backend, monkeypatch):
+    from bot_amd.nn import fused
+    monkeypatch.setattr(fused, "FORCE", True)  # the GAT cases go through the fused hidden-layer node
+    c0 = fused.CALLS
     PC.check_train_step_golden(golden, "cpu")
+    assert fused.CALLS > c0
