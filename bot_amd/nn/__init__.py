@@ -338,11 +338,17 @@ class GAT(nn.Module):
         h = self.input_drop(feat)
         h_last = None
         for i in range(self.n_layers):
-            if (self.fuse_layers and i < self.n_layers - 1 and len(self.norms) and h.is_cuda | fused.FORCE
-                    and fused.can_fuse(self.convs[i], self.norms[i], self.activation, graph, self.training, self.residual)):
-                h = fused.gat_hidden_layer(self.convs[i], self.norms[i], graph, h, self.dropout.p, self.training)
-                continue
-            h = self.convs[i](graph, h)
+            last = i == self.n_layers - 1
+            norm = None if last else (self.norms[i] if len(self.norms) else False)
+            if (self.fuse_layers and norm is not False and h.is_cuda | fused.FORCE
+                    and fused.can_fuse(self.convs[i], norm, self.activation, graph, self.training, self.residual)):
+                h = fused.gat_hidden_layer(self.convs[i], norm, graph, h, self.dropout.p, self.training)
+                if last:
+                    h = h.view(h.shape[0], self.convs[i]._num_heads, -1)
+                else:
+                    continue
+            else:
+                h = self.convs[i](graph, h)
             if i < self.n_layers - 1:
                 if self.residual and h_last is not None:
                     h = h + h_last

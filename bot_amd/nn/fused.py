@@ -29,8 +29,9 @@ CALLS = 0      # number of fused-layer invocations (tests assert the path was ac
 
 
 def can_fuse(conv, norm, activation, graph, training, stack_residual) -> bool:
-    return (isinstance(norm, nn.BatchNorm1d) and activation in (F.relu, torch.relu) and not stack_residual
-            and hasattr(conv, "fc") and not conv._use_symmetric_norm and conv._activation is None
+    """`norm` None = the layer has no BatchNorm/ReLU/dropout epilogue (the stack's output layer)."""
+    epilogue_ok = norm is None or (isinstance(norm, nn.BatchNorm1d) and activation in (F.relu, torch.relu) and not stack_residual)
+    return (epilogue_ok and hasattr(conv, "fc") and not conv._use_symmetric_norm and conv._activation is None
             and not (training and (conv.edge_drop > 0 or conv.feat_drop.p > 0))
             and graph.halo is None and not graph.is_block and conv._out_feats <= 256)
 
@@ -71,32 +72,44 @@ class _GATHidden(torch.autograd.Function):
         a_d = a * amask if amask is not None else a
         res = out[:, HD:2 * HD].unflatten(1, (H, D)) if has_res else None
         x = _C.spmm(csc, ft, a_d, None, addend=res).view(N, HD)         # aggregation + residual (models.py:547-560)
+        ctx.graph = graph
+        if bn is None:                                                  # output layer: no epilogue
+            ctx.save_for_backward(h, Wcat, out, el, er, a, amask, a_d)
+            ctx.cfg = (H, D, has_res, has_er, slope, None)
+            return x
         mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
         seed = new_dropout_seed(drop_p)
         y = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
         ctx.save_for_backward(h, Wcat, out, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b)
-        ctx.graph = graph
-        ctx.cfg = (H, D, has_res, has_er, slope, drop_p, seed, bn_training, sync, group, total)
+        ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         import torch.distributed as dist
-        h, Wcat, out, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
-        H, D, has_res, has_er, slope, drop_p, seed, bn_training, sync, group, total = ctx.cfg
+        H, D, has_res, has_er, slope, epi = ctx.cfg
         g = ctx.graph
-        N, HD, P = h.shape[0], H * D, Wcat.shape[0]
         dy = dy.contiguous()
-        sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
-        d_bn_w, d_bn_b = sgx, sg                                         # local sums (ranks' parameter grads are summed later)
-        if bn_training and sync:
-            both = torch.stack([sg, sgx])
-            dist.all_reduce(both, group=group)
-            sg, sgx = both[0].contiguous(), both[1].contiguous()
+        d_bn_w = d_bn_b = None
+        if epi is None:
+            h, Wcat, out, el, er, a, amask, a_d = ctx.saved_tensors
+        else:
+            h, Wcat, out, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
+            drop_p, seed, bn_training, sync, group, total = epi
+        N, HD, P = h.shape[0], H * D, Wcat.shape[0]
         dout = torch.empty((N, P), dtype=h.dtype, device=h.device)
         dx = dout[:, HD:2 * HD] if has_res else torch.empty((N, HD), dtype=h.dtype, device=h.device)
-        _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
-                            sgx if bn_training else None, total, out=dx)
+        if epi is None:
+            dx.copy_(dy)
+        else:
+            sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
+            d_bn_w, d_bn_b = sgx, sg                                     # local sums (ranks' parameter grads are summed later)
+            if bn_training and sync:
+                both = torch.stack([sg, sgx])
+                dist.all_reduce(both, group=group)
+                sg, sgx = both[0].contiguous(), both[1].contiguous()
+            _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
+                                sgx if bn_training else None, total, out=dx)
         ft = out[:, :HD].unflatten(1, (H, D))
         _, da = _C.spmm_dot(g.csr, dx.unflatten(1, (H, D)), a_d, g.csr2csc, ft, out=dout[:, :HD].unflatten(1, (H, D)))
         if amask is not None:
@@ -116,13 +129,18 @@ class _GATHidden(torch.autograd.Function):
 
 
 def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
-    """`dropout(relu(bn(conv(graph, h).flatten(1))))` as one autograd node.  h: [N, Fin] -> [N, H*D]."""
+    """`dropout(relu(bn(conv(graph, h).flatten(1))))` as one autograd node (bn None: just `conv(graph, h).flatten(1)`,
+    the stack's output layer).  h: [N, Fin] -> [N, H*D]."""
     from . import has_zero_in_degree
     if not conv._allow_zero_in_degree:
         assert not has_zero_in_degree(graph), "0-in-degree nodes (models.py:477-479)"
     global CALLS
     CALLS += 1
     H, D = conv._num_heads, conv._out_feats
+    if bn is None:
+        return _GATHidden.apply(h, cat_weight(conv), None, None, graph, None, H, D, conv.res_fc is not None,
+                                conv.attn_r is not None, conv.leaky_relu.negative_slope,
+                                conv.attn_drop.p if training else 0.0, 0.0, False)
     bn_training = bn.training or not bn.track_running_stats
     return _GATHidden.apply(h, cat_weight(conv), bn.weight if bn.affine else None, bn.bias if bn.affine else None, graph, bn,
                             H, D, conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
