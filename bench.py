@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; reported in config)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--gemm-tuning", default="file", choices=["file", "off"],
+                    help="file: hipBLASLt/rocBLAS kernel selections from bot_amd/tuning (TunableOp, read-only)")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the 1-D partitioned code path even with one rank (exercises the RCCL plumbing on a 1-GPU box)")
     return ap.parse_args()
@@ -105,8 +107,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import bot_amd
-    from bot_amd import _C, synth, train
+    from bot_amd import _C, synth, train, tuning
     from bot_amd import nn as bnn
+    tuned = tuning.enable() if args.gemm_tuning == "file" else False
 
     ds = synth.make_dataset(args.workload, device="cpu", seed=0, scale=args.scale)
     n, C = ds.graph.number_of_nodes(), ds.n_classes
@@ -187,6 +190,7 @@ def main():
             "config": {"workload": f"S-{args.workload}: power-law graph N={n} E={E} (raw {ds.raw_edges}), F={ds.feat.shape[1]}, "
                                    f"C={C}; GAT 3 layers x 3 heads x 250, --labels --loss=loge --linear --norm=batch, "
                                    f"dropout 0.75/0.25/0.1, RMSprop step included",
+                       "gemm_kernel_selection": "TunableOp file" if tuned else "library default",
                        "scale": args.scale, "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world}"},
             "roofline": roof, "cpu_baseline": cpu,
         }
