@@ -24,9 +24,10 @@ def enable(tune_missing: bool = False) -> bool:
         from torch.cuda import tunable
         tunable.enable(True)
         tunable.tuning_enable(bool(tune_missing))
-        tunable.write_file_on_exit(False)
-        if os.path.exists(FILE):
-            tunable.read_file(FILE)
-        return True
+        if hasattr(tunable, "write_file_on_exit"):
+            tunable.write_file_on_exit(False)
+        # whatever TunableOp writes at exit goes to scratch, never into the package directory
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"bot_amd_tunableop_{os.getpid()}.csv"))
+        return bool(tunable.read_file(FILE)) if os.path.exists(FILE) else False
     except Exception:  # noqa: BLE001 - optional optimisation only
         return False
