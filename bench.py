@@ -157,8 +157,8 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
 
-    # ---- roofline of the dominant kernel: weighted SpMM of the hidden layers (H=3, D=250), forward (CSC sweep)
-    # and transposed backward (CSR sweep) launches alike; HIP events recorded around each launch on the launch stream.
+    # ---- roofline of the dominant kernel: the weighted SpMM of the hidden layers (H=3, D=250; the CSC sweep of the
+    # forward pass), HIP events recorded around each launch on the launch stream inside the timed region.
     H, D = CFG["n_heads"], CFG["n_hidden"]
     durs = [e0.elapsed_time(e1) * 1e-3 for (name, key, e0, e1) in prof if name == "spmm" and key == (H, D, True)]
     roof = None
@@ -172,7 +172,7 @@ def main():
         tf = os.path.join(ROOT, "profiles", "spmm_traffic.json")
         if world == 1 and args.scale == 1.0 and os.path.exists(tf):
             traffic = json.load(open(tf)).get("bytes_per_launch")
-        roof = {"bound": "hbm", "kernel": "bot::spmm_kernel<2,64,2,true> (u_mul_e_sum H=3 D=250, fwd + transposed bwd)",
+        roof = {"bound": "hbm", "kernel": "bot::spmm_kernel<2,64,2,true> (u_mul_e_sum forward, H=3 D=250, hidden layers)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg * 1e3, 4),
                 "launches_timed": len(durs)}
