@@ -285,13 +285,15 @@ def segment_sum(d, vals, perm=None):
     return out
 
 
-def gather_rows(x, rows):
-    """out[i,:] = x[rows[i],:]   x: [n,F] float32 (row stride allowed), rows: int32."""
+def gather_rows(x, rows, out=None):
+    """out[i,:] = x[rows[i],:]   x: [n,F] float32 (row stride allowed), rows: int32; `out` may be row-strided."""
     _dev(x, rows)
     _f32(x, "x")
     if x.stride(1) != 1:
         x = x.contiguous()
-    out = torch.empty((rows.numel(), x.shape[1]), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((rows.numel(), x.shape[1]), dtype=torch.float32, device=x.device)
+    assert out.stride(1) == 1 and out.shape == (rows.numel(), x.shape[1])
     _check(_lib.bot_gather_rows_f32(x.data_ptr(), x.stride(0), _i32(rows, "rows").data_ptr(), rows.numel(), x.shape[1],
                                     out.data_ptr(), out.stride(0), _stream()), "gather_rows")
     return out

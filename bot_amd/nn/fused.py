@@ -33,7 +33,7 @@ def can_fuse(conv, norm, activation, graph, training, stack_residual) -> bool:
     epilogue_ok = norm is None or (isinstance(norm, nn.BatchNorm1d) and activation in (F.relu, torch.relu) and not stack_residual)
     return (epilogue_ok and hasattr(conv, "fc") and not conv._use_symmetric_norm and conv._activation is None
             and not (training and (conv.edge_drop > 0 or conv.feat_drop.p > 0))
-            and graph.halo is None and not graph.is_block and conv._out_feats <= 256)
+            and (graph.halo is not None or not graph.is_block) and conv._out_feats <= 256)
 
 
 def cat_weight(conv):
@@ -55,15 +55,59 @@ def cat_weight(conv):
     return torch.cat(rows)
 
 
+def _ext_width(HD, H):
+    """Row width of the halo-extended table [ft | el | pad]: keeps the slab's vector alignment."""
+    return HD + (H + 3) // 4 * 4
+
+
+def _extend_forward(graph, out, HD, H, c):
+    """Partitioned mode: build the source table [n_ext, W] = [ft | el] for owned + halo rows.  Owned rows are copied out of
+    the GEMM output, the rows other ranks need are packed by the row-gather kernel and exchanged with ONE all-to-all."""
+    import torch.distributed as dist
+    plan = graph.halo
+    n_own = out.shape[0]
+    W = _ext_width(HD, H)
+    ext = torch.empty((n_own + plan.n_halo, W), dtype=out.dtype, device=out.device)
+    ext[:n_own, :HD] = out[:, :HD]
+    ext[:n_own, HD:HD + H] = out[:, c:c + H]
+    if W > HD + H:
+        ext[:n_own, HD + H:].zero_()
+    send = _C.gather_rows(ext[:n_own], plan.send_rows) if plan.n_send else ext.new_empty((0, W))
+    dist.all_to_all_single(ext[n_own:], send, plan.recv_splits, plan.send_splits, group=plan.group)
+    return ext
+
+
+def _extend_backward(graph, dext, n_own):
+    """Reverse exchange: halo-row gradients go back to their owners and are added into the owned rows, peer by peer in
+    rank order (each peer's rows are sorted-unique: one writer per row, deterministic)."""
+    import torch.distributed as dist
+    plan = graph.halo
+    back = torch.empty((plan.n_send, dext.shape[1]), dtype=dext.dtype, device=dext.device)
+    dist.all_to_all_single(back, dext[n_own:], plan.send_splits, plan.recv_splits, group=plan.group)
+    own = dext[:n_own]
+    off = 0
+    for cnt in plan.send_splits:
+        if cnt:
+            _C.scatter_add_rows(own, plan.send_rows[off:off + cnt], back[off:off + cnt])
+        off += cnt
+    return own
+
+
 class _GATHidden(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, Wcat, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training):
         N, HD = h.shape[0], H * D
         csc = graph.csc
         out = torch.mm(h, Wcat.t())                                     # [N, P] = [ft | res | el | er | pad]
-        ft = out[:, :HD].unflatten(1, (H, D))
         c = 2 * HD if has_res else HD
-        el = out[:, c:c + H].contiguous()
+        ext = None
+        if graph.halo is not None:                                      # partitioned: owned + halo source rows
+            ext = _extend_forward(graph, out, HD, H, c)
+            ft = ext[:, :HD].unflatten(1, (H, D))
+            el = ext[:, HD:HD + H].contiguous()
+        else:
+            ft = out[:, :HD].unflatten(1, (H, D))
+            el = out[:, c:c + H].contiguous()
         er = out[:, c + H:c + 2 * H].contiguous() if has_er else None
         a = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None)
         amask = None
@@ -73,14 +117,15 @@ class _GATHidden(torch.autograd.Function):
         res = out[:, HD:2 * HD].unflatten(1, (H, D)) if has_res else None
         x = _C.spmm(csc, ft, a_d, None, addend=res).view(N, HD)         # aggregation + residual (models.py:547-560)
         ctx.graph = graph
+        keep = (h, Wcat, ext if ext is not None else out, el, er, a, amask, a_d)
         if bn is None:                                                  # output layer: no epilogue
-            ctx.save_for_backward(h, Wcat, out, el, er, a, amask, a_d)
+            ctx.save_for_backward(*keep)
             ctx.cfg = (H, D, has_res, has_er, slope, None)
             return x
         mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
         seed = new_dropout_seed(drop_p)
         y = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
-        ctx.save_for_backward(h, Wcat, out, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b)
+        ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
         ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
         return y
 
@@ -92,9 +137,9 @@ class _GATHidden(torch.autograd.Function):
         dy = dy.contiguous()
         d_bn_w = d_bn_b = None
         if epi is None:
-            h, Wcat, out, el, er, a, amask, a_d = ctx.saved_tensors
+            h, Wcat, table, el, er, a, amask, a_d = ctx.saved_tensors
         else:
-            h, Wcat, out, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
+            h, Wcat, table, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
             drop_p, seed, bn_training, sync, group, total = epi
         N, HD, P = h.shape[0], H * D, Wcat.shape[0]
         dout = torch.empty((N, P), dtype=h.dtype, device=h.device)
@@ -110,13 +155,28 @@ class _GATHidden(torch.autograd.Function):
                 sg, sgx = both[0].contiguous(), both[1].contiguous()
             _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
                                 sgx if bn_training else None, total, out=dx)
-        ft = out[:, :HD].unflatten(1, (H, D))
-        _, da = _C.spmm_dot(g.csr, dx.unflatten(1, (H, D)), a_d, g.csr2csc, ft, out=dout[:, :HD].unflatten(1, (H, D)))
+        c = 2 * HD if has_res else HD
+        halo = g.halo is not None
+        ft = table[:, :HD].unflatten(1, (H, D))
+        if halo:                                                        # gradients of the extended table [d ft | d el]
+            dext = torch.empty_like(table)
+            dft_dst = dext[:, :HD].unflatten(1, (H, D))
+        else:
+            dft_dst = dout[:, :HD].unflatten(1, (H, D))
+        _, da = _C.spmm_dot(g.csr, dx.unflatten(1, (H, D)), a_d, g.csr2csc, ft, out=dft_dst)
         if amask is not None:
             da = da * amask
         dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er)
-        c = 2 * HD if has_res else HD
-        dout[:, c:c + H] = _C.segment_sum(g.csr, dz, g.csr2csc)
+        d_el = _C.segment_sum(g.csr, dz, g.csr2csc)
+        if halo:
+            dext[:, HD:HD + H] = d_el
+            if dext.shape[1] > HD + H:
+                dext[:, HD + H:].zero_()
+            own = _extend_backward(g, dext, N)
+            dout[:, :HD] = own[:, :HD]
+            dout[:, c:c + H] = own[:, HD:HD + H]
+        else:
+            dout[:, c:c + H] = d_el
         if has_er:
             dout[:, c + H:c + 2 * H] = der
         used = c + (2 * H if has_er else H)

@@ -112,8 +112,12 @@ def segment_sum(d, vals, perm=None):
     return torch.zeros(d.n_rows, vals.shape[1]).index_add(0, _rows(d), vals[_perm(perm, d.nnz)])
 
 
-def gather_rows(x, rows):
-    return x[rows.long()].clone()
+def gather_rows(x, rows, out=None):
+    res = x[rows.long()].clone()
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def scatter_add_rows(x, rows, vals):

@@ -50,7 +50,7 @@ def test_partition_plan_invariants(golden):
                 off += cnt
 
 
-def _worker(rank, world, port, kind, tmp):
+def _worker(rank, world, port, kind, tmp, fuse=False):
     import torch.distributed as dist
     import torch.nn.functional as F
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -60,6 +60,8 @@ def _worker(rank, world, port, kind, tmp):
         from tests import _oracle_backend
         _oracle_backend.install_direct()
         import bot_amd
+        from bot_amd.nn import fused
+        fused.FORCE = fuse
         from bot_amd import dist as bdist
         from bot_amd import nn as bnn
         from bot_amd import train as T
@@ -77,6 +79,9 @@ def _worker(rank, world, port, kind, tmp):
             if kind == "gat":
                 return bnn.GAT(dim_node=fin + C, dim_edge=0, dim_output=C, n_hidden=6, n_layers=3, n_heads=2,
                                activation=F.relu, norm="batch", non_interactive_attn=True, use_symmetric_norm=True, linear=True)
+            if kind == "gat_plain":  # BASELINE config-2 options (no symmetric norm): eligible for the fused layer node
+                return bnn.GAT(dim_node=fin + C, dim_edge=0, dim_output=C, n_hidden=6, n_layers=3, n_heads=3,
+                               activation=F.relu, norm="batch", non_interactive_attn=True, linear=True)
             return bnn.GCN(in_feats=fin + C, n_classes=C, n_hidden=16, n_layers=3, activation=F.relu, norm="batch",
                            norm_adj="symm", use_linear=True)
 
@@ -91,7 +96,9 @@ def _worker(rank, world, port, kind, tmp):
         part.feat, part.labels = feat[part.lo:part.hi], labels[part.lo:part.hi]
         tr_own = tr[(tr >= part.lo) & (tr < part.hi)]
         part.train_idx = tr_own - part.lo
+        calls0 = fused.CALLS
         loss, pred = bdist.forward_backward(model, part, use_labels=True, loss="loge", n_classes=C, mask=mask_full[tr_own])
+        assert (fused.CALLS > calls0) == (fuse and kind == "gat_plain"), (fused.CALLS, calls0)
         assert abs(loss.item() - loss_ref.item()) < 1e-5, (loss.item(), loss_ref.item())
         np.testing.assert_allclose(pred.detach().numpy(), pred_ref.detach()[part.lo:part.hi].numpy(), rtol=1e-4, atol=1e-5)
         for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
@@ -103,7 +110,8 @@ def _worker(rank, world, port, kind, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world", [("gat", 2), ("gcn", 2), ("gat", 3)])
-def test_partitioned_step_matches_single_process(kind, world, tmp_path):
-    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("kind,world,fuse", [("gat", 2, False), ("gcn", 2, False), ("gat", 3, False), ("gat_plain", 2, True),
+                                             ("gat_plain", 3, True), ("gat_plain", 2, False)])
+def test_partitioned_step_matches_single_process(kind, world, fuse, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), fuse), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))

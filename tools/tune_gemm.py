@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Regenerate bot_amd/tuning/tunableop_gfx950.csv: time the hipBLASLt/rocBLAS candidates (PyTorch TunableOp) for every fp32
+GEMM shape of the config-2 train step — single GPU (N rows) and the per-rank row counts of the node-balanced 2/4/8-way
+partitions — and write the winners.  Run on an MI355X:  python tools/tune_gemm.py gpurun_out/tunableop_gfx950.csv
+"""
+import os
+import sys
+
+import torch
+from torch.cuda import tunable
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bot_amd import tuning  # noqa: E402
+
+out = sys.argv[1]
+tunable.enable(True)
+tunable.tuning_enable(True)
+tunable.set_filename(out)
+if os.path.exists(tuning.FILE):
+    tunable.read_file(tuning.FILE)
+tunable.set_max_tuning_iterations(30)
+tunable.set_max_tuning_duration(15)
+N = 169343
+rows = [N]
+for w in (2, 4, 8):
+    rows += sorted({(N * (k + 1) + w - 1) // w - (N * k + w - 1) // w for k in range(w)}, reverse=True)
+layers = [(168, 1536), (750, 1536), (750, 128)]  # (Fin, padded merged width) of the three GAT layers
+dev = "cuda"
+for n in rows:
+    for K, P in layers:
+        h = torch.randn(n, K, device=dev)
+        W = torch.randn(P, K, device=dev)
+        d = torch.randn(n, P, device=dev)
+        torch.mm(h, W.t())      # forward
+        torch.mm(d.t(), h)      # dW
+        torch.mm(d, W)          # dh
+        torch.cuda.synchronize()
+        print("tuned", n, K, P, flush=True)
+getattr(tunable, "write_file", lambda f: None)(out)  # older TunableOp: the file is written at exit
+print("results:", len(tunable.get_results()))
