@@ -47,6 +47,9 @@ _SIGS = {
     "bot_segment_sum_f32": (ctypes.c_int, [_P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, c_int32, _P, _P]),
     "bot_gather_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
     "bot_scatter_add_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
+    "bot_edge_mlp_workspace_floats": (c_int64, []),
+    "bot_edge_mlp_fwd_f32": (ctypes.c_int, [_P, c_int32, _P, _P, c_int32, _P, c_int32, c_int64, _P, _P]),
+    "bot_edge_mlp_bwd_f32": (ctypes.c_int, [_P, c_int32, _P, _P, c_int32, _P, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
     "bot_bn_workspace_floats": (c_int64, [c_int32]),
     "bot_colstats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
     "bot_bn_act_fwd_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, c_int64, _P]),
@@ -373,3 +376,32 @@ def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, su
                                          _ptr(sum_g), _ptr(sum_gx), float(total_count), dx.data_ptr(), dx.stride(0), _stream()),
            "bn_act_bwd_apply")
     return dx
+
+
+# ------------------------------------------------------------------------------------------------ fused edge MLP (ogbn-proteins)
+def edge_mlp_supported(I, J, H):
+    return I == 8 and J == 16 and 1 <= H <= 8
+
+
+def edge_mlp_fwd(ef, W1, b1, W2):
+    """ee[e,:] = W2 . relu(W1 . ef[e,:] + b1)   ef [E,8], W1 [16,8], b1 [16], W2 [H,16] -> [E,H]"""
+    _dev(ef, W1, b1, W2)
+    ef, W1, b1, W2 = (_f32(t, "edge_mlp operand").contiguous() for t in (ef, W1, b1, W2))
+    E, H = ef.shape[0], W2.shape[0]
+    out = torch.empty((E, H), dtype=torch.float32, device=ef.device)
+    _check(_lib.bot_edge_mlp_fwd_f32(ef.data_ptr(), ef.shape[1], W1.data_ptr(), b1.data_ptr(), W1.shape[0], W2.data_ptr(), H, E,
+                                     out.data_ptr(), _stream()), "edge_mlp_fwd")
+    return out
+
+
+def edge_mlp_bwd(ef, W1, b1, W2, dz):
+    """Weight gradients (dW1 [16,8], db1 [16], dW2 [H,16]) of edge_mlp_fwd for upstream dz [E,H]."""
+    _dev(ef, W1, b1, W2, dz)
+    ef, W1, b1, W2, dz = (_f32(t, "edge_mlp operand").contiguous() for t in (ef, W1, b1, W2, dz))
+    E, H = ef.shape[0], W2.shape[0]
+    dW1, db1, dW2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2)
+    ws = torch.empty(int(_lib.bot_edge_mlp_workspace_floats()), dtype=torch.float32, device=ef.device)
+    _check(_lib.bot_edge_mlp_bwd_f32(ef.data_ptr(), ef.shape[1], W1.data_ptr(), b1.data_ptr(), W1.shape[0], W2.data_ptr(), H,
+                                     dz.data_ptr(), E, dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), ws.data_ptr(), _stream()),
+           "edge_mlp_bwd")
+    return dW1, db1, dW2

@@ -1,0 +1,166 @@
+// Edge-feature attention term of the ogbn-proteins GAT, fused (gfx950).
+//
+// Reference, per layer (src/ogbn-proteins/models.py:244-248 and :130-133):
+//     emb  = relu(edge_encoder_i(efeat))        Linear(8 -> 16) + bias     [E,16]   (5 GB at E = 77.7 M)
+//     ee   = attn_edge_fc(emb)                  Linear(16 -> H), no bias    [E,H]
+// and `ee` is added to the attention logits.  Done with library ops that materialises [E,16] four times per layer per
+// step (forward, ReLU mask, two backward intermediates).  Here the 8->16->H MLP is evaluated per edge in registers:
+//
+//   edge_mlp_fwd : ee[e,:] = W2 . relu(W1 . ef[e,:] + b1)        reads 32 B, writes 4H B per edge, 224 FMAs
+//   edge_mlp_bwd : the three weight gradients are tiny GEMMs with K = E,
+//                      dW2^T[j,h] = sum_e r[e,j] * dz[e,h]          (16 x H)
+//                      [dW1 | db1][j,:] = sum_e du[e,j] * [ef[e,:] | 1]   (16 x 9),  du = (dz . W2) * [pre > 0]
+//                  run on the fp32 MFMA (v_mfma_f32_16x16x4_f32: one instruction folds 4 edges into a 16x16 accumulator
+//                  tile).  Lane l = (hidden unit j = l & 15, edge slot k = l >> 4) recomputes r and du for its (edge, unit)
+//                  with its row of W1 / column of W2 held in registers — exactly the A-operand layout of the instruction —
+//                  so nothing crosses lanes and nothing of size E x 16 ever exists in memory.  Per-wave accumulator tiles go
+//                  to a workspace and are summed in wave order (deterministic, no atomics).
+//
+// Edge features are consumed in CSC position order (permuted once per graph; they are constant inputs), so both kernels
+// stream with unit stride.  HBM roofline: fwd 4*E*(8+H) bytes, bwd 4*E*(8+H) bytes.
+#include "common.h"
+
+namespace bot {
+
+constexpr int kI = 8;    // raw edge features   (ogbn-proteins: 8)
+constexpr int kJ = 16;   // edge embedding      (ogbn-proteins/gat.py:83 edge_emb=16)
+constexpr int kMlpBlocks = 2048;
+
+template <int H>
+__global__ __launch_bounds__(kBlock) void edge_mlp_fwd_kernel(const float* __restrict__ ef, const float* __restrict__ W1,
+                                                             const float* __restrict__ b1, const float* __restrict__ W2,
+                                                             int64_t E, float* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += (int64_t)gridDim.x * kBlock) {
+        float f[kI];
+        vload<4>(*reinterpret_cast<float(*)[4]>(&f[0]), ef + e * kI);
+        vload<4>(*reinterpret_cast<float(*)[4]>(&f[4]), ef + e * kI + 4);
+        float r[kJ];
+#pragma unroll
+        for (int j = 0; j < kJ; ++j) {
+            float acc = b1[j];
+#pragma unroll
+            for (int i = 0; i < kI; ++i) acc = fmaf(W1[j * kI + i], f[i], acc);
+            r[j] = fmaxf(acc, 0.f);
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < kJ; ++j) v = fmaf(W2[h * kJ + j], r[j], v);
+            out[e * H + h] = v;
+        }
+    }
+}
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// part[wave][0][j][n] : dW2^T tile (n = head), part[wave][1][j][n] : [dW1 | db1] tile (n < 8: input i, n == 8: bias)
+__global__ __launch_bounds__(kBlock) void edge_mlp_bwd_kernel(const float* __restrict__ ef, const float* __restrict__ W1,
+                                                             const float* __restrict__ b1, const float* __restrict__ W2,
+                                                             const float* __restrict__ dz, int64_t E, int32_t H,
+                                                             float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, k = lane >> 4;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    float w1[kI], w2[8];
+#pragma unroll
+    for (int i = 0; i < kI; ++i) w1[i] = W1[j * kI + i];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) w2[h] = h < H ? W2[h * kJ + j] : 0.f;
+    const float bj = b1[j];
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t base = wave * 4; base < E; base += n_waves * 4) {
+        const int64_t e = base + k;
+        const bool live = e < E;
+        const int64_t ec = live ? e : E - 1;  // tail: re-read a valid edge, contributions zeroed below
+        float f[kI];
+        vload<4>(*reinterpret_cast<float(*)[4]>(&f[0]), ef + ec * kI);
+        vload<4>(*reinterpret_cast<float(*)[4]>(&f[4]), ef + ec * kI + 4);
+        float pre = bj, t = 0.f;
+#pragma unroll
+        for (int i = 0; i < kI; ++i) pre = fmaf(w1[i], f[i], pre);
+#pragma unroll
+        for (int h = 0; h < 8; ++h)
+            if (h < H) t = fmaf(dz[ec * H + h], w2[h], t);
+        const float r = live ? fmaxf(pre, 0.f) : 0.f;
+        const float du = (live && pre > 0.f) ? t : 0.f;
+        // B operands: column n = lane & 15 of this lane's edge slot
+        const float bz = (j < H) ? dz[ec * H + j] : 0.f;
+        const float bf = (j < kI) ? ef[ec * kI + j] : (j == kI ? 1.f : 0.f);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, bz, acc2, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(du, bf, acc1, 0, 0, 0);
+    }
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+    float* p = part + wave * 512;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = k * 4 + r;
+        p[row * 16 + j] = acc2[r];
+        p[256 + row * 16 + j] = acc1[r];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void edge_mlp_bwd_final_kernel(const float* part, int64_t n_waves, int32_t H, float* dW1,
+                                                                   float* db1, float* dW2) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;  // 0..511
+    if (t >= 512) return;
+    double s = 0.0;
+    for (int64_t w = 0; w < n_waves; ++w) s += (double)part[w * 512 + t];
+    const int which = t >> 8, row = (t & 255) >> 4, col = t & 15;  // row = hidden unit j
+    if (which == 0) {
+        if (col < H) dW2[col * kJ + row] = (float)s;
+    } else {
+        if (col < kI) dW1[row * kI + col] = (float)s;
+        else if (col == kI) db1[row] = (float)s;
+    }
+}
+
+}  // namespace bot
+
+extern "C" {
+
+int64_t bot_edge_mlp_workspace_floats(void) { return (int64_t)bot::kMlpBlocks * (bot::kBlock / 64) * 512; }
+
+int bot_edge_mlp_fwd_f32(const float* ef, int32_t I, const float* W1, const float* b1, int32_t J, const float* W2, int32_t H,
+                         int64_t n_edges, float* out, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(I == kI && J == kJ, BOT_E_RANGE, "edge_mlp: only the 8 -> 16 -> H shape of ogbn-proteins is fused (got %d -> %d)", I, J);
+    BOT_REQUIRE(H >= 1 && H <= 8 && n_edges >= 0, BOT_E_RANGE, "edge_mlp: H=%d n_edges=%lld", H, (long long)n_edges);
+    if (n_edges == 0) return 0;
+    BOT_REQUIRE(ef && W1 && b1 && W2 && out, BOT_E_NULL, "edge_mlp_fwd: NULL pointer");
+    BOT_REQUIRE(aligned(ef, 16), BOT_E_ALIGN, "edge_mlp_fwd: ef must be 16-byte aligned");
+    int64_t blocks = (n_edges + kBlock - 1) / kBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t st = (hipStream_t)stream;
+#define BOT_MLP_FWD(HH) hipLaunchKernelGGL((edge_mlp_fwd_kernel<HH>), dim3((unsigned)blocks), dim3(kBlock), 0, st, ef, W1, b1, W2, n_edges, out)
+    switch (H) {
+        case 1: BOT_MLP_FWD(1); break;
+        case 2: BOT_MLP_FWD(2); break;
+        case 3: BOT_MLP_FWD(3); break;
+        case 4: BOT_MLP_FWD(4); break;
+        case 5: BOT_MLP_FWD(5); break;
+        case 6: BOT_MLP_FWD(6); break;
+        case 7: BOT_MLP_FWD(7); break;
+        default: BOT_MLP_FWD(8); break;
+    }
+#undef BOT_MLP_FWD
+    return hip_status("edge_mlp_fwd launch");
+}
+
+int bot_edge_mlp_bwd_f32(const float* ef, int32_t I, const float* W1, const float* b1, int32_t J, const float* W2, int32_t H,
+                         const float* dz, int64_t n_edges, float* dW1, float* db1, float* dW2, float* workspace,
+                         bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(I == kI && J == kJ, BOT_E_RANGE, "edge_mlp: only the 8 -> 16 -> H shape of ogbn-proteins is fused (got %d -> %d)", I, J);
+    BOT_REQUIRE(H >= 1 && H <= 8 && n_edges >= 1, BOT_E_RANGE, "edge_mlp_bwd: H=%d n_edges=%lld", H, (long long)n_edges);
+    BOT_REQUIRE(ef && W1 && b1 && W2 && dz && dW1 && db1 && dW2 && workspace, BOT_E_NULL, "edge_mlp_bwd: NULL pointer");
+    BOT_REQUIRE(aligned(ef, 16), BOT_E_ALIGN, "edge_mlp_bwd: ef must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(kMlpBlocks), dim3(kBlock), 0, st, ef, W1, b1, W2, dz, n_edges, H, workspace);
+    hipLaunchKernelGGL(edge_mlp_bwd_final_kernel, dim3(2), dim3(kBlock), 0, st, workspace, (int64_t)kMlpBlocks * (kBlock / 64), H, dW1,
+                       db1, dW2);
+    return hip_status("edge_mlp_bwd launch");
+}
+
+}  // extern "C"

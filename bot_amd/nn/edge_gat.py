@@ -55,7 +55,9 @@ class GATConv(nn.Module):
     def set_allow_zero_in_degree(self, set_value):
         self._allow_zero_in_degree = set_value
 
-    def forward(self, graph, feat_src, feat_edge=None, keep=None):
+    def forward(self, graph, feat_src, feat_edge=None, keep=None, edge_encoder=None):
+        """`edge_encoder` (the stack's nn.Linear(8 -> 16)) given: `feat_edge` holds the RAW edge features and the
+        encoder + ReLU + attn_edge_fc run fused per edge (bot_amd.ops.edge_mlp); otherwise `feat_edge` is the embedding."""
         if not self._allow_zero_in_degree:
             assert not has_zero_in_degree(graph), "0-in-degree nodes (ogbn-proteins/models.py:89-91)"
         H, D = self._n_heads, self._out_feats
@@ -65,13 +67,18 @@ class GATConv(nn.Module):
         ft = graph.extend(self.src_fc(feat_src).view(-1, H, D))
         attn_src = graph.extend(self.attn_src_fc(feat_src).view(-1, H, 1))
         attn_dst = self.attn_dst_fc(feat_dst).view(-1, H, 1) if self.attn_dst_fc is not None else None
-        ee = self.attn_edge_fc(feat_edge).view(-1, H, 1) if feat_edge is not None else None
+        ee, ee_order = None, "eid"
+        if feat_edge is not None and edge_encoder is not None:
+            ee = ops.edge_mlp(graph, feat_edge, edge_encoder.weight, edge_encoder.bias, self.attn_edge_fc.weight).view(-1, H, 1)
+            ee_order = "csc"
+        elif feat_edge is not None:
+            ee = self.attn_edge_fc(feat_edge).view(-1, H, 1)
         if keep is None and self.training and self.edge_drop > 0:
             E = graph.number_of_edges()
             keep = torch.zeros(E, dtype=torch.uint8, device=graph.device)
             keep[torch.randperm(E, device=graph.device)[int(E * self.edge_drop):]] = 1
         a = ops.gat_attention(graph, attn_src, attn_dst, ee, keep=keep, negative_slope=self.leaky_relu.negative_slope,
-                              order="csc")
+                              order="csc", ee_order=ee_order)
         rst = ops.u_mul_e_sum(graph, ft, self.attn_drop(a), order="csc")
         if self._use_symmetric_norm:
             rst = rst * _bcast(degree_norm(graph, "in", 0.5), rst)
@@ -105,13 +112,24 @@ class _EdgeGAT(nn.Module):
         self.input_drop, self.dropout = nn.Dropout(input_drop), nn.Dropout(dropout)
         self.activation = activation
 
+    fuse_edge_mlp = True
+
+    def _fusable_edge_mlp(self, i, efeat):
+        from .. import _C
+        enc, conv = self.edge_encoder[i], self.convs[i]
+        return (self.fuse_edge_mlp and conv.attn_edge_fc is not None and not efeat.requires_grad and enc.bias is not None
+                and _C.edge_mlp_supported(enc.in_features, enc.out_features, conv._n_heads))
+
     def _body(self, g, h, residual):
         h = self.input_drop(h)
         h_last = None
         efeat = g.edata.get("feat") if self.edge_encoder is not None else None
         for i in range(self.n_layers):
-            emb = F.relu(self.edge_encoder[i](efeat), inplace=True) if efeat is not None else None
-            h = self.convs[i](g, h, emb).flatten(1, -1)
+            if efeat is not None and self._fusable_edge_mlp(i, efeat):
+                h = self.convs[i](g, h, efeat, edge_encoder=self.edge_encoder[i]).flatten(1, -1)  # f2: no [E,16] tensor exists
+            else:
+                emb = F.relu(self.edge_encoder[i](efeat), inplace=True) if efeat is not None else None
+                h = self.convs[i](g, h, emb).flatten(1, -1)
             if residual and h_last is not None:
                 h = h + h_last[: h.shape[0], :]
             h_last = h

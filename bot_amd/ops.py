@@ -137,18 +137,51 @@ def u_add_v(g, x, y):
     return _UAddV.apply(g, x, y)
 
 
+class _EdgeMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ef_csc, W1, b1, W2):
+        ctx.save_for_backward(ef_csc, W1, b1, W2)
+        return _C.edge_mlp_fwd(ef_csc, W1, b1, W2)
+
+    @staticmethod
+    def backward(ctx, dz):
+        ef_csc, W1, b1, W2 = ctx.saved_tensors
+        dW1, db1, dW2 = _C.edge_mlp_bwd(ef_csc, W1, b1, W2, dz.contiguous())
+        return None, dW1, db1, dW2
+
+
+def edge_features_csc(g, efeat):
+    """Edge features permuted once into CSC position order (they are constant inputs of the model)."""
+    cache = getattr(g, "_bot_cache", None)
+    if cache is None:
+        cache = g._bot_cache = {}
+    key = ("ef_csc", efeat.data_ptr(), efeat._version, tuple(efeat.shape))
+    if key not in cache:
+        cache[key] = efeat[g.csc.eid.long()].contiguous()
+    return cache[key]
+
+
+def edge_mlp(g, efeat, W1, b1, W2):
+    """`attn_edge_fc(relu(edge_encoder(efeat)))` of the ogbn-proteins layer (src/ogbn-proteins/models.py:244-248, :130-131)
+    evaluated per edge in registers; returns the logit term [E,H] in CSC position order (use with
+    `gat_attention(..., ee=..., ee_order="csc")`).  efeat [E,8] is an input (no gradient), W1 [16,8], b1 [16], W2 [H,16]."""
+    return _EdgeMLP.apply(edge_features_csc(g, efeat), W1, b1, W2)
+
+
 class _GatAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, g, el, er, ee, keep, slope, order):
+    def forward(ctx, g, el, er, ee, keep, slope, order, ee_csc=False):
         csc = g.csc
         H = (el if el is not None else ee).reshape((el if el is not None else ee).shape[0], -1).shape[1]
         el2 = None if el is None else el.reshape(-1, H)
         er2 = None if er is None else er.reshape(-1, H)
         ee2 = None if ee is None else ee.reshape(-1, H)
         aperm = csc.eid if order == "eid" else None
-        eperm = csc.eid if (ee is not None or keep is not None) else None
+        if ee_csc and keep is not None:  # one permutation serves both edge-indexed inputs: bring the mask to CSC order too
+            keep = keep[csc.eid.long()].contiguous()
+        eperm = csc.eid if ((ee is not None or keep is not None) and not ee_csc) else None
         a = _C.gat_attn_fwd(csc, el2, er2, ee2, eperm, keep, slope, H, aperm)
-        ctx.g, ctx.slope, ctx.order, ctx.H = g, slope, order, H
+        ctx.g, ctx.slope, ctx.order, ctx.H, ctx.ee_csc = g, slope, order, H, ee_csc
         ctx.shapes = tuple(None if t is None else t.shape for t in (el, er, ee))
         ctx.save_for_backward(el2, er2, ee2, a)
         return a.view(-1, H, 1)
@@ -159,9 +192,9 @@ class _GatAttention(torch.autograd.Function):
         csc, csr = g.csc, g.csr
         el2, er2, ee2, a = ctx.saved_tensors
         aperm = csc.eid if ctx.order == "eid" else None
-        eperm = csc.eid if ee2 is not None else None
+        eperm = csc.eid if (ee2 is not None and not ctx.ee_csc) else None
         # dz is written in edge-id order when something edge-indexed consumes it, else CSC position order
-        z_eid = ee2 is not None
+        z_eid = ee2 is not None and not ctx.ee_csc
         dz, der = _C.gat_attn_bwd(csc, el2, er2, ee2, eperm, ctx.slope, H, a, da.reshape(-1, H), aperm,
                                   csc.eid if z_eid else None, er2 is not None)
         d_el = d_er = d_ee = None
@@ -171,18 +204,19 @@ class _GatAttention(torch.autograd.Function):
             d_er = der.view(ctx.shapes[1])
         if ee2 is not None and ctx.needs_input_grad[3]:
             d_ee = dz.view(ctx.shapes[2])
-        return None, d_el, d_er, d_ee, None, None, None
+        return None, d_el, d_er, d_ee, None, None, None, None
 
 
-def gat_attention(g, el=None, er=None, ee=None, *, keep=None, negative_slope=0.2, order="eid"):
+def gat_attention(g, el=None, er=None, ee=None, *, keep=None, negative_slope=0.2, order="eid", ee_order="eid"):
     """Attention weights of one GAT layer in a single sweep over the in-edges (models.py:517-544):
 
         z_e = el[src] (+ er[dst]) (+ ee_e);  a = softmax over in-edges of leaky_relu(z, negative_slope)
 
     el, er: [N,H,1]; ee: [E,H,1] in edge-id order; keep: optional uint8 [E] in edge-id order — edges
     with keep == 0 are excluded from the softmax and get a == 0 (the edge-drop branch, models.py:528-539).
+    `ee_order="csc"`: `ee` is already in CSC position order (what `edge_mlp` returns).
     Returns a [E,H,1] in edge-id order (order="eid") or CSC position order (order="csc")."""
-    return _GatAttention.apply(g, el, er, ee, keep, float(negative_slope), order)
+    return _GatAttention.apply(g, el, er, ee, keep, float(negative_slope), order, ee_order == "csc")
 
 
 def edge_softmax(graph, logits, eids=None, norm_by="dst"):

@@ -229,6 +229,23 @@ int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int6
                              int32_t relu, float p, uint64_t seed, const float* sum_g, const float* sum_gx,
                              double total_count, float* dx, int64_t lddx, bot_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Edge-feature attention term of the ogbn-proteins GAT, fused.  Replaces, per layer,
+ *   efeat_emb = relu(edge_encoder[i](efeat))                 src/ogbn-proteins/models.py:244-248
+ *   attn_edge = attn_edge_fc(efeat_emb)                      src/ogbn-proteins/models.py:130-131
+ * and their autograd:   ee[e,:] = W2 . relu(W1 . ef[e,:] + b1),   ef [E,I], W1 [J,I], b1 [J], W2 [H,J].
+ * Only the reference's shape I = 8, J = 16 (H <= 8) is implemented (BOT_E_RANGE otherwise; callers fall back to
+ * library ops).  `ef` and `ee`/`dz` are in the SAME edge order (the layers use CSC position order).  The backward
+ * returns the three weight gradients (the edge features are inputs, not parameters); it runs the K = E reductions
+ * on the fp32 MFMA and sums per-wavefront tiles in a fixed order.  workspace: bot_edge_mlp_workspace_floats().
+ * ------------------------------------------------------------------------------------------- */
+int64_t bot_edge_mlp_workspace_floats(void);
+int bot_edge_mlp_fwd_f32(const float* ef, int32_t I, const float* W1, const float* b1, int32_t J, const float* W2,
+                         int32_t H, int64_t n_edges, float* ee, bot_stream_t stream);
+int bot_edge_mlp_bwd_f32(const float* ef, int32_t I, const float* W1, const float* b1, int32_t J, const float* W2,
+                         int32_t H, const float* dz, int64_t n_edges, float* dW1, float* db1, float* dW2,
+                         float* workspace, bot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,7 +159,22 @@ def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, su
     return res
 
 
-NAMES = ["spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+def edge_mlp_supported(I, J, H):
+    return I == 8 and J == 16 and 1 <= H <= 8
+
+
+def edge_mlp_fwd(ef, W1, b1, W2):
+    return torch.relu(ef @ W1.t() + b1) @ W2.t()
+
+
+def edge_mlp_bwd(ef, W1, b1, W2, dz):
+    pre = ef @ W1.t() + b1
+    r = torch.relu(pre)
+    du = (dz @ W2) * (pre > 0)
+    return du.t() @ ef, du.sum(0), dz.t() @ r
+
+
+NAMES = ["edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -299,13 +299,14 @@ def check_proteins_golden(golden, device):
         for k, p in conv.named_parameters():
             grad_close(p.grad, c[f"g.{k}"])
     f = golden.file("proteins")
-    for training in (0, 1):
+    for training, fuse in ((0, True), (1, True), (0, False), (1, False)):  # fused per-edge MLP kernels / library ops
         pre = f"s{training}."
         c = Case({k[len(pre):]: v for k, v in f.items() if k.startswith(pre)})
         g = make_graph(golden, "g64", device)
         model = edge_gat.ProteinsGAT(node_feats=9, edge_feats=8, n_classes=6, n_layers=2, n_heads=2, n_hidden=5, edge_emb=16,
                                      activation=F.relu, dropout=0.0, input_drop=0.0, attn_drop=0.0, edge_drop=0.0)
         model = load_params(model, c, device).train(bool(training))
+        model.fuse_edge_mlp = fuse
         assert sum(p.numel() for p in model.parameters()) == int(c["n_params"])
         g.ndata["feat"], g.edata["feat"] = c.t("nfeat").to(device), c.t("efeat").to(device)
         logits = model(g)
