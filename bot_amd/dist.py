@@ -57,7 +57,7 @@ class _HaloExchange(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_own, plan):
         n_own = x_own.shape[0]
-        x2 = x_own.reshape(n_own, -1)
+        x2 = x_own.reshape(n_own, x_own[0].numel() if n_own else int(torch.tensor(x_own.shape[1:]).prod()))
         F = x2.shape[1]
         ext = torch.empty((n_own + plan.n_halo, F), dtype=x2.dtype, device=x2.device)
         ext[:n_own] = x2

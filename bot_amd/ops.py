@@ -31,12 +31,23 @@ def _as3(x):
         return x.unsqueeze(1)
     if x.dim() == 3:
         return x
-    return x.reshape(x.shape[0], 1, -1)
+    return _flat2(x).unsqueeze(1)
+
+
+def _flat2(t):
+    """[n, ...] -> [n, prod(rest)] with an explicit width (n may be 0)."""
+    w = 1
+    for s in t.shape[1:]:
+        w *= int(s)
+    return t.reshape(t.shape[0], w)
 
 
 def _edge2(a, H=None):
-    """[E,H,1] / [E,H] / [E] -> [E,H]."""
-    return a.reshape(a.shape[0], -1)
+    """[E,H,1] / [E,H] / [E] -> [E,H]  (explicit width: E may be 0)."""
+    w = 1
+    for s in a.shape[1:]:
+        w *= int(s)
+    return a.reshape(a.shape[0], w)
 
 
 class _CopyUSum(torch.autograd.Function):
@@ -100,7 +111,7 @@ class _CopyESum(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         g = ctx.g
-        return None, _C.u_add_v(g.dst32, None, dout.reshape(dout.shape[0], -1).contiguous()).view(ctx.shape)
+        return None, _C.u_add_v(g.dst32, None, _flat2(dout).contiguous()).view(ctx.shape)
 
 
 def copy_e_sum(g, w):
@@ -114,14 +125,14 @@ class _UAddV(torch.autograd.Function):
         ctx.g, ctx.xshape = g, x.shape
         ctx.has_y = y is not None
         ctx.yshape = y.shape if ctx.has_y else None
-        x2 = x.reshape(x.shape[0], -1)
-        y2 = None if y is None else y.reshape(y.shape[0], -1)
+        x2 = _flat2(x)
+        y2 = None if y is None else _flat2(y)
         return _C.u_add_v(g.src32, g.dst32 if ctx.has_y else None, x2, y2).view((g.number_of_edges(),) + tuple(x.shape[1:]))
 
     @staticmethod
     def backward(ctx, de):
         g = ctx.g
-        de2 = de.reshape(de.shape[0], -1).contiguous()
+        de2 = _flat2(de).contiguous()
         dx = _C.segment_sum(g.csr, de2, g.csr.eid).view(ctx.xshape) if ctx.needs_input_grad[1] else None
         dy = _C.segment_sum(g.csc, de2, g.csc.eid).view(ctx.yshape) if ctx.has_y and ctx.needs_input_grad[2] else None
         return None, dx, dy
@@ -172,7 +183,7 @@ class _GatAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, el, er, ee, keep, slope, order, ee_csc=False):
         csc = g.csc
-        H = (el if el is not None else ee).reshape((el if el is not None else ee).shape[0], -1).shape[1]
+        H = _flat2(el if el is not None else ee).shape[1]
         el2 = None if el is None else el.reshape(-1, H)
         er2 = None if er is None else er.reshape(-1, H)
         ee2 = None if ee is None else ee.reshape(-1, H)

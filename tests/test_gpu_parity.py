@@ -289,3 +289,46 @@ def test_edge_mlp_kernels(H):
         assert torch.allclose(dW1, W1.grad, atol=2e-5 * scale, rtol=1e-4)
         assert torch.allclose(db1, b1.grad, atol=2e-5 * scale, rtol=1e-4)
         assert torch.allclose(dW2, W2.grad, atol=2e-5 * scale, rtol=1e-4)
+
+
+def test_edge_cases():
+    """Empty graphs, isolated nodes, single node, degree == chunk and chunk + 1, many heads, D = 1, D beyond one launch tile."""
+    # no edges at all
+    g = bot_amd.Graph(torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), 7).to(DEV)
+    assert g.in_degrees().tolist() == [0] * 7 and g.out_degrees().tolist() == [0] * 7
+    x = torch.randn(7, 2, 5, device=DEV, requires_grad=True)
+    out = ops.copy_u_sum(g, x)
+    assert torch.all(out == 0)
+    out.sum().backward()
+    assert torch.all(x.grad == 0)
+    a = ops.gat_attention(g, torch.randn(7, 2, 1, device=DEV), torch.randn(7, 2, 1, device=DEV), order="csc")
+    assert a.shape == (0, 2, 1)
+    assert torch.all(ops.u_mul_e_sum(g, x, a, order="csc") == 0)
+    # single node with a self loop
+    g1 = bot_amd.Graph(torch.tensor([0]), torch.tensor([0]), 1).to(DEV)
+    x1 = torch.randn(1, 3, 4, device=DEV)
+    a1 = ops.gat_attention(g1, torch.randn(1, 3, 1, device=DEV), None, order="csc")
+    assert torch.allclose(a1, torch.ones_like(a1)) and torch.allclose(ops.u_mul_e_sum(g1, x1, a1, order="csc"), x1)
+    # star + isolated nodes, degrees straddling the chunk size
+    gen = torch.Generator().manual_seed(3)
+    chunk = 16
+    for hub_deg in (chunk - 1, chunk, chunk + 1, 5 * chunk + 3):
+        n = hub_deg + 5
+        src = torch.arange(1, hub_deg + 1)
+        dst = torch.zeros(hub_deg, dtype=torch.int64)
+        g = bot_amd.Graph(src, dst, n, chunk=chunk).to(DEV)
+        for H, D in ((8, 3), (1, 1), (2, 1100)):
+            x = torch.randn(n, H, D, generator=gen)
+            el = torch.randn(n, H, 1, generator=gen)
+            gout = torch.randn(n, H, D, generator=gen)
+            xo, lo = PC.leaf(x), PC.leaf(el)
+            e = torch.nn.functional.leaky_relu(R.copy_u(src, lo), 0.2)
+            ref = R.u_mul_e_sum(src, dst, n, xo, R.edge_softmax(dst, n, e))
+            (ref * gout).sum().backward()
+            xt, lt = PC.leaf(x, DEV), PC.leaf(el, DEV)
+            out = ops.u_mul_e_sum(g, xt, ops.gat_attention(g, lt, None, order="csc"), order="csc")
+            (out * gout.to(DEV)).sum().backward()
+            PC.fwd_close(out, ref.detach().numpy(), 1e-5)
+            PC.grad_close(xt.grad, xo.grad.numpy())
+            PC.grad_close(lt.grad, lo.grad.numpy())
+            assert torch.all(out[1:] == 0)  # nodes without in-edges aggregate nothing
