@@ -37,6 +37,10 @@ _SIGS = {
                                     c_int32, c_int32, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P]),
     "bot_spmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                         _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P]),
+    "bot_spmm_bcast_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, _P, _P, c_int32,
+                                          c_int32, _P, c_int64, c_int64, _P, _P]),
+    "bot_spmm_dot_bcast_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P,
+                                              _P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     "bot_sddmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                          c_int32, c_int32, _P, _P, c_int32, _P]),
     "bot_sddmm_u_add_v_f32": (ctypes.c_int, [_P, _P, c_int64, _P, _P, c_int32, _P, _P]),
@@ -216,6 +220,56 @@ def spmm_dot(d, x, w, wperm, y, out=None):
         d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
         _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, w.data_ptr(), _ptr(_i32(wperm, "wperm")), y.data_ptr(), ldy, hsy,
         H, D, out.data_ptr(), ldo, hso, dot.data_ptr(), _ptr(partial), _stream())), "spmm_dot")
+    return out, dot
+
+
+def spmm_bcast(d, x, w, wperm=None, head_outer=True):
+    """out[r,h,:] = sum_k w[wperm[k],h] * x[indices[k],:]   x: [n_src, D] (row stride allowed), w: [nnz, H<=4].
+    Returns [H, n_rows, D] (head_outer, the batched-GEMM layout) or [n_rows, H, D]."""
+    _dev(x, w, d.indptr)
+    _f32(x, "x")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    w = _f32(w, "w").contiguous()
+    H, D = w.shape[1], x.shape[1]
+    if head_outer:
+        out = torch.empty((H, d.n_rows, D), dtype=torch.float32, device=x.device)
+        ldo, hso = D, d.n_rows * D
+    else:
+        out = torch.empty((d.n_rows, H, D), dtype=torch.float32, device=x.device)
+        ldo, hso = H * D, D
+    partial = None
+    if d.n_long:
+        partial = torch.empty(int(_lib.bot_spmm_workspace_floats(d.n_slots, H, D)), dtype=torch.float32, device=x.device)
+    _check(_timed("spmm_bcast", (H, D), lambda: _lib.bot_spmm_bcast_f32(
+        d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
+        _ptr(d.long_ptr), d.n_long, x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(_i32(wperm, "wperm")), H, D, out.data_ptr(),
+        ldo, hso, _ptr(partial), _stream())), "spmm_bcast")
+    return out
+
+
+def spmm_dot_bcast(d, x, w, wperm, y, out=None):
+    """Backward of spmm_bcast on direction `d`: x [H, n, D] head-outer (gradient of the aggregated slab), y [n_rows, D] the
+    layer input.  Returns (out [n_rows, D] = sum_k sum_h w x, dot [nnz, H] = <y[r], x[indices[k],h]>); `out` may be a
+    row-strided [n_rows, D] view."""
+    _dev(x, w, y, d.indptr)
+    _f32(x, "x"), _f32(y, "y")
+    assert x.dim() == 3 and x.is_contiguous()
+    if y.stride(1) != 1:
+        y = y.contiguous()
+    H, n, D = x.shape
+    w = _f32(w, "w").contiguous()
+    if out is None:
+        out = torch.empty((d.n_rows, D), dtype=torch.float32, device=x.device)
+    assert out.stride(1) == 1 and out.shape == (d.n_rows, D)
+    dot = torch.empty((d.nnz, H), dtype=torch.float32, device=x.device)
+    partial = None
+    if d.n_long:
+        partial = torch.empty(int(_lib.bot_spmm_workspace_floats(d.n_slots, 1, D)), dtype=torch.float32, device=x.device)
+    _check(_timed("spmm_dot_bcast", (H, D), lambda: _lib.bot_spmm_dot_bcast_f32(
+        d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
+        _ptr(d.long_ptr), d.n_long, x.data_ptr(), D, n * D, w.data_ptr(), _ptr(_i32(wperm, "wperm")), y.data_ptr(), y.stride(0),
+        H, D, out.data_ptr(), out.stride(0), dot.data_ptr(), _ptr(partial), _stream())), "spmm_dot_bcast")
     return out, dot
 
 

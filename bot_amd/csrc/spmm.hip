@@ -263,6 +263,220 @@ __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(const int32_t* lon
     out[(int64_t)long_rows[i] * ldo + (int64_t)h * hso + d] = s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Aggregate-before-project forms ("aggregate first then mult W" is what GraphConv already does when the input is
+// narrower than the output, models.py:377-385; the same reordering for GAT: sum_e a[e,h] (W_h x[u]) = W_h (sum_e a[e,h] x[u])).
+// The source row x[u,:] has NO head axis and is gathered ONCE per edge for all H heads:
+//   spmm_bcast     out[r,h,:]          = sum_k w[wperm[k],h] * x[indices[k],:]
+//   spmm_dot_bcast out[r,:]            = sum_k sum_h w[wperm[k],h] * x[indices[k],h,:]      (backward: d of the source rows)
+//                  dot_out[wperm[k],h] = < y[r,:] , x[indices[k],h,:] >                      (backward: d of the weights)
+// At BASELINE config 2, layer 0 (168 -> 3 x 250) this gathers 672 B per edge forward and 2 016 B backward instead of
+// 3 000 B + 3 000 B, and in partitioned mode shrinks that layer's halo rows by the same 4.5x.
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int LANES, int NCHUNK, int HB>
+__global__ __launch_bounds__(kBlock) void spmm_bcast_kernel(SpmmArgs a) {
+    constexpr int U = 4;
+    const int lane = threadIdx.x % LANES;
+    const int64_t item = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+    if (item >= a.n_items) return;
+    const int4 it = a.items[item];
+    int row = it.x, beg = it.y, end = it.z, slot = it.w;
+    if constexpr (LANES == 64) {
+        row = __builtin_amdgcn_readfirstlane(row);
+        beg = __builtin_amdgcn_readfirstlane(beg);
+        end = __builtin_amdgcn_readfirstlane(end);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+    }
+    int off[NCHUNK];
+    bool act[NCHUNK];
+    float acc[HB][NCHUNK][VEC];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int e = (c * LANES + lane) * VEC;
+        act[c] = e < a.D;
+        off[c] = act[c] ? e : 0;
+#pragma unroll
+        for (int h = 0; h < HB; ++h)
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) acc[h][c][t] = 0.f;
+    }
+    for (int k0 = beg; k0 < end; k0 += LANES) {
+        const int k = k0 + lane;
+        int idx = 0;
+        float wv[HB];
+#pragma unroll
+        for (int h = 0; h < HB; ++h) wv[h] = 0.f;
+        if (k < end) {
+            idx = a.indices[k];
+            const int wp = a.wperm ? a.wperm[k] : k;
+#pragma unroll
+            for (int h = 0; h < HB; ++h) wv[h] = a.w[(int64_t)wp * HB + h];
+        }
+        const int cnt = min(LANES, end - k0);
+        for (int i = 0; i < cnt; i += U) {
+            float v[U][NCHUNK][VEC], ww[U][HB];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = min(i + u, cnt - 1);
+                const int s = group_bcast<LANES>(idx, j);
+#pragma unroll
+                for (int h = 0; h < HB; ++h) ww[u][h] = i + u < cnt ? group_bcast<LANES>(wv[h], j) : 0.f;
+                const float* px = a.x + (int64_t)s * a.ldx;
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + off[c]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int h = 0; h < HB; ++h)
+#pragma unroll
+                    for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                        for (int t = 0; t < VEC; ++t) acc[h][c][t] = fmaf(ww[u][h], v[u][c][t], acc[h][c][t]);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < HB; ++h) {
+        float* ob = slot < 0 ? a.out + (int64_t)row * a.ldo + (int64_t)h * a.hso : a.partial + (int64_t)slot * a.ldp + (int64_t)h * a.D;
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c)
+            if (act[c]) vstore<VEC>(ob + off[c], acc[h][c]);
+    }
+}
+
+// Reduce 16 values per lane across a LANES-wide group (LANES >= 16); on return lane l holds the total of value l % 16.
+template <int LANES>
+__device__ __forceinline__ float transpose_reduce16(float (&p)[16], int lane) {
+    float q[8], r[4], s2[2];
+    const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = (b8 ? p[i + 8] : p[i]) + __shfl_xor(b8 ? p[i] : p[i + 8], 8, LANES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (b4 ? q[i + 4] : q[i]) + __shfl_xor(b4 ? q[i] : q[i + 4], 4, LANES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) s2[i] = (b2 ? r[i + 2] : r[i]) + __shfl_xor(b2 ? r[i] : r[i + 2], 2, LANES);
+    float s = (b1 ? s2[1] : s2[0]) + __shfl_xor(b1 ? s2[0] : s2[1], 1, LANES);
+#pragma unroll
+    for (int m = 16; m < LANES; m <<= 1) s += __shfl_xor(s, m, LANES);
+    return s;  // value index = 8*b8 + 4*b4 + 2*b2 + b1 = lane % 16
+}
+
+template <int VEC, int LANES, int NCHUNK, int HB>
+__global__ __launch_bounds__(kBlock) void spmm_dot_bcast_kernel(SpmmArgs a) {
+    static_assert(LANES >= 16 && HB <= 4, "butterfly layout");
+    constexpr int U = 4;
+    const int lane = threadIdx.x % LANES;
+    const int64_t item = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+    if (item >= a.n_items) return;
+    const int4 it = a.items[item];
+    int row = it.x, beg = it.y, end = it.z, slot = it.w;
+    if constexpr (LANES == 64) {
+        row = __builtin_amdgcn_readfirstlane(row);
+        beg = __builtin_amdgcn_readfirstlane(beg);
+        end = __builtin_amdgcn_readfirstlane(end);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+    }
+    const float* yb = a.y + (int64_t)row * a.ldy;
+    int off[NCHUNK];
+    bool act[NCHUNK];
+    float acc[NCHUNK][VEC], yv[NCHUNK][VEC];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int e = (c * LANES + lane) * VEC;
+        act[c] = e < a.D;
+        off[c] = act[c] ? e : 0;
+        vload<VEC>(yv[c], yb + off[c]);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+            acc[c][t] = 0.f;
+            if (!act[c]) yv[c][t] = 0.f;
+        }
+    }
+    for (int k0 = beg; k0 < end; k0 += LANES) {
+        const int k = k0 + lane;
+        int idx = 0, wp = 0;
+        float wv[HB];
+#pragma unroll
+        for (int h = 0; h < HB; ++h) wv[h] = 0.f;
+        if (k < end) {
+            idx = a.indices[k];
+            wp = a.wperm ? a.wperm[k] : k;
+#pragma unroll
+            for (int h = 0; h < HB; ++h) wv[h] = a.w[(int64_t)wp * HB + h];
+        }
+        const int cnt = min(LANES, end - k0);
+        for (int i = 0; i < cnt; i += U) {
+            float p[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) p[q] = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = min(i + u, cnt - 1);
+                const int s = group_bcast<LANES>(idx, j);
+                const float* px = a.x + (int64_t)s * a.ldx;
+                float v[HB][NCHUNK][VEC];
+#pragma unroll
+                for (int h = 0; h < HB; ++h)
+#pragma unroll
+                    for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[h][c], px + (int64_t)h * a.hsx + off[c]);
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                    const float ww = i + u < cnt ? group_bcast<LANES>(wv[h], j) : 0.f;
+                    float d = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                        for (int t = 0; t < VEC; ++t) {
+                            acc[c][t] = fmaf(ww, v[h][c][t], acc[c][t]);
+                            d = fmaf(v[h][c][t], yv[c][t], d);
+                        }
+                    p[u * 4 + h] = d;  // value slot = 4*u + h
+                }
+            }
+            const float tot = transpose_reduce16<LANES>(p, lane);
+            const int slot16 = lane & 15, u = slot16 >> 2, h = slot16 & 3;
+            const int mywp = __shfl(wp, min(i + u, LANES - 1), LANES);
+            if (lane < 16 && h < HB && i + u < cnt) a.dot_out[(int64_t)mywp * HB + h] = tot;
+        }
+    }
+    float* ob = slot < 0 ? a.out + (int64_t)row * a.ldo : a.partial + (int64_t)slot * a.ldp;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+        if (act[c]) vstore<VEC>(ob + off[c], acc[c]);
+}
+
+template <int VEC, int HB, bool DOT>
+static void dispatch_bcast(SpmmArgs& a, hipStream_t st) {
+    const int L = (a.D + VEC - 1) / VEC;
+#define BOT_BCAST(LN, NC)                                                                                                     \
+    do {                                                                                                                      \
+        const int64_t blocks = (a.n_items * LN + kBlock - 1) / kBlock;                                                        \
+        if (blocks == 0) break;                                                                                               \
+        if constexpr (DOT) hipLaunchKernelGGL((spmm_dot_bcast_kernel<VEC, LN, NC, HB>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a); \
+        else hipLaunchKernelGGL((spmm_bcast_kernel<VEC, LN, NC, HB>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);        \
+    } while (0)
+    if (L <= 16) BOT_BCAST(16, 1);
+    else if (L <= 32) BOT_BCAST(32, 1);
+    else if (L <= 64) BOT_BCAST(64, 1);
+    else if (L <= 128) BOT_BCAST(64, 2);
+    else BOT_BCAST(64, 4);
+#undef BOT_BCAST
+}
+
+template <bool DOT>
+static int run_bcast(SpmmArgs& a, int vec, int H, hipStream_t st) {
+#define BOT_BCAST_H(V)                                \
+    switch (H) {                                      \
+        case 1: dispatch_bcast<V, 1, DOT>(a, st); break; \
+        case 2: dispatch_bcast<V, 2, DOT>(a, st); break; \
+        case 3: dispatch_bcast<V, 3, DOT>(a, st); break; \
+        default: dispatch_bcast<V, 4, DOT>(a, st); break; \
+    }
+    if (vec == 4) { BOT_BCAST_H(4) } else if (vec == 2) { BOT_BCAST_H(2) } else { BOT_BCAST_H(1) }
+#undef BOT_BCAST_H
+    return hip_status(DOT ? "spmm_dot_bcast launch" : "spmm_bcast launch");
+}
+
 template <int VEC, int LANES, int NCHUNK>
 static void launch_spmm(const SpmmArgs& a, hipStream_t st) {
     const int64_t groups = a.n_items * a.H * a.n_tiles;
@@ -382,6 +596,61 @@ int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_ro
         hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows,
                            long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso, (const float*)nullptr, (int64_t)0, (int64_t)0);
         if (int rc = hip_status("spmm_dot combine launch")) return rc;
+    }
+    return 0;
+}
+
+int bot_spmm_bcast_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz, const int32_t* items,
+                       int64_t n_items, const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, const float* x,
+                       int64_t ldx, const float* w, const int32_t* wperm, int32_t H, int32_t D, float* out, int64_t ldo,
+                       int64_t hso, float* partial, bot_stream_t stream) {
+    using namespace bot;
+    (void)indptr;
+    BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_items >= 0 && n_long >= 0 && nnz < INT32_MAX, BOT_E_RANGE, "spmm_bcast: bad size");
+    BOT_REQUIRE(H >= 1 && H <= 4 && D >= 1 && D <= 1024, BOT_E_RANGE, "spmm_bcast: H=%d (1..4) D=%d (1..1024)", H, D);
+    if (n_rows == 0) return 0;
+    BOT_REQUIRE(items && x && out && (nnz == 0 || (indices && w)), BOT_E_NULL, "spmm_bcast: NULL pointer");
+    BOT_REQUIRE(n_long == 0 || (long_rows && long_ptr && partial), BOT_E_NULL, "spmm_bcast: long rows need long_rows/long_ptr/partial");
+    BOT_REQUIRE(ldx >= D && (hso >= D || H == 1) && ldo >= D, BOT_E_RANGE, "spmm_bcast: strides smaller than the slab");
+    hipStream_t st = (hipStream_t)stream;
+    SpmmArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, 0, w, wperm, H, D, 1, out, ldo, hso, partial,
+               (int64_t)H * D, nullptr, 0, 0, nullptr, nullptr, 0, 0};
+    const int vec = pick_vec(D, {ldx, ldo, hso}, {x, out, partial});
+    BOT_REQUIRE(D <= vec * 256, BOT_E_RANGE, "spmm_bcast: D=%d exceeds one launch tile", D);
+    if (int rc = run_bcast<false>(a, vec, H, st)) return rc;
+    if (n_long > 0) {
+        const int64_t n = n_long * H * D;
+        hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows,
+                           long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso, (const float*)nullptr, (int64_t)0, (int64_t)0);
+        if (int rc = hip_status("spmm_bcast combine launch")) return rc;
+    }
+    return 0;
+}
+
+int bot_spmm_dot_bcast_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz, const int32_t* items,
+                           int64_t n_items, const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, const float* x,
+                           int64_t ldx, int64_t hsx, const float* w, const int32_t* wperm, const float* y, int64_t ldy,
+                           int32_t H, int32_t D, float* out, int64_t ldo, float* dot_out, float* partial,
+                           bot_stream_t stream) {
+    using namespace bot;
+    (void)indptr;
+    BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_items >= 0 && n_long >= 0 && nnz < INT32_MAX, BOT_E_RANGE, "spmm_dot_bcast: bad size");
+    BOT_REQUIRE(H >= 1 && H <= 4 && D >= 1 && D <= 1024, BOT_E_RANGE, "spmm_dot_bcast: H=%d (1..4) D=%d (1..1024)", H, D);
+    if (n_rows == 0) return 0;
+    BOT_REQUIRE(items && x && out && y && (nnz == 0 || (indices && w && dot_out)), BOT_E_NULL, "spmm_dot_bcast: NULL pointer");
+    BOT_REQUIRE(n_long == 0 || (long_rows && long_ptr && partial), BOT_E_NULL, "spmm_dot_bcast: long rows need long_rows/long_ptr/partial");
+    BOT_REQUIRE(ldx >= D && ldy >= D && ldo >= D && (hsx >= D || H == 1), BOT_E_RANGE, "spmm_dot_bcast: strides smaller than the slab");
+    hipStream_t st = (hipStream_t)stream;
+    SpmmArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, hsx, w, wperm, H, D, 1, out, ldo, D, partial,
+               (int64_t)D, y, ldy, 0, dot_out, nullptr, 0, 0};
+    const int vec = pick_vec(D, {ldx, hsx, ldo, ldy}, {x, out, partial, y});
+    BOT_REQUIRE(D <= vec * 256, BOT_E_RANGE, "spmm_dot_bcast: D=%d exceeds one launch tile", D);
+    if (int rc = run_bcast<true>(a, vec, H, st)) return rc;
+    if (n_long > 0) {
+        const int64_t n = n_long * D;
+        hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows,
+                           long_ptr, n_long, 1, D, partial, (int64_t)D, out, ldo, (int64_t)D, (const float*)nullptr, (int64_t)0, (int64_t)0);
+        if (int rc = hip_status("spmm_dot_bcast combine launch")) return rc;
     }
     return 0;
 }

@@ -26,6 +26,7 @@ from ..ops import bn_batch_stats, new_dropout_seed
 
 FORCE = False  # tests set this to run the fused node over the emulated (CPU) backend
 CALLS = 0      # number of fused-layer invocations (tests assert the path was actually taken)
+AGG_CALLS = 0  # ... of which aggregate-before-project
 
 
 def can_fuse(conv, norm, activation, graph, training, stack_residual) -> bool:
@@ -188,6 +189,144 @@ class _GATHidden(torch.autograd.Function):
                 None, None, None, None, None, None, None, None, None, None)
 
 
+def cat_weight_aggfirst(conv):
+    """[W_res ; wl ; wr ; 0-pad] — the GEMM that remains on the layer INPUT when the aggregation runs before the projection."""
+    H, D = conv._num_heads, conv._out_feats
+    W = conv.fc.weight
+    Wh = W.view(H, D, -1)
+    rows = [conv.res_fc.weight] if conv.res_fc is not None else []
+    rows.append((Wh * conv.attn_l.view(H, D, 1)).sum(1))
+    if conv.attn_r is not None:
+        rows.append((Wh * conv.attn_r.view(H, D, 1)).sum(1))
+    used = sum(r.shape[0] for r in rows)
+    pad = (-used) % 128
+    if pad:
+        rows.append(W.new_zeros(pad, W.shape[1]))
+    return torch.cat(rows)
+
+
+AGG_FIRST = True  # aggregate-before-project for layers whose input is narrower than one head (Fin <= D, H <= 4)
+
+
+def use_agg_first(conv) -> bool:
+    return AGG_FIRST and conv._in_src_feats <= conv._out_feats and conv._num_heads <= 4 and conv._in_src_feats <= 256
+
+
+class _GATHiddenAggFirst(torch.autograd.Function):
+    """Same layer as _GATHidden with the aggregation moved in front of the projection:
+        rst[v,h,:] = W_h (sum_e a[e,h] x[u,:]) + res[v,h,:]      (models.py:490-492, :547, :558-560, linearity of the sum)
+    The sparse sweeps gather Fin floats per edge forward and H*Fin backward instead of H*D both ways, the projection becomes
+    a batched GEMM over heads on the aggregated slab [H, N, Fin], and in partitioned mode the halo rows are [x | el]."""
+
+    @staticmethod
+    def forward(ctx, h, W, Wr, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training):
+        N, Fin, HD = h.shape[0], h.shape[1], H * D
+        csc = graph.csc
+        out2 = torch.mm(h, Wr.t())                                      # [N, P2] = [res | el | er | pad]
+        c = HD if has_res else 0
+        ext = None
+        if graph.halo is not None:
+            import torch.distributed as dist
+            plan = graph.halo
+            Wd = _ext_width(Fin, H)
+            ext = torch.empty((N + plan.n_halo, Wd), dtype=h.dtype, device=h.device)
+            ext[:N, :Fin] = h
+            ext[:N, Fin:Fin + H] = out2[:, c:c + H]
+            if Wd > Fin + H:
+                ext[:N, Fin + H:].zero_()
+            send = _C.gather_rows(ext[:N], plan.send_rows) if plan.n_send else ext.new_empty((0, Wd))
+            dist.all_to_all_single(ext[N:], send, plan.recv_splits, plan.send_splits, group=plan.group)
+            xsrc = ext[:, :Fin]
+            el = ext[:, Fin:Fin + H].contiguous()
+        else:
+            xsrc = h
+            el = out2[:, c:c + H].contiguous()
+        er = out2[:, c + H:c + 2 * H].contiguous() if has_er else None
+        a = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None)
+        amask = None
+        if attn_p > 0:
+            amask = (torch.rand_like(a) >= attn_p).to(a.dtype).mul_(1.0 / (1.0 - attn_p))
+        a_d = a * amask if amask is not None else a
+        z = _C.spmm_bcast(csc, xsrc, a_d, None, head_outer=True)        # [H, N, Fin]
+        agg = torch.bmm(z, W.view(H, D, Fin).transpose(1, 2))          # [H, N, D]
+        if has_res:
+            x = torch.add(out2[:, :HD].unflatten(1, (H, D)), agg.permute(1, 0, 2)).view(N, HD)
+        else:
+            x = agg.permute(1, 0, 2).reshape(N, HD)
+        ctx.graph = graph
+        keep = (h, W, Wr, z, ext if ext is not None else h, el, er, a, amask, a_d)
+        if bn is None:
+            ctx.save_for_backward(*keep)
+            ctx.cfg = (H, D, has_res, has_er, slope, None)
+            return x
+        mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
+        seed = new_dropout_seed(drop_p)
+        y = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
+        ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
+        ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        H, D, has_res, has_er, slope, epi = ctx.cfg
+        g = ctx.graph
+        dy = dy.contiguous()
+        d_bn_w = d_bn_b = None
+        if epi is None:
+            h, W, Wr, z, table, el, er, a, amask, a_d = ctx.saved_tensors
+        else:
+            h, W, Wr, z, table, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
+            drop_p, seed, bn_training, sync, group, total = epi
+        N, Fin, HD, P2 = h.shape[0], h.shape[1], H * D, Wr.shape[0]
+        dout2 = torch.empty((N, P2), dtype=h.dtype, device=h.device)
+        dx = dout2[:, :HD] if has_res else torch.empty((N, HD), dtype=h.dtype, device=h.device)
+        if epi is None:
+            dx.copy_(dy)
+        else:
+            sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
+            d_bn_w, d_bn_b = sgx, sg
+            if bn_training and sync:
+                both = torch.stack([sg, sgx])
+                dist.all_reduce(both, group=group)
+                sg, sgx = both[0].contiguous(), both[1].contiguous()
+            _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
+                                sgx if bn_training else None, total, out=dx)
+        dx3 = dx.unflatten(1, (H, D)).permute(1, 0, 2)                  # [H, N, D] view
+        Wh = W.view(H, D, Fin)
+        dz = torch.bmm(dx3, Wh)                                          # [H, N, Fin]: gradient of the aggregated slab
+        dW = torch.bmm(dx3.transpose(1, 2), z).reshape(HD, Fin) if ctx.needs_input_grad[1] else None
+        halo = g.halo is not None
+        c = HD if has_res else 0
+        if halo:
+            dext = torch.empty_like(table)
+            _, da = _C.spmm_dot_bcast(g.csr, dz, a_d, g.csr2csc, table[:, :Fin], out=dext[:, :Fin])
+        else:
+            dh_g, da = _C.spmm_dot_bcast(g.csr, dz, a_d, g.csr2csc, h)
+        if amask is not None:
+            da = da * amask
+        dz_e, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er)
+        d_el = _C.segment_sum(g.csr, dz_e, g.csr2csc)
+        if halo:
+            dext[:, Fin:Fin + H] = d_el
+            if dext.shape[1] > Fin + H:
+                dext[:, Fin + H:].zero_()
+            own = _extend_backward(g, dext, N)
+            dh_g = own[:, :Fin]
+            dout2[:, c:c + H] = own[:, Fin:Fin + H]
+        else:
+            dout2[:, c:c + H] = d_el
+        if has_er:
+            dout2[:, c + H:c + 2 * H] = der
+        used = c + (2 * H if has_er else H)
+        if used < P2:
+            dout2[:, used:].zero_()
+        dWr = torch.mm(dout2.t(), h) if ctx.needs_input_grad[2] else None
+        dh = torch.addmm(dh_g, dout2, Wr) if ctx.needs_input_grad[0] else None
+        return (dh, dW, dWr, d_bn_w if ctx.needs_input_grad[3] else None, d_bn_b if ctx.needs_input_grad[4] else None,
+                None, None, None, None, None, None, None, None, None, None)
+
+
 def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
     """`dropout(relu(bn(conv(graph, h).flatten(1))))` as one autograd node (bn None: just `conv(graph, h).flatten(1)`,
     the stack's output layer).  h: [N, Fin] -> [N, H*D]."""
@@ -197,11 +336,19 @@ def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
     global CALLS
     CALLS += 1
     H, D = conv._num_heads, conv._out_feats
+    attn_p = conv.attn_drop.p if training else 0.0
+    bn_w = bn.weight if bn is not None and bn.affine else None
+    bn_b = bn.bias if bn is not None and bn.affine else None
+    bn_training = bn is not None and (bn.training or not bn.track_running_stats)
+    if use_agg_first(conv):
+        global AGG_CALLS
+        AGG_CALLS += 1
+        return _GATHiddenAggFirst.apply(h, conv.fc.weight, cat_weight_aggfirst(conv), bn_w, bn_b, graph, bn, H, D,
+                                        conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
+                                        attn_p, dropout_p if training and bn is not None else 0.0, bn_training)
     if bn is None:
         return _GATHidden.apply(h, cat_weight(conv), None, None, graph, None, H, D, conv.res_fc is not None,
-                                conv.attn_r is not None, conv.leaky_relu.negative_slope,
-                                conv.attn_drop.p if training else 0.0, 0.0, False)
-    bn_training = bn.training or not bn.track_running_stats
+                                conv.attn_r is not None, conv.leaky_relu.negative_slope, attn_p, 0.0, False)
     return _GATHidden.apply(h, cat_weight(conv), bn.weight if bn.affine else None, bn.bias if bn.affine else None, graph, bn,
                             H, D, conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
                             conv.attn_drop.p if training else 0.0, dropout_p if training else 0.0, bn_training)

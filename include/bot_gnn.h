@@ -116,6 +116,32 @@ int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_ro
                      float* dot_out, float* partial, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Aggregate-before-project forms of u_mul_e_sum (models.py:547) for layers whose input is narrower than H*D — the
+ * reordering GraphConv already applies for in_feats <= out_feats (models.py:377-385), valid for GAT because the
+ * aggregation is linear:  sum_e a[e,h] (W_h x[u]) = W_h (sum_e a[e,h] x[u]).  The source row has no head axis and is
+ * gathered once per edge for all H <= 4 heads (D <= 1024):
+ *
+ *   bot_spmm_bcast_f32       out[r,h,:] = sum_{k in row r} w[wperm[k],h] * x[indices[k],:]            x: [n_src, D]
+ *   bot_spmm_dot_bcast_f32   out[r,:]   = sum_{k in row r} sum_h w[wperm[k],h] * x[indices[k],h,:]    x: [n, H, D] (ldx, hsx)
+ *                            dot_out[wperm[k],h] = < y[r,:] , x[indices[k],h,:] >                     y: [n_rows, D]
+ *
+ * The second is the backward of the first on the transposed direction (x = gradient of the aggregated slab, y = the
+ * layer input).  `out` of the first may be head-outer ([H, n, D]: hso = n*D, ldo = D) — the layout batched GEMMs want.
+ * ------------------------------------------------------------------------------------------- */
+int bot_spmm_bcast_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                       const int32_t* items, int64_t n_items,
+                       const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long,
+                       const float* x, int64_t ldx, const float* w, const int32_t* wperm,
+                       int32_t H, int32_t D, float* out, int64_t ldo, int64_t hso,
+                       float* partial, bot_stream_t stream);
+int bot_spmm_dot_bcast_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                           const int32_t* items, int64_t n_items,
+                           const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long,
+                           const float* x, int64_t ldx, int64_t hsx, const float* w, const int32_t* wperm,
+                           const float* y, int64_t ldy, int32_t H, int32_t D,
+                           float* out, int64_t ldo, float* dot_out, float* partial, bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * SDDMM dot.  The backward of u_mul_e_sum with respect to the edge weights (models.py:547):
  *
  *   out[operm[k], h] = < x[indices[k],h,:] , y[r,h,:] >        for every position k of every row r

@@ -53,6 +53,27 @@ def spmm_dot(d, x, w, wperm, y, out=None):
     return out, dot
 
 
+def spmm_bcast(d, x, w, wperm=None, head_outer=True):
+    ww = w[_perm(wperm, d.nnz)]                                  # [nnz, H]
+    xs = x[d.indices.long()]                                     # [nnz, D]
+    res = torch.zeros(d.n_rows, w.shape[1], x.shape[1]).index_add(0, _rows(d), ww.unsqueeze(-1) * xs.unsqueeze(1))
+    return res.permute(1, 0, 2).contiguous() if head_outer else res
+
+
+def spmm_dot_bcast(d, x, w, wperm, y, out=None):
+    xs = x[:, d.indices.long(), :].permute(1, 0, 2)               # [nnz, H, D]
+    ww = w[_perm(wperm, d.nnz)]
+    res = torch.zeros(d.n_rows, x.shape[2]).index_add(0, _rows(d), (ww.unsqueeze(-1) * xs).sum(1))
+    if out is not None:
+        out.copy_(res)
+    else:
+        out = res
+    val = (xs * y[_rows(d)].unsqueeze(1)).sum(-1)                # [nnz, H]
+    dot = torch.empty_like(val)
+    dot[_perm(wperm, d.nnz)] = val
+    return out, dot
+
+
 def sddmm_dot(d, x, y, operm=None, out=None):
     val = (x[d.indices.long()] * y[_rows(d)]).sum(-1)
     res = torch.empty_like(val)
@@ -174,7 +195,7 @@ def edge_mlp_bwd(ef, W1, b1, W2, dz):
     return du.t() @ ef, du.sum(0), dz.t() @ r
 
 
-NAMES = ["edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

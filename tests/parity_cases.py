@@ -364,3 +364,36 @@ def check_train_step_golden(golden, device):
         for k, v in model.state_dict().items():  # post-step parameters and BN buffers
             if v.is_floating_point():
                 np.testing.assert_allclose(v.cpu().numpy(), c[f"p1.{k}"], rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------- aggregate-before-project
+def check_agg_first_against_oracle(golden, device):
+    """A stack whose first layer is narrower than one head (9 -> 3 x 16, like 168 -> 3 x 250 at config 2) takes the
+    aggregate-before-project node; logits and every gradient must match the oracle's project-first definition."""
+    from bot_amd.nn import fused
+    s, d, n = golden.graph("g300")
+    g = bot_amd.Graph(s, d, n, chunk=8).to(device)
+    fin, C = 9, 5
+    cfg = dict(n_layers=3, n_heads=3, n_hidden=16, norm="batch", non_interactive_attn=True, use_symmetric_norm=False,
+               linear=True, residual=False)
+    for attn_r, linear in ((True, True), (False, True), (True, False)):
+        cfg.update(non_interactive_attn=attn_r, linear=linear)
+        torch.manual_seed(11)
+        model = bnn.GAT(dim_node=fin, dim_edge=0, dim_output=C, activation=F.relu, **cfg).train()
+        gen = torch.Generator().manual_seed(12)
+        feat, gout = torch.randn(n, fin, generator=gen), torch.randn(n, C, generator=gen)
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        p = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+        ref = RM.gat_forward(RM.CooGraph(s, d, n), feat, p, n_classes=C, training=True, **cfg)
+        names = [k for k, v in p.items() if v.requires_grad]
+        ref_grads = torch.autograd.grad((ref * gout).sum(), [p[k] for k in names])
+        model = model.to(device)
+        a0 = fused.AGG_CALLS
+        x = leaf(feat, device)
+        logits = model(g, x)
+        assert fused.AGG_CALLS == a0 + 1  # layer 0 only (9 <= 16); layers 1, 2 have 48 inputs
+        (logits * gout.to(device)).sum().backward()
+        fwd_close(logits, ref.detach().numpy())
+        got = dict(model.named_parameters())
+        for k, rg in zip(names, ref_grads):
+            grad_close(got[k].grad, rg.numpy(), 3e-4)

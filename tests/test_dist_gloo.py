@@ -80,8 +80,8 @@ def _worker(rank, world, port, kind, tmp, fuse=False):
                 return bnn.GAT(dim_node=fin + C, dim_edge=0, dim_output=C, n_hidden=6, n_layers=3, n_heads=2,
                                activation=F.relu, norm="batch", non_interactive_attn=True, use_symmetric_norm=True, linear=True)
             if kind == "gat_plain":  # BASELINE config-2 options (no symmetric norm): eligible for the fused layer node
-                return bnn.GAT(dim_node=fin + C, dim_edge=0, dim_output=C, n_hidden=6, n_layers=3, n_heads=3,
-                               activation=F.relu, norm="batch", non_interactive_attn=True, linear=True)
+                return bnn.GAT(dim_node=fin + C, dim_edge=0, dim_output=C, n_hidden=16, n_layers=3, n_heads=3,
+                               activation=F.relu, norm="batch", non_interactive_attn=True, linear=True)  # layer 0: 14 <= 16 -> aggregate-first
             return bnn.GCN(in_feats=fin + C, n_classes=C, n_hidden=16, n_layers=3, activation=F.relu, norm="batch",
                            norm_adj="symm", use_linear=True)
 
@@ -99,6 +99,7 @@ def _worker(rank, world, port, kind, tmp, fuse=False):
         calls0 = fused.CALLS
         loss, pred = bdist.forward_backward(model, part, use_labels=True, loss="loge", n_classes=C, mask=mask_full[tr_own])
         assert (fused.CALLS > calls0) == (fuse and kind == "gat_plain"), (fused.CALLS, calls0)
+        assert (fused.AGG_CALLS > 0) == (fuse and kind == "gat_plain")
         assert abs(loss.item() - loss_ref.item()) < 1e-5, (loss.item(), loss_ref.item())
         np.testing.assert_allclose(pred.detach().numpy(), pred_ref.detach()[part.lo:part.hi].numpy(), rtol=1e-4, atol=1e-5)
         for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):

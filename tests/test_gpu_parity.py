@@ -332,3 +332,34 @@ def test_edge_cases():
             PC.grad_close(xt.grad, xo.grad.numpy())
             PC.grad_close(lt.grad, lo.grad.numpy())
             assert torch.all(out[1:] == 0)  # nodes without in-edges aggregate nothing
+
+
+def test_agg_first_against_oracle(golden):
+    PC.check_agg_first_against_oracle(golden, DEV)
+
+
+def test_bcast_kernels_direct(golden):
+    """spmm_bcast / spmm_dot_bcast (aggregate-before-project forms) against plain torch indexing."""
+    s, d, n = golden.graph("g300")
+    g = bot_amd.Graph(s, d, n, chunk=8).to(DEV)
+    E = s.numel()
+    gen = torch.Generator().manual_seed(8)
+    for H, D in ((3, 168), (1, 40), (4, 9), (2, 250)):
+        x = torch.randn(n, D, generator=gen).to(DEV)
+        w = torch.rand(E, H, generator=gen).to(DEV)
+        csc, csr = g.csc, g.csr
+        rows = torch.repeat_interleave(torch.arange(n, device=DEV), (csc.indptr[1:] - csc.indptr[:-1]).long())
+        ref = torch.zeros(n, H, D, device=DEV).index_add_(0, rows, w.unsqueeze(-1) * x[csc.indices.long()].unsqueeze(1))
+        out = _C.spmm_bcast(csc, x, w, None, head_outer=True)
+        assert torch.allclose(out.permute(1, 0, 2), ref, atol=1e-4, rtol=1e-4)
+        assert torch.allclose(_C.spmm_bcast(csc, x, w, None, head_outer=False), ref, atol=1e-4, rtol=1e-4)
+        dz = torch.randn(H, n, D, generator=gen).to(DEV)
+        rows_r = torch.repeat_interleave(torch.arange(n, device=DEV), (csr.indptr[1:] - csr.indptr[:-1]).long())
+        wr = w[g.csr2csc.long()]
+        xs = dz[:, csr.indices.long(), :].permute(1, 0, 2)
+        ref_out = torch.zeros(n, D, device=DEV).index_add_(0, rows_r, (wr.unsqueeze(-1) * xs).sum(1))
+        ref_dot = torch.empty(E, H, device=DEV)
+        ref_dot[g.csr2csc.long()] = (xs * x[rows_r].unsqueeze(1)).sum(-1)
+        o, dot = _C.spmm_dot_bcast(csr, dz, w, g.csr2csc, x)
+        assert torch.allclose(o, ref_out, atol=2e-4, rtol=1e-4)
+        assert torch.allclose(dot, ref_dot, atol=1e-3 * D ** 0.5, rtol=1e-4)

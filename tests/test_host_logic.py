@@ -103,3 +103,9 @@ def test_train_step_golden(golden, cpu_backend, monkeypatch):
     c0 = fused.CALLS
     PC.check_train_step_golden(golden, "cpu")
     assert fused.CALLS > c0
+
+
+def test_agg_first_against_oracle(golden, cpu_backend, monkeypatch):
+    from bot_amd.nn import fused
+    monkeypatch.setattr(fused, "FORCE", True)
+    PC.check_agg_first_against_oracle(golden, "cpu")
