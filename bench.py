@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; reported in config)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--gemm-tuning", default="file", choices=["file", "off"],
-                    help="file: hipBLASLt/rocBLAS kernel selections from bot_amd/tuning (TunableOp, read-only)")
+    ap.add_argument("--gemm-tuning", default="file", choices=["file", "off", "tune"],
+                    help="file: hipBLASLt/rocBLAS kernel selections from bot_amd/tuning (TunableOp, read-only); "
+                         "tune: also time shapes missing from the file and write them to gpurun_out/ (maintenance)")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the 1-D partitioned code path even with one rank (exercises the RCCL plumbing on a 1-GPU box)")
     return ap.parse_args()
@@ -109,7 +110,10 @@ def main():
     import bot_amd
     from bot_amd import _C, synth, train, tuning
     from bot_amd import nn as bnn
-    tuned = tuning.enable() if args.gemm_tuning == "file" else False
+    tuned = tuning.enable(tune_missing=args.gemm_tuning == "tune") if args.gemm_tuning != "off" else False
+    if args.gemm_tuning == "tune":
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        torch.cuda.tunable.set_filename(os.path.join(ROOT, "gpurun_out", f"tunableop_new_rank{rank}.csv"))
 
     ds = synth.make_dataset(args.workload, device="cpu", seed=0, scale=args.scale)
     n, C = ds.graph.number_of_nodes(), ds.n_classes

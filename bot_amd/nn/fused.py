@@ -248,7 +248,10 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             amask = (torch.rand_like(a) >= attn_p).to(a.dtype).mul_(1.0 / (1.0 - attn_p))
         a_d = a * amask if amask is not None else a
         z = _C.spmm_bcast(csc, xsrc, a_d, None, head_outer=True)        # [H, N, Fin]
-        agg = torch.bmm(z, W.view(H, D, Fin).transpose(1, 2))          # [H, N, D]
+        Wh = W.view(H, D, Fin)
+        agg = torch.empty((H, N, D), dtype=h.dtype, device=h.device)    # per-head projection (plain 2-D GEMMs: each has its
+        for i in range(H):                                              # own tuned kernel selection, see bot_amd/tuning)
+            torch.mm(z[i], Wh[i].t(), out=agg[i])
         if has_res:
             x = torch.add(out2[:, :HD].unflatten(1, (H, D)), agg.permute(1, 0, 2)).view(N, HD)
         else:
@@ -292,10 +295,15 @@ class _GATHiddenAggFirst(torch.autograd.Function):
                 sg, sgx = both[0].contiguous(), both[1].contiguous()
             _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
                                 sgx if bn_training else None, total, out=dx)
-        dx3 = dx.unflatten(1, (H, D)).permute(1, 0, 2)                  # [H, N, D] view
         Wh = W.view(H, D, Fin)
-        dz = torch.bmm(dx3, Wh)                                          # [H, N, Fin]: gradient of the aggregated slab
-        dW = torch.bmm(dx3.transpose(1, 2), z).reshape(HD, Fin) if ctx.needs_input_grad[1] else None
+        dz = torch.empty((H, N, Fin), dtype=h.dtype, device=h.device)    # gradient of the aggregated slab
+        dW3 = torch.empty((H, D, Fin), dtype=h.dtype, device=h.device) if ctx.needs_input_grad[1] else None
+        for i in range(H):
+            dxi = dx[:, i * D:(i + 1) * D]                               # [N, D] column slice (row-strided)
+            torch.mm(dxi, Wh[i], out=dz[i])
+            if dW3 is not None:
+                torch.mm(dxi.t(), z[i], out=dW3[i])
+        dW = dW3.view(HD, Fin) if dW3 is not None else None
         halo = g.halo is not None
         c = HD if has_res else 0
         if halo:

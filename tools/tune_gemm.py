@@ -36,5 +36,25 @@ for n in rows:
         torch.mm(d, W)          # dh
         torch.cuda.synchronize()
         print("tuned", n, K, P, flush=True)
+    # aggregate-before-project layer 0 (bot_amd/nn/fused.py _GATHiddenAggFirst): Fin = 168, H = 3, D = 250, P2 = 768
+    Fin, H, D, P2 = 168, 3, 250, 768
+    h = torch.randn(n, Fin, device=dev)
+    Wr = torch.randn(P2, Fin, device=dev)
+    W = torch.randn(H, D, Fin, device=dev)
+    z = torch.randn(H, n, Fin, device=dev)
+    dout2 = torch.randn(n, P2, device=dev)
+    agg = torch.empty(H, n, D, device=dev)
+    dz = torch.empty(H, n, Fin, device=dev)
+    dW3 = torch.empty(H, D, Fin, device=dev)
+    torch.mm(h, Wr.t())
+    torch.mm(dout2.t(), h)
+    torch.mm(dout2, Wr)
+    for i in range(1):  # the three heads share one shape / leading dimensions
+        torch.mm(z[i], W[i].t(), out=agg[i])
+        dxi = dout2[:, i * D:(i + 1) * D]
+        torch.mm(dxi, W[i], out=dz[i])
+        torch.mm(dxi.t(), z[i], out=dW3[i])
+    torch.cuda.synchronize()
+    print("tuned agg-first", n, flush=True)
 getattr(tunable, "write_file", lambda f: None)(out)  # older TunableOp: the file is written at exit
 print("results:", len(tunable.get_results()))
