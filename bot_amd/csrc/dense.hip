@@ -90,6 +90,7 @@ __global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float*
     for (int t = 0; t < VEC; ++t) s[t] = q[t] = 0.f;
     if (c < F) {
         vload<VEC>(piv, x + c);
+#pragma unroll 4
         for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < n; r += (int64_t)gridDim.y * kTY) {
             float v[VEC];
             vload<VEC>(v, x + r * ldx + c);
@@ -116,15 +117,32 @@ __global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float*
     }
 }
 
-// mean[c] = pivot + S/n ; m2[c] = Q - S^2/n      (fixed order, double)
+// Second stage of the column reductions: 64 columns x 4 row-groups per workgroup; group g adds the partials
+// b = g, g+4, g+8, ... in double, the four group sums are combined in fixed order through LDS (deterministic).
+__device__ __forceinline__ void pair_reduce(const float* part, int nblk, int32_t F, int c, int grp, double (&lds)[2][4][64],
+                                            double& S, double& Q) {
+    double s = 0.0, q = 0.0;
+    if (c < F)
+        for (int b = grp; b < nblk; b += 4) s += (double)part[((int64_t)b * 2 + 0) * F + c], q += (double)part[((int64_t)b * 2 + 1) * F + c];
+    lds[0][grp][threadIdx.x & 63] = s;
+    lds[1][grp][threadIdx.x & 63] = q;
+    __syncthreads();
+    S = Q = 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) S += lds[0][g][threadIdx.x & 63], Q += lds[1][g][threadIdx.x & 63];
+}
+
+// mean[c] = pivot + S/n ; m2[c] = Q - S^2/n
 __global__ __launch_bounds__(kBlock) void colstats_final_kernel(const float* x, int64_t n, int32_t F, const float* part, int nblk,
                                                                float* mean, float* m2) {
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= F) return;
-    double S = 0.0, Q = 0.0;
-    for (int b = 0; b < nblk; ++b) S += (double)part[((int64_t)b * 2 + 0) * F + c], Q += (double)part[((int64_t)b * 2 + 1) * F + c];
-    mean[c] = (float)((double)x[c] + S / (double)n);
-    m2[c] = (float)fmax(Q - S * S / (double)n, 0.0);
+    __shared__ double lds[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    double S, Q;
+    pair_reduce(part, nblk, F, c, grp, lds, S, Q);
+    if (grp == 0 && c < F) {
+        mean[c] = (float)((double)x[c] + S / (double)n);
+        m2[c] = (float)fmax(Q - S * S / (double)n, 0.0);
+    }
 }
 
 template <int VEC>
@@ -142,18 +160,30 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
     }
     const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
     const int64_t ngrp = (a.F + VEC - 1) / VEC;
-    for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < a.n; r += (int64_t)gridDim.y * kTY) {
-        float v[VEC], f[VEC];
-        vload<VEC>(v, a.x + r * a.ldx + c);
-        if (a.p > 0.f) drop_factors<VEC>(a.seed, (uint64_t)(r * ngrp + c / VEC), a.p, scale, f);
+    constexpr int UR = 4;  // rows in flight per thread: loads first, then compute + store (x and y may alias for the compiler)
+    const int64_t step = (int64_t)gridDim.y * kTY;
+    for (int64_t r0 = (int64_t)blockIdx.y * kTY + ty; r0 < a.n; r0 += step * UR) {
+        float v[UR][VEC];
 #pragma unroll
-        for (int t = 0; t < VEC; ++t) {
-            float o = fmaf(v[t] - mu[t], sc[t], sh[t]);
-            if (a.relu) o = fmaxf(o, 0.f);
-            if (a.p > 0.f) o *= f[t];
-            v[t] = o;
+        for (int u = 0; u < UR; ++u) {
+            const int64_t r = r0 + u * step;
+            if (r < a.n) vload<VEC>(v[u], a.x + r * a.ldx + c);
         }
-        vstore<VEC>(a.y + r * a.ldy + c, v);
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int64_t r = r0 + u * step;
+            if (r >= a.n) break;
+            float f[VEC];
+            if (a.p > 0.f) drop_factors<VEC>(a.seed, (uint64_t)(r * ngrp + c / VEC), a.p, scale, f);
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                float o = fmaf(v[u][t] - mu[t], sc[t], sh[t]);
+                if (a.relu) o = fmaxf(o, 0.f);
+                if (a.p > 0.f) o *= f[t];
+                v[u][t] = o;
+            }
+            vstore<VEC>(a.y + r * a.ldy + c, v[u]);
+        }
     }
 }
 
@@ -177,6 +207,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_reduce_kernel(BnArgs a) {
         }
         const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
         const int64_t ngrp = (a.F + VEC - 1) / VEC;
+#pragma unroll 4
         for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < a.n; r += (int64_t)gridDim.y * kTY) {
             float v[VEC], g[VEC], f[VEC];
             vload<VEC>(v, a.x + r * a.ldx + c);
@@ -209,12 +240,14 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_reduce_kernel(BnArgs a) {
 }
 
 __global__ __launch_bounds__(kBlock) void pair_final_kernel(int32_t F, const float* part, int nblk, float* s0, float* s1) {
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= F) return;
-    double A = 0.0, B = 0.0;
-    for (int b = 0; b < nblk; ++b) A += (double)part[((int64_t)b * 2 + 0) * F + c], B += (double)part[((int64_t)b * 2 + 1) * F + c];
-    s0[c] = (float)A;
-    s1[c] = (float)B;
+    __shared__ double lds[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    double A, B;
+    pair_reduce(part, nblk, F, c, grp, lds, A, B);
+    if (grp == 0 && c < F) {
+        s0[c] = (float)A;
+        s1[c] = (float)B;
+    }
 }
 
 template <int VEC>
@@ -234,20 +267,34 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
     }
     const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
     const int64_t ngrp = (a.F + VEC - 1) / VEC;
-    for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < a.n; r += (int64_t)gridDim.y * kTY) {
-        float v[VEC], g[VEC], f[VEC];
-        vload<VEC>(v, a.x + r * a.ldx + c);
-        vload<VEC>(g, a.dy + r * a.lddy + c);
-        if (a.p > 0.f) drop_factors<VEC>(a.seed, (uint64_t)(r * ngrp + c / VEC), a.p, scale, f);
+    constexpr int UR = 4;
+    const int64_t step = (int64_t)gridDim.y * kTY;
+    for (int64_t r0 = (int64_t)blockIdx.y * kTY + ty; r0 < a.n; r0 += step * UR) {
+        float v[UR][VEC], g[UR][VEC];
 #pragma unroll
-        for (int t = 0; t < VEC; ++t) {
-            const float xh = (v[t] - mu[t]) * is[t];
-            float gg = g[t];
-            if (a.p > 0.f) gg *= f[t];
-            if (a.relu && !(fmaf(xh, sc[t], sh[t]) > 0.f)) gg = 0.f;
-            v[t] = sc[t] * is[t] * (gg - mg[t] - xh * mgx[t]);
+        for (int u = 0; u < UR; ++u) {
+            const int64_t r = r0 + u * step;
+            if (r < a.n) {
+                vload<VEC>(v[u], a.x + r * a.ldx + c);
+                vload<VEC>(g[u], a.dy + r * a.lddy + c);
+            }
         }
-        vstore<VEC>(a.dx + r * a.lddx + c, v);
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int64_t r = r0 + u * step;
+            if (r >= a.n) break;
+            float f[VEC];
+            if (a.p > 0.f) drop_factors<VEC>(a.seed, (uint64_t)(r * ngrp + c / VEC), a.p, scale, f);
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                const float xh = (v[u][t] - mu[t]) * is[t];
+                float gg = g[u][t];
+                if (a.p > 0.f) gg *= f[t];
+                if (a.relu && !(fmaf(xh, sc[t], sh[t]) > 0.f)) gg = 0.f;
+                v[u][t] = sc[t] * is[t] * (gg - mg[t] - xh * mgx[t]);
+            }
+            vstore<VEC>(a.dx + r * a.lddx + c, v[u]);
+        }
     }
 }
 
@@ -273,7 +320,7 @@ int bot_colstats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* m
     if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
     else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
     else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
-    hipLaunchKernelGGL(colstats_final_kernel, dim3((F + kBlock - 1) / kBlock), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
+    hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
                        mean, m2);
     return hip_status("colstats launch");
 }
@@ -313,7 +360,7 @@ int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int
     if (vec == 4) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<4>), grid, dim3(kTX * kTY), 0, st, a);
     else if (vec == 2) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<2>), grid, dim3(kTX * kTY), 0, st, a);
     else hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<1>), grid, dim3(kTX * kTY), 0, st, a);
-    hipLaunchKernelGGL(pair_final_kernel, dim3((F + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F, workspace, (int)grid.y, sum_g,
+    hipLaunchKernelGGL(pair_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, F, workspace, (int)grid.y, sum_g,
                        sum_gx);
     return hip_status("bn_act_bwd_reduce launch");
 }
