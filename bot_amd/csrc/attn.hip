@@ -195,18 +195,24 @@ __global__ __launch_bounds__(kBlock) void attn_long_kernel(AttnArgs p) {
 template <bool BWD>
 static int launch_attn(AttnArgs p, int64_t n_long, hipStream_t st) {
     const int64_t blocks = (p.n_rows * kRowLanes + kBlock - 1) / kBlock;
-    for (int h0 = 0; h0 < p.H;) {  // heads in register tiles of up to 4
-        const int ht = p.H - h0 >= 4 ? 4 : p.H - h0;
+    for (int h0 = 0; h0 < p.H;) {  // heads in register tiles of up to 8 (one sweep over the edges for H <= 8)
+        const int ht = p.H - h0 >= 8 ? 8 : p.H - h0;
         p.h0 = h0;
 #define BOT_LAUNCH_ATTN(HT)                                                                                             \
     do {                                                                                                                \
         hipLaunchKernelGGL((attn_short_kernel<HT, BWD>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);                \
         if (n_long > 0) hipLaunchKernelGGL((attn_long_kernel<HT, BWD>), dim3((unsigned)n_long), dim3(kBlock), 0, st, p); \
     } while (0)
-        if (ht == 4) BOT_LAUNCH_ATTN(4);
-        else if (ht == 3) BOT_LAUNCH_ATTN(3);
-        else if (ht == 2) BOT_LAUNCH_ATTN(2);
-        else BOT_LAUNCH_ATTN(1);
+        switch (ht) {
+            case 8: BOT_LAUNCH_ATTN(8); break;
+            case 7: BOT_LAUNCH_ATTN(7); break;
+            case 6: BOT_LAUNCH_ATTN(6); break;
+            case 5: BOT_LAUNCH_ATTN(5); break;
+            case 4: BOT_LAUNCH_ATTN(4); break;
+            case 3: BOT_LAUNCH_ATTN(3); break;
+            case 2: BOT_LAUNCH_ATTN(2); break;
+            default: BOT_LAUNCH_ATTN(1); break;
+        }
 #undef BOT_LAUNCH_ATTN
         h0 += ht;
     }

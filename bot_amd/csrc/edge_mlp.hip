@@ -101,12 +101,19 @@ __global__ __launch_bounds__(kBlock) void edge_mlp_bwd_kernel(const float* __res
     }
 }
 
+// One workgroup per output element: 256 threads add the per-wave tiles in a fixed interleaved order, then a fixed-order
+// LDS combine (deterministic).
 __global__ __launch_bounds__(kBlock) void edge_mlp_bwd_final_kernel(const float* part, int64_t n_waves, int32_t H, float* dW1,
                                                                    float* db1, float* dW2) {
-    const int t = blockIdx.x * kBlock + threadIdx.x;  // 0..511
-    if (t >= 512) return;
+    __shared__ double lds[kBlock];
+    const int t = blockIdx.x;  // 0..511
     double s = 0.0;
-    for (int64_t w = 0; w < n_waves; ++w) s += (double)part[w * 512 + t];
+    for (int64_t w = threadIdx.x; w < n_waves; w += kBlock) s += (double)part[w * 512 + t];
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s = 0.0;
+    for (int i = 0; i < kBlock; ++i) s += lds[i];
     const int which = t >> 8, row = (t & 255) >> 4, col = t & 15;  // row = hidden unit j
     if (which == 0) {
         if (col < H) dW2[col * kJ + row] = (float)s;
@@ -158,7 +165,7 @@ int bot_edge_mlp_bwd_f32(const float* ef, int32_t I, const float* W1, const floa
     BOT_REQUIRE(aligned(ef, 16), BOT_E_ALIGN, "edge_mlp_bwd: ef must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(kMlpBlocks), dim3(kBlock), 0, st, ef, W1, b1, W2, dz, n_edges, H, workspace);
-    hipLaunchKernelGGL(edge_mlp_bwd_final_kernel, dim3(2), dim3(kBlock), 0, st, workspace, (int64_t)kMlpBlocks * (kBlock / 64), H, dW1,
+    hipLaunchKernelGGL(edge_mlp_bwd_final_kernel, dim3(512), dim3(kBlock), 0, st, workspace, (int64_t)kMlpBlocks * (kBlock / 64), H, dW1,
                        db1, dW2);
     return hip_status("edge_mlp_bwd launch");
 }

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from . import _bcast, _pair, degree_norm, has_zero_in_degree
+from . import _bcast, _epilogue, _pair, degree_norm, has_zero_in_degree
 
 __all__ = ["GATConv", "ProteinsGAT", "ProductsGAT"]
 
@@ -133,7 +133,7 @@ class _EdgeGAT(nn.Module):
             if residual and h_last is not None:
                 h = h + h_last[: h.shape[0], :]
             h_last = h
-            h = self.dropout(self.activation(self.norms[i](h), inplace=True))
+            h = _epilogue(h, self.norms[i], self.activation, self.dropout, self.training)  # BatchNorm + ReLU + dropout, fused
         return self.pred_linear(h)
 
 
