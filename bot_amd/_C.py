@@ -35,6 +35,8 @@ _SIGS = {
     "bot_spmm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "bot_spmm_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                     c_int32, c_int32, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P]),
+    "bot_spmm_blocked_f32": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P, c_int32,
+                                            c_int32, _P, c_int64, _P]),
     "bot_spmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                         _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P]),
     "bot_spmm_bcast_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, _P, _P, c_int32,
@@ -168,10 +170,31 @@ def _slab(x, name):
     return x, x.stride(0), x.stride(1)
 
 
+def spmm_blocked(bp, x, w, out):
+    """L2-blocked SpMM over the tiles of `bp` (bot_amd.blocked.BlockedPlan); writes only the rows bp covers."""
+    H, D = x.shape[1], x.shape[2]
+    _check(_timed("spmm_blocked", (H, D, w is not None), lambda: _lib.bot_spmm_blocked_f32(
+        bp.tile_rows.data_ptr(), bp.ptr.data_ptr(), bp.b_src.data_ptr(), bp.b_lrow.data_ptr(), bp.b_pos.data_ptr(), bp.n_tiles,
+        bp.nblk, bp.T, bp.round_tiles, x.data_ptr(), x.stride(0), _ptr(w), H, D, out.data_ptr(), out.stride(0), _stream())),
+        "spmm_blocked")
+    return out
+
+
 def spmm(d, x, w=None, wperm=None, out=None, addend=None):
     """out[r,h,:] = sum_k w[wperm[k],h] * x[indices[k],h,:] (+ addend[r,h,:])   (w None: plain sum).  x: [n_src,H,D]."""
     _dev(x, w, d.indptr)
     x, ldx, hsx = _slab(x, "x")
+    if wperm is None and addend is None and out is None and x.is_contiguous():
+        from . import blocked
+        bp = blocked.plan_for(d, x.shape[0], x.shape[1], x.shape[2])
+        if bp is not None:  # dense graph: L2-blocked sweep for the regular rows, row-per-group kernel for the hubs
+            if w is not None:
+                w = _f32(w, "w").contiguous()
+            out = torch.empty((d.n_rows, x.shape[1], x.shape[2]), dtype=torch.float32, device=x.device)
+            spmm_blocked(bp, x, w, out)
+            if bp.heavy is not None:
+                spmm(bp.heavy, x, w, None, out=out)
+            return out
     lda = hsa = 0
     if addend is not None:
         addend, lda, hsa = _slab(addend, "addend")

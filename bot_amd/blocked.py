@@ -1,0 +1,97 @@
+"""Host side of the L2-blocked SpMM (bot_amd/csrc/blocked.hip): builds, once per graph direction and row width, the
+(tile, column block, wave)-sorted edge structure and the restricted plan for hub rows.  Integer work with torch on the
+device the graph lives on."""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass
+
+import torch
+
+ENABLED = True
+MIN_MEAN_DEGREE = 96       # below this a (row, block) visit holds < 1 edge: nothing to reuse
+L2_BLOCK_BYTES = 1 << 20   # source rows per column block * row bytes (4 MiB L2 per XCD holds a few blocks of skew)
+ROUND_WORKGROUPS = 512     # 256 CUs x 2 resident workgroups
+HUB_FACTOR = 8             # rows longer than HUB_FACTOR x mean stay on the row-per-group kernel
+
+
+@dataclass
+class BlockedPlan:
+    tile_rows: torch.Tensor
+    ptr: torch.Tensor
+    b_src: torch.Tensor
+    b_lrow: torch.Tensor
+    b_pos: torch.Tensor
+    n_tiles: int
+    nblk: int
+    T: int
+    round_tiles: int
+    heavy: object  # Direction restricted to the hub rows, or None
+
+
+def _heavy_direction(d, heavy_rows):
+    """A copy of direction `d` whose plan covers only `heavy_rows` (every one is split into chunk-sized items)."""
+    dev = d.indptr.device
+    beg = d.indptr[heavy_rows.long()].long()
+    end = d.indptr[heavy_rows.long() + 1].long()
+    nchunk = (end - beg + d.chunk - 1) // d.chunk
+    long_ptr = torch.zeros(heavy_rows.numel() + 1, dtype=torch.int64, device=dev)
+    long_ptr[1:] = torch.cumsum(nchunk, 0)
+    n_slots = int(long_ptr[-1])
+    owner = torch.repeat_interleave(torch.arange(heavy_rows.numel(), device=dev), nchunk)
+    j = torch.arange(n_slots, device=dev) - long_ptr[owner]
+    ib = beg[owner] + j * d.chunk
+    ie = torch.minimum(ib + d.chunk, end[owner])
+    items = torch.stack([heavy_rows.long()[owner], ib, ie, torch.arange(n_slots, device=dev)], 1).to(torch.int32).contiguous()
+    return dataclasses.replace(d, items=items, long_rows=heavy_rows.to(torch.int32).contiguous(),
+                               long_ptr=long_ptr.to(torch.int32).contiguous(), n_items=n_slots,
+                               n_long=int(heavy_rows.numel()), n_slots=n_slots, blocked={})
+
+
+def build(d, n_src: int, F: int) -> BlockedPlan:
+    dev = d.indptr.device
+    deg = (d.indptr[1:] - d.indptr[:-1]).long()
+    mean = max(1.0, d.nnz / max(1, d.n_rows))
+    hub_thr = max(int(HUB_FACTOR * mean), d.chunk)
+    T = 64 if F * 4 * 64 <= 64 * 1024 else (32 if F * 4 * 32 <= 64 * 1024 else 16)
+    cb = max(64, L2_BLOCK_BYTES // (F * 4))
+    cb = 1 << (cb.bit_length() - 1)
+    nblk = (n_src + cb - 1) // cb
+    regular = deg <= hub_thr
+    reg_rows = torch.nonzero(regular).squeeze(1)
+    order = torch.argsort(deg[reg_rows], descending=True, stable=True)
+    reg_rows = reg_rows[order]                                    # similar degrees share a tile / a launch round
+    n_reg = int(reg_rows.numel())
+    n_tiles = (n_reg + T - 1) // T
+    tile_rows = torch.full((n_tiles * T,), -1, dtype=torch.int32, device=dev)
+    tile_rows[:n_reg] = reg_rows.to(torch.int32)
+    slot_of_row = torch.full((d.n_rows,), -1, dtype=torch.int64, device=dev)
+    slot_of_row[reg_rows] = torch.arange(n_reg, device=dev)
+    row_of_pos = torch.repeat_interleave(torch.arange(d.n_rows, device=dev), deg)
+    slot = slot_of_row[row_of_pos]
+    pos = torch.nonzero(slot >= 0).squeeze(1)                     # positions of the blocked edges, ascending
+    slot = slot[pos]
+    src = d.indices[pos].long()
+    tile, lrow = slot // T, slot % T
+    group = (tile * nblk + src // cb) * 4 + (lrow % 4)            # (tile, block, wave)
+    key = group * T + lrow
+    perm = torch.argsort(key, stable=True)                        # ties keep position order = ascending edge id
+    counts = torch.bincount(group, minlength=n_tiles * nblk * 4)
+    ptr = torch.zeros(n_tiles * nblk * 4 + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(counts, 0)
+    heavy_rows = torch.nonzero(~regular).squeeze(1)
+    heavy = _heavy_direction(d, heavy_rows) if heavy_rows.numel() else None
+    return BlockedPlan(tile_rows, ptr.to(torch.int32).contiguous(), src[perm].to(torch.int32).contiguous(),
+                       lrow[perm].to(torch.uint8).contiguous(), pos[perm].to(torch.int32).contiguous(), n_tiles, nblk, T,
+                       ROUND_WORKGROUPS if T * F * 4 <= 64 * 1024 else ROUND_WORKGROUPS // 2, heavy)
+
+
+def plan_for(d, n_src: int, H: int, D: int):
+    """BlockedPlan for direction `d` and row width H*D, or None when the row-per-group kernel is the right one."""
+    F = H * D
+    if not ENABLED or F > 1024 or d.n_rows == 0 or d.nnz < MIN_MEAN_DEGREE * d.n_rows or not d.indptr.is_cuda:
+        return None
+    cache = d.blocked
+    if F not in cache:
+        cache[F] = build(d, n_src, F)
+    return cache[F]

@@ -1,0 +1,215 @@
+// L2-blocked SpMM for DENSE graphs (mean degree in the hundreds: S-reddit 488, S-proteins 586) — gfx950.
+//
+// Why a second SpMM: on those graphs every source row is gathered ~500 times per pass.  The row-per-group kernel
+// (spmm.hip) serves the re-reads from the 256 MiB Infinity Cache at its random-row ceiling (7.5 TB/s delivered, 15.5 ms
+// for S-reddit F=256); the only faster level with useful capacity is the 4 MiB L2 of each XCD (16.8-18.8 TB/s for L2-
+// resident row gathers, MI355X_MICROARCH.md "Indexed rows").  So the sweep is re-ordered to make the L2 working set small:
+//
+//   * sources are cut into column blocks of CB rows (CB * row bytes ~ 1-2 MB);
+//   * destination rows are grouped (by degree) into tiles of T rows; ONE 256-thread workgroup owns a tile for the whole
+//     pass and keeps its T output rows in LDS (T * F * 4 bytes <= 64 KB) — the neighbour tile is what is staged on chip;
+//   * every workgroup walks the column blocks in the SAME order, so at any moment all workgroups of an XCD gather from the
+//     same ~CB source rows, which therefore live in that XCD's L2; the host launches the tiles in rounds of one
+//     resident wave of workgroups (kernel boundaries keep the rounds aligned — no in-kernel grid barrier);
+//   * within (tile, block) the edge list is pre-sorted by (wave, local row): wave w owns local rows w, w+4, ...; it sums
+//     a row's neighbours of this block in registers and folds them into the LDS row when the row changes (one LDS
+//     read-modify-write per (row, block) visit, none per edge); no two waves touch the same LDS row: no atomics, no
+//     barriers, fixed summation order (block-major, then edge id) => bitwise reproducible.
+//
+// Rows far above the mean degree (hubs) and everything else stay on the row-per-group kernel.
+// HBM roofline unchanged: 4*[2*n*F + nnz + ...] algorithmic bytes; what changes is where the re-reads are served.
+#include "common.h"
+
+namespace bot {
+
+struct BlockedArgs {
+    const int32_t* tile_rows;  // [n_tiles * T]  destination row of each tile slot, -1 = padding
+    const int32_t* ptr;        // [n_tiles * nblk * 4 + 1]  edge offsets, (tile, block, wave)-major
+    const int32_t* b_src;      // [nnz_b] source row of each blocked edge
+    const uint8_t* b_lrow;     // [nnz_b] slot of the destination row inside its tile
+    const int32_t* b_pos;      // [nnz_b] position in the unblocked edge order (row of w), used when weighted
+    int32_t tile0, n_tiles, nblk;
+    const float* x;
+    int64_t ldx;
+    const float* w;            // [nnz, H] or NULL
+    int32_t H, D, F;           // F = H * D floats per row
+    float* out;
+    int64_t ldo;
+};
+
+template <int VEC, int NCHUNK, bool WEIGHTED, int T>
+__global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float acc_lds[];  // [T][Fp]
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = a.tile0 + blockIdx.x;
+    if (tile >= a.n_tiles) return;
+    const int Fp = NCHUNK * 64 * VEC;
+    int off[NCHUNK], hd[NCHUNK];
+    bool act[NCHUNK];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int e = (c * 64 + lane) * VEC;
+        act[c] = e < a.F;
+        off[c] = act[c] ? e : 0;
+        hd[c] = act[c] ? e / a.D : 0;  // head of this lane's elements (D % VEC == 0: a vector never straddles heads)
+    }
+    // zero the rows this wave owns
+    for (int r = wave; r < T; r += 4)
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+            float z[VEC];
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) z[t] = 0.f;
+            vstore<VEC>(acc_lds + r * Fp + (c * 64 + lane) * VEC, z);
+        }
+    const int32_t* p = a.ptr + ((int64_t)tile * a.nblk) * 4 + wave;
+    for (int blk = 0; blk < a.nblk; ++blk, p += 4) {
+        const int beg = __builtin_amdgcn_readfirstlane(p[0]);
+        const int end = __builtin_amdgcn_readfirstlane(p[1]);
+        int cur = -1;
+        float racc[NCHUNK][VEC];
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) racc[c][t] = 0.f;
+        for (int k0 = beg; k0 < end; k0 += 64) {
+            const int k = k0 + lane;
+            int idx = 0, lr = 0, pos = 0;
+            if (k < end) {
+                idx = a.b_src[k];
+                lr = a.b_lrow[k];
+                if constexpr (WEIGHTED) pos = a.b_pos[k];
+            }
+            const int cnt = min(64, end - k0);
+            for (int i = 0; i < cnt; i += U) {
+                float v[U][NCHUNK][VEC], ww[U][NCHUNK];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = min(i + u, cnt - 1);
+                    const int s = __builtin_amdgcn_readlane(idx, j);
+                    const float* px = a.x + (int64_t)s * a.ldx;
+#pragma unroll
+                    for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + off[c]);
+                    if constexpr (WEIGHTED) {
+                        const int ps = __builtin_amdgcn_readlane(pos, j);
+#pragma unroll
+                        for (int c = 0; c < NCHUNK; ++c) ww[u][c] = a.w[(int64_t)ps * a.H + hd[c]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (i + u < cnt) {  // wave-uniform
+                        const int r = __builtin_amdgcn_readlane(lr, i + u);
+                        if (r != cur) {
+                            if (cur >= 0) {
+#pragma unroll
+                                for (int c = 0; c < NCHUNK; ++c) {
+                                    float* q = acc_lds + cur * Fp + (c * 64 + lane) * VEC;
+                                    float o[VEC];
+                                    vload<VEC>(o, q);
+#pragma unroll
+                                    for (int t = 0; t < VEC; ++t) o[t] += racc[c][t], racc[c][t] = 0.f;
+                                    vstore<VEC>(q, o);
+                                }
+                            }
+                            cur = r;
+                        }
+#pragma unroll
+                        for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                            for (int t = 0; t < VEC; ++t) {
+                                if constexpr (WEIGHTED) racc[c][t] = fmaf(ww[u][c], v[u][c][t], racc[c][t]);
+                                else racc[c][t] += v[u][c][t];
+                            }
+                    }
+                }
+            }
+        }
+        if (cur >= 0) {
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) {
+                float* q = acc_lds + cur * Fp + (c * 64 + lane) * VEC;
+                float o[VEC];
+                vload<VEC>(o, q);
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) o[t] += racc[c][t];
+                vstore<VEC>(q, o);
+            }
+        }
+    }
+    // rows of this wave -> global (each row one coalesced store)
+    for (int r = wave; r < T; r += 4) {
+        const int row = a.tile_rows[(int64_t)tile * T + r];
+        if (row < 0) continue;
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c)
+            if (act[c]) {
+                float o[VEC];
+                vload<VEC>(o, acc_lds + r * Fp + (c * 64 + lane) * VEC);
+                vstore<VEC>(a.out + (int64_t)row * a.ldo + off[c], o);
+            }
+    }
+}
+
+template <int VEC, int NCHUNK, int T>
+static int launch_blocked(const BlockedArgs& a0, int round_tiles, hipStream_t st) {
+    const size_t lds = (size_t)T * NCHUNK * 64 * VEC * sizeof(float);
+    auto k1 = spmm_blocked_kernel<VEC, NCHUNK, true, T>;
+    auto k0 = spmm_blocked_kernel<VEC, NCHUNK, false, T>;
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    BlockedArgs a = a0;
+    for (int t0 = 0; t0 < a.n_tiles; t0 += round_tiles) {  // one resident wave of workgroups per launch keeps the sweeps aligned
+        a.tile0 = t0;
+        const int n = a.n_tiles - t0 < round_tiles ? a.n_tiles - t0 : round_tiles;
+        if (a.w) hipLaunchKernelGGL(k1, dim3(n), dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL(k0, dim3(n), dim3(kBlock), lds, st, a);
+    }
+    return hip_status("spmm_blocked launch");
+}
+
+}  // namespace bot
+
+extern "C" {
+
+int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int32_t* b_src, const uint8_t* b_lrow,
+                         const int32_t* b_pos, int32_t n_tiles, int32_t nblk, int32_t T, int32_t round_tiles, const float* x,
+                         int64_t ldx, const float* w, int32_t H, int32_t D, float* out, int64_t ldo, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n_tiles >= 0 && nblk >= 1 && round_tiles >= 1, BOT_E_RANGE, "spmm_blocked: n_tiles=%d nblk=%d round=%d", n_tiles, nblk, round_tiles);
+    BOT_REQUIRE(T == 64 || T == 32 || T == 16, BOT_E_RANGE, "spmm_blocked: tile height %d (16, 32 or 64)", T);
+    BOT_REQUIRE(H >= 1 && D >= 1 && (int64_t)H * D <= 1024, BOT_E_RANGE, "spmm_blocked: H*D=%lld exceeds 1024", (long long)H * D);
+    if (n_tiles == 0) return 0;
+    BOT_REQUIRE(tile_rows && ptr && b_src && b_lrow && x && out && (w == nullptr || b_pos), BOT_E_NULL, "spmm_blocked: NULL pointer");
+    const int F = H * D;
+    BOT_REQUIRE(ldx >= F && ldo >= F, BOT_E_RANGE, "spmm_blocked: row stride smaller than H*D");
+    const int vec = pick_vec(D, {ldx, ldo}, {x, out});
+    const int L = (F + vec - 1) / vec;
+    const int nchunk = (L + 63) / 64;
+    BOT_REQUIRE(nchunk <= 4 && (size_t)T * nchunk * 64 * vec * 4 <= 160 * 1024, BOT_E_RANGE, "spmm_blocked: tile does not fit LDS");
+    BlockedArgs a{tile_rows, ptr, b_src, b_lrow, b_pos, 0, n_tiles, nblk, x, ldx, w, H, D, F, out, ldo};
+    hipStream_t st = (hipStream_t)stream;
+#define BOT_BLK(V, NC)                                            \
+    do {                                                          \
+        if (T == 64) return launch_blocked<V, NC, 64>(a, round_tiles, st); \
+        if (T == 32) return launch_blocked<V, NC, 32>(a, round_tiles, st); \
+        return launch_blocked<V, NC, 16>(a, round_tiles, st);     \
+    } while (0)
+#define BOT_BLK_V(V)                     \
+    do {                                 \
+        if (nchunk == 1) BOT_BLK(V, 1);  \
+        if (nchunk == 2) BOT_BLK(V, 2);  \
+        if (nchunk == 3) BOT_BLK(V, 3);  \
+        BOT_BLK(V, 4);                   \
+    } while (0)
+    if (vec == 4) BOT_BLK_V(4);
+    if (vec == 2) BOT_BLK_V(2);
+    BOT_BLK_V(1);
+#undef BOT_BLK_V
+#undef BOT_BLK
+}
+
+}  // extern "C"

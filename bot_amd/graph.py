@@ -31,6 +31,11 @@ class Direction:
     n_long: int
     n_slots: int
     chunk: int
+    blocked: dict = None     # row width -> bot_amd.blocked.BlockedPlan (dense graphs; built lazily on the device)
+
+    def __post_init__(self):
+        if self.blocked is None:
+            self.blocked = {}
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)

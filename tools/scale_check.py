@@ -105,10 +105,15 @@ def main():
         x = torch.randn(n, H, D, device=DEV)
         a = torch.rand(E, H, device=DEV)
         w = None if name == "reddit" else a
+        from bot_amd import blocked
+        blocked.ENABLED = False
+        ms_spmm_row = timed(lambda: _C.spmm(g.csc, x, w, None), 5)
+        blocked.ENABLED = True
         ms_spmm = timed(lambda: _C.spmm(g.csc, x, w, None), 5)
         alg = 4 * (2 * n * H * D + E + n + 1 + (E * H if w is not None else 0))
         print(json.dumps({"workload": f"S-{name}", **props, "graph_build_s": round(t_build, 2), "fwd_bwd_ms": round(ms, 2),
-                          "edges_per_s": round(E / ms * 1e3), "spmm_ms": round(ms_spmm, 3),
+                          "edges_per_s": round(E / ms * 1e3), "spmm_ms": round(ms_spmm, 3), "spmm_row_kernel_ms": round(ms_spmm_row, 3),
+                          "spmm_blocked": blocked.plan_for(g.csc, n, H, D) is not None,
                           "spmm_alg_GBs": round(alg / ms_spmm / 1e6, 1), "spmm_frac_of_8TBs": round(alg / ms_spmm / 1e6 / 8000, 4),
                           "spmm_gather_model_GBs": round(4 * (E * H * D + n * H * D + E) / ms_spmm / 1e6, 1),
                           "hbm_GB_allocated": round(torch.cuda.max_memory_allocated() / 1e9, 1)}), flush=True)
