@@ -73,11 +73,11 @@ def build(d, n_src: int, F: int) -> BlockedPlan:
     slot = slot[pos]
     src = d.indices[pos].long()
     tile, lrow = slot // T, slot % T
-    group = (tile * nblk + src // cb) * 4 + (lrow % 4)            # (tile, block, wave)
-    key = group * T + lrow
+    stream = tile * 4 + (lrow % 4)                                # (tile, wave): one contiguous edge stream per wave
+    key = (stream * nblk + src // cb) * T + lrow                  # inside a stream: by column block, then row
     perm = torch.argsort(key, stable=True)                        # ties keep position order = ascending edge id
-    counts = torch.bincount(group, minlength=n_tiles * nblk * 4)
-    ptr = torch.zeros(n_tiles * nblk * 4 + 1, dtype=torch.int64, device=dev)
+    counts = torch.bincount(stream, minlength=n_tiles * 4)
+    ptr = torch.zeros(n_tiles * 4 + 1, dtype=torch.int64, device=dev)
     ptr[1:] = torch.cumsum(counts, 0)
     heavy_rows = torch.nonzero(~regular).squeeze(1)
     heavy = _heavy_direction(d, heavy_rows) if heavy_rows.numel() else None
@@ -89,7 +89,8 @@ def build(d, n_src: int, F: int) -> BlockedPlan:
 def plan_for(d, n_src: int, H: int, D: int):
     """BlockedPlan for direction `d` and row width H*D, or None when the row-per-group kernel is the right one."""
     F = H * D
-    if not ENABLED or F > 1024 or d.n_rows == 0 or d.nnz < MIN_MEAN_DEGREE * d.n_rows or not d.indptr.is_cuda:
+    vec = 4 if D % 4 == 0 else (2 if D % 2 == 0 else 1)
+    if not ENABLED or F > 256 * vec or d.n_rows == 0 or d.nnz < MIN_MEAN_DEGREE * d.n_rows or not d.indptr.is_cuda:
         return None
     cache = d.blocked
     if F not in cache:

@@ -11,10 +11,12 @@
 //   * every workgroup walks the column blocks in the SAME order, so at any moment all workgroups of an XCD gather from the
 //     same ~CB source rows, which therefore live in that XCD's L2; the host launches the tiles in rounds of one
 //     resident wave of workgroups (kernel boundaries keep the rounds aligned — no in-kernel grid barrier);
-//   * within (tile, block) the edge list is pre-sorted by (wave, local row): wave w owns local rows w, w+4, ...; it sums
-//     a row's neighbours of this block in registers and folds them into the LDS row when the row changes (one LDS
-//     read-modify-write per (row, block) visit, none per edge); no two waves touch the same LDS row: no atomics, no
-//     barriers, fixed summation order (block-major, then edge id) => bitwise reproducible.
+//   * wave w of the workgroup owns the tile rows w, w+4, ...; its edges are pre-sorted into ONE contiguous stream ordered by
+//     (column block, row, edge id), which it walks linearly (next 64 edges' metadata prefetched, 8 gathers in flight): it
+//     sums a row's neighbours of the current block in registers and folds them into the LDS row when the row changes (one
+//     LDS read-modify-write per (row, block) visit, none per edge); no two waves touch the same LDS row: no atomics, no
+//     barriers, fixed summation order (block-major, then edge id) => bitwise reproducible.  Workgroups are not
+//     synchronised per block: equal-degree tiles progress through the blocks at the same rate.
 //
 // Rows far above the mean degree (hubs) and everything else stay on the row-per-group kernel.
 // HBM roofline unchanged: 4*[2*n*F + nnz + ...] algorithmic bytes; what changes is where the re-reads are served.
@@ -24,7 +26,7 @@ namespace bot {
 
 struct BlockedArgs {
     const int32_t* tile_rows;  // [n_tiles * T]  destination row of each tile slot, -1 = padding
-    const int32_t* ptr;        // [n_tiles * nblk * 4 + 1]  edge offsets, (tile, block, wave)-major
+    const int32_t* ptr;        // [n_tiles * 4 + 1]  edge-stream offsets, (tile, wave)-major
     const int32_t* b_src;      // [nnz_b] source row of each blocked edge
     const uint8_t* b_lrow;     // [nnz_b] slot of the destination row inside its tile
     const int32_t* b_pos;      // [nnz_b] position in the unblocked edge order (row of w), used when weighted
@@ -37,10 +39,23 @@ struct BlockedArgs {
     int64_t ldo;
 };
 
+template <int VEC, int NCHUNK>
+__device__ __forceinline__ void lds_fold(float* q_row, int lane, float (&racc)[NCHUNK][VEC]) {
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        float* q = q_row + (c * 64 + lane) * VEC;
+        float o[VEC];
+        vload<VEC>(o, q);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) o[t] += racc[c][t], racc[c][t] = 0.f;
+        vstore<VEC>(q, o);
+    }
+}
+
 template <int VEC, int NCHUNK, bool WEIGHTED, int T>
 __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];  // [T][Fp]
-    constexpr int U = 4;
+    constexpr int U = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = a.tile0 + blockIdx.x;
     if (tile >= a.n_tiles) return;
@@ -54,8 +69,7 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
         off[c] = act[c] ? e : 0;
         hd[c] = act[c] ? e / a.D : 0;  // head of this lane's elements (D % VEC == 0: a vector never straddles heads)
     }
-    // zero the rows this wave owns
-    for (int r = wave; r < T; r += 4)
+    for (int r = wave; r < T; r += 4)  // zero the rows this wave owns
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c) {
             float z[VEC];
@@ -63,83 +77,67 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
             for (int t = 0; t < VEC; ++t) z[t] = 0.f;
             vstore<VEC>(acc_lds + r * Fp + (c * 64 + lane) * VEC, z);
         }
-    const int32_t* p = a.ptr + ((int64_t)tile * a.nblk) * 4 + wave;
-    for (int blk = 0; blk < a.nblk; ++blk, p += 4) {
-        const int beg = __builtin_amdgcn_readfirstlane(p[0]);
-        const int end = __builtin_amdgcn_readfirstlane(p[1]);
-        int cur = -1;
-        float racc[NCHUNK][VEC];
+    // this wave's edge stream: the edges of its rows, sorted by (column block, row, edge id)
+    const int beg = __builtin_amdgcn_readfirstlane(a.ptr[(int64_t)tile * 4 + wave]);
+    const int end = __builtin_amdgcn_readfirstlane(a.ptr[(int64_t)tile * 4 + wave + 1]);
+    int cur = -1;
+    float racc[NCHUNK][VEC];
 #pragma unroll
-        for (int c = 0; c < NCHUNK; ++c)
+    for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
-            for (int t = 0; t < VEC; ++t) racc[c][t] = 0.f;
-        for (int k0 = beg; k0 < end; k0 += 64) {
-            const int k = k0 + lane;
-            int idx = 0, lr = 0, pos = 0;
-            if (k < end) {
-                idx = a.b_src[k];
-                lr = a.b_lrow[k];
-                if constexpr (WEIGHTED) pos = a.b_pos[k];
-            }
-            const int cnt = min(64, end - k0);
-            for (int i = 0; i < cnt; i += U) {
-                float v[U][NCHUNK][VEC], ww[U][NCHUNK];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int j = min(i + u, cnt - 1);
-                    const int s = __builtin_amdgcn_readlane(idx, j);
-                    const float* px = a.x + (int64_t)s * a.ldx;
-#pragma unroll
-                    for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + off[c]);
-                    if constexpr (WEIGHTED) {
-                        const int ps = __builtin_amdgcn_readlane(pos, j);
-#pragma unroll
-                        for (int c = 0; c < NCHUNK; ++c) ww[u][c] = a.w[(int64_t)ps * a.H + hd[c]];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (i + u < cnt) {  // wave-uniform
-                        const int r = __builtin_amdgcn_readlane(lr, i + u);
-                        if (r != cur) {
-                            if (cur >= 0) {
-#pragma unroll
-                                for (int c = 0; c < NCHUNK; ++c) {
-                                    float* q = acc_lds + cur * Fp + (c * 64 + lane) * VEC;
-                                    float o[VEC];
-                                    vload<VEC>(o, q);
-#pragma unroll
-                                    for (int t = 0; t < VEC; ++t) o[t] += racc[c][t], racc[c][t] = 0.f;
-                                    vstore<VEC>(q, o);
-                                }
-                            }
-                            cur = r;
-                        }
-#pragma unroll
-                        for (int c = 0; c < NCHUNK; ++c)
-#pragma unroll
-                            for (int t = 0; t < VEC; ++t) {
-                                if constexpr (WEIGHTED) racc[c][t] = fmaf(ww[u][c], v[u][c][t], racc[c][t]);
-                                else racc[c][t] += v[u][c][t];
-                            }
-                    }
-                }
-            }
+        for (int t = 0; t < VEC; ++t) racc[c][t] = 0.f;
+    // metadata of the next 64 edges is fetched while the current 64 are gathered
+    int idx_n = 0, lr_n = 0, pos_n = 0;
+    if (beg + lane < end) {
+        idx_n = a.b_src[beg + lane];
+        lr_n = a.b_lrow[beg + lane];
+        if constexpr (WEIGHTED) pos_n = a.b_pos[beg + lane];
+    }
+    for (int k0 = beg; k0 < end; k0 += 64) {
+        const int idx = idx_n, lr = lr_n, pos = pos_n;
+        const int kn = k0 + 64 + lane;
+        if (kn < end) {
+            idx_n = a.b_src[kn];
+            lr_n = a.b_lrow[kn];
+            if constexpr (WEIGHTED) pos_n = a.b_pos[kn];
         }
-        if (cur >= 0) {
+        const int cnt = min(64, end - k0);
+        for (int i = 0; i < cnt; i += U) {
+            float v[U][NCHUNK][VEC], ww[U][NCHUNK];
 #pragma unroll
-            for (int c = 0; c < NCHUNK; ++c) {
-                float* q = acc_lds + cur * Fp + (c * 64 + lane) * VEC;
-                float o[VEC];
-                vload<VEC>(o, q);
+            for (int u = 0; u < U; ++u) {
+                const int j = min(i + u, cnt - 1);
+                const int s = __builtin_amdgcn_readlane(idx, j);
+                const float* px = a.x + (int64_t)s * a.ldx;
 #pragma unroll
-                for (int t = 0; t < VEC; ++t) o[t] += racc[c][t];
-                vstore<VEC>(q, o);
+                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + off[c]);
+                if constexpr (WEIGHTED) {
+                    const int ps = __builtin_amdgcn_readlane(pos, j);
+#pragma unroll
+                    for (int c = 0; c < NCHUNK; ++c) ww[u][c] = a.w[(int64_t)ps * a.H + hd[c]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (i + u < cnt) {  // wave-uniform
+                    const int r = __builtin_amdgcn_readlane(lr, i + u);
+                    if (r != cur) {
+                        if (cur >= 0) lds_fold<VEC, NCHUNK>(acc_lds + cur * Fp, lane, racc);
+                        cur = r;
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                        for (int t = 0; t < VEC; ++t) {
+                            if constexpr (WEIGHTED) racc[c][t] = fmaf(ww[u][c], v[u][c][t], racc[c][t]);
+                            else racc[c][t] += v[u][c][t];
+                        }
+                }
             }
         }
     }
-    // rows of this wave -> global (each row one coalesced store)
-    for (int r = wave; r < T; r += 4) {
+    if (cur >= 0) lds_fold<VEC, NCHUNK>(acc_lds + cur * Fp, lane, racc);
+    for (int r = wave; r < T; r += 4) {  // rows of this wave -> global (each row one coalesced store)
         const int row = a.tile_rows[(int64_t)tile * T + r];
         if (row < 0) continue;
 #pragma unroll

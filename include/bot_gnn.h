@@ -100,9 +100,9 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
  * addend) for the destination rows listed in `tile_rows`; other rows of `out` are not touched (the caller runs hub rows
  * through bot_spmm_f32 with a plan restricted to them).  The blocked edge structure is built once per graph direction
  * by the host (bot_amd/blocked.py): destination rows grouped into tiles of T (16/32/64) rows, sources cut into `nblk`
- * column blocks, edges sorted by (tile, block, wave = slot % 4, slot, position):
+ * column blocks, edges sorted by (tile, wave = slot % 4, block, slot, position):
  *   tile_rows[n_tiles*T]      destination row of each tile slot (-1: padding)
- *   ptr[n_tiles*nblk*4 + 1]   edge offsets, (tile, block, wave)-major
+ *   ptr[n_tiles*4 + 1]        offsets of each wave's edge stream, (tile, wave)-major; a stream is sorted by (block, slot, position)
  *   b_src / b_lrow / b_pos    per blocked edge: source row, tile slot of its destination, position in the unblocked order
  * One workgroup owns a tile and keeps its T output rows in LDS; all workgroups walk the column blocks in the same order so
  * the block being gathered is resident in every XCD's L2; tiles are launched `round_tiles` at a time (one resident wave
