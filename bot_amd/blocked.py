@@ -11,7 +11,8 @@ import torch
 ENABLED = True
 MIN_MEAN_DEGREE = 96       # below this a (row, block) visit holds < 1 edge: nothing to reuse
 L2_BLOCK_BYTES = 1 << 20   # source rows per column block * row bytes (4 MiB L2 per XCD holds a few blocks of skew)
-ROUND_WORKGROUPS = 512     # 256 CUs x 2 resident workgroups
+TILE_ROWS = 32             # destination rows per workgroup (16 / 32 / 64)
+TILE_LDS_BYTES = 32 * 1024 # LDS per workgroup: 4-5 workgroups (16-20 waves) resident per CU
 HUB_FACTOR = 8             # rows longer than HUB_FACTOR x mean stay on the row-per-group kernel
 
 
@@ -53,7 +54,9 @@ def build(d, n_src: int, F: int) -> BlockedPlan:
     deg = (d.indptr[1:] - d.indptr[:-1]).long()
     mean = max(1.0, d.nnz / max(1, d.n_rows))
     hub_thr = max(int(HUB_FACTOR * mean), d.chunk)
-    T = 64 if F * 4 * 64 <= 64 * 1024 else (32 if F * 4 * 32 <= 64 * 1024 else 16)
+    T = TILE_ROWS
+    while T > 16 and F * 4 * T > TILE_LDS_BYTES:
+        T //= 2
     cb = max(64, L2_BLOCK_BYTES // (F * 4))
     cb = 1 << (cb.bit_length() - 1)
     nblk = (n_src + cb - 1) // cb
@@ -81,9 +84,10 @@ def build(d, n_src: int, F: int) -> BlockedPlan:
     ptr[1:] = torch.cumsum(counts, 0)
     heavy_rows = torch.nonzero(~regular).squeeze(1)
     heavy = _heavy_direction(d, heavy_rows) if heavy_rows.numel() else None
+    per_cu = max(1, min(8, (160 * 1024) // max(1, T * F * 4)))      # resident workgroups per CU (LDS-limited)
     return BlockedPlan(tile_rows, ptr.to(torch.int32).contiguous(), src[perm].to(torch.int32).contiguous(),
                        lrow[perm].to(torch.uint8).contiguous(), pos[perm].to(torch.int32).contiguous(), n_tiles, nblk, T,
-                       ROUND_WORKGROUPS if T * F * 4 <= 64 * 1024 else ROUND_WORKGROUPS // 2, heavy)
+                       256 * per_cu, heavy)
 
 
 def plan_for(d, n_src: int, H: int, D: int):

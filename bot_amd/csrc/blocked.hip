@@ -55,7 +55,7 @@ __device__ __forceinline__ void lds_fold(float* q_row, int lane, float (&racc)[N
 template <int VEC, int NCHUNK, bool WEIGHTED, int T>
 __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];  // [T][Fp]
-    constexpr int U = 8;
+    constexpr int U = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = a.tile0 + blockIdx.x;
     if (tile >= a.n_tiles) return;
@@ -102,21 +102,24 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
             if constexpr (WEIGHTED) pos_n = a.b_pos[kn];
         }
         const int cnt = min(64, end - k0);
-        for (int i = 0; i < cnt; i += U) {
-            float v[U][NCHUNK][VEC], ww[U][NCHUNK];
+        // software pipeline over groups of U edges: the gathers of group g+1 are in flight while group g is summed
+        float v[2][U][NCHUNK][VEC], ww[2][U][NCHUNK];
+        auto issue = [&](int buf, int i) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int j = min(i + u, cnt - 1);
                 const int s = __builtin_amdgcn_readlane(idx, j);
                 const float* px = a.x + (int64_t)s * a.ldx;
 #pragma unroll
-                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + off[c]);
+                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[buf][u][c], px + off[c]);
                 if constexpr (WEIGHTED) {
                     const int ps = __builtin_amdgcn_readlane(pos, j);
 #pragma unroll
-                    for (int c = 0; c < NCHUNK; ++c) ww[u][c] = a.w[(int64_t)ps * a.H + hd[c]];
+                    for (int c = 0; c < NCHUNK; ++c) ww[buf][u][c] = a.w[(int64_t)ps * a.H + hd[c]];
                 }
             }
+        };
+        auto consume = [&](int buf, int i) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (i + u < cnt) {  // wave-uniform
@@ -129,11 +132,18 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
                     for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
                         for (int t = 0; t < VEC; ++t) {
-                            if constexpr (WEIGHTED) racc[c][t] = fmaf(ww[u][c], v[u][c][t], racc[c][t]);
-                            else racc[c][t] += v[u][c][t];
+                            if constexpr (WEIGHTED) racc[c][t] = fmaf(ww[buf][u][c], v[buf][u][c][t], racc[c][t]);
+                            else racc[c][t] += v[buf][u][c][t];
                         }
                 }
             }
+        };
+        issue(0, 0);
+        for (int i = 0; i < cnt; i += 2 * U) {
+            if (i + U < cnt) issue(1, i + U);
+            consume(0, i);
+            if (i + 2 * U < cnt) issue(0, i + 2 * U);
+            if (i + U < cnt) consume(1, i + U);
         }
     }
     if (cur >= 0) lds_fold<VEC, NCHUNK>(acc_lds + cur * Fp, lane, racc);
