@@ -35,9 +35,8 @@ _SIGS = {
     "bot_spmm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "bot_spmm_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                     c_int32, c_int32, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P]),
-    "bot_spmm_blocked_sync_ints": (c_int64, [c_int32, c_int32, c_int32]),
     "bot_spmm_blocked_f32": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P, c_int32,
-                                            c_int32, _P, c_int64, _P, c_int32, c_int32, _P]),
+                                            c_int32, _P, c_int64, _P]),
     "bot_spmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                         _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P]),
     "bot_spmm_bcast_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, _P, _P, c_int32,
@@ -174,14 +173,10 @@ def _slab(x, name):
 def spmm_blocked(bp, x, w, out):
     """L2-blocked SpMM over the tiles of `bp` (bot_amd.blocked.BlockedPlan); writes only the rows bp covers."""
     H, D = x.shape[1], x.shape[2]
-    sync = None
-    if bp.window > 0:
-        sync = torch.empty(int(_lib.bot_spmm_blocked_sync_ints(bp.n_tiles, bp.nblk, bp.round_tiles)), dtype=torch.int32,
-                           device=x.device)
     _check(_timed("spmm_blocked", (H, D, w is not None), lambda: _lib.bot_spmm_blocked_f32(
         bp.tile_rows.data_ptr(), bp.ptr.data_ptr(), bp.b_src.data_ptr(), bp.b_lrow.data_ptr(), bp.b_pos.data_ptr(), bp.n_tiles,
-        bp.nblk, bp.T, bp.round_tiles, x.data_ptr(), x.stride(0), _ptr(w), H, D, out.data_ptr(), out.stride(0), _ptr(sync),
-        bp.block_rows, bp.window, _stream())), "spmm_blocked")
+        bp.nblk, bp.T, bp.round_tiles, x.data_ptr(), x.stride(0), _ptr(w), H, D, out.data_ptr(), out.stride(0), _stream())),
+        "spmm_blocked")
     return out
 
 

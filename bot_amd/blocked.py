@@ -13,7 +13,6 @@ MIN_MEAN_DEGREE = 96       # below this a (row, block) visit holds < 1 edge: not
 L2_BLOCK_BYTES = 1 << 20   # source rows per column block * row bytes (4 MiB L2 per XCD holds a few blocks of skew)
 TILE_ROWS = 32             # destination rows per workgroup (16 / 32 / 64)
 TILE_LDS_BYTES = 32 * 1024 # LDS per workgroup: 4-5 workgroups (16-20 waves) resident per CU
-PACE_WINDOW = 2            # a wave runs at most this many column blocks ahead of the slowest on its XCD (0: no pacing)
 HUB_FACTOR = 8             # rows longer than HUB_FACTOR x mean stay on the row-per-group kernel
 
 
@@ -29,8 +28,6 @@ class BlockedPlan:
     T: int
     round_tiles: int
     heavy: object  # Direction restricted to the hub rows, or None
-    block_rows: int = 0
-    window: int = 0
 
 
 def _heavy_direction(d, heavy_rows):
@@ -90,7 +87,7 @@ def build(d, n_src: int, F: int) -> BlockedPlan:
     per_cu = max(1, min(8, (160 * 1024) // max(1, T * F * 4)))      # resident workgroups per CU (LDS-limited)
     return BlockedPlan(tile_rows, ptr.to(torch.int32).contiguous(), src[perm].to(torch.int32).contiguous(),
                        lrow[perm].to(torch.uint8).contiguous(), pos[perm].to(torch.int32).contiguous(), n_tiles, nblk, T,
-                       256 * per_cu, heavy, cb, PACE_WINDOW)
+                       256 * per_cu, heavy)
 
 
 def plan_for(d, n_src: int, H: int, D: int):

@@ -37,30 +37,7 @@ struct BlockedArgs {
     int32_t H, D, F;           // F = H * D floats per row
     float* out;
     int64_t ldo;
-    int32_t* sync;             // [rounds][8][nblk + 2] progress counters (zeroed by the caller) or NULL: no pacing
-    int32_t cb_shift;          // log2(source rows per column block)
-    int32_t window;            // a wave may run at most `window` column blocks ahead of the slowest wave of its XCD
 };
-
-// Pacing across the workgroups of one XCD (speed only — results never depend on it).  Every wave counts itself in
-// reg[0] when it starts and bumps done[b] when it has left column block b; before entering block b it waits (bounded
-// spin) until all registered waves have left block b - window.  Only resident, running waves are ever waited for, and a
-// finished wave bumps all its remaining blocks, so the wait cannot deadlock; the spin bound makes a hang impossible.
-__device__ __forceinline__ void pace_leave(int32_t* done, int from, int to) {
-    if (threadIdx.x % 64 == 0)
-        for (int b = from; b < to; ++b) atomicAdd(done + 1 + b, 1);
-}
-__device__ __forceinline__ void pace_wait(int32_t* done, int blk, int window) {
-    const int need = blk - window;
-    if (need < 0) return;
-    if (threadIdx.x % 64 == 0) {
-        const int registered = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int spin = 0; spin < 4096; ++spin) {
-            if (__hip_atomic_load(done + 1 + need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= registered) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-}
 
 template <int VEC, int NCHUNK>
 __device__ __forceinline__ void lds_fold(float* q_row, int lane, float (&racc)[NCHUNK][VEC]) {
@@ -109,13 +86,6 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
     for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
         for (int t = 0; t < VEC; ++t) racc[c][t] = 0.f;
-    int32_t* done = nullptr;
-    int cur_blk = 0;
-    if (a.sync) {
-        const int xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11)) & 7;
-        done = a.sync + ((int64_t)(a.tile0 / max(1, (int)gridDim.x)) * 8 + xcc) * (a.nblk + 2);
-        if (lane == 0) atomicAdd(done, 1);
-    }
     // metadata of the next 64 edges is fetched while the current 64 are gathered
     int idx_n = 0, lr_n = 0, pos_n = 0;
     if (beg + lane < end) {
@@ -132,14 +102,6 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
             if constexpr (WEIGHTED) pos_n = a.b_pos[kn];
         }
         const int cnt = min(64, end - k0);
-        if (done) {  // pace on the column block of the batch's first edge (wave-uniform)
-            const int blk = __builtin_amdgcn_readlane(idx, 0) >> a.cb_shift;
-            if (blk != cur_blk) {
-                pace_leave(done, cur_blk, blk);
-                cur_blk = blk;
-                pace_wait(done, blk, a.window);
-            }
-        }
         // software pipeline over groups of U edges: the gathers of group g+1 are in flight while group g is summed
         float v[2][U][NCHUNK][VEC], ww[2][U][NCHUNK];
         auto issue = [&](int buf, int i) {
@@ -185,7 +147,6 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
         }
     }
     if (cur >= 0) lds_fold<VEC, NCHUNK>(acc_lds + cur * Fp, lane, racc);
-    if (done) pace_leave(done, cur_blk, a.nblk);  // nobody waits for a finished wave
     for (int r = wave; r < T; r += 4) {  // rows of this wave -> global (each row one coalesced store)
         const int row = a.tile_rows[(int64_t)tile * T + r];
         if (row < 0) continue;
@@ -222,14 +183,9 @@ static int launch_blocked(const BlockedArgs& a0, int round_tiles, hipStream_t st
 
 extern "C" {
 
-int64_t bot_spmm_blocked_sync_ints(int32_t n_tiles, int32_t nblk, int32_t round_tiles) {
-    return (int64_t)((n_tiles + round_tiles - 1) / (round_tiles > 0 ? round_tiles : 1)) * 8 * (nblk + 2);
-}
-
 int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int32_t* b_src, const uint8_t* b_lrow,
                          const int32_t* b_pos, int32_t n_tiles, int32_t nblk, int32_t T, int32_t round_tiles, const float* x,
-                         int64_t ldx, const float* w, int32_t H, int32_t D, float* out, int64_t ldo, int32_t* sync,
-                         int32_t block_rows, int32_t window, bot_stream_t stream) {
+                         int64_t ldx, const float* w, int32_t H, int32_t D, float* out, int64_t ldo, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n_tiles >= 0 && nblk >= 1 && round_tiles >= 1, BOT_E_RANGE, "spmm_blocked: n_tiles=%d nblk=%d round=%d", n_tiles, nblk, round_tiles);
     BOT_REQUIRE(T == 64 || T == 32 || T == 16, BOT_E_RANGE, "spmm_blocked: tile height %d (16, 32 or 64)", T);
@@ -242,16 +198,8 @@ int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int
     const int L = (F + vec - 1) / vec;
     const int nchunk = (L + 63) / 64;
     BOT_REQUIRE(nchunk <= 4 && (size_t)T * nchunk * 64 * vec * 4 <= 160 * 1024, BOT_E_RANGE, "spmm_blocked: tile does not fit LDS");
-    int shift = 0;
-    while ((1 << shift) < block_rows) ++shift;
-    BOT_REQUIRE(sync == nullptr || ((1 << shift) == block_rows && window >= 1), BOT_E_RANGE,
-                "spmm_blocked: pacing needs a power-of-two block_rows (%d) and window >= 1 (%d)", block_rows, window);
-    BlockedArgs a{tile_rows, ptr, b_src, b_lrow, b_pos, 0, n_tiles, nblk, x, ldx, w, H, D, F, out, ldo, sync, shift, window};
+    BlockedArgs a{tile_rows, ptr, b_src, b_lrow, b_pos, 0, n_tiles, nblk, x, ldx, w, H, D, F, out, ldo};
     hipStream_t st = (hipStream_t)stream;
-    if (sync) {
-        if (hipMemsetAsync(sync, 0, sizeof(int32_t) * bot_spmm_blocked_sync_ints(n_tiles, nblk, round_tiles), st) != hipSuccess)
-            return hip_status("spmm_blocked memset");
-    }
 #define BOT_BLK(V, NC)                                            \
     do {                                                          \
         if (T == 64) return launch_blocked<V, NC, 64>(a, round_tiles, st); \

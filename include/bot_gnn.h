@@ -106,17 +106,12 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
  *   b_src / b_lrow / b_pos    per blocked edge: source row, tile slot of its destination, position in the unblocked order
  * One workgroup owns a tile and keeps its T output rows in LDS; all workgroups walk the column blocks in the same order so
  * the block being gathered is resident in every XCD's L2; tiles are launched `round_tiles` at a time (one resident wave
- * of workgroups per launch).  H*D <= 1024 floats, T*H*D*4 <= 160 KB.  Deterministic: no float atomics.
- * `sync` (may be NULL) is a caller-provided scratch of bot_spmm_blocked_sync_ints() int32 used to PACE the workgroups of
- * each XCD (a wavefront runs at most `window` column blocks of `block_rows` sources ahead of the slowest one on its XCD;
- * bounded spins, speed only — the result never depends on it); the call zeroes it with a memset node on the stream.
+ * of workgroups per launch).  H*D <= 1024 floats, T*H*D*4 <= 160 KB.  Deterministic, no atomics.
  * ------------------------------------------------------------------------------------------- */
-int64_t bot_spmm_blocked_sync_ints(int32_t n_tiles, int32_t nblk, int32_t round_tiles);
 int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int32_t* b_src, const uint8_t* b_lrow,
                          const int32_t* b_pos, int32_t n_tiles, int32_t nblk, int32_t T, int32_t round_tiles,
                          const float* x, int64_t ldx, const float* w, int32_t H, int32_t D,
-                         float* out, int64_t ldo, int32_t* sync, int32_t block_rows, int32_t window,
-                         bot_stream_t stream);
+                         float* out, int64_t ldo, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused backward of u_mul_e_sum (models.py:547) in ONE sweep over the transposed direction (rows = sources u,
