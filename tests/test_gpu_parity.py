@@ -373,6 +373,8 @@ def test_blocked_spmm_matches_row_kernel():
     gen = torch.Generator().manual_seed(21)
     src = torch.randint(0, n, (450000,), generator=gen)
     dst = (n * torch.rand(450000, generator=gen, dtype=torch.float64) ** 1.6).long().clamp_(max=n - 1)  # skewed in-degrees
+    src = torch.cat([src, torch.arange(n), torch.arange(n)])   # two hubs: every node points at nodes 0 and 1
+    dst = torch.cat([dst, torch.zeros(n, dtype=torch.int64), torch.ones(n, dtype=torch.int64)])
     s, d = R.preprocess_edges(src, dst, n)
     g = bot_amd.Graph(s, d, n).to(DEV)
     assert g.csc.nnz / n > blocked.MIN_MEAN_DEGREE
