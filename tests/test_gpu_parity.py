@@ -121,7 +121,8 @@ def test_full_size_properties():
     (out * y).sum().backward()
     lhs = (out.detach().double() * y.double()).sum()
     rhs = (x1.double() * xr.grad.double()).sum()
-    assert abs(lhs - rhs) / abs(lhs) < 1e-5
+    # scaled by the norms, not by |lhs|: the inner product of random tensors can be arbitrarily close to zero
+    assert abs(lhs - rhs) <= 1e-5 * float(out.detach().double().norm() * y.double().norm())
     assert E > 2_000_000
 
 

@@ -52,7 +52,8 @@ def properties(g, H, D):
     out = ops.u_mul_e_sum(g, x, a, order="csc")
     (out * y).sum().backward()
     lhs, rhs = (out.detach().double() * y.double()).sum(), (x.detach().double() * x.grad.double()).sum()
-    assert abs(lhs - rhs) / abs(lhs) < 1e-5, "adjoint identity violated"
+    # scale by the norms, not by |lhs|: the inner product of random tensors can be arbitrarily close to zero
+    assert abs(lhs - rhs) <= 1e-5 * float(out.detach().double().norm() * y.double().norm()), "adjoint identity violated"
     return {"N": n, "E": E, "max_in_deg": int(g.in_degrees().max()), "long_rows": g.csc.n_long, "chunk": g.csc.chunk}
 
 
