@@ -11,8 +11,10 @@ import torch
 ENABLED = True
 MIN_MEAN_DEGREE = 96       # below this a (row, block) visit holds < 1 edge: nothing to reuse
 L2_BLOCK_BYTES = 1 << 20   # source rows per column block * row bytes (4 MiB L2 per XCD holds a few blocks of skew)
-TILE_ROWS = 32             # destination rows per workgroup (16 / 32 / 64)
-TILE_LDS_BYTES = 32 * 1024 # LDS per workgroup: 4-5 workgroups (16-20 waves) resident per CU
+TILE_ROWS = 128            # destination rows per workgroup (32 / 64 / 128)
+TILE_LDS_BYTES = 128 * 1024  # LDS per workgroup: one 16-wave workgroup per CU
+WAVES = 16                 # wavefronts per workgroup (bot_amd/csrc/blocked.hip kBWaves)
+ROUND_WORKGROUPS = 256     # one resident 16-wave workgroup per CU
 HUB_FACTOR = 8             # rows longer than HUB_FACTOR x mean stay on the row-per-group kernel
 
 
@@ -28,6 +30,7 @@ class BlockedPlan:
     T: int
     round_tiles: int
     heavy: object  # Direction restricted to the hub rows, or None
+    block_rows: int = 0
 
 
 def _heavy_direction(d, heavy_rows):
@@ -54,8 +57,10 @@ def build(d, n_src: int, F: int) -> BlockedPlan:
     deg = (d.indptr[1:] - d.indptr[:-1]).long()
     mean = max(1.0, d.nnz / max(1, d.n_rows))
     hub_thr = max(int(HUB_FACTOR * mean), d.chunk)
+    vec = 4 if F % 4 == 0 else (2 if F % 2 == 0 else 1)
+    Fp = (F + 64 * vec - 1) // (64 * vec) * (64 * vec)             # LDS row pitch of the kernel
     T = TILE_ROWS
-    while T > 16 and F * 4 * T > TILE_LDS_BYTES:
+    while T > 32 and Fp * 4 * T > TILE_LDS_BYTES:
         T //= 2
     cb = max(64, L2_BLOCK_BYTES // (F * 4))
     cb = 1 << (cb.bit_length() - 1)
@@ -76,18 +81,17 @@ def build(d, n_src: int, F: int) -> BlockedPlan:
     slot = slot[pos]
     src = d.indices[pos].long()
     tile, lrow = slot // T, slot % T
-    stream = tile * 4 + (lrow % 4)                                # (tile, wave): one contiguous edge stream per wave
+    stream = tile * WAVES + (lrow % WAVES)                        # (tile, wave): one contiguous edge stream per wave
     key = (stream * nblk + src // cb) * T + lrow                  # inside a stream: by column block, then row
     perm = torch.argsort(key, stable=True)                        # ties keep position order = ascending edge id
-    counts = torch.bincount(stream, minlength=n_tiles * 4)
-    ptr = torch.zeros(n_tiles * 4 + 1, dtype=torch.int64, device=dev)
+    counts = torch.bincount(stream, minlength=n_tiles * WAVES)
+    ptr = torch.zeros(n_tiles * WAVES + 1, dtype=torch.int64, device=dev)
     ptr[1:] = torch.cumsum(counts, 0)
     heavy_rows = torch.nonzero(~regular).squeeze(1)
     heavy = _heavy_direction(d, heavy_rows) if heavy_rows.numel() else None
-    per_cu = max(1, min(8, (160 * 1024) // max(1, T * F * 4)))      # resident workgroups per CU (LDS-limited)
     return BlockedPlan(tile_rows, ptr.to(torch.int32).contiguous(), src[perm].to(torch.int32).contiguous(),
                        lrow[perm].to(torch.uint8).contiguous(), pos[perm].to(torch.int32).contiguous(), n_tiles, nblk, T,
-                       256 * per_cu, heavy)
+                       ROUND_WORKGROUPS, heavy, cb)
 
 
 def plan_for(d, n_src: int, H: int, D: int):

@@ -11,12 +11,14 @@
 //   * every workgroup walks the column blocks in the SAME order, so at any moment all workgroups of an XCD gather from the
 //     same ~CB source rows, which therefore live in that XCD's L2; the host launches the tiles in rounds of one
 //     resident wave of workgroups (kernel boundaries keep the rounds aligned — no in-kernel grid barrier);
-//   * wave w of the workgroup owns the tile rows w, w+4, ...; its edges are pre-sorted into ONE contiguous stream ordered by
-//     (column block, row, edge id), which it walks linearly (next 64 edges' metadata prefetched, 8 gathers in flight): it
-//     sums a row's neighbours of the current block in registers and folds them into the LDS row when the row changes (one
-//     LDS read-modify-write per (row, block) visit, none per edge); no two waves touch the same LDS row: no atomics, no
-//     barriers, fixed summation order (block-major, then edge id) => bitwise reproducible.  Workgroups are not
-//     synchronised per block: equal-degree tiles progress through the blocks at the same rate.
+//   * the workgroup is 16 wavefronts (one per CU, T = 128 rows of 1 KB in LDS); wave w owns the tile rows w, w+16, ...;
+//     its edges are pre-sorted into ONE contiguous stream ordered by (column block, row, edge id), which it walks linearly,
+//     8 gathers in flight: it sums a row's neighbours of the current block in registers and folds them into the LDS row
+//     when the row changes (one LDS read-modify-write per (row, block) visit, none per edge); no two waves touch the same
+//     LDS row: no atomics, fixed summation order (block-major, then edge id) => bitwise reproducible;
+//   * the 16 waves of a workgroup cross the column blocks in lockstep (one __syncthreads per block), which makes the
+//     workgroup ONE sweeper with ~T*deg/nblk edges per block: the spread between the 32 sweepers of an XCD (a random walk
+//     in the per-block work) then stays a fraction of the L2.  Sweepers of different workgroups are not synchronised.
 //
 // Rows far above the mean degree (hubs) and everything else stay on the row-per-group kernel.
 // HBM roofline unchanged: 4*[2*n*F + nnz + ...] algorithmic bytes; what changes is where the re-reads are served.
@@ -26,7 +28,7 @@ namespace bot {
 
 struct BlockedArgs {
     const int32_t* tile_rows;  // [n_tiles * T]  destination row of each tile slot, -1 = padding
-    const int32_t* ptr;        // [n_tiles * 4 + 1]  edge-stream offsets, (tile, wave)-major
+    const int32_t* ptr;        // [n_tiles * 16 + 1]  edge-stream offsets, (tile, wave)-major
     const int32_t* b_src;      // [nnz_b] source row of each blocked edge
     const uint8_t* b_lrow;     // [nnz_b] slot of the destination row inside its tile
     const int32_t* b_pos;      // [nnz_b] position in the unblocked edge order (row of w), used when weighted
@@ -35,6 +37,7 @@ struct BlockedArgs {
     int64_t ldx;
     const float* w;            // [nnz, H] or NULL
     int32_t H, D, F;           // F = H * D floats per row
+    int32_t cb_shift;          // log2(source rows per column block)
     float* out;
     int64_t ldo;
 };
@@ -52,13 +55,15 @@ __device__ __forceinline__ void lds_fold(float* q_row, int lane, float (&racc)[N
     }
 }
 
+constexpr int kBWaves = 16;             // wavefronts per workgroup (1024 threads): one workgroup per CU, 128 KB of LDS rows
+constexpr int kBThreads = kBWaves * 64;
+
 template <int VEC, int NCHUNK, bool WEIGHTED, int T>
-__global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
+__global__ __launch_bounds__(kBThreads) void spmm_blocked_kernel(BlockedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];  // [T][Fp]
-    constexpr int U = 4;
+    constexpr int U = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = a.tile0 + blockIdx.x;
-    if (tile >= a.n_tiles) return;
+    const int tile = a.tile0 + blockIdx.x;  // grid never exceeds the tile count: every workgroup runs every barrier below
     const int Fp = NCHUNK * 64 * VEC;
     int off[NCHUNK], hd[NCHUNK];
     bool act[NCHUNK];
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
         off[c] = act[c] ? e : 0;
         hd[c] = act[c] ? e / a.D : 0;  // head of this lane's elements (D % VEC == 0: a vector never straddles heads)
     }
-    for (int r = wave; r < T; r += 4)  // zero the rows this wave owns
+    for (int r = wave; r < T; r += kBWaves)  // zero the rows this wave owns
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c) {
             float z[VEC];
@@ -78,51 +83,60 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
             vstore<VEC>(acc_lds + r * Fp + (c * 64 + lane) * VEC, z);
         }
     // this wave's edge stream: the edges of its rows, sorted by (column block, row, edge id)
-    const int beg = __builtin_amdgcn_readfirstlane(a.ptr[(int64_t)tile * 4 + wave]);
-    const int end = __builtin_amdgcn_readfirstlane(a.ptr[(int64_t)tile * 4 + wave + 1]);
+    int k0 = __builtin_amdgcn_readfirstlane(a.ptr[(int64_t)tile * kBWaves + wave]);
+    const int end = __builtin_amdgcn_readfirstlane(a.ptr[(int64_t)tile * kBWaves + wave + 1]);
     int cur = -1;
     float racc[NCHUNK][VEC];
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
         for (int t = 0; t < VEC; ++t) racc[c][t] = 0.f;
-    // metadata of the next 64 edges is fetched while the current 64 are gathered
-    int idx_n = 0, lr_n = 0, pos_n = 0;
-    if (beg + lane < end) {
-        idx_n = a.b_src[beg + lane];
-        lr_n = a.b_lrow[beg + lane];
-        if constexpr (WEIGHTED) pos_n = a.b_pos[beg + lane];
-    }
-    for (int k0 = beg; k0 < end; k0 += 64) {
-        const int idx = idx_n, lr = lr_n, pos = pos_n;
-        const int kn = k0 + 64 + lane;
-        if (kn < end) {
-            idx_n = a.b_src[kn];
-            lr_n = a.b_lrow[kn];
-            if constexpr (WEIGHTED) pos_n = a.b_pos[kn];
+    // current batch of up to 64 edges: (idx, lr, pos) one per lane, `i` consumed so far
+    int idx = 0, lr = 0, pos = 0, i = 0, cnt = 0;
+    auto load_batch = [&]() {
+        cnt = min(64, end - k0);
+        i = 0;
+        if (lane < cnt) {
+            idx = a.b_src[k0 + lane];
+            lr = a.b_lrow[k0 + lane];
+            if constexpr (WEIGHTED) pos = a.b_pos[k0 + lane];
         }
-        const int cnt = min(64, end - k0);
-        // software pipeline over groups of U edges: the gathers of group g+1 are in flight while group g is summed
-        float v[2][U][NCHUNK][VEC], ww[2][U][NCHUNK];
-        auto issue = [&](int buf, int i) {
+    };
+    if (k0 < end) load_batch();
+    // All 16 waves of the workgroup take the column blocks in lockstep (one barrier per block): the workgroup is ONE sweeper
+    // with T rows' worth of edges per block, so the spread between the sweepers of an XCD stays a fraction of the L2.
+    for (int b = 0; b < a.nblk; ++b) {
+        while (cnt > 0) {
+            if (i == cnt) {  // batch used up
+                k0 += 64;
+                if (k0 >= end) {
+                    cnt = 0;
+                    break;
+                }
+                load_batch();
+            }
+            // edges of this batch that still belong to column block b form a prefix of [i, cnt)
+            const bool mine = lane >= i && lane < cnt && (idx >> a.cb_shift) == b;
+            const int nb = __popcll(__ballot(mine));
+            if (nb == 0) break;  // next edge is in a later block
+            const int g = min(U, nb);
+            float v[U][NCHUNK][VEC], ww[U][NCHUNK];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = min(i + u, cnt - 1);
+                const int j = min(i + u, i + g - 1);
                 const int s = __builtin_amdgcn_readlane(idx, j);
                 const float* px = a.x + (int64_t)s * a.ldx;
 #pragma unroll
-                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[buf][u][c], px + off[c]);
+                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + off[c]);
                 if constexpr (WEIGHTED) {
                     const int ps = __builtin_amdgcn_readlane(pos, j);
 #pragma unroll
-                    for (int c = 0; c < NCHUNK; ++c) ww[buf][u][c] = a.w[(int64_t)ps * a.H + hd[c]];
+                    for (int c = 0; c < NCHUNK; ++c) ww[u][c] = a.w[(int64_t)ps * a.H + hd[c]];
                 }
             }
-        };
-        auto consume = [&](int buf, int i) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (i + u < cnt) {  // wave-uniform
+                if (u < g) {  // wave-uniform
                     const int r = __builtin_amdgcn_readlane(lr, i + u);
                     if (r != cur) {
                         if (cur >= 0) lds_fold<VEC, NCHUNK>(acc_lds + cur * Fp, lane, racc);
@@ -132,22 +146,17 @@ __global__ __launch_bounds__(kBlock) void spmm_blocked_kernel(BlockedArgs a) {
                     for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
                         for (int t = 0; t < VEC; ++t) {
-                            if constexpr (WEIGHTED) racc[c][t] = fmaf(ww[buf][u][c], v[buf][u][c][t], racc[c][t]);
-                            else racc[c][t] += v[buf][u][c][t];
+                            if constexpr (WEIGHTED) racc[c][t] = fmaf(ww[u][c], v[u][c][t], racc[c][t]);
+                            else racc[c][t] += v[u][c][t];
                         }
                 }
             }
-        };
-        issue(0, 0);
-        for (int i = 0; i < cnt; i += 2 * U) {
-            if (i + U < cnt) issue(1, i + U);
-            consume(0, i);
-            if (i + 2 * U < cnt) issue(0, i + 2 * U);
-            if (i + U < cnt) consume(1, i + U);
+            i += g;
         }
+        __syncthreads();
     }
     if (cur >= 0) lds_fold<VEC, NCHUNK>(acc_lds + cur * Fp, lane, racc);
-    for (int r = wave; r < T; r += 4) {  // rows of this wave -> global (each row one coalesced store)
+    for (int r = wave; r < T; r += kBWaves) {  // rows of this wave -> global (each row one coalesced store)
         const int row = a.tile_rows[(int64_t)tile * T + r];
         if (row < 0) continue;
 #pragma unroll
@@ -173,8 +182,8 @@ static int launch_blocked(const BlockedArgs& a0, int round_tiles, hipStream_t st
     for (int t0 = 0; t0 < a.n_tiles; t0 += round_tiles) {  // one resident wave of workgroups per launch keeps the sweeps aligned
         a.tile0 = t0;
         const int n = a.n_tiles - t0 < round_tiles ? a.n_tiles - t0 : round_tiles;
-        if (a.w) hipLaunchKernelGGL(k1, dim3(n), dim3(kBlock), lds, st, a);
-        else hipLaunchKernelGGL(k0, dim3(n), dim3(kBlock), lds, st, a);
+        if (a.w) hipLaunchKernelGGL(k1, dim3(n), dim3(kBThreads), lds, st, a);
+        else hipLaunchKernelGGL(k0, dim3(n), dim3(kBThreads), lds, st, a);
     }
     return hip_status("spmm_blocked launch");
 }
@@ -184,11 +193,15 @@ static int launch_blocked(const BlockedArgs& a0, int round_tiles, hipStream_t st
 extern "C" {
 
 int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int32_t* b_src, const uint8_t* b_lrow,
-                         const int32_t* b_pos, int32_t n_tiles, int32_t nblk, int32_t T, int32_t round_tiles, const float* x,
-                         int64_t ldx, const float* w, int32_t H, int32_t D, float* out, int64_t ldo, bot_stream_t stream) {
+                         const int32_t* b_pos, int32_t n_tiles, int32_t nblk, int32_t block_rows, int32_t T,
+                         int32_t round_tiles, const float* x, int64_t ldx, const float* w, int32_t H, int32_t D, float* out,
+                         int64_t ldo, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n_tiles >= 0 && nblk >= 1 && round_tiles >= 1, BOT_E_RANGE, "spmm_blocked: n_tiles=%d nblk=%d round=%d", n_tiles, nblk, round_tiles);
-    BOT_REQUIRE(T == 64 || T == 32 || T == 16, BOT_E_RANGE, "spmm_blocked: tile height %d (16, 32 or 64)", T);
+    BOT_REQUIRE(T == 128 || T == 64 || T == 32, BOT_E_RANGE, "spmm_blocked: tile height %d (32, 64 or 128)", T);
+    int shift = 0;
+    while ((1 << shift) < block_rows) ++shift;
+    BOT_REQUIRE(block_rows >= 1 && (1 << shift) == block_rows, BOT_E_RANGE, "spmm_blocked: block_rows=%d must be a power of two", block_rows);
     BOT_REQUIRE(H >= 1 && D >= 1 && (int64_t)H * D <= 1024, BOT_E_RANGE, "spmm_blocked: H*D=%lld exceeds 1024", (long long)H * D);
     if (n_tiles == 0) return 0;
     BOT_REQUIRE(tile_rows && ptr && b_src && b_lrow && x && out && (w == nullptr || b_pos), BOT_E_NULL, "spmm_blocked: NULL pointer");
@@ -198,13 +211,13 @@ int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int
     const int L = (F + vec - 1) / vec;
     const int nchunk = (L + 63) / 64;
     BOT_REQUIRE(nchunk <= 4 && (size_t)T * nchunk * 64 * vec * 4 <= 160 * 1024, BOT_E_RANGE, "spmm_blocked: tile does not fit LDS");
-    BlockedArgs a{tile_rows, ptr, b_src, b_lrow, b_pos, 0, n_tiles, nblk, x, ldx, w, H, D, F, out, ldo};
+    BlockedArgs a{tile_rows, ptr, b_src, b_lrow, b_pos, 0, n_tiles, nblk, x, ldx, w, H, D, F, shift, out, ldo};
     hipStream_t st = (hipStream_t)stream;
 #define BOT_BLK(V, NC)                                            \
     do {                                                          \
+        if (T == 128) return launch_blocked<V, NC, 128>(a, round_tiles, st); \
         if (T == 64) return launch_blocked<V, NC, 64>(a, round_tiles, st); \
-        if (T == 32) return launch_blocked<V, NC, 32>(a, round_tiles, st); \
-        return launch_blocked<V, NC, 16>(a, round_tiles, st);     \
+        return launch_blocked<V, NC, 32>(a, round_tiles, st);     \
     } while (0)
 #define BOT_BLK_V(V)                     \
     do {                                 \
