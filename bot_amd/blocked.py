@@ -68,13 +68,36 @@ def build(d, n_src: int, F: int) -> BlockedPlan:
     regular = deg <= hub_thr
     reg_rows = torch.nonzero(regular).squeeze(1)
     order = torch.argsort(deg[reg_rows], descending=True, stable=True)
-    reg_rows = reg_rows[order]                                    # similar degrees share a tile / a launch round
+    reg_rows = reg_rows[order]                                    # heaviest first
     n_reg = int(reg_rows.numel())
-    n_tiles = (n_reg + T - 1) // T
+    # Tiles of equal WORK, not equal height: sweepers that carry the same number of edges cross the column blocks at the
+    # same pace (measured: with equal-height tiles the round of the heaviest rows ran at 34 % L2 hits, the uniform rounds at
+    # 80 %).  A tile takes rows until it holds ~target edges or T rows.
+    rdeg = deg[reg_rows]
+    target = max(int(rdeg.sum()) // max(1, (n_reg + T - 1) // T), 1)      # edges per tile if all tiles were full-height
+    heavy_part = rdeg * T > target                                          # rows whose tile fills up by edges first
+    n_hp = int(heavy_part.sum())                                            # (a prefix: rows are sorted by degree)
+    tile_hp = torch.div(torch.cumsum(rdeg[:n_hp], 0) - rdeg[:n_hp], target, rounding_mode="floor")
+    if n_hp:                                                                # make ids dense and cap the height at T
+        _, tile_hp = torch.unique_consecutive(tile_hp, return_inverse=True)
+        first = torch.ones(n_hp, dtype=torch.bool, device=dev)
+        first[1:] = tile_hp[1:] != tile_hp[:-1]
+        start = torch.nonzero(first).squeeze(1)
+        within = torch.arange(n_hp, device=dev) - start[tile_hp]
+        within_hp = within                                                  # heights stay below T: every row here has deg > target / T
+        n_t_hp = int(tile_hp.max()) + 1
+    else:
+        within_hp = torch.zeros(0, dtype=torch.int64, device=dev)
+        n_t_hp = 0
+    rest = torch.arange(n_reg - n_hp, device=dev)
+    tile_of = torch.cat([tile_hp, n_t_hp + rest // T])
+    slot_in_tile = torch.cat([within_hp, rest % T])
+    assert int(slot_in_tile.max()) < T if n_reg else True
+    n_tiles = int(tile_of.max()) + 1 if n_reg else 0
     tile_rows = torch.full((n_tiles * T,), -1, dtype=torch.int32, device=dev)
-    tile_rows[:n_reg] = reg_rows.to(torch.int32)
+    tile_rows[tile_of * T + slot_in_tile] = reg_rows.to(torch.int32)
     slot_of_row = torch.full((d.n_rows,), -1, dtype=torch.int64, device=dev)
-    slot_of_row[reg_rows] = torch.arange(n_reg, device=dev)
+    slot_of_row[reg_rows] = tile_of * T + slot_in_tile
     row_of_pos = torch.repeat_interleave(torch.arange(d.n_rows, device=dev), deg)
     slot = slot_of_row[row_of_pos]
     pos = torch.nonzero(slot >= 0).squeeze(1)                     # positions of the blocked edges, ascending
