@@ -107,7 +107,6 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    import bot_amd
     from bot_amd import _C, synth, train, tuning
     from bot_amd import nn as bnn
     tuned = tuning.enable(tune_missing=args.gemm_tuning == "tune") if args.gemm_tuning != "off" else False

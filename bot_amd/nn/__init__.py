@@ -340,7 +340,7 @@ class GAT(nn.Module):
         for i in range(self.n_layers):
             last = i == self.n_layers - 1
             norm = None if last else (self.norms[i] if len(self.norms) else False)
-            if (self.fuse_layers and norm is not False and h.is_cuda | fused.FORCE
+            if (self.fuse_layers and norm is not False and (h.is_cuda or fused.FORCE)
                     and fused.can_fuse(self.convs[i], norm, self.activation, graph, self.training, self.residual)):
                 h = fused.gat_hidden_layer(self.convs[i], norm, graph, h, self.dropout.p, self.training)
                 if last:

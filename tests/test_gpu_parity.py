@@ -1,6 +1,5 @@
 """GPU parity suite: the HIP kernels, called through the C ABI, against the golden vectors and the
 oracle.  Run with `-m gpu` on an MI355X."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,6 +1,5 @@
 """CPU suite for the host logic above the C ABI: graph structures, transforms, autograd wrappers and
 layer modules, run over the emulated backend (tests/_oracle_backend.py) against the golden vectors."""
-import numpy as np
 import pytest
 import torch
 
