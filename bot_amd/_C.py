@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_double, c_float, c_int32, c_int64, c_uint64, c_vo
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbot_gnn.so")
+LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
 ABI_VERSION = 1
 
 if not os.path.exists(LIB_PATH):

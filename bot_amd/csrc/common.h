@@ -47,6 +47,18 @@ __device__ __forceinline__ void vload(float (&r)[VEC], const float* p) {
     if constexpr (VEC == 4) { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
 }
 
+// Streaming variants (non-temporal hint): for data touched once per launch (index / weight streams, output rows), so that it
+// does not push the gather table out of the L2 / Infinity Cache.  Enabled per kernel where measured to help.
+template <int VEC>
+__device__ __forceinline__ void vstore_nt(float* p, const float (&r)[VEC]) {
+    using T = typename Vec<VEC>::type;
+    T v;
+    if constexpr (VEC == 1) { v = r[0]; }
+    if constexpr (VEC == 2) { v.x = r[0]; v.y = r[1]; }
+    if constexpr (VEC == 4) { v.x = r[0]; v.y = r[1]; v.z = r[2]; v.w = r[3]; }
+    __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
+}
+
 template <int VEC>
 __device__ __forceinline__ void vstore(float* p, const float (&r)[VEC]) {
     using T = typename Vec<VEC>::type;

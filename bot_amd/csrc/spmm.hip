@@ -183,10 +183,18 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs a) {
         int idx = 0;
         float wv = 0.f;
         if (k < end) {
+#ifdef BOT_NT
+            idx = __builtin_nontemporal_load(a.indices + k);
+#else
             idx = a.indices[k];
+#endif
             if constexpr (WEIGHTED) {
                 const int wp = a.wperm ? a.wperm[k] : k;
+#ifdef BOT_NT
+                wv = __builtin_nontemporal_load(a.w + (int64_t)wp * a.H + head);
+#else
                 wv = a.w[(int64_t)wp * a.H + head];
+#endif
             }
         }
         const int cnt = min(LANES, end - k0);
@@ -242,7 +250,11 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs a) {
 #pragma unroll
                 for (int t = 0; t < VEC; ++t) acc[c][t] += r[t];
             }
+#ifdef BOT_NT
+            vstore_nt<VEC>(ob + off[c], acc[c]);
+#else
             vstore<VEC>(ob + off[c], acc[c]);
+#endif
         }
 }
 
