@@ -51,12 +51,11 @@ __device__ __forceinline__ void vload(float (&r)[VEC], const float* p) {
 // does not push the gather table out of the L2 / Infinity Cache.  Enabled per kernel where measured to help.
 template <int VEC>
 __device__ __forceinline__ void vstore_nt(float* p, const float (&r)[VEC]) {
-    using T = typename Vec<VEC>::type;
-    T v;
-    if constexpr (VEC == 1) { v = r[0]; }
-    if constexpr (VEC == 2) { v.x = r[0]; v.y = r[1]; }
-    if constexpr (VEC == 4) { v.x = r[0]; v.y = r[1]; v.z = r[2]; v.w = r[3]; }
-    __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
+    typedef float nv __attribute__((ext_vector_type(VEC)));  // the builtin wants a native vector type
+    nv v;
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) v[t] = r[t];
+    __builtin_nontemporal_store(v, reinterpret_cast<nv*>(p));
 }
 
 template <int VEC>
