@@ -50,15 +50,30 @@ def _edge2(a, H=None):
     return a.reshape(a.shape[0], w)
 
 
+def _pad4(x2):
+    """[n,F] -> [n,F'] with F' the next multiple of 4 (zero columns): odd widths such as 41 classes would otherwise force
+    4-byte lanes and one row per wavefront; padded they run with 16-byte lanes and several rows per wavefront."""
+    F = x2.shape[1]
+    return x2 if F % 4 == 0 or F < 5 else torch.nn.functional.pad(x2, (0, 4 - F % 4))
+
+
 class _CopyUSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, x):
         ctx.g, ctx.shape = g, x.shape
+        if x.dim() == 2:
+            F = x.shape[1]
+            out = _C.spmm(g.csc, _as3(_pad4(x)))
+            return out.view(out.shape[0], -1)[:, :F].contiguous() if out.shape[2] != F else out.view(out.shape[0], F)
         return _C.spmm(g.csc, _as3(x)).view((g.number_of_dst_nodes(),) + tuple(x.shape[1:]))
 
     @staticmethod
     def backward(ctx, dout):
         g = ctx.g
+        if len(ctx.shape) == 2:
+            F = ctx.shape[1]
+            dx = _C.spmm(g.csr, _as3(_pad4(dout.contiguous())))
+            return None, (dx.view(dx.shape[0], -1)[:, :F].contiguous() if dx.shape[2] != F else dx.view(ctx.shape))
         return None, _C.spmm(g.csr, _as3(dout.contiguous())).view(ctx.shape)
 
 
