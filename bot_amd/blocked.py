@@ -15,6 +15,7 @@ TILE_ROWS = 128            # destination rows per workgroup (32 / 64 / 128)
 TILE_LDS_BYTES = 128 * 1024  # LDS per workgroup: one 16-wave workgroup per CU
 WAVES = 16                 # wavefronts per workgroup (bot_amd/csrc/blocked.hip kBWaves)
 ROUND_WORKGROUPS = 256     # one resident 16-wave workgroup per CU
+MIN_ROW_FLOATS = 128       # narrower rows leave most of the 64 lanes of the per-edge gather idle: row kernel (sub-wave groups)
 HUB_FACTOR = 8             # rows longer than HUB_FACTOR x mean stay on the row-per-group kernel
 
 
@@ -121,7 +122,7 @@ def plan_for(d, n_src: int, H: int, D: int):
     """BlockedPlan for direction `d` and row width H*D, or None when the row-per-group kernel is the right one."""
     F = H * D
     vec = 4 if D % 4 == 0 else (2 if D % 2 == 0 else 1)
-    if not ENABLED or F > 256 * vec or d.n_rows == 0 or d.nnz < MIN_MEAN_DEGREE * d.n_rows or not d.indptr.is_cuda:
+    if not ENABLED or F > 256 * vec or F < MIN_ROW_FLOATS or d.n_rows == 0 or d.nnz < MIN_MEAN_DEGREE * d.n_rows or not d.indptr.is_cuda:
         return None
     cache = d.blocked
     if F not in cache:
