@@ -386,7 +386,8 @@ def test_blocked_spmm_matches_row_kernel():
         for weights in (None, w):
             blocked.ENABLED = True
             out_b = _C.spmm(csc, x, weights, None)
-            assert (blocked.plan_for(csc, n, H, D) is not None) == (H * D <= 256 * (4 if D % 4 == 0 else 2 if D % 2 == 0 else 1))
+            vec = 4 if D % 4 == 0 else 2 if D % 2 == 0 else 1
+            assert (blocked.plan_for(csc, n, H, D) is not None) == (blocked.MIN_ROW_FLOATS <= H * D <= 256 * vec)
             blocked.ENABLED = False
             out_r = _C.spmm(csc, x, weights, None)
             blocked.ENABLED = True
