@@ -1,0 +1,31 @@
+"""The TunableOp kernel selections must not change results: one deterministic (eval-mode, no dropout) forward+backward of the
+config-2 model on S-arxiv with library-default GEMM kernels vs with bot_amd/tuning enabled."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+import bench
+from bot_amd import synth, tuning, nn as bnn
+dev = torch.device("cuda:0")
+ds = synth.make_dataset("arxiv", device="cpu")
+C = ds.n_classes
+g = ds.graph.to(dev); g.create_formats_()
+cfg = dict(bench.CFG, dropout=0.0, input_drop=0.0, attn_drop=0.0)
+torch.manual_seed(0)
+model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **cfg).to(dev).train()
+x = torch.cat([ds.feat, torch.zeros(ds.feat.shape[0], C)], 1).to(dev)
+gout = torch.randn(x.shape[0], C, device=dev)
+def run():
+    model.zero_grad(set_to_none=True)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.reset_running_stats()
+    out = model(g, x)
+    (out * gout).sum().backward()
+    return out.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+o0, g0 = run()
+print("tuning enabled:", tuning.enable())
+o1, g1 = run()
+print("max |logit diff| default vs tuned GEMM kernels: %.3e (logit scale %.2f)" % ((o0 - o1).abs().max().item(), o0.abs().max().item()))
+worst = max(((g0[k] - g1[k]).abs().max().item() / max(1e-12, g0[k].abs().max().item()), k) for k in g0)
+print("max relative grad diff: %.3e (%s)" % worst)
+assert (o0 - o1).abs().max().item() < 1e-4 and worst[0] < 1e-4
