@@ -283,10 +283,16 @@ def bn_batch_stats(x, bn, bn_training):
         return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps), total, sync, group
     mean, m2 = _C.colstats(x)
     if sync:
-        pack = torch.cat([mean * n, mean.new_tensor([float(n)])])
-        dist.all_reduce(pack, group=group)
-        total = float(pack[-1].item())
-        gmean = pack[:-1] / total
+        # the global row count is a constant of the partition: ask for it once (one host sync), then never again, so the
+        # host keeps running ahead of the GPU during the step
+        totals = bn.__dict__.setdefault("_bot_total_rows", {})
+        if n not in totals:
+            cnt = mean.new_tensor([float(n)])
+            dist.all_reduce(cnt, group=group)
+            totals[n] = float(cnt.item())
+        total = totals[n]
+        gmean = mean * (n / total)
+        dist.all_reduce(gmean, group=group)
         m2 = m2 + n * (mean - gmean) ** 2
         dist.all_reduce(m2, group=group)
         mean = gmean
