@@ -362,6 +362,11 @@ def main():
         out.update(grads2n(k + "g.", model))
         out.update(sd2n(k + "p1.", model.state_dict()))
         out[k + "aug"] = t2n(RUN.add_labels(feat, labels, tr[mask]))  # run.py:240-243
+        # evaluate() on the post-step model — run.py:290-322 (eval mode, all training labels as inputs, label reuse)
+        ev = RUN.evaluate(a, model, g, labels, tr, va, te, RUN.compute_acc, epoch)
+        out[k + "eval_accs"] = np.array([float(v) for v in ev[:3]])
+        out[k + "eval_losses"] = np.array([float(v) for v in ev[3:6]])
+        out[k + "eval_pred"] = t2n(ev[6])
     RUN.n_classes = 5
     x = torch.randn(40, 5, generator=gen)
     y = torch.randint(0, 5, (40, 1), generator=gen)
