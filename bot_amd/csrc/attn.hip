@@ -22,12 +22,45 @@ struct GroupCtx {
     int lane;
     __device__ __forceinline__ float sum(float v) const { return group_sum<LANES>(v); }
     __device__ __forceinline__ float max(float v) const { return group_max<LANES>(v); }
+    template <int N>
+    __device__ __forceinline__ void sum_n(float (&v)[N]) const {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = group_sum<LANES>(v[j]);
+    }
+    template <int N>
+    __device__ __forceinline__ void max_n(float (&v)[N]) const {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = group_max<LANES>(v[j]);
+    }
 };
 
 struct BlockCtx {
     static constexpr int kStride = kBlock;
     int lane;    // thread id in the workgroup
-    float* lds;  // kBlock / 64 floats
+    float* lds;  // (kBlock / 64) * 8 floats
+    // all N <= 8 values of a row reduced with ONE pair of barriers (one per value cost 12 barriers a row at H = 6)
+    template <int N, bool MAX>
+    __device__ __forceinline__ void reduce_n(float (&v)[N]) const {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = MAX ? group_max<64>(v[j]) : group_sum<64>(v[j]);
+        __syncthreads();
+        if ((lane & 63) == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) lds[(lane >> 6) * 8 + j] = v[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float s = lds[j];
+#pragma unroll
+            for (int i = 1; i < kBlock / 64; ++i) s = MAX ? fmaxf(s, lds[i * 8 + j]) : s + lds[i * 8 + j];
+            v[j] = s;
+        }
+    }
+    template <int N>
+    __device__ __forceinline__ void sum_n(float (&v)[N]) const { reduce_n<N, false>(v); }
+    template <int N>
+    __device__ __forceinline__ void max_n(float (&v)[N]) const { reduce_n<N, true>(v); }
     __device__ __forceinline__ float sum(float v) const {
         v = group_sum<64>(v);
         __syncthreads();
@@ -110,12 +143,13 @@ __device__ __forceinline__ void attn_fwd_row(const AttnArgs& p, const Ctx& ctx, 
     }
     float M[HT], inv[HT];
 #pragma unroll
-    for (int j = 0; j < HT; ++j) {
-        M[j] = ctx.max(m[j]);
-        const float mine = m[j] > NEG_INF ? s[j] * expf(m[j] - M[j]) : 0.f;
-        const float S = ctx.sum(mine);
-        inv[j] = S > 0.f ? 1.f / S : 0.f;
-    }
+    for (int j = 0; j < HT; ++j) M[j] = m[j];
+    ctx.max_n(M);
+#pragma unroll
+    for (int j = 0; j < HT; ++j) inv[j] = m[j] > NEG_INF ? s[j] * expf(m[j] - M[j]) : 0.f;
+    ctx.sum_n(inv);
+#pragma unroll
+    for (int j = 0; j < HT; ++j) inv[j] = inv[j] > 0.f ? 1.f / inv[j] : 0.f;
     for (int k = beg + ctx.lane; k < end; k += Ctx::kStride) {
         const int src = p.indices ? p.indices[k] : 0;
         const int ep = p.eperm ? p.eperm[k] : k;
@@ -142,8 +176,7 @@ __device__ __forceinline__ void attn_bwd_row(const AttnArgs& p, const Ctx& ctx, 
 #pragma unroll
         for (int j = 0; j < HT; ++j) t[j] = fmaf(p.a[o + j], p.da[o + j], t[j]);
     }
-#pragma unroll
-    for (int j = 0; j < HT; ++j) t[j] = ctx.sum(t[j]);
+    ctx.sum_n(t);
     const bool need_z = p.slope != 1.f;
     for (int k = beg + ctx.lane; k < end; k += Ctx::kStride) {
         const int64_t o = (int64_t)(p.aperm ? p.aperm[k] : k) * p.H + p.h0;
@@ -163,10 +196,10 @@ __device__ __forceinline__ void attn_bwd_row(const AttnArgs& p, const Ctx& ctx, 
         }
     }
     if (p.der) {
+        ctx.sum_n(dacc);
+        if (ctx.lane == 0) {
 #pragma unroll
-        for (int j = 0; j < HT; ++j) {
-            const float d = ctx.sum(dacc[j]);
-            if (ctx.lane == 0) p.der[(int64_t)row * p.H + p.h0 + j] = d;
+            for (int j = 0; j < HT; ++j) p.der[(int64_t)row * p.H + p.h0 + j] = dacc[j];
         }
     }
 }
@@ -184,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void attn_short_kernel(AttnArgs p) {
 
 template <int HT, bool BWD>
 __global__ __launch_bounds__(kBlock) void attn_long_kernel(AttnArgs p) {
-    __shared__ float lds[kBlock / 64];
+    __shared__ float lds[(kBlock / 64) * 8];
     const int row = p.long_rows[blockIdx.x];
     const int beg = p.indptr[row], end = p.indptr[row + 1];
     BlockCtx ctx{(int)threadIdx.x, lds};
@@ -243,10 +276,10 @@ __device__ __forceinline__ void seg_row(const SegArgs& p, const Ctx& ctx, int ro
 #pragma unroll
         for (int j = 0; j < WT; ++j) acc[j] += p.vals[o + j];
     }
+    ctx.sum_n(acc);
+    if (ctx.lane == 0) {
 #pragma unroll
-    for (int j = 0; j < WT; ++j) {
-        const float s = ctx.sum(acc[j]);
-        if (ctx.lane == 0) p.out[(int64_t)row * p.W + p.w0 + j] = s;
+        for (int j = 0; j < WT; ++j) p.out[(int64_t)row * p.W + p.w0 + j] = acc[j];
     }
 }
 
@@ -262,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void seg_short_kernel(SegArgs p) {
 
 template <int WT>
 __global__ __launch_bounds__(kBlock) void seg_long_kernel(SegArgs p) {
-    __shared__ float lds[kBlock / 64];
+    __shared__ float lds[(kBlock / 64) * 8];
     const int row = p.long_rows[blockIdx.x];
     BlockCtx ctx{(int)threadIdx.x, lds};
     seg_row<WT>(p, ctx, row, p.indptr[row], p.indptr[row + 1]);
