@@ -35,7 +35,7 @@ _SIGS = {
     "bot_spmm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "bot_spmm_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                     c_int32, c_int32, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P]),
-    "bot_spmm_blocked_f32": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P,
+    "bot_spmm_blocked_f32": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P,
                                             c_int32, c_int32, _P, c_int64, _P]),
     "bot_spmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                         _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P]),
@@ -175,7 +175,7 @@ def spmm_blocked(bp, x, w, out):
     H, D = x.shape[1], x.shape[2]
     _check(_timed("spmm_blocked", (H, D, w is not None), lambda: _lib.bot_spmm_blocked_f32(
         bp.tile_rows.data_ptr(), bp.ptr.data_ptr(), bp.b_src.data_ptr(), bp.b_lrow.data_ptr(), bp.b_pos.data_ptr(), bp.n_tiles,
-        bp.nblk, bp.block_rows, bp.T, bp.round_tiles, x.data_ptr(), x.stride(0), _ptr(w), H, D, out.data_ptr(), out.stride(0),
+        bp.nblk, bp.block_rows, bp.T, bp.epi, bp.round_tiles, x.data_ptr(), x.stride(0), _ptr(w), H, D, out.data_ptr(), out.stride(0),
         _stream())),
         "spmm_blocked")
     return out

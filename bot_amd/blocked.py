@@ -10,12 +10,12 @@ import torch
 
 ENABLED = True
 MIN_MEAN_DEGREE = 96       # below this a (row, block) visit holds < 1 edge: nothing to reuse
-L2_BLOCK_BYTES = 1 << 20   # source rows per column block * row bytes (4 MiB L2 per XCD holds a few blocks of skew)
-TILE_ROWS = 128            # destination rows per workgroup (32 / 64 / 128)
+L2_BLOCK_BYTES = 2 << 20   # source rows per column block * row bytes (half of the 4 MiB L2 of an XCD; 1 / 2 / 4 / 8 MiB: 7.80 / 6.54 / 6.44 / 7.95 ms on S-reddit)
+TILE_ROWS = 128            # destination rows per workgroup (32 / 64 / 128; 256 when rows are gathered by lane groups)
 TILE_LDS_BYTES = 128 * 1024  # LDS per workgroup: one 16-wave workgroup per CU
 WAVES = 16                 # wavefronts per workgroup (bot_amd/csrc/blocked.hip kBWaves)
 ROUND_WORKGROUPS = 256     # one resident 16-wave workgroup per CU
-MIN_ROW_FLOATS = 128       # narrower rows leave most of the 64 lanes of the per-edge gather idle: row kernel (sub-wave groups)
+MIN_ROW_FLOATS = 16        # rows of <= 32 (16) vector lanes are gathered 2 (4) edges per instruction by lane groups
 HUB_FACTOR = 8             # rows longer than HUB_FACTOR x mean stay on the row-per-group kernel
 
 
@@ -29,6 +29,7 @@ class BlockedPlan:
     n_tiles: int
     nblk: int
     T: int
+    epi: int   # edges per gather instruction (lane groups of 64 / epi lanes)
     round_tiles: int
     heavy: object  # Direction restricted to the hub rows, or None
     block_rows: int = 0
@@ -53,14 +54,23 @@ def _heavy_direction(d, heavy_rows):
                                n_long=int(heavy_rows.numel()), n_slots=n_slots, blocked={})
 
 
-def build(d, n_src: int, F: int) -> BlockedPlan:
+def layout(H: int, D: int):
+    """(vec, epi, LDS row pitch in floats) the kernel uses for rows of H x D floats (contiguous, 16-byte aligned base)."""
+    vec = 4 if D % 4 == 0 else (2 if D % 2 == 0 else 1)
+    lanes = (H * D + vec - 1) // vec
+    epi = 4 if lanes <= 16 else (2 if lanes <= 32 else 1)
+    group = 64 // epi
+    return vec, epi, (lanes + group - 1) // group * group * vec
+
+
+def build(d, n_src: int, H: int, D: int) -> BlockedPlan:
+    F = H * D
     dev = d.indptr.device
     deg = (d.indptr[1:] - d.indptr[:-1]).long()
     mean = max(1.0, d.nnz / max(1, d.n_rows))
     hub_thr = max(int(HUB_FACTOR * mean), d.chunk)
-    vec = 4 if F % 4 == 0 else (2 if F % 2 == 0 else 1)
-    Fp = (F + 64 * vec - 1) // (64 * vec) * (64 * vec)             # LDS row pitch of the kernel
-    T = TILE_ROWS
+    vec, epi, Fp = layout(H, D)
+    T = 256 if epi > 1 else TILE_ROWS
     while T > 32 and Fp * 4 * T > TILE_LDS_BYTES:
         T //= 2
     cb = max(64, L2_BLOCK_BYTES // (F * 4))
@@ -107,24 +117,44 @@ def build(d, n_src: int, F: int) -> BlockedPlan:
     tile, lrow = slot // T, slot % T
     stream = tile * WAVES + (lrow % WAVES)                        # (tile, wave): one contiguous edge stream per wave
     key = (stream * nblk + src // cb) * T + lrow                  # inside a stream: by column block, then row
-    perm = torch.argsort(key, stable=True)                        # ties keep position order = ascending edge id
+    key, perm = torch.sort(key, stable=True)                      # ties keep position order = ascending edge id
+    b_src, b_lrow, b_pos = src[perm], lrow[perm], pos[perm]
     counts = torch.bincount(stream, minlength=n_tiles * WAVES)
+    if epi > 1 and key.numel():
+        # lane groups: every (stream, block, row) run is padded to a multiple of `epi` slots (source -1), so the slots of
+        # one gather instruction always share their destination row
+        run_key, run_len = torch.unique_consecutive(key, return_counts=True)
+        pad_len = (run_len + epi - 1) // epi * epi
+        run_start = torch.cumsum(run_len, 0) - run_len
+        pad_start = torch.cumsum(pad_len, 0) - pad_len
+        run_of = torch.repeat_interleave(torch.arange(run_len.numel(), device=dev), run_len)
+        dest = pad_start[run_of] + (torch.arange(key.numel(), device=dev) - run_start[run_of])
+        total = int(pad_len.sum())
+        run_lrow = run_key % T
+        p_src = torch.full((total,), -1, dtype=torch.int64, device=dev)
+        p_pos = torch.full((total,), -1, dtype=torch.int64, device=dev)
+        p_src[dest], p_pos[dest] = b_src, b_pos
+        b_src, b_pos = p_src, p_pos
+        b_lrow = torch.repeat_interleave(run_lrow, pad_len)
+        counts = torch.zeros(n_tiles * WAVES, dtype=torch.int64, device=dev)
+        counts.index_add_(0, torch.div(run_key, nblk * T, rounding_mode="floor"), pad_len)
     ptr = torch.zeros(n_tiles * WAVES + 1, dtype=torch.int64, device=dev)
     ptr[1:] = torch.cumsum(counts, 0)
+    assert int(ptr[-1]) < 2 ** 31, "blocked edge stream exceeds int32 offsets"
     heavy_rows = torch.nonzero(~regular).squeeze(1)
     heavy = _heavy_direction(d, heavy_rows) if heavy_rows.numel() else None
-    return BlockedPlan(tile_rows, ptr.to(torch.int32).contiguous(), src[perm].to(torch.int32).contiguous(),
-                       lrow[perm].to(torch.uint8).contiguous(), pos[perm].to(torch.int32).contiguous(), n_tiles, nblk, T,
+    return BlockedPlan(tile_rows, ptr.to(torch.int32).contiguous(), b_src.to(torch.int32).contiguous(),
+                       b_lrow.to(torch.uint8).contiguous(), b_pos.to(torch.int32).contiguous(), n_tiles, nblk, T, epi,
                        ROUND_WORKGROUPS, heavy, cb)
 
 
 def plan_for(d, n_src: int, H: int, D: int):
     """BlockedPlan for direction `d` and row width H*D, or None when the row-per-group kernel is the right one."""
     F = H * D
-    vec = 4 if D % 4 == 0 else (2 if D % 2 == 0 else 1)
+    vec = layout(H, D)[0]
     if not ENABLED or F > 256 * vec or F < MIN_ROW_FLOATS or d.n_rows == 0 or d.nnz < MIN_MEAN_DEGREE * d.n_rows or not d.indptr.is_cuda:
         return None
     cache = d.blocked
-    if F not in cache:
-        cache[F] = build(d, n_src, F)
-    return cache[F]
+    if (H, D) not in cache:
+        cache[(H, D)] = build(d, n_src, H, D)
+    return cache[(H, D)]

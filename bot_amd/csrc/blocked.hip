@@ -42,47 +42,68 @@ struct BlockedArgs {
     int64_t ldo;
 };
 
-template <int VEC, int NCHUNK>
+constexpr int kBWaves = 16;             // wavefronts per workgroup (1024 threads): one workgroup per CU
+constexpr int kBThreads = kBWaves * 64;
+
+// Sum racc over the EPI lane groups of the wave (EPI > 1), then add it to the LDS row (lanes of group 0) and clear it.
+template <int VEC, int NCHUNK, int EPI>
 __device__ __forceinline__ void lds_fold(float* q_row, int lane, float (&racc)[NCHUNK][VEC]) {
+    constexpr int G = 64 / EPI;
+    const int li = lane & (G - 1);
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
-        float* q = q_row + (c * 64 + lane) * VEC;
-        float o[VEC];
-        vload<VEC>(o, q);
 #pragma unroll
-        for (int t = 0; t < VEC; ++t) o[t] += racc[c][t], racc[c][t] = 0.f;
-        vstore<VEC>(q, o);
+        for (int t = 0; t < VEC; ++t) {
+            float v = racc[c][t];
+            if constexpr (EPI >= 2) v += __shfl_xor(v, 32);
+            if constexpr (EPI >= 4) v += __shfl_xor(v, 16);
+            racc[c][t] = v;
+        }
+        if (EPI == 1 || lane < G) {
+            float* q = q_row + (c * G + li) * VEC;
+            float o[VEC];
+            vload<VEC>(o, q);
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) o[t] += racc[c][t];
+            vstore<VEC>(q, o);
+        }
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) racc[c][t] = 0.f;
     }
 }
 
-constexpr int kBWaves = 16;             // wavefronts per workgroup (1024 threads): one workgroup per CU, 128 KB of LDS rows
-constexpr int kBThreads = kBWaves * 64;
-
-template <int VEC, int NCHUNK, bool WEIGHTED, int T>
+// EPI = edges per gather instruction: rows of <= 32 (16) vector lanes are gathered 2 (4) at a time, one per 32- (16-) lane
+// group of the wave; the host pads every (row, block) visit of a stream to a multiple of EPI slots (source -1 = no edge), so
+// the EPI slots of one instruction always belong to the same destination row and their partial sums share `racc`.
+template <int VEC, int NCHUNK, bool WEIGHTED, int T, int EPI>
 __global__ __launch_bounds__(kBThreads) void spmm_blocked_kernel(BlockedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];  // [T][Fp]
+    static_assert(EPI == 1 || NCHUNK == 1, "lane groups only for rows that fit one chunk");
     constexpr int U = 8;
+    constexpr int G = 64 / EPI;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gi = lane / G, li = lane & (G - 1);
     const int tile = a.tile0 + blockIdx.x;  // grid never exceeds the tile count: every workgroup runs every barrier below
-    const int Fp = NCHUNK * 64 * VEC;
+    constexpr int Fp = NCHUNK * G * VEC;
     int off[NCHUNK], hd[NCHUNK];
     bool act[NCHUNK];
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
-        const int e = (c * 64 + lane) * VEC;
+        const int e = (c * G + li) * VEC;
         act[c] = e < a.F;
         off[c] = act[c] ? e : 0;
         hd[c] = act[c] ? e / a.D : 0;  // head of this lane's elements (D % VEC == 0: a vector never straddles heads)
     }
-    for (int r = wave; r < T; r += kBWaves)  // zero the rows this wave owns
+    // wave w owns the tile rows w, w+16, ...: it zeroes them, accumulates into them and stores them; no other wave touches them
+    for (int r = wave + kBWaves * gi; r < T; r += kBWaves * EPI)
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c) {
             float z[VEC];
 #pragma unroll
             for (int t = 0; t < VEC; ++t) z[t] = 0.f;
-            vstore<VEC>(acc_lds + r * Fp + (c * 64 + lane) * VEC, z);
+            vstore<VEC>(acc_lds + r * Fp + (c * G + li) * VEC, z);
         }
-    // this wave's edge stream: the edges of its rows, sorted by (column block, row, edge id)
+    // this wave's slot stream: the edges of its rows, sorted by (column block, row, edge id)
     int k0 = __builtin_amdgcn_readfirstlane(a.ptr[(int64_t)tile * kBWaves + wave]);
     const int end = __builtin_amdgcn_readfirstlane(a.ptr[(int64_t)tile * kBWaves + wave + 1]);
     int cur = -1;
@@ -91,7 +112,7 @@ __global__ __launch_bounds__(kBThreads) void spmm_blocked_kernel(BlockedArgs a) 
     for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
         for (int t = 0; t < VEC; ++t) racc[c][t] = 0.f;
-    // current batch of up to 64 edges: (idx, lr, pos) one per lane, `i` consumed so far
+    // current batch of up to 64 slots: (idx, lr, pos) one per lane, `i` consumed so far
     int idx = 0, lr = 0, pos = 0, i = 0, cnt = 0;
     auto load_batch = [&]() {
         cnt = min(64, end - k0);
@@ -103,77 +124,85 @@ __global__ __launch_bounds__(kBThreads) void spmm_blocked_kernel(BlockedArgs a) 
         }
     };
     if (k0 < end) load_batch();
-    // All 16 waves of the workgroup take the column blocks in lockstep (one barrier per block): the workgroup is ONE sweeper
-    // with T rows' worth of edges per block, so the spread between the sweepers of an XCD stays a fraction of the L2.
-    for (int b = 0; b < a.nblk; ++b) {
-        while (cnt > 0) {
-            if (i == cnt) {  // batch used up
-                k0 += 64;
-                if (k0 >= end) {
-                    cnt = 0;
-                    break;
-                }
-                load_batch();
-            }
-            // edges of this batch that still belong to column block b form a prefix of [i, cnt)
-            const bool mine = lane >= i && lane < cnt && (idx >> a.cb_shift) == b;
-            const int nb = __popcll(__ballot(mine));
-            if (nb == 0) break;  // next edge is in a later block
-            const int g = min(U, nb);
-            float v[U][NCHUNK][VEC], ww[U][NCHUNK];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = min(i + u, i + g - 1);
-                const int s = __builtin_amdgcn_readlane(idx, j);
-                const float* px = a.x + (int64_t)s * a.ldx;
-#pragma unroll
-                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + off[c]);
-                if constexpr (WEIGHTED) {
-                    const int ps = __builtin_amdgcn_readlane(pos, j);
-#pragma unroll
-                    for (int c = 0; c < NCHUNK; ++c) ww[u][c] = a.w[(int64_t)ps * a.H + hd[c]];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (u < g) {  // wave-uniform
-                    const int r = __builtin_amdgcn_readlane(lr, i + u);
-                    if (r != cur) {
-                        if (cur >= 0) lds_fold<VEC, NCHUNK>(acc_lds + cur * Fp, lane, racc);
-                        cur = r;
-                    }
-#pragma unroll
-                    for (int c = 0; c < NCHUNK; ++c)
-#pragma unroll
-                        for (int t = 0; t < VEC; ++t) {
-                            if constexpr (WEIGHTED) racc[c][t] = fmaf(ww[u][c], v[u][c][t], racc[c][t]);
-                            else racc[c][t] += v[u][c][t];
-                        }
-                }
-            }
-            i += g;
+    // All 16 waves of the workgroup take the column blocks in lockstep: a wave executes barrier #b+1 when the next edge of its
+    // stream lies beyond block b, so every wave runs exactly `nblk` barriers and the workgroup is ONE sweeper with T rows'
+    // worth of edges per block (the spread between the sweepers of an XCD then stays a fraction of the L2).  Gather groups
+    // are always full (U instructions) and may reach a few edges into the next block: those rows are about to be fetched by
+    // every sweeper anyway, and no group pays the memory latency for one or two trailing edges of a block.
+    int synced = 0;
+    while (cnt > 0) {
+        if (i == cnt) {  // batch used up
+            k0 += 64;
+            if (k0 >= end) break;
+            load_batch();
         }
-        __syncthreads();
+        const int fb = __builtin_amdgcn_readlane(idx, i) >> a.cb_shift;  // first slot of an instruction is a real edge
+        for (; synced < fb; ++synced) __syncthreads();
+        const int g = min(U, (cnt - i) / EPI);
+        float v[U][NCHUNK][VEC], ww[U][NCHUNK];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = min(i + u * EPI, i + (g - 1) * EPI);
+            int s;
+            if constexpr (EPI == 1) s = __builtin_amdgcn_readlane(idx, j);
+            else s = __builtin_amdgcn_ds_bpermute((j + gi) << 2, idx);
+            const bool real = EPI == 1 || s >= 0;
+            const float* px = a.x + (int64_t)(real ? s : 0) * a.ldx;
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) {
+                vload<VEC>(v[u][c], px + off[c]);
+                if constexpr (EPI > 1) {
+#pragma unroll
+                    for (int t = 0; t < VEC; ++t) v[u][c][t] = real ? v[u][c][t] : 0.f;
+                }
+            }
+            if constexpr (WEIGHTED) {
+                int ps;
+                if constexpr (EPI == 1) ps = __builtin_amdgcn_readlane(pos, j);
+                else ps = max(__builtin_amdgcn_ds_bpermute((j + gi) << 2, pos), 0);
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c) ww[u][c] = a.w[(int64_t)ps * a.H + hd[c]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u < g) {  // wave-uniform
+                const int r = __builtin_amdgcn_readlane(lr, i + u * EPI);
+                if (r != cur) {
+                    if (cur >= 0) lds_fold<VEC, NCHUNK, EPI>(acc_lds + cur * Fp, lane, racc);
+                    cur = r;
+                }
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                    for (int t = 0; t < VEC; ++t) {
+                        if constexpr (WEIGHTED) racc[c][t] = fmaf(ww[u][c], v[u][c][t], racc[c][t]);
+                        else racc[c][t] += v[u][c][t];
+                    }
+            }
+        }
+        i += g * EPI;
     }
-    if (cur >= 0) lds_fold<VEC, NCHUNK>(acc_lds + cur * Fp, lane, racc);
-    for (int r = wave; r < T; r += kBWaves) {  // rows of this wave -> global (each row one coalesced store)
+    for (; synced < a.nblk; ++synced) __syncthreads();
+    if (cur >= 0) lds_fold<VEC, NCHUNK, EPI>(acc_lds + cur * Fp, lane, racc);
+    for (int r = wave + kBWaves * gi; r < T; r += kBWaves * EPI) {  // rows of this wave -> global, EPI rows per store
         const int row = a.tile_rows[(int64_t)tile * T + r];
         if (row < 0) continue;
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c)
             if (act[c]) {
                 float o[VEC];
-                vload<VEC>(o, acc_lds + r * Fp + (c * 64 + lane) * VEC);
+                vload<VEC>(o, acc_lds + r * Fp + (c * G + li) * VEC);
                 vstore<VEC>(a.out + (int64_t)row * a.ldo + off[c], o);
             }
     }
 }
 
-template <int VEC, int NCHUNK, int T>
+template <int VEC, int NCHUNK, int T, int EPI>
 static int launch_blocked(const BlockedArgs& a0, int round_tiles, hipStream_t st) {
-    const size_t lds = (size_t)T * NCHUNK * 64 * VEC * sizeof(float);
-    auto k1 = spmm_blocked_kernel<VEC, NCHUNK, true, T>;
-    auto k0 = spmm_blocked_kernel<VEC, NCHUNK, false, T>;
+    const size_t lds = (size_t)T * NCHUNK * (64 / EPI) * VEC * sizeof(float);
+    auto k1 = spmm_blocked_kernel<VEC, NCHUNK, true, T, EPI>;
+    auto k0 = spmm_blocked_kernel<VEC, NCHUNK, false, T, EPI>;
     if (lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -193,12 +222,13 @@ static int launch_blocked(const BlockedArgs& a0, int round_tiles, hipStream_t st
 extern "C" {
 
 int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int32_t* b_src, const uint8_t* b_lrow,
-                         const int32_t* b_pos, int32_t n_tiles, int32_t nblk, int32_t block_rows, int32_t T,
+                         const int32_t* b_pos, int32_t n_tiles, int32_t nblk, int32_t block_rows, int32_t T, int32_t epi,
                          int32_t round_tiles, const float* x, int64_t ldx, const float* w, int32_t H, int32_t D, float* out,
                          int64_t ldo, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n_tiles >= 0 && nblk >= 1 && round_tiles >= 1, BOT_E_RANGE, "spmm_blocked: n_tiles=%d nblk=%d round=%d", n_tiles, nblk, round_tiles);
-    BOT_REQUIRE(T == 128 || T == 64 || T == 32, BOT_E_RANGE, "spmm_blocked: tile height %d (32, 64 or 128)", T);
+    BOT_REQUIRE(T == 256 || T == 128 || T == 64 || T == 32, BOT_E_RANGE, "spmm_blocked: tile height %d (32, 64, 128 or 256)", T);
+    BOT_REQUIRE(epi == 1 || epi == 2 || epi == 4, BOT_E_RANGE, "spmm_blocked: %d edges per instruction (1, 2 or 4)", epi);
     int shift = 0;
     while ((1 << shift) < block_rows) ++shift;
     BOT_REQUIRE(block_rows >= 1 && (1 << shift) == block_rows, BOT_E_RANGE, "spmm_blocked: block_rows=%d must be a power of two", block_rows);
@@ -209,18 +239,30 @@ int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int
     BOT_REQUIRE(ldx >= F && ldo >= F, BOT_E_RANGE, "spmm_blocked: row stride smaller than H*D");
     const int vec = pick_vec(D, {ldx, ldo}, {x, out});
     const int L = (F + vec - 1) / vec;
-    const int nchunk = (L + 63) / 64;
-    BOT_REQUIRE(nchunk <= 4 && (size_t)T * nchunk * 64 * vec * 4 <= 160 * 1024, BOT_E_RANGE, "spmm_blocked: tile does not fit LDS");
+    const int G = 64 / epi;
+    const int nchunk = (L + G - 1) / G;
+    BOT_REQUIRE(epi == 1 || nchunk == 1, BOT_E_RANGE, "spmm_blocked: rows of %d x %d-float vectors do not fit the %d-lane groups of epi=%d (plan built for another row layout?)", L, vec, G, epi);
+    BOT_REQUIRE(epi > 1 || T <= 128, BOT_E_RANGE, "spmm_blocked: T=256 only with lane groups (epi > 1)");
+    BOT_REQUIRE(nchunk <= 4 && (size_t)T * nchunk * G * vec * 4 <= 160 * 1024, BOT_E_RANGE, "spmm_blocked: tile does not fit LDS");
     BlockedArgs a{tile_rows, ptr, b_src, b_lrow, b_pos, 0, n_tiles, nblk, x, ldx, w, H, D, F, shift, out, ldo};
     hipStream_t st = (hipStream_t)stream;
-#define BOT_BLK(V, NC)                                            \
-    do {                                                          \
-        if (T == 128) return launch_blocked<V, NC, 128>(a, round_tiles, st); \
-        if (T == 64) return launch_blocked<V, NC, 64>(a, round_tiles, st); \
-        return launch_blocked<V, NC, 32>(a, round_tiles, st);     \
+#define BOT_BLK(V, NC)                                                        \
+    do {                                                                      \
+        if (T == 128) return launch_blocked<V, NC, 128, 1>(a, round_tiles, st); \
+        if (T == 64) return launch_blocked<V, NC, 64, 1>(a, round_tiles, st);  \
+        return launch_blocked<V, NC, 32, 1>(a, round_tiles, st);              \
+    } while (0)
+#define BOT_BLK_G(V, EP)                                                      \
+    do {                                                                      \
+        if (T == 256) return launch_blocked<V, 1, 256, EP>(a, round_tiles, st); \
+        if (T == 128) return launch_blocked<V, 1, 128, EP>(a, round_tiles, st); \
+        if (T == 64) return launch_blocked<V, 1, 64, EP>(a, round_tiles, st);  \
+        return launch_blocked<V, 1, 32, EP>(a, round_tiles, st);              \
     } while (0)
 #define BOT_BLK_V(V)                     \
     do {                                 \
+        if (epi == 4) BOT_BLK_G(V, 4);   \
+        if (epi == 2) BOT_BLK_G(V, 2);   \
         if (nchunk == 1) BOT_BLK(V, 1);  \
         if (nchunk == 2) BOT_BLK(V, 2);  \
         if (nchunk == 3) BOT_BLK(V, 3);  \
@@ -230,6 +272,7 @@ int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int
     if (vec == 2) BOT_BLK_V(2);
     BOT_BLK_V(1);
 #undef BOT_BLK_V
+#undef BOT_BLK_G
 #undef BOT_BLK
 }
 

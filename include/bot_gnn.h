@@ -99,19 +99,22 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
  * L2-blocked SpMM for dense graphs (mean degree in the hundreds).  Same result as bot_spmm_f32 (w in position order, no
  * addend) for the destination rows listed in `tile_rows`; other rows of `out` are not touched (the caller runs hub rows
  * through bot_spmm_f32 with a plan restricted to them).  The blocked edge structure is built once per graph direction
- * by the host (bot_amd/blocked.py): destination rows grouped into tiles of T (32/64/128) rows, sources cut into `nblk`
+ * by the host (bot_amd/blocked.py): destination rows grouped into tiles of T (32/64/128/256) rows, sources cut into `nblk`
  * column blocks of `block_rows` (a power of two) rows, edges sorted by (tile, wave = slot % 16, block, slot, position):
  *   tile_rows[n_tiles*T]      destination row of each tile slot (-1: padding)
  *   ptr[n_tiles*16 + 1]       offsets of each wave's edge stream, (tile, wave)-major; a stream is sorted by (block, slot, position)
  *   b_src / b_lrow / b_pos    per blocked edge: source row, tile slot of its destination, position in the unblocked order
+ * Rows of at most 32 (16) vector lanes are gathered `epi` = 2 (4) edges per instruction, one per 32- (16-) lane group; the
+ * host then pads every (slot, block) run of a stream to a multiple of `epi` entries with b_src = -1 (no edge), streams
+ * start at multiples of `epi`, and T may be 256.  epi = 1 otherwise.
  * One 1024-thread workgroup owns a tile and keeps its T output rows in LDS; its 16 waves cross the column blocks in
  * lockstep and all workgroups walk the blocks in the same order, so the block being gathered is resident in the XCD's L2; tiles are launched `round_tiles` at a time (one resident wave
  * of workgroups per launch).  H*D <= 1024 floats, T*H*D*4 <= 160 KB.  Deterministic, no atomics.
  * ------------------------------------------------------------------------------------------- */
 int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int32_t* b_src, const uint8_t* b_lrow,
-                         const int32_t* b_pos, int32_t n_tiles, int32_t nblk, int32_t block_rows, int32_t T,
-                         int32_t round_tiles, const float* x, int64_t ldx, const float* w, int32_t H, int32_t D,
-                         float* out, int64_t ldo, bot_stream_t stream);
+                         const int32_t* b_pos, int32_t n_tiles, int32_t nblk, int32_t block_rows, int32_t T, int32_t epi,
+                         int32_t round_tiles, const float* x, int64_t ldx, const float* w, int32_t H, int32_t D, float* out,
+                         int64_t ldo, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused backward of u_mul_e_sum (models.py:547) in ONE sweep over the transposed direction (rows = sources u,

@@ -380,14 +380,19 @@ def test_blocked_spmm_matches_row_kernel():
     assert g.csc.nnz / n > blocked.MIN_MEAN_DEGREE
     csc = g.csc
     rows = torch.repeat_interleave(torch.arange(n, device=DEV), (csc.indptr[1:] - csc.indptr[:-1]).long())
-    for H, D in ((1, 256), (6, 80), (1, 41), (3, 250)):
+    # (1,128) / (2,60): 2 edges per gather instruction; (1,44) (2,24) (1,30) (1,16): 4 (lane groups, padded streams, T=256)
+    for H, D in ((1, 256), (6, 80), (1, 41), (3, 250), (1, 128), (2, 60), (1, 44), (2, 24), (1, 30), (1, 16), (4, 2)):
         x = torch.randn(n, H, D, generator=gen).to(DEV)
         w = torch.rand(csc.nnz, H, generator=gen).to(DEV)
         for weights in (None, w):
             blocked.ENABLED = True
             out_b = _C.spmm(csc, x, weights, None)
             vec = 4 if D % 4 == 0 else 2 if D % 2 == 0 else 1
-            assert (blocked.plan_for(csc, n, H, D) is not None) == (blocked.MIN_ROW_FLOATS <= H * D <= 256 * vec)
+            bp = blocked.plan_for(csc, n, H, D)
+            assert (bp is not None) == (blocked.MIN_ROW_FLOATS <= H * D <= 256 * vec)
+            if bp is not None:
+                lanes = -(-H * D // vec)
+                assert bp.epi == (4 if lanes <= 16 else 2 if lanes <= 32 else 1)
             blocked.ENABLED = False
             out_r = _C.spmm(csc, x, weights, None)
             blocked.ENABLED = True

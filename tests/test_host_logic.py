@@ -108,3 +108,59 @@ def test_agg_first_against_oracle(golden, cpu_backend, monkeypatch):
     from bot_amd.nn import fused
     monkeypatch.setattr(fused, "FORCE", True)
     PC.check_agg_first_against_oracle(golden, "cpu")
+
+
+def test_blocked_plan_streams_cover_every_edge_once():
+    """bot_amd/blocked.py: walking the (tile, wave) slot streams exactly as the kernel does — `epi` slots per instruction,
+    all of one destination row, the first a real edge, column blocks non-decreasing — reproduces the SpMM; hub rows are
+    left to the restricted row plan."""
+    import bot_amd
+    from bot_amd import blocked
+    n = 400
+    gen = torch.Generator().manual_seed(3)
+    src = torch.randint(0, n, (60000,), generator=gen)
+    dst = (n * torch.rand(60000, generator=gen, dtype=torch.float64) ** 1.5).long().clamp_(max=n - 1)
+    src = torch.cat([src, torch.arange(n).repeat(4)])            # one hub: node 0 gets 4 n extra edges
+    dst = torch.cat([dst, torch.zeros(4 * n, dtype=torch.int64)])
+    g = bot_amd.Graph(src, dst, n)
+    csc = g.csc
+    deg = (csc.indptr[1:] - csc.indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n), deg)
+    old = blocked.L2_BLOCK_BYTES
+    blocked.L2_BLOCK_BYTES = 1 << 14                             # several column blocks on this small graph
+    try:
+        for H, D in ((1, 256), (1, 128), (2, 24), (1, 44)):
+            vec, epi, Fp = blocked.layout(H, D)
+            bp = blocked.build(csc, n, H, D)
+            assert bp.epi == epi and bp.nblk > 1 and Fp * 4 * bp.T <= blocked.TILE_LDS_BYTES
+            assert bp.heavy is not None and bp.heavy.long_rows.tolist() == [0]
+            x = torch.randn(n, H * D, generator=gen, dtype=torch.float64)
+            w = torch.rand(csc.nnz, generator=gen, dtype=torch.float64)
+            out = torch.zeros(n, H * D, dtype=torch.float64)
+            ptr, b_src, b_lrow, b_pos = bp.ptr.tolist(), bp.b_src.tolist(), bp.b_lrow.tolist(), bp.b_pos.tolist()
+            shift = bp.block_rows.bit_length() - 1
+            seen = 0
+            for tile in range(bp.n_tiles):
+                for wave in range(blocked.WAVES):
+                    k0, k1 = ptr[tile * blocked.WAVES + wave], ptr[tile * blocked.WAVES + wave + 1]
+                    assert k0 % epi == 0 and k1 % epi == 0
+                    last_block = 0
+                    for k in range(k0, k1, epi):
+                        lr = b_lrow[k]
+                        assert lr % blocked.WAVES == wave and b_src[k] >= 0
+                        assert (b_src[k] >> shift) >= last_block
+                        last_block = b_src[k] >> shift
+                        row = int(bp.tile_rows[tile * bp.T + lr])
+                        assert row >= 0
+                        for j in range(k, k + epi):
+                            assert b_lrow[j] == lr
+                            if b_src[j] < 0:
+                                continue
+                            assert (b_src[j] >> shift) == last_block and int(csc.indices[b_pos[j]]) == b_src[j]
+                            out[row] += w[b_pos[j]] * x[b_src[j]]
+                            seen += 1
+            assert seen == csc.nnz - int(deg[0])
+            ref = torch.zeros(n, H * D, dtype=torch.float64).index_add_(0, rows, w.unsqueeze(1) * x[csc.indices.long()])
+            assert torch.allclose(out[1:], ref[1:], rtol=1e-12, atol=1e-12) and float(out[0].abs().max()) == 0.0
+    finally:
+        blocked.L2_BLOCK_BYTES = old
