@@ -13,6 +13,9 @@
 // HBM roofline: algorithmic bytes per launch = 4*[2*n*H*D + nnz + (n+1) + (w? nnz*H : 0)].
 #include "common.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 namespace bot {
 
 struct SpmmArgs {
@@ -137,6 +140,101 @@ __global__ __launch_bounds__(kBlock) void spmm_dot_kernel(SpmmArgs a) {
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
         if (act[c]) vstore<VEC>(ob + off[c], acc[c]);
+}
+
+// The same fused backward with ONE wavefront per work item covering ALL heads of the row.  CPH == 1: each head occupies a
+// segment of HL (16/32/64) lanes, 64/HL heads per 64-lane chunk; CPH > 1 (HL == 64): each head spans CPH whole chunks.
+// A neighbour row is then ONE contiguous H*D*4-byte read instead of H reads of D*4 bytes issued by different workgroups
+// at different times, and the H dot products of an edge are stored back to back into one 4*H-byte record instead of by H
+// unrelated workgroups (H separate partial-line writes).  Measured against the head-major kernel above: S-products H=4
+// D=120 83.9 -> 51.1 ms, S-proteins H=6 D=80 35.7 -> 21.6 ms, S-arxiv H=3 D=40 0.53 -> 0.31 ms.
+template <int VEC, int HL, int NCHUNK, int CPH>
+__global__ __launch_bounds__(kBlock) void spmm_dot_rows_kernel(SpmmArgs a) {
+    static_assert(CPH == 1 || HL == 64, "multi-chunk heads use whole waves");
+    static_assert(NCHUNK % CPH == 0, "whole heads only");
+    constexpr int U = 4;
+    constexpr int HPC = 64 / HL;        // heads per chunk (CPH == 1)
+    constexpr int NSLOT = NCHUNK / CPH;  // dot-product slots per lane segment
+    const int lane = threadIdx.x & 63;
+    const int64_t item = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (item >= a.n_items) return;
+    const int4 it = a.items[item];
+    const int row = __builtin_amdgcn_readfirstlane(it.x), beg = __builtin_amdgcn_readfirstlane(it.y);
+    const int end = __builtin_amdgcn_readfirstlane(it.z), slot = __builtin_amdgcn_readfirstlane(it.w);
+    const int hl = lane & (HL - 1);
+    int xoff[NCHUNK], hd[NCHUNK], el[NCHUNK];
+    bool act[NCHUNK], live[NCHUNK];  // live: the lane's head exists; act: and its elements lie inside the head slab
+    float acc[NCHUNK][VEC], yv[NCHUNK][VEC];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int head = CPH > 1 ? c / CPH : c * HPC + lane / HL;
+        const int e = CPH > 1 ? ((c % CPH) * 64 + lane) * VEC : hl * VEC;
+        live[c] = head < a.H;
+        act[c] = live[c] && e < a.D;
+        hd[c] = live[c] ? head : 0;
+        el[c] = e;
+        xoff[c] = act[c] ? (int)(head * a.hsx) + e : 0;  // idle lanes re-read element 0: in bounds, never stored
+        const float* yb = a.y + (int64_t)row * a.ldy + (act[c] ? head * a.hsy + e : 0);
+        vload<VEC>(yv[c], yb);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+            acc[c][t] = 0.f;
+            if (!act[c]) yv[c][t] = 0.f;
+        }
+    }
+    for (int k0 = beg; k0 < end; k0 += 64) {
+        const int k = k0 + lane;
+        int idx = 0, wp = 0;
+        if (k < end) {
+            idx = a.indices[k];
+            wp = a.wperm ? a.wperm[k] : k;
+        }
+        const int cnt = min(64, end - k0);
+        for (int i = 0; i < cnt; i += U) {
+            float v[U][NCHUNK][VEC], ww[U][NSLOT], p[NSLOT][U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = min(i + u, cnt - 1);  // past the end: re-read a valid neighbour with weight 0, result not stored
+                const int s = __builtin_amdgcn_readlane(idx, j);
+                const int ps = __builtin_amdgcn_readlane(wp, j);
+                const float* px = a.x + (int64_t)s * a.ldx;
+                const float* pw = a.w + (int64_t)ps * a.H;
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + xoff[c]);
+#pragma unroll
+                for (int q = 0; q < NSLOT; ++q) ww[u][q] = i + u < cnt ? pw[hd[q * CPH]] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int q = 0; q < NSLOT; ++q) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int cc = 0; cc < CPH; ++cc) {
+                        const int c = q * CPH + cc;
+#pragma unroll
+                        for (int t = 0; t < VEC; ++t) {
+                            acc[c][t] = fmaf(ww[u][q], v[u][c][t], acc[c][t]);
+                            d = fmaf(v[u][c][t], yv[c][t], d);
+                        }
+                    }
+                    p[q][u] = d;
+                }
+            const int mywp = __shfl(wp, i + (lane & 3));  // position whose dot products this lane holds after the reduction
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) {
+                const float tot = transpose_reduce4<HL>(p[q], hl);
+                if (hl < U && i + hl < cnt && live[q * CPH]) a.dot_out[(int64_t)mywp * a.H + hd[q * CPH]] = tot;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+        if (act[c]) {
+            float* ob = slot < 0 ? a.out + (int64_t)row * a.ldo + (int64_t)hd[c] * a.hso + el[c]
+                                 : a.partial + (int64_t)slot * a.ldp + (int64_t)hd[c] * a.D + el[c];
+            vstore<VEC>(ob, acc[c]);
+        }
 }
 
 template <int VEC, int LANES, int NCHUNK, bool WEIGHTED>
@@ -518,6 +616,52 @@ static void dispatch_spmm_dot(SpmmArgs& a, hipStream_t st) {
     else launch_spmm_dot<VEC, 64, 4>(a, st);
 }
 
+// "rows" layout of spmm_dot (one wave per item, all heads) is taken whenever the shape fits it; BOT_SPMM_DOT_LAYOUT=heads
+// forces the head-major kernel (measurements / debugging).
+static bool spmm_dot_rows_wanted() {
+    const char* e = getenv("BOT_SPMM_DOT_LAYOUT");
+    return !(e && !strcmp(e, "heads"));
+}
+
+template <int VEC, int HL, int NCHUNK, int CPH>
+static void launch_spmm_dot_rows(const SpmmArgs& a, hipStream_t st) {
+    const int64_t blocks = (a.n_items * 64 + kBlock - 1) / kBlock;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL((spmm_dot_rows_kernel<VEC, HL, NCHUNK, CPH>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+}
+
+// Returns false when the shape does not fit the rows layout: H == 1 (the head-major kernel is the same thing), head
+// segments under 9 lanes, or more register chunks than a wave can hold.
+template <int VEC>
+static bool dispatch_spmm_dot_rows(const SpmmArgs& a, hipStream_t st) {
+    if (a.H < 2 || !spmm_dot_rows_wanted()) return false;
+    const int L = (a.D + VEC - 1) / VEC;
+    if (L <= 8) return false;
+    if (L > 64) {  // a head spans two chunks: H = 2 or 3 (ogbn-arxiv: 3 x 250 floats = 3 x 125 float2 lanes)
+        if (L > 128 || VEC == 4 || a.H > 3) return false;
+        if constexpr (VEC != 4) {
+            if (a.H == 2) launch_spmm_dot_rows<VEC, 64, 4, 2>(a, st);
+            else launch_spmm_dot_rows<VEC, 64, 6, 2>(a, st);
+        }
+        return true;
+    }
+    const int HL = L <= 16 ? 16 : (L <= 32 ? 32 : 64);
+    const int nchunk = (a.H * HL + 63) / 64;
+    if (nchunk > 4) return false;
+#define BOT_ROWS(HLV)                                                      \
+    do {                                                                   \
+        if (nchunk == 1) launch_spmm_dot_rows<VEC, HLV, 1, 1>(a, st);      \
+        else if (nchunk == 2) launch_spmm_dot_rows<VEC, HLV, 2, 1>(a, st); \
+        else if (nchunk == 3) launch_spmm_dot_rows<VEC, HLV, 3, 1>(a, st); \
+        else launch_spmm_dot_rows<VEC, HLV, 4, 1>(a, st);                  \
+    } while (0)
+    if (HL == 16) BOT_ROWS(16);
+    else if (HL == 32) BOT_ROWS(32);
+    else BOT_ROWS(64);
+#undef BOT_ROWS
+    return true;
+}
+
 template <int VEC>
 static void dispatch_spmm(SpmmArgs& a, hipStream_t st) {
     const int L = (a.D + VEC - 1) / VEC;  // lanes needed for one head slab
@@ -598,9 +742,12 @@ int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_ro
     const int vec = pick_vec(D, {ldx, hsx, ldo, hso, ldy, hsy}, {x, out, partial, y});
     BOT_REQUIRE(D <= vec * 256, BOT_E_RANGE, "spmm_dot: D=%d exceeds the %d floats one launch tile covers (use bot_spmm_f32 + bot_sddmm_dot_f32)",
                 D, vec * 256);
-    if (vec == 4) dispatch_spmm_dot<4>(a, st);
-    else if (vec == 2) dispatch_spmm_dot<2>(a, st);
-    else dispatch_spmm_dot<1>(a, st);
+    const bool rows = vec == 4 ? dispatch_spmm_dot_rows<4>(a, st) : (vec == 2 ? dispatch_spmm_dot_rows<2>(a, st) : dispatch_spmm_dot_rows<1>(a, st));
+    if (!rows) {
+        if (vec == 4) dispatch_spmm_dot<4>(a, st);
+        else if (vec == 2) dispatch_spmm_dot<2>(a, st);
+        else dispatch_spmm_dot<1>(a, st);
+    }
     if (int rc = hip_status("spmm_dot launch")) return rc;
     if (n_long > 0) {
         const int64_t n = n_long * H * D;

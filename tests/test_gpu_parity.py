@@ -1,5 +1,7 @@
 """GPU parity suite: the HIP kernels, called through the C ABI, against the golden vectors and the
 oracle.  Run with `-m gpu` on an MI355X."""
+import os
+
 import pytest
 import torch
 
@@ -251,7 +253,12 @@ def test_sddmm_dot_and_fused_backward_direct(golden):
     g = bot_amd.Graph(s, d, n, chunk=8).to(DEV)
     E = s.numel()
     gen = torch.Generator().manual_seed(6)
-    for H, D in ((3, 250), (1, 40), (2, 7), (1, 1100)):
+    # "rows" = the one-wave-per-item / all-heads layout of spmm_dot (the default where the shape fits), "heads" = the
+    # head-major kernel: segments of 16 / 32 / 64 lanes per head, 1..4 chunks, heads of two chunks (D=250), odd head counts, vec 4 / 2 / 1
+    cases = [((3, 250), "heads"), ((1, 40), "heads"), ((2, 7), "heads"), ((1, 1100), "heads")]
+    cases += [(hd, "rows") for hd in ((4, 120), (6, 80), (2, 64), (3, 40), (8, 32), (5, 36), (2, 250), (3, 250), (3, 125), (3, 126), (2, 16))]
+    for (H, D), layout in cases:
+        os.environ["BOT_SPMM_DOT_LAYOUT"] = layout
         x = torch.randn(n, H, D, generator=gen).to(DEV)
         y = torch.randn(n, H, D, generator=gen).to(DEV)
         a = torch.rand(E, H, generator=gen).to(DEV)
@@ -261,6 +268,12 @@ def test_sddmm_dot_and_fused_backward_direct(golden):
         assert torch.allclose(_C.sddmm_dot(csc, x, y), ref, atol=1e-3 * D ** 0.5, rtol=1e-4)
         if D <= _C.spmm_dot_max_d(x):
             out, dot = _C.spmm_dot(csr, x, a, g.csr2csc, y)
+            if layout == "rows":  # and the strided-slab form the fused layer uses (row pitch > H*D)
+                big = torch.randn(n, H * D + 8, generator=gen).to(DEV)
+                xs = big[:, 4:4 + H * D].view(n, H, D)
+                o2, d2 = _C.spmm_dot(csr, xs, a, g.csr2csc, y)
+                o3, d3 = _C.spmm_dot(csr, xs.contiguous(), a, g.csr2csc, y)
+                assert torch.equal(o2, o3) and torch.equal(d2, d3)
             rows_r = torch.repeat_interleave(torch.arange(n, device=DEV), (csr.indptr[1:] - csr.indptr[:-1]).long())
             w = a[g.csr2csc.long()]
             ref_out = torch.zeros(n, H, D, device=DEV).index_add_(0, rows_r, x[csr.indices.long()] * w.unsqueeze(-1))
@@ -268,6 +281,7 @@ def test_sddmm_dot_and_fused_backward_direct(golden):
             ref_dot[g.csr2csc.long()] = (x[csr.indices.long()] * y[rows_r]).sum(-1)
             assert torch.allclose(out, ref_out, atol=1e-4, rtol=1e-4)
             assert torch.allclose(dot, ref_dot, atol=1e-3 * D ** 0.5, rtol=1e-4)
+    os.environ.pop("BOT_SPMM_DOT_LAYOUT", None)
 
 
 @pytest.mark.parametrize("H", [1, 3, 6, 8])
