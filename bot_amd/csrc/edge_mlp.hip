@@ -29,7 +29,7 @@ constexpr int kMlpBlocks = 2048;
 template <int H>
 __global__ __launch_bounds__(kBlock) void edge_mlp_fwd_kernel(const float* __restrict__ ef, const float* __restrict__ W1,
                                                              const float* __restrict__ b1, const float* __restrict__ W2,
-                                                             int64_t E, float* __restrict__ out) {
+                                                             int64_t E, float* __restrict__ out, bool wide) {
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += (int64_t)gridDim.x * kBlock) {
         float f[kI];
         vload<4>(*reinterpret_cast<float(*)[4]>(&f[0]), ef + e * kI);
@@ -42,13 +42,30 @@ __global__ __launch_bounds__(kBlock) void edge_mlp_fwd_kernel(const float* __res
             for (int i = 0; i < kI; ++i) acc = fmaf(W1[j * kI + i], f[i], acc);
             r[j] = fmaxf(acc, 0.f);
         }
+        float o[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < kJ; ++j) v = fmaf(W2[h * kJ + j], r[j], v);
-            out[e * H + h] = v;
+            o[h] = v;
         }
+        // one record per edge: 8- / 16-byte stores where H allows (a 4-byte store per head touches the line H times)
+        if constexpr (H % 4 == 0) {
+            if (wide) {
+#pragma unroll
+                for (int h = 0; h < H; h += 4) *reinterpret_cast<float4*>(out + e * H + h) = make_float4(o[h], o[h + 1], o[h + 2], o[h + 3]);
+                continue;
+            }
+        } else if constexpr (H % 2 == 0) {
+            if (wide) {
+#pragma unroll
+                for (int h = 0; h < H; h += 2) *reinterpret_cast<float2*>(out + e * H + h) = make_float2(o[h], o[h + 1]);
+                continue;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) out[e * H + h] = o[h];
     }
 }
 
@@ -70,26 +87,38 @@ __global__ __launch_bounds__(kBlock) void edge_mlp_bwd_kernel(const float* __res
     for (int h = 0; h < 8; ++h) w2[h] = h < H ? W2[h * kJ + j] : 0.f;
     const float bj = b1[j];
     f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t base = wave * 4; base < E; base += n_waves * 4) {
-        const int64_t e = base + k;
-        const bool live = e < E;
-        const int64_t ec = live ? e : E - 1;  // tail: re-read a valid edge, contributions zeroed below
-        float f[kI];
-        vload<4>(*reinterpret_cast<float(*)[4]>(&f[0]), ef + ec * kI);
-        vload<4>(*reinterpret_cast<float(*)[4]>(&f[4]), ef + ec * kI + 4);
-        float pre = bj, t = 0.f;
+    // One MFMA step folds 4 edges; a wave takes U steps (16 edges) per trip with all their loads issued before the first
+    // MFMA — with one step per trip a wave had a single round of loads in flight (6.0 ms per call at E = 77.7 M,
+    // latency-bound).
+    constexpr int U = 4;
+    for (int64_t base = wave * (4 * U); base < E; base += n_waves * (4 * U)) {
+        float f[U][kI], dzv[U][8], bz[U], bf[U];
+        bool live[U];
 #pragma unroll
-        for (int i = 0; i < kI; ++i) pre = fmaf(w1[i], f[i], pre);
+        for (int u = 0; u < U; ++u) {
+            const int64_t e = base + u * 4 + k;
+            live[u] = e < E;
+            const int64_t ec = live[u] ? e : E - 1;  // tail: re-read a valid edge, contributions zeroed below
+            vload<4>(*reinterpret_cast<float(*)[4]>(&f[u][0]), ef + ec * kI);
+            vload<4>(*reinterpret_cast<float(*)[4]>(&f[u][4]), ef + ec * kI + 4);
 #pragma unroll
-        for (int h = 0; h < 8; ++h)
-            if (h < H) t = fmaf(dz[ec * H + h], w2[h], t);
-        const float r = live ? fmaxf(pre, 0.f) : 0.f;
-        const float du = (live && pre > 0.f) ? t : 0.f;
-        // B operands: column n = lane & 15 of this lane's edge slot
-        const float bz = (j < H) ? dz[ec * H + j] : 0.f;
-        const float bf = (j < kI) ? ef[ec * kI + j] : (j == kI ? 1.f : 0.f);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, bz, acc2, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(du, bf, acc1, 0, 0, 0);
+            for (int h = 0; h < 8; ++h) dzv[u][h] = h < H ? dz[ec * H + h] : 0.f;
+            // B operands: column n = lane & 15 of this lane's edge slot
+            bz[u] = (j < H) ? dz[ec * H + j] : 0.f;
+            bf[u] = (j < kI) ? ef[ec * kI + j] : (j == kI ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float pre = bj, t = 0.f;
+#pragma unroll
+            for (int i = 0; i < kI; ++i) pre = fmaf(w1[i], f[u][i], pre);
+#pragma unroll
+            for (int h = 0; h < 8; ++h) t = fmaf(dzv[u][h], w2[h], t);
+            const float r = live[u] ? fmaxf(pre, 0.f) : 0.f;
+            const float du = (live[u] && pre > 0.f) ? t : 0.f;
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, bz[u], acc2, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(du, bf[u], acc1, 0, 0, 0);
+        }
     }
     // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
     float* p = part + wave * 512;
@@ -140,7 +169,7 @@ int bot_edge_mlp_fwd_f32(const float* ef, int32_t I, const float* W1, const floa
     int64_t blocks = (n_edges + kBlock - 1) / kBlock;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipStream_t st = (hipStream_t)stream;
-#define BOT_MLP_FWD(HH) hipLaunchKernelGGL((edge_mlp_fwd_kernel<HH>), dim3((unsigned)blocks), dim3(kBlock), 0, st, ef, W1, b1, W2, n_edges, out)
+#define BOT_MLP_FWD(HH) hipLaunchKernelGGL((edge_mlp_fwd_kernel<HH>), dim3((unsigned)blocks), dim3(kBlock), 0, st, ef, W1, b1, W2, n_edges, out, aligned(out, 16))
     switch (H) {
         case 1: BOT_MLP_FWD(1); break;
         case 2: BOT_MLP_FWD(2); break;
