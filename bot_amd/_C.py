@@ -56,6 +56,8 @@ _SIGS = {
     "bot_edge_mlp_workspace_floats": (c_int64, []),
     "bot_edge_mlp_fwd_f32": (ctypes.c_int, [_P, c_int32, _P, _P, c_int32, _P, c_int32, c_int64, _P, _P]),
     "bot_edge_mlp_bwd_f32": (ctypes.c_int, [_P, c_int32, _P, _P, c_int32, _P, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
+    "bot_random_keep_workspace_bytes": (c_int64, []),
+    "bot_random_keep_u8": (ctypes.c_int, [c_int64, c_int64, c_uint64, _P, _P, _P]),
     "bot_bn_workspace_floats": (c_int64, [c_int32]),
     "bot_colstats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
     "bot_bn_act_fwd_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, c_int64, _P]),
@@ -459,6 +461,19 @@ def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, su
 # ------------------------------------------------------------------------------------------------ fused edge MLP (ogbn-proteins)
 def edge_mlp_supported(I, J, H):
     return I == 8 and J == 16 and 1 <= H <= 8
+
+
+def random_keep(n, n_keep, seed, device):
+    """uint8 [n] mask of a uniformly random subset of exactly n_keep elements (the edge-drop mask), a pure function of
+    (n, n_keep, seed)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise BotKernelError("random_keep: the HIP kernels need a GPU device")
+    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    ws = torch.empty(int(_lib.bot_random_keep_workspace_bytes()), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        _check(_lib.bot_random_keep_u8(n, n_keep, seed & 0xFFFFFFFFFFFFFFFF, keep.data_ptr(), ws.data_ptr(), _stream()), "random_keep")
+    return keep
 
 
 def edge_mlp_fwd(ef, W1, b1, W2):

@@ -93,6 +93,27 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+struct Philox {
+    // Philox4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0,k1)
+    static __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+    }
+    static __device__ __forceinline__ void gen(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            round(c, k0, k1);
+            k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = c[i];
+    }
+};
+
 // Vector width usable for a feature slab: every stride and base must keep VEC*4-byte alignment.
 inline int pick_vec(int32_t D, std::initializer_list<int64_t> strides, std::initializer_list<const void*> ptrs) {
     for (int v : {4, 2}) {

@@ -220,11 +220,7 @@ class GATConv(nn.Module):
 
     def _kept_edges(self, graph):
         """Training-time edge drop, models.py:528-532: a random subset of int(E*p) edges is left out."""
-        E = graph.number_of_edges()
-        perm = torch.randperm(E, device=graph.device)
-        keep = torch.zeros(E, dtype=torch.uint8, device=graph.device)
-        keep[perm[int(E * self.edge_drop):]] = 1
-        return keep
+        return ops.random_edge_keep(graph, self.edge_drop)
 
     def forward(self, graph, feat, keep=None):
         """`keep` (uint8 [E], edge-id order) overrides the random edge-drop mask — used by parity tests."""

@@ -74,9 +74,7 @@ class GATConv(nn.Module):
         elif feat_edge is not None:
             ee = self.attn_edge_fc(feat_edge).view(-1, H, 1)
         if keep is None and self.training and self.edge_drop > 0:
-            E = graph.number_of_edges()
-            keep = torch.zeros(E, dtype=torch.uint8, device=graph.device)
-            keep[torch.randperm(E, device=graph.device)[int(E * self.edge_drop):]] = 1
+            keep = ops.random_edge_keep(graph, self.edge_drop)
         a = ops.gat_attention(graph, attn_src, attn_dst, ee, keep=keep, negative_slope=self.leaky_relu.negative_slope,
                               order="csc", ee_order=ee_order)
         rst = ops.u_mul_e_sum(graph, ft, self.attn_drop(a), order="csc")

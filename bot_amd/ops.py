@@ -306,6 +306,13 @@ def bn_batch_stats(x, bn, bn_training):
     return mean, invstd, total, sync, group
 
 
+def random_edge_keep(graph, drop):
+    """Edge-drop mask of one training step (models.py:528-532: `perm = randperm(E); eids = perm[int(E * drop):]`): uint8
+    [E], 1 for a uniformly random subset of exactly E - int(E * drop) edges.  The seed comes from torch's CPU generator."""
+    E = graph.number_of_edges()
+    return _C.random_keep(E, E - int(E * drop), new_dropout_seed(1.0), graph.device)
+
+
 def new_dropout_seed(p):
     """Seed of the Philox stream of one fused-dropout call, drawn from torch's CPU generator (so torch.manual_seed governs it)."""
     return int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0

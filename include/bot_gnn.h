@@ -293,6 +293,18 @@ int bot_edge_mlp_bwd_f32(const float* ef, int32_t I, const float* W1, const floa
                          int32_t H, const float* dz, int64_t n_edges, float* dW1, float* db1, float* dW2,
                          float* workspace, bot_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-time edge drop of the GAT layers.  Replaces
+ *   perm = torch.randperm(graph.number_of_edges()); bound = int(E * edge_drop); eids = perm[bound:]
+ *                                      src/no-sampling/models.py:528-532, src/ogbn-proteins/models.py:120-127
+ * keep[e] = 1 for a uniformly random subset of exactly n_keep of the n edges, 0 for the others — the mask the
+ * attention kernel takes (bot_gat_attn_fwd_f32 `keep`).  The subset is a pure function of (n, n_keep, seed): every
+ * edge gets a 64-bit Philox4x32-10 key and the n - n_keep smallest keys are dropped, found by a radix select (no
+ * sort, no n-sized temporary).  workspace: bot_random_keep_workspace_bytes() bytes, 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int64_t bot_random_keep_workspace_bytes(void);
+int bot_random_keep_u8(int64_t n, int64_t n_keep, uint64_t seed, uint8_t* keep, void* workspace, bot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

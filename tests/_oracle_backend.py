@@ -195,7 +195,15 @@ def edge_mlp_bwd(ef, W1, b1, W2, dz):
     return du.t() @ ef, du.sum(0), dz.t() @ r
 
 
-NAMES = ["spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+def random_keep(n, n_keep, seed, device):
+    """Same distribution as the HIP radix select (a uniformly random n_keep-subset), not the same bits."""
+    gen = torch.Generator().manual_seed(seed & 0x7FFFFFFFFFFFFFFF)
+    keep = torch.zeros(n, dtype=torch.uint8)
+    keep[torch.randperm(n, generator=gen)[n - n_keep:]] = 1
+    return keep.to(device)
+
+
+NAMES = ["random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -491,3 +491,38 @@ def test_random_shapes_against_torch():
         if e:
             z = torch.nn.functional.leaky_relu(el[csc.indices.long()] + er[rows], 0.2)
             assert torch.allclose(a, R.edge_softmax(rows.cpu(), n, z.cpu()).to(DEV), atol=1e-6), (trial, H, e)
+
+
+def test_random_keep_exact_uniform_and_reproducible():
+    """Edge-drop mask (bot_random_keep_u8): exactly n_keep ones, a pure function of the seed, different for another seed,
+    every element kept with probability n_keep / n (2 000 seeds), and the layers' edge drop leaves out exactly
+    int(E * p) edges (models.py:528-532)."""
+    for n, n_keep in ((1, 1), (1, 0), (2, 1), (7, 3), (1000, 900), (4097, 1), (100001, 100000), (3000017, 2700015)):
+        a = _C.random_keep(n, n_keep, 1234, DEV)
+        assert a.dtype == torch.uint8 and a.shape == (n,) and int(a.sum()) == n_keep and int(a.max()) <= 1
+        assert torch.equal(a, _C.random_keep(n, n_keep, 1234, DEV))
+        if 0 < n_keep < n and n > 7:
+            assert not torch.equal(a, _C.random_keep(n, n_keep, 1235, DEV))
+    n, n_keep, trials = 50, 35, 2000
+    hits = torch.zeros(n, device=DEV)
+    for seed in range(trials):
+        hits += _C.random_keep(n, n_keep, seed * 7919 + 1, DEV)
+    p = n_keep / n
+    sigma = (trials * p * (1 - p)) ** 0.5
+    assert float((hits - trials * p).abs().max()) < 4.5 * sigma   # 50 elements: 4.5 sigma never trips by chance
+    pairs = torch.zeros((), device=DEV)                           # and pairs are (nearly) independent: P(both kept) = k(k-1)/(n(n-1))
+    for seed in range(trials):
+        k = _C.random_keep(n, n_keep, seed * 104729 + 3, DEV)
+        pairs += k[0].float() * k[1].float()
+    pp = n_keep * (n_keep - 1) / (n * (n - 1))
+    assert abs(float(pairs) - trials * pp) < 4.5 * (trials * pp * (1 - pp)) ** 0.5
+    import bot_amd.nn as bnn
+    s, d = R.preprocess_edges(torch.randint(0, 300, (5000,)), torch.randint(0, 300, (5000,)), 300)
+    g = bot_amd.Graph(s, d, 300).to(DEV)
+    conv = bnn.GATConv(8, 4, num_heads=2, edge_drop=0.3).to(DEV).train()
+    E = g.number_of_edges()
+    keep = conv._kept_edges(g)
+    assert int(keep.sum()) == E - int(E * 0.3)
+    torch.manual_seed(0); k1 = conv._kept_edges(g)
+    torch.manual_seed(0); k2 = conv._kept_edges(g)
+    assert torch.equal(k1, k2)                                    # torch.manual_seed governs the mask
