@@ -20,7 +20,7 @@ def t(fn, it=5):
     for _ in range(it): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e3
 from bot_amd import blocked
-blocked.ENABLED = False
+blocked.ENABLED = os.environ.get("BOT_BLOCKED", "0") == "1"
 print("E", E, "gather GB", E * H * D * 4 / 1e9)
 print("spmm  [N,%d,%d] unweighted %.2f ms" % (H, D, t(lambda: _C.spmm(g.csc, x, None, None))))
 print("spmm  [N,1,%d] unweighted %.2f ms" % (H * D, t(lambda: _C.spmm(g.csc, x.view(n, 1, H * D), None, None))))
