@@ -68,7 +68,19 @@ def timed(fn, it=3):
 
 
 def main():
-    which = sys.argv[1:] or ["reddit", "proteins", "products"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["reddit", "proteins", "products"]
+    # --gemm-tuning=file (default): shipped TunableOp selections; =tune: also time missing shapes and write them to
+    # gpurun_out/tunableop_scale.csv (maintenance); =off: library heuristics
+    mode = ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--gemm-tuning=")] or ["file"])[0]
+    if mode != "off":
+        from bot_amd import tuning
+        tuning.enable(tune_missing=mode == "tune")
+        if mode == "tune":
+            from torch.cuda import tunable
+            tunable.set_max_tuning_iterations(5)
+            tunable.set_max_tuning_duration(10)
+            os.makedirs("gpurun_out", exist_ok=True)
+            tunable.set_filename(os.path.join("gpurun_out", "tunableop_scale.csv"))
     for name in which:
         g, f, c, t_build = build(name)
         n, E = g.number_of_nodes(), g.number_of_edges()
@@ -120,6 +132,9 @@ def main():
                           "hbm_GB_allocated": round(torch.cuda.max_memory_allocated() / 1e9, 1)}), flush=True)
         del model, g, x, a
         torch.cuda.empty_cache()
+    if mode == "tune":
+        from torch.cuda import tunable
+        getattr(tunable, "write_file", lambda f=None: None)(os.path.join("gpurun_out", "tunableop_scale.csv"))
 
 
 if __name__ == "__main__":
