@@ -12,9 +12,6 @@
 // HBM roofline: forward 4*[2*nnz*H + nnz + (n+1) + n*H*k] bytes, backward 4*[3*nnz*H + nnz + (n+1)].
 #include "common.h"
 
-#include <stdlib.h>
-#include <string.h>
-
 namespace bot {
 
 constexpr int kRowLanes = 16;
@@ -288,178 +285,6 @@ __global__ __launch_bounds__(kBlock) void attn_long_kernel(AttnArgs p) {
     else attn_fwd_row<HT>(p, ctx, row, beg, end);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Flat (edge, head) lanes — the layout used for H <= 16.  Lane l of a G-lane group owns head l % H and edge slot l / H
-// (G / H edges per step; the G % H trailing lanes idle), so with edges in position order the loads of ee / a / da and the
-// stores of a / dz are one contiguous run per instruction (the HT-heads-per-lane routines above issue H loads of 4 bytes
-// with a 4*H-byte lane stride instead, H times the cache-line transactions; at H = 6 on S-proteins: see DESIGN.md).
-// Lanes of one head are H apart: the per-head reductions run over the edge-slot index with ds_bpermute (log2(G/H) steps
-// and a broadcast), across the 4 waves of a long row's workgroup through LDS.  The forward stores the logits in `a`
-// during the first pass and rescales them in place in the second, which therefore needs no gather at all.
-// ---------------------------------------------------------------------------------------------
-struct FlatCtx {
-    int lane;    // lane in the wavefront
-    int H, h, es, epi;  // head of this lane, its edge slot, edge slots per group
-    int slot0, stride;  // first edge of this lane within a row, edges per step of the whole group / workgroup
-    bool active;
-    float* lds;  // workgroup-per-row only: 4 * 16 floats
-    int wave;
-};
-
-template <int G, bool MAX>
-__device__ __forceinline__ float head_reduce_wave(float v, const FlatCtx& c) {
-    for (int step = 1; step < c.epi; step <<= 1) {
-        const float pv = __shfl(v, (c.lane + step * c.H) & 63);  // same head, `step` edge slots further
-        if (c.es + step < c.epi) v = MAX ? fmaxf(v, pv) : v + pv;
-    }
-    return __shfl(v, (c.lane & ~(G - 1)) + c.h);  // slot 0 of the group holds the result
-}
-
-template <int G, bool BLOCK, bool MAX>
-__device__ __forceinline__ float head_reduce(float v, const FlatCtx& c) {
-    v = head_reduce_wave<G, MAX>(v, c);
-    if constexpr (BLOCK) {
-        __syncthreads();
-        if (c.active && c.es == 0) c.lds[c.wave * 16 + c.h] = v;
-        __syncthreads();
-        float r = c.lds[c.h];
-#pragma unroll
-        for (int i = 1; i < kBlock / 64; ++i) r = MAX ? fmaxf(r, c.lds[i * 16 + c.h]) : r + c.lds[i * 16 + c.h];
-        v = r;
-    }
-    return v;
-}
-
-template <int G, bool BLOCK>
-__device__ __forceinline__ void attn_fwd_flat(const AttnArgs& p, const FlatCtx& c, int row, int beg, int end) {
-    const float NEG_INF = -__builtin_inff();
-    const int H = c.H, h = c.h;
-    const float erv = (p.er && c.active) ? p.er[(int64_t)row * H + h] : 0.f;
-    float m = NEG_INF, s = 0.f;
-    if (c.active) {
-#pragma unroll 2
-        for (int k = beg + c.slot0; k < end; k += c.stride) {
-            const int ep = p.eperm ? p.eperm[k] : k;
-            const int64_t o = (int64_t)(p.aperm ? p.aperm[k] : k) * H + h;
-            if (p.keep && p.keep[ep] == 0) {
-                p.a[o] = NEG_INF;  // exp(-inf - M) = 0 in the second pass
-                continue;
-            }
-            float z = erv;
-            if (p.el) z += p.el[(int64_t)p.indices[k] * H + h];
-            if (p.ee) z += p.ee[(int64_t)ep * H + h];
-            const float e = z > 0.f ? z : z * p.slope;
-            p.a[o] = e;
-            const float mn = fmaxf(m, e);
-            s = s * expf(m - mn) + expf(e - mn);  // m = -inf on first use: s = 0 * 0 + 1
-            m = mn;
-        }
-    }
-    const float M = head_reduce<G, BLOCK, true>(m, c);
-    float inv = head_reduce<G, BLOCK, false>(m > NEG_INF ? s * expf(m - M) : 0.f, c);
-    inv = inv > 0.f ? 1.f / inv : 0.f;
-    if (c.active) {
-#pragma unroll 4
-        for (int k = beg + c.slot0; k < end; k += c.stride) {
-            const int64_t o = (int64_t)(p.aperm ? p.aperm[k] : k) * H + h;
-            const float e = p.a[o];
-            p.a[o] = e > NEG_INF ? expf(e - M) * inv : 0.f;
-        }
-    }
-}
-
-template <int G, bool BLOCK>
-__device__ __forceinline__ void attn_bwd_flat(const AttnArgs& p, const FlatCtx& c, int row, int beg, int end) {
-    const int H = c.H, h = c.h;
-    float t = 0.f, dacc = 0.f;
-    if (c.active) {
-#pragma unroll 4
-        for (int k = beg + c.slot0; k < end; k += c.stride) {
-            const int64_t o = (int64_t)(p.aperm ? p.aperm[k] : k) * H + h;
-            t = fmaf(p.a[o], p.da[o], t);
-        }
-    }
-    t = head_reduce<G, BLOCK, false>(t, c);
-    const bool need_z = p.slope != 1.f;
-    const float erv = (p.er && c.active) ? p.er[(int64_t)row * H + h] : 0.f;
-    if (c.active) {
-#pragma unroll 2
-        for (int k = beg + c.slot0; k < end; k += c.stride) {
-            const int64_t o = (int64_t)(p.aperm ? p.aperm[k] : k) * H + h;
-            float g = p.a[o] * (p.da[o] - t);
-            if (need_z) {
-                float z = erv;
-                if (p.el) z += p.el[(int64_t)p.indices[k] * H + h];
-                if (p.ee) z += p.ee[(int64_t)(p.eperm ? p.eperm[k] : k) * H + h];
-                if (!(z > 0.f)) g *= p.slope;
-            }
-            p.dz[(int64_t)(p.zperm ? p.zperm[k] : k) * H + h] = g;
-            dacc += g;
-        }
-    }
-    if (p.der) {
-        dacc = head_reduce<G, BLOCK, false>(dacc, c);
-        if (c.active && c.es == 0 && (!BLOCK || c.wave == 0)) p.der[(int64_t)row * H + h] = dacc;
-    }
-}
-
-template <int G>
-__device__ __forceinline__ FlatCtx flat_ctx(int H, float* lds, bool block) {
-    FlatCtx c;
-    c.lane = threadIdx.x & 63;
-    c.wave = threadIdx.x >> 6;
-    const int gl = c.lane & (G - 1);
-    c.H = H;
-    c.epi = G / H;
-    c.es = gl / H;
-    c.h = gl - c.es * H;
-    c.active = c.es < c.epi;
-    if (!c.active) c.h = 0;
-    c.slot0 = block ? c.wave * c.epi + c.es : c.es;
-    c.stride = block ? (kBlock / 64) * c.epi : c.epi;
-    c.lds = lds;
-    return c;
-}
-
-template <int G, bool BWD>
-__global__ __launch_bounds__(kBlock) void attn_flat_short_kernel(AttnArgs p) {
-    const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / G;
-    if (row >= p.n_rows) return;  // whole groups leave together; a wave's surviving groups still shuffle among themselves only
-    const int beg = p.indptr[row], end = p.indptr[row + 1];
-    if (end - beg > p.chunk) return;  // the workgroup-per-row kernel owns it
-    const FlatCtx c = flat_ctx<G>(p.H, nullptr, false);
-    if constexpr (BWD) attn_bwd_flat<G, false>(p, c, (int)row, beg, end);
-    else attn_fwd_flat<G, false>(p, c, (int)row, beg, end);
-}
-
-template <bool BWD>
-__global__ __launch_bounds__(kBlock) void attn_flat_long_kernel(AttnArgs p) {
-    __shared__ float lds[(kBlock / 64) * 16];
-    const int row = p.long_rows[blockIdx.x];
-    const int beg = p.indptr[row], end = p.indptr[row + 1];
-    const FlatCtx c = flat_ctx<64>(p.H, lds, true);
-    if constexpr (BWD) attn_bwd_flat<64, true>(p, c, row, beg, end);
-    else attn_fwd_flat<64, true>(p, c, row, beg, end);
-}
-
-// G: the smallest group that holds one step of an average row (mean degree * H flat elements), at least H lanes.
-template <bool BWD>
-static int launch_attn_flat(const AttnArgs& p, int64_t nnz, int64_t n_long, hipStream_t st) {
-    const int64_t per_row = (nnz / (p.n_rows > 0 ? p.n_rows : 1) + 1) * p.H;
-    const int G = (per_row <= 16 && p.H <= 16) ? 16 : (per_row <= 32 ? 32 : 64);
-    const int64_t blocks = (p.n_rows * G + kBlock - 1) / kBlock;
-    if (G == 16) hipLaunchKernelGGL((attn_flat_short_kernel<16, BWD>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
-    else if (G == 32) hipLaunchKernelGGL((attn_flat_short_kernel<32, BWD>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
-    else hipLaunchKernelGGL((attn_flat_short_kernel<64, BWD>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);
-    if (n_long > 0) hipLaunchKernelGGL((attn_flat_long_kernel<BWD>), dim3((unsigned)n_long), dim3(kBlock), 0, st, p);
-    return hip_status(BWD ? "gat_attn_bwd launch" : "gat_attn_fwd launch");
-}
-
-static bool attn_flat_wanted(int H) {
-    const char* e = getenv("BOT_ATTN_LAYOUT");  // "flat": the (edge, head)-lane kernels instead of the heads-per-lane ones
-    return H <= 16 && e && !strcmp(e, "flat");
-}
-
 template <bool BWD>
 static int launch_attn(AttnArgs p, int64_t n_long, hipStream_t st) {
     const int64_t blocks = (p.n_rows * kRowLanes + kBlock - 1) / kBlock;
@@ -570,7 +395,6 @@ int bot_gat_attn_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t 
     BOT_REQUIRE(el || er || ee, BOT_E_NULL, "gat_attn_fwd: no logit source (el, er, ee all NULL)");
     AttnArgs p{indptr, indices, n_rows, long_rows, chunk, el, er, ee, eperm, keep, slope, H, 0, a, nullptr, aperm, nullptr,
                nullptr, nullptr};
-    if (attn_flat_wanted(H)) return launch_attn_flat<false>(p, nnz, n_long, (hipStream_t)stream);
     return launch_attn<false>(p, n_long, (hipStream_t)stream);
 }
 
@@ -585,7 +409,6 @@ int bot_gat_attn_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t 
     BOT_REQUIRE(slope == 1.f || el || er || ee, BOT_E_NULL, "gat_attn_bwd: slope != 1 needs el/er/ee to recompute the sign");
     AttnArgs p{indptr, indices, n_rows, long_rows, chunk, el, er, ee, eperm, nullptr, slope, H, 0, const_cast<float*>(a), da,
                aperm, dz, zperm, der};
-    if (attn_flat_wanted(H)) return launch_attn_flat<true>(p, nnz, n_long, (hipStream_t)stream);
     return launch_attn<true>(p, n_long, (hipStream_t)stream);
 }
 
