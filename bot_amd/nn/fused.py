@@ -96,10 +96,11 @@ def _extend_backward(graph, dext, n_own):
 
 class _GATHidden(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, Wcat, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training):
+    def forward(ctx, h, Wcat, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp):
         N, HD = h.shape[0], H * D
         csc = graph.csc
-        out = torch.mm(h, Wcat.t())                                     # [N, P] = [ft | res | el | er | pad]
+        ctx.kp = kp                                                     # Wcat is [K, P] (see WEIGHT_KP) instead of [P, K]
+        out = torch.mm(h, Wcat) if kp else torch.mm(h, Wcat.t())        # [N, P] = [ft | res | el | er | pad]
         c = 2 * HD if has_res else HD
         ext = None
         if graph.halo is not None:                                      # partitioned: owned + halo source rows
@@ -142,7 +143,8 @@ class _GATHidden(torch.autograd.Function):
         else:
             h, Wcat, table, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
             drop_p, seed, bn_training, sync, group, total = epi
-        N, HD, P = h.shape[0], H * D, Wcat.shape[0]
+        kp = ctx.kp
+        N, HD, P = h.shape[0], H * D, Wcat.shape[1 if kp else 0]
         dout = torch.empty((N, P), dtype=h.dtype, device=h.device)
         dx = dout[:, HD:2 * HD] if has_res else torch.empty((N, HD), dtype=h.dtype, device=h.device)
         if epi is None:
@@ -183,10 +185,14 @@ class _GATHidden(torch.autograd.Function):
         used = c + (2 * H if has_er else H)
         if used < P:
             dout[:, used:].zero_()
-        dW = torch.mm(dout.t(), h) if ctx.needs_input_grad[1] else None
-        dh = torch.mm(dout, Wcat) if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            dW = torch.mm(h.t(), dout) if kp else torch.mm(dout.t(), h)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.mm(dout, Wcat.t()) if kp else torch.mm(dout, Wcat)
         return (dh, dW, d_bn_w if ctx.needs_input_grad[2] else None, d_bn_b if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 def cat_weight_aggfirst(conv):
@@ -205,6 +211,16 @@ def cat_weight_aggfirst(conv):
     return torch.cat(rows)
 
 
+# Layout of the merged weight handed to the layer node: [K, P] (a transposed copy, K*P floats per step) instead of [P, K].
+# Same three GEMMs, other operand layouts, i.e. other library kernels: on [169 343, 750] x [750, 1536] the best kernels reach
+# 128 / 134 / 147 TFLOP/s (forward / dX / dW) against 123 / 118 / 142 for the [P, K] form (tools/exp_gemm_layouts.py).
+WEIGHT_KP = True
+
+
+def _kp(w):
+    return w.t().contiguous() if WEIGHT_KP else w
+
+
 AGG_FIRST = True  # aggregate-before-project for layers whose input is narrower than one head (Fin <= D, H <= 4)
 
 
@@ -219,10 +235,11 @@ class _GATHiddenAggFirst(torch.autograd.Function):
     a batched GEMM over heads on the aggregated slab [H, N, Fin], and in partitioned mode the halo rows are [x | el]."""
 
     @staticmethod
-    def forward(ctx, h, W, Wr, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training):
+    def forward(ctx, h, W, Wr, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp):
         N, Fin, HD = h.shape[0], h.shape[1], H * D
         csc = graph.csc
-        out2 = torch.mm(h, Wr.t())                                      # [N, P2] = [res | el | er | pad]
+        ctx.kp = kp                                                     # Wr is [Fin, P2] (see WEIGHT_KP) instead of [P2, Fin]
+        out2 = torch.mm(h, Wr) if kp else torch.mm(h, Wr.t())           # [N, P2] = [res | el | er | pad]
         c = HD if has_res else 0
         ext = None
         if graph.halo is not None:
@@ -281,7 +298,8 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         else:
             h, W, Wr, z, table, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
             drop_p, seed, bn_training, sync, group, total = epi
-        N, Fin, HD, P2 = h.shape[0], h.shape[1], H * D, Wr.shape[0]
+        kp = ctx.kp
+        N, Fin, HD, P2 = h.shape[0], h.shape[1], H * D, Wr.shape[1 if kp else 0]
         dout2 = torch.empty((N, P2), dtype=h.dtype, device=h.device)
         dx = dout2[:, :HD] if has_res else torch.empty((N, HD), dtype=h.dtype, device=h.device)
         if epi is None:
@@ -329,10 +347,14 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         used = c + (2 * H if has_er else H)
         if used < P2:
             dout2[:, used:].zero_()
-        dWr = torch.mm(dout2.t(), h) if ctx.needs_input_grad[2] else None
-        dh = torch.addmm(dh_g, dout2, Wr) if ctx.needs_input_grad[0] else None
+        dWr = None
+        if ctx.needs_input_grad[2]:
+            dWr = torch.mm(h.t(), dout2) if kp else torch.mm(dout2.t(), h)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.addmm(dh_g, dout2, Wr.t() if kp else Wr)
         return (dh, dW, dWr, d_bn_w if ctx.needs_input_grad[3] else None, d_bn_b if ctx.needs_input_grad[4] else None,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
@@ -351,12 +373,12 @@ def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
     if use_agg_first(conv):
         global AGG_CALLS
         AGG_CALLS += 1
-        return _GATHiddenAggFirst.apply(h, conv.fc.weight, cat_weight_aggfirst(conv), bn_w, bn_b, graph, bn, H, D,
+        return _GATHiddenAggFirst.apply(h, conv.fc.weight, _kp(cat_weight_aggfirst(conv)), bn_w, bn_b, graph, bn, H, D,
                                         conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
-                                        attn_p, dropout_p if training and bn is not None else 0.0, bn_training)
+                                        attn_p, dropout_p if training and bn is not None else 0.0, bn_training, WEIGHT_KP)
     if bn is None:
-        return _GATHidden.apply(h, cat_weight(conv), None, None, graph, None, H, D, conv.res_fc is not None,
-                                conv.attn_r is not None, conv.leaky_relu.negative_slope, attn_p, 0.0, False)
-    return _GATHidden.apply(h, cat_weight(conv), bn.weight if bn.affine else None, bn.bias if bn.affine else None, graph, bn,
+        return _GATHidden.apply(h, _kp(cat_weight(conv)), None, None, graph, None, H, D, conv.res_fc is not None,
+                                conv.attn_r is not None, conv.leaky_relu.negative_slope, attn_p, 0.0, False, WEIGHT_KP)
+    return _GATHidden.apply(h, _kp(cat_weight(conv)), bn.weight if bn.affine else None, bn.bias if bn.affine else None, graph, bn,
                             H, D, conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
-                            conv.attn_drop.p if training else 0.0, dropout_p if training else 0.0, bn_training)
+                            conv.attn_drop.p if training else 0.0, dropout_p if training else 0.0, bn_training, WEIGHT_KP)

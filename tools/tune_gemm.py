@@ -26,29 +26,33 @@ for w in (2, 4, 8):
     rows += sorted({(N * (k + 1) + w - 1) // w - (N * k + w - 1) // w for k in range(w)}, reverse=True)
 layers = [(168, 1536), (750, 1536), (750, 128)]  # (Fin, padded merged width) of the three GAT layers
 dev = "cuda"
+from bot_amd.nn import fused  # noqa: E402
+KP = fused.WEIGHT_KP  # merged weights handed to the layer node as [K, P] (True) or [P, K]
 for n in rows:
     for K, P in layers:
         h = torch.randn(n, K, device=dev)
-        W = torch.randn(P, K, device=dev)
+        W = torch.randn(K, P, device=dev) if KP else torch.randn(P, K, device=dev)
         d = torch.randn(n, P, device=dev)
-        torch.mm(h, W.t())      # forward
-        torch.mm(d.t(), h)      # dW
-        torch.mm(d, W)          # dh
+        if KP:
+            torch.mm(h, W); torch.mm(h.t(), d); torch.mm(d, W.t())      # forward, dW, dh
+        else:
+            torch.mm(h, W.t()); torch.mm(d.t(), h); torch.mm(d, W)
         torch.cuda.synchronize()
         print("tuned", n, K, P, flush=True)
     # aggregate-before-project layer 0 (bot_amd/nn/fused.py _GATHiddenAggFirst): Fin = 168, H = 3, D = 250, P2 = 768
     Fin, H, D, P2 = 168, 3, 250, 768
     h = torch.randn(n, Fin, device=dev)
-    Wr = torch.randn(P2, Fin, device=dev)
+    Wr = torch.randn(Fin, P2, device=dev) if KP else torch.randn(P2, Fin, device=dev)
     W = torch.randn(H, D, Fin, device=dev)
     z = torch.randn(H, n, Fin, device=dev)
     dout2 = torch.randn(n, P2, device=dev)
     agg = torch.empty(H, n, D, device=dev)
     dz = torch.empty(H, n, Fin, device=dev)
     dW3 = torch.empty(H, D, Fin, device=dev)
-    torch.mm(h, Wr.t())
-    torch.mm(dout2.t(), h)
-    torch.mm(dout2, Wr)
+    if KP:
+        torch.mm(h, Wr); torch.mm(h.t(), dout2); torch.mm(dout2, Wr.t())
+    else:
+        torch.mm(h, Wr.t()); torch.mm(dout2.t(), h); torch.mm(dout2, Wr)
     for i in range(1):  # the three heads share one shape / leading dimensions
         torch.mm(z[i], W[i].t(), out=agg[i])
         dxi = dout2[:, i * D:(i + 1) * D]
