@@ -266,12 +266,16 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         a_d = a * amask if amask is not None else a
         z = _C.spmm_bcast(csc, xsrc, a_d, None, head_outer=True)        # [H, N, Fin]
         Wh = W.view(H, D, Fin)
-        agg = torch.empty((H, N, D), dtype=h.dtype, device=h.device)    # per-head projection (plain 2-D GEMMs: each has its
-        for i in range(H):                                              # own tuned kernel selection, see bot_amd/tuning)
-            torch.mm(z[i], Wh[i].t(), out=agg[i])
+        # per-head projection (plain 2-D GEMMs: each has its own tuned kernel selection, see bot_amd/tuning), accumulated in
+        # place onto the residual columns of the [N, P2] buffer (beta = 1): no [N, H, D] add pass, x is a row-strided view
         if has_res:
-            x = torch.add(out2[:, :HD].unflatten(1, (H, D)), agg.permute(1, 0, 2)).view(N, HD)
+            for i in range(H):
+                out2[:, i * D:(i + 1) * D].addmm_(z[i], Wh[i].t())
+            x = out2[:, :HD]
         else:
+            agg = torch.empty((H, N, D), dtype=h.dtype, device=h.device)
+            for i in range(H):
+                torch.mm(z[i], Wh[i].t(), out=agg[i])
             x = agg.permute(1, 0, 2).reshape(N, HD)
         ctx.graph = graph
         keep = (h, W, Wr, z, ext if ext is not None else h, el, er, a, amask, a_d)

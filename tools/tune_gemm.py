@@ -55,6 +55,8 @@ for n in rows:
         torch.mm(h, Wr.t()); torch.mm(dout2.t(), h); torch.mm(dout2, Wr)
     for i in range(1):  # the three heads share one shape / leading dimensions
         torch.mm(z[i], W[i].t(), out=agg[i])
+        res = torch.randn(n, P2, device=dev)
+        res[:, i * D:(i + 1) * D].addmm_(z[i], W[i].t())               # the in-place form on the residual columns (ldc = P2)
         dxi = dout2[:, i * D:(i + 1) * D]
         torch.mm(dxi, W[i], out=dz[i])
         torch.mm(dxi.t(), z[i], out=dW3[i])
