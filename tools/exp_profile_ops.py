@@ -19,8 +19,9 @@ torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step(); torch.cuda.synchronize()
-evs = [e for e in prof.events() if e.device_time_total > 40 and e.name.startswith("aten::") and not e.name.startswith("aten::mm") and not e.name.startswith("aten::addmm")]
-evs.sort(key=lambda e: -e.device_time_total)
-for e in evs[:25]:
-    st = [s for s in (e.stack or []) if "repo" in s][:3]
-    print(f"{e.device_time_total:8.1f}us {e.name:28s} {str(e.input_shapes)[:70]:70s} {' | '.join(s.split('/')[-1] for s in st)}")
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.self_device_time_total > 0]
+rows.sort(key=lambda e: -e.self_device_time_total)
+print("ops with device time: %d kinds, %d calls, %.1f us" % (len(rows), sum(e.count for e in rows), sum(e.self_device_time_total for e in rows)))
+for e in rows[:60]:
+    if e.key in ("aten::mm", "aten::addmm", "aten::addmm_"): continue
+    print(f"{e.self_device_time_total:8.1f}us x{e.count:<3d} {e.key:34s} {str(e.input_shapes)[:80]}")
