@@ -72,6 +72,7 @@ def grads2n(prefix, module):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=OUT)
+    ap.add_argument("--only", default="", help="\"products\": stop after the products fixtures")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
 
@@ -323,6 +324,39 @@ def main():
                 activation=F.relu, dropout=0.25, input_drop=0.1, attn_drop=0.0, edge_drop=0.1)
     out["count.proteins_gat"] = np.int64(sum(p.numel() for p in big.parameters()))
     np.savez_compressed(os.path.join(args.out, "proteins.npz"), **out)
+
+    # ------------------------------------------------------------------ products GAT stack (src/ogbn-products/models.py:170-265)
+    if args.only in ("", "products"):
+        PR = _import_ref("ogbn-products", "models", "ref_products_models")
+        out = {}
+        case = 0
+        for residual, edge_emb, training in ((False, 0, True), (True, 0, True), (True, 16, True), (False, 0, False)):
+            g = G("g64")
+            n, E = g.number_of_nodes(), g.number_of_edges()
+            torch.manual_seed(4200 + case)
+            edge_feats = 8 if edge_emb else 0
+            model = PR.GAT(node_feats=9, edge_feats=edge_feats, n_classes=6, n_layers=3, n_heads=2, n_hidden=5, edge_emb=edge_emb,
+                           activation=F.relu, dropout=0.0, input_drop=0.0, attn_drop=0.0, edge_drop=0.0, residual=residual)
+            model.train(training)
+            g.ndata["feat"] = torch.randn(n, 9, generator=gen)
+            if edge_emb:
+                g.edata["feat"] = torch.rand(E, 8, generator=gen)
+            k = f"s{case}."
+            out.update(sd2n(k + "p.", model.state_dict()))
+            gout = torch.randn(n, 6, generator=gen)
+            logits = model(g)
+            (logits * gout).sum().backward()
+            out.update(grads2n(k + "g.", model))
+            out[k + "nfeat"], out[k + "gout"], out[k + "logits"] = t2n(g.ndata["feat"]), t2n(gout), t2n(logits)
+            if edge_emb:
+                out[k + "efeat"] = t2n(g.edata["feat"])
+            out[k + "meta"] = np.array([str(int(residual)), str(edge_emb), str(int(training))])
+            out[k + "n_params"] = np.int64(sum(p.numel() for p in model.parameters()))
+            case += 1
+        out["n_cases"] = np.int64(case)
+        np.savez_compressed(os.path.join(args.out, "products.npz"), **out)
+        if args.only == "products":
+            return
 
     # ------------------------------------------------------------------ callers: run.py add_labels/compute_loss/train
     out = {}

@@ -317,6 +317,34 @@ def check_proteins_golden(golden, device):
                 grad_close(p.grad, c[f"g.{k}"], 3e-4)
 
 
+def check_products_golden(golden, device):
+    """bot_amd.nn.edge_gat.ProductsGAT against fixtures produced by executing src/ogbn-products/models.py."""
+    from bot_amd.nn import edge_gat
+    from tests._golden import Case
+    f = golden.file("products")
+    for ci in range(int(f["n_cases"])):
+        pre = f"s{ci}."
+        c = Case({k[len(pre):]: v for k, v in f.items() if k.startswith(pre)})
+        residual, edge_emb, training = (int(x) for x in c["meta"])
+        for fuse in ((True, False) if edge_emb else (True,)):
+            g = make_graph(golden, "g64", device)
+            model = edge_gat.ProductsGAT(node_feats=9, edge_feats=8 if edge_emb else 0, n_classes=6, n_layers=3, n_heads=2,
+                                         n_hidden=5, edge_emb=edge_emb, activation=F.relu, dropout=0.0, input_drop=0.0,
+                                         attn_drop=0.0, edge_drop=0.0, residual=bool(residual))
+            model = load_params(model, c, device).train(bool(training))
+            model.fuse_edge_mlp = fuse
+            assert sum(p.numel() for p in model.parameters()) == int(c["n_params"])
+            g.ndata["feat"] = c.t("nfeat").to(device)
+            if edge_emb:
+                g.edata["feat"] = c.t("efeat").to(device)
+            logits = model(g)
+            fwd_close(logits, c["logits"])
+            (logits * c.t("gout").to(device)).sum().backward()
+            for k, p in model.named_parameters():
+                if f"g.{k}" in c and p.grad is not None:
+                    grad_close(p.grad, c[f"g.{k}"], 3e-4)
+
+
 def check_copy_e_sum_preprocess(golden, device):
     """ogbn-proteins/gat.py:58 — node features = sum of incident edge features."""
     s, d, n = golden.graph("g300")

@@ -176,6 +176,10 @@ def test_proteins_golden(golden):
     PC.check_proteins_golden(golden, DEV)
 
 
+def test_products_golden(golden):
+    PC.check_products_golden(golden, DEV)
+
+
 def test_copy_e_sum_preprocess(golden):
     PC.check_copy_e_sum_preprocess(golden, DEV)
 

@@ -92,6 +92,10 @@ def test_proteins_golden(golden, cpu_backend):
     PC.check_proteins_golden(golden, "cpu")
 
 
+def test_products_golden(golden, cpu_backend):
+    PC.check_products_golden(golden, "cpu")
+
+
 def test_copy_e_sum_preprocess(golden, cpu_backend):
     PC.check_copy_e_sum_preprocess(golden, "cpu")
 

@@ -189,6 +189,27 @@ def test_proteins_layer_and_stack_match_reference(golden):
                 close(gr, c[f"g.{k}"], "float32", 50)
 
 
+def test_products_stack_matches_reference(golden):
+    """`GAT` of src/ogbn-products/models.py:170-265 (no node encoder, residual flag, optional edge encoder), fixtures produced
+    by executing that file."""
+    f = golden.file("products")
+    g = coo(golden, "g64")
+    from tests._golden import Case
+    for ci in range(int(f["n_cases"])):
+        pre = f"s{ci}."
+        c = Case({k[len(pre):]: v for k, v in f.items() if k.startswith(pre)})
+        residual, edge_emb, training = (int(x) for x in c["meta"])
+        p = c.params()
+        logits = RM.proteins_gat_forward(g, c.t("nfeat"), c.t("efeat") if edge_emb else None, p, n_layers=3, n_heads=2,
+                                         n_hidden=5, training=bool(training), use_node_encoder=False, residual=bool(residual))
+        close(logits, c["logits"], "float32", 8)
+        names = [k for k in p if f"g.{k}" in c]
+        grads = _backward(logits, c.t("gout"), [p[k] for k in names])
+        for k, gr in zip(names, grads):
+            if gr is not None:
+                close(gr, c[f"g.{k}"], "float32", 50)
+
+
 # ------------------------------------------------------------------ callers (run.py)
 def test_losses_and_add_labels_match_reference(golden):
     f = golden.file("train")
