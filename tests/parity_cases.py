@@ -321,6 +321,10 @@ def check_products_golden(golden, device):
     """bot_amd.nn.edge_gat.ProductsGAT against fixtures produced by executing src/ogbn-products/models.py."""
     from bot_amd.nn import edge_gat
     from tests._golden import Case
+    # the count the authors recorded for the full-size model (ogbn-products/gat.py:441)
+    full = edge_gat.ProductsGAT(node_feats=100, edge_feats=0, n_classes=47, n_layers=3, n_heads=4, n_hidden=120, edge_emb=0,
+                                activation=F.relu, dropout=0.5, input_drop=0.1, attn_drop=0.0, edge_drop=0.1)
+    assert sum(p.numel() for p in full.parameters()) == 1065127
     f = golden.file("products")
     for ci in range(int(f["n_cases"])):
         pre = f"s{ci}."
