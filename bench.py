@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--gemm-tuning", default="file", choices=["file", "off", "tune"],
                     help="file: hipBLASLt/rocBLAS kernel selections from bot_amd/tuning (TunableOp, read-only); "
                          "tune: also time shapes missing from the file and write them to gpurun_out/ (maintenance)")
+    ap.add_argument("--norm-adj", default="rw", choices=["rw", "symm"],
+                    help="rw: BASELINE config 2 (run.py:1011-1013); symm: the --norm-adj=symm variant of the same command "
+                         "(run.py:1023-1025), reported in config")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the 1-D partitioned code path even with one rank (exercises the RCCL plumbing on a 1-GPU box)")
     return ap.parse_args()
@@ -119,7 +122,8 @@ def main():
     E = ds.graph.number_of_edges()
     src_cpu, dst_cpu = ds.graph.edges()
     torch.manual_seed(0)
-    model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **CFG).to(dev)
+    cfg = dict(CFG, use_symmetric_norm=args.norm_adj == "symm")
+    model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **cfg).to(dev)
     opt = torch.optim.RMSprop(model.parameters(), lr=0.002)
 
     if not partitioned:
@@ -191,7 +195,8 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"S-{args.workload}: power-law graph N={n} E={E} (raw {ds.raw_edges}), F={ds.feat.shape[1]}, "
-                                   f"C={C}; GAT 3 layers x 3 heads x 250, --labels --loss=loge --linear --norm=batch, "
+                                   f"C={C}; GAT 3 layers x 3 heads x 250, --labels --loss=loge --linear --norm=batch"
+                                   f"{' --norm-adj=symm' if args.norm_adj == 'symm' else ''}, "
                                    f"dropout 0.75/0.25/0.1, RMSprop step included",
                        "gemm_kernel_selection": "TunableOp file" if tuned else "library default",
                        "scale": args.scale, "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world}"},

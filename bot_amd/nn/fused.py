@@ -32,9 +32,26 @@ AGG_CALLS = 0  # ... of which aggregate-before-project
 def can_fuse(conv, norm, activation, graph, training, stack_residual) -> bool:
     """`norm` None = the layer has no BatchNorm/ReLU/dropout epilogue (the stack's output layer)."""
     epilogue_ok = norm is None or (isinstance(norm, nn.BatchNorm1d) and activation in (F.relu, torch.relu) and not stack_residual)
-    return (epilogue_ok and hasattr(conv, "fc") and not conv._use_symmetric_norm and conv._activation is None
+    return (epilogue_ok and hasattr(conv, "fc") and not (conv._use_symmetric_norm and graph.halo is not None)
+            and conv._activation is None
             and not (training and (conv.edge_drop > 0 or conv.feat_drop.p > 0))
             and (graph.halo is not None or not graph.is_block) and conv._out_feats <= 256)
+
+
+def sym_scales(graph):
+    """Symmetric normalisation of the attention (models.py:500-505, :550-555: `feat_src *= out_deg^-1/2` before the logits,
+    `rst *= in_deg^+1/2` after the aggregation) folded into the EDGE WEIGHTS, so the layer node needs no pass over [N,H,D]:
+        rst[v] = s_in[v] * sum_e a_e * (s_out[u] ft[u])  =  sum_e (a_e * s_out[u_e] * s_in[v_e]) ft[u]
+    Returns (s_out [N] for the logits `el`, w_e [E] = s_out[src] * s_in[dst] in CSC position order); static per graph."""
+    from . import _graph_cache, degree_norm
+    c = _graph_cache(graph)
+    if "sym_scales" not in c:
+        csc = graph.csc
+        s_out, s_in = degree_norm(graph, "out", -0.5), degree_norm(graph, "in", 0.5)
+        deg = (csc.indptr[1:] - csc.indptr[:-1]).long()
+        dst = torch.repeat_interleave(torch.arange(csc.n_rows, device=deg.device), deg)
+        c["sym_scales"] = (s_out, (s_out[csc.indices.long()] * s_in[dst]).unsqueeze(1).contiguous())
+    return c["sym_scales"]
 
 
 def cat_weight(conv):
@@ -96,9 +113,10 @@ def _extend_backward(graph, dext, n_own):
 
 class _GATHidden(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, Wcat, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp):
+    def forward(ctx, h, Wcat, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp, sym):
         N, HD = h.shape[0], H * D
         csc = graph.csc
+        ctx.sym = sym                                                   # symmetric normalisation folded into the edge weights
         ctx.kp = kp                                                     # Wcat is [K, P] (see WEIGHT_KP) instead of [P, K]
         out = torch.mm(h, Wcat) if kp else torch.mm(h, Wcat.t())        # [N, P] = [ft | res | el | er | pad]
         c = 2 * HD if has_res else HD
@@ -111,11 +129,16 @@ class _GATHidden(torch.autograd.Function):
             ft = out[:, :HD].unflatten(1, (H, D))
             el = out[:, c:c + H].contiguous()
         er = out[:, c + H:c + 2 * H].contiguous() if has_er else None
+        if sym:
+            s_out, w_e = sym_scales(graph)
+            el = el * s_out.unsqueeze(1)                                # logits see the scaled projection (models.py:505, :517)
         a = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None)
         amask = None
         if attn_p > 0:                                                  # nn.Dropout on the attention weights (models.py:544)
             amask = (torch.rand_like(a) >= attn_p).to(a.dtype).mul_(1.0 / (1.0 - attn_p))
         a_d = a * amask if amask is not None else a
+        if sym:
+            a_d = a_d * w_e                                             # the SpMM weights; d a below is scaled back by w_e
         res = out[:, HD:2 * HD].unflatten(1, (H, D)) if has_res else None
         x = _C.spmm(csc, ft, a_d, None, addend=res).view(N, HD)         # aggregation + residual (models.py:547-560)
         ctx.graph = graph
@@ -167,10 +190,15 @@ class _GATHidden(torch.autograd.Function):
         else:
             dft_dst = dout[:, :HD].unflatten(1, (H, D))
         _, da = _C.spmm_dot(g.csr, dx.unflatten(1, (H, D)), a_d, g.csr2csc, ft, out=dft_dst)
+        if ctx.sym:
+            s_out, w_e = sym_scales(g)
+            da = da * w_e
         if amask is not None:
             da = da * amask
         dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er)
         d_el = _C.segment_sum(g.csr, dz, g.csr2csc)
+        if ctx.sym:
+            d_el = d_el * s_out.unsqueeze(1)
         if halo:
             dext[:, HD:HD + H] = d_el
             if dext.shape[1] > HD + H:
@@ -192,7 +220,7 @@ class _GATHidden(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dh = torch.mm(dout, Wcat.t()) if kp else torch.mm(dout, Wcat)
         return (dh, dW, d_bn_w if ctx.needs_input_grad[2] else None, d_bn_b if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def cat_weight_aggfirst(conv):
@@ -235,9 +263,10 @@ class _GATHiddenAggFirst(torch.autograd.Function):
     a batched GEMM over heads on the aggregated slab [H, N, Fin], and in partitioned mode the halo rows are [x | el]."""
 
     @staticmethod
-    def forward(ctx, h, W, Wr, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp):
+    def forward(ctx, h, W, Wr, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp, sym):
         N, Fin, HD = h.shape[0], h.shape[1], H * D
         csc = graph.csc
+        ctx.sym = sym
         ctx.kp = kp                                                     # Wr is [Fin, P2] (see WEIGHT_KP) instead of [P2, Fin]
         out2 = torch.mm(h, Wr) if kp else torch.mm(h, Wr.t())           # [N, P2] = [res | el | er | pad]
         c = HD if has_res else 0
@@ -259,11 +288,16 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             xsrc = h
             el = out2[:, c:c + H].contiguous()
         er = out2[:, c + H:c + 2 * H].contiguous() if has_er else None
+        if sym:
+            s_out, w_e = sym_scales(graph)
+            el = el * s_out.unsqueeze(1)
         a = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None)
         amask = None
         if attn_p > 0:
             amask = (torch.rand_like(a) >= attn_p).to(a.dtype).mul_(1.0 / (1.0 - attn_p))
         a_d = a * amask if amask is not None else a
+        if sym:
+            a_d = a_d * w_e
         z = _C.spmm_bcast(csc, xsrc, a_d, None, head_outer=True)        # [H, N, Fin]
         Wh = W.view(H, D, Fin)
         # per-head projection (plain 2-D GEMMs: each has its own tuned kernel selection, see bot_amd/tuning), accumulated in
@@ -333,10 +367,15 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             _, da = _C.spmm_dot_bcast(g.csr, dz, a_d, g.csr2csc, table[:, :Fin], out=dext[:, :Fin])
         else:
             dh_g, da = _C.spmm_dot_bcast(g.csr, dz, a_d, g.csr2csc, h)
+        if ctx.sym:
+            s_out, w_e = sym_scales(g)
+            da = da * w_e
         if amask is not None:
             da = da * amask
         dz_e, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er)
         d_el = _C.segment_sum(g.csr, dz_e, g.csr2csc)
+        if ctx.sym:
+            d_el = d_el * s_out.unsqueeze(1)
         if halo:
             dext[:, Fin:Fin + H] = d_el
             if dext.shape[1] > Fin + H:
@@ -358,7 +397,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dh = torch.addmm(dh_g, dout2, Wr.t() if kp else Wr)
         return (dh, dW, dWr, d_bn_w if ctx.needs_input_grad[3] else None, d_bn_b if ctx.needs_input_grad[4] else None,
-                None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
@@ -379,10 +418,13 @@ def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
         AGG_CALLS += 1
         return _GATHiddenAggFirst.apply(h, conv.fc.weight, _kp(cat_weight_aggfirst(conv)), bn_w, bn_b, graph, bn, H, D,
                                         conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
-                                        attn_p, dropout_p if training and bn is not None else 0.0, bn_training, WEIGHT_KP)
+                                        attn_p, dropout_p if training and bn is not None else 0.0, bn_training, WEIGHT_KP,
+                                        conv._use_symmetric_norm)
     if bn is None:
         return _GATHidden.apply(h, _kp(cat_weight(conv)), None, None, graph, None, H, D, conv.res_fc is not None,
-                                conv.attn_r is not None, conv.leaky_relu.negative_slope, attn_p, 0.0, False, WEIGHT_KP)
+                                conv.attn_r is not None, conv.leaky_relu.negative_slope, attn_p, 0.0, False, WEIGHT_KP,
+                                conv._use_symmetric_norm)
     return _GATHidden.apply(h, _kp(cat_weight(conv)), bn.weight if bn.affine else None, bn.bias if bn.affine else None, graph, bn,
                             H, D, conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
-                            conv.attn_drop.p if training else 0.0, dropout_p if training else 0.0, bn_training, WEIGHT_KP)
+                            conv.attn_drop.p if training else 0.0, dropout_p if training else 0.0, bn_training, WEIGHT_KP,
+                            conv._use_symmetric_norm)

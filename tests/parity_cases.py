@@ -264,7 +264,10 @@ def check_stacks_golden(golden, device, fuse=True):
         assert sum(p.numel() for p in model.parameters()) == int(c["n_params"])
         model.train(bool(int(training)))
         feat = leaf(c.t("feat"), device)
+        before = fused.CALLS
         logits = model(g, feat)
+        if fuse and kind == "gat" and cfg.get("use_symmetric_norm") and cfg["norm"] == "batch":
+            assert fused.CALLS - before == cfg["n_layers"]  # symmetric normalisation folded into the edge weights: fused too
         fwd_close(logits, c["logits"])
         (logits * c.t("gout").to(device)).sum().backward()
         grad_close(feat.grad, c["dfeat"], 3e-4)
