@@ -1,3 +1,5 @@
+"""Experiment: per-op device time of one config-2 train step (torch.profiler, grouped by op and input shape): what is left
+outside the GEMMs and the HIP kernels."""
 import os, sys, torch, torch.nn.functional as F
 sys.path.insert(0, "/root/repo")
 import bench

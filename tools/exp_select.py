@@ -1,3 +1,4 @@
+"""Experiment: primitives for the edge-drop draw at E = 77.7 M (randperm, sort, histograms, kthvalue) vs bot_random_keep_u8."""
 import torch, time
 E = 77753180
 dev = "cuda"

@@ -1,3 +1,5 @@
+# Regenerates what profiles/ holds for a round: bench line, rocprofv3 kernel stats of the same command, the --pmc passes over
+# tools/microbench.py (FETCH_SIZE / WRITE_SIZE / TCC hits in separate passes), microbench and config 3-5 checks -> gpurun_out/final/.
 set -x
 cd /root/repo
 mkdir -p gpurun_out/final
