@@ -136,6 +136,8 @@ class Partition:
     hi: int
     halo_global: torch.Tensor     # int64 [n_halo] global ids of the halo sources
     n_edges: int
+    edge_ids: torch.Tensor = None    # int64 [n_edges] global ids of the local edges, ascending = local edge-id order
+                                     # (edge features of the block: efeat[edge_ids]; configs 4/5, src/ogbn-proteins/models.py:244)
     feat: torch.Tensor = None
     labels: torch.Tensor = None
     train_idx: torch.Tensor = None   # LOCAL ids of owned training nodes (same for val/test)
@@ -179,7 +181,7 @@ def build_partition(src, dst, num_nodes: int, rank: int, world: int, device="cpu
     g.halo = HaloPlan(send_rows.contiguous(), send_splits, recv_splits, group)
     g = g.to(device)
     g.create_formats_()
-    return Partition(g, rank, world, lo, hi, halo_global, int(ls.numel()))
+    return Partition(g, rank, world, lo, hi, halo_global, int(ls.numel()), edge_ids=torch.nonzero(m).squeeze(1))
 
 
 def partition_dataset(ds, rank: int, world: int, device, group=None) -> Partition:

@@ -116,3 +116,69 @@ def _worker(rank, world, port, kind, tmp, fuse=False):
 def test_partitioned_step_matches_single_process(kind, world, fuse, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), fuse), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _worker_edge(rank, world, port, kind, tmp):
+    """The edge-feature GAT stacks of BASELINE configs 4 / 5 (ogbn-proteins / ogbn-products models) on a 1-D partition:
+    logits of the owned rows and the all-reduced parameter gradients equal the single-process ones."""
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from tests import _oracle_backend
+        _oracle_backend.install_direct()
+        import bot_amd
+        from bot_amd import dist as bdist
+        from bot_amd.nn import edge_gat
+        s, d, n = Golden().graph("g300")
+        E = s.numel()
+        gen = torch.Generator().manual_seed(11)
+        nf = torch.randn(n, 9, generator=gen)
+        ef = torch.rand(E, 8, generator=gen)
+        gout = torch.randn(n, 6, generator=gen)
+
+        def make():
+            torch.manual_seed(5)
+            if kind == "proteins":
+                return edge_gat.ProteinsGAT(node_feats=9, edge_feats=8, n_classes=6, n_layers=3, n_heads=2, n_hidden=5, edge_emb=16,
+                                            activation=F.relu, dropout=0.0, input_drop=0.0, attn_drop=0.0, edge_drop=0.0)
+            return edge_gat.ProductsGAT(node_feats=9, edge_feats=0, n_classes=6, n_layers=3, n_heads=2, n_hidden=5, edge_emb=0,
+                                        activation=F.relu, dropout=0.0, input_drop=0.0, attn_drop=0.0, edge_drop=0.0, residual=True)
+
+        ref = make().train()
+        g = bot_amd.Graph(s, d, n)
+        g.ndata["feat"] = nf
+        if kind == "proteins":
+            g.edata["feat"] = ef
+        logits_ref = ref(g)
+        (logits_ref * gout).sum().backward()
+
+        model = bdist.wrap_model(make().train())
+        part = bdist.build_partition(s, d, n, rank, world)
+        assert torch.equal(s[part.edge_ids] >= 0, torch.ones(part.n_edges, dtype=torch.bool)) and part.edge_ids.numel() == part.n_edges
+        pg = part.graph
+        pg.ndata["feat"] = nf[part.lo:part.hi]
+        if kind == "proteins":
+            pg.edata["feat"] = ef[part.edge_ids]
+        logits = model(pg)
+        (logits * gout[part.lo:part.hi]).sum().backward()
+        bdist.all_reduce_grads(model)
+        np.testing.assert_allclose(logits.detach().numpy(), logits_ref.detach()[part.lo:part.hi].numpy(), rtol=1e-4, atol=1e-5)
+        for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            if q.grad is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                continue
+            np.testing.assert_allclose(p.grad.numpy(), q.grad.numpy(), rtol=2e-4, atol=2e-5 * max(1.0, q.grad.abs().max().item()), err_msg=k)
+        for (k, b), (_, c) in zip(model.named_buffers(), ref.named_buffers()):
+            np.testing.assert_allclose(b.numpy(), c.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,world", [("proteins", 2), ("products", 2), ("proteins", 3)])
+def test_partitioned_edge_gat_matches_single_process(kind, world, tmp_path):
+    mp.spawn(_worker_edge, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
