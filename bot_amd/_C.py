@@ -36,7 +36,7 @@ _SIGS = {
     "bot_spmm_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                     c_int32, c_int32, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P]),
     "bot_spmm_blocked_f32": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P,
-                                            c_int32, c_int32, _P, c_int64, _P]),
+                                            c_int32, c_int32, _P, c_int64, _P, c_int64, _P]),
     "bot_spmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                         _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P]),
     "bot_spmm_bcast_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, _P, _P, c_int32,
@@ -172,31 +172,38 @@ def _slab(x, name):
     return x, x.stride(0), x.stride(1)
 
 
-def spmm_blocked(bp, x, w, out):
-    """L2-blocked SpMM over the tiles of `bp` (bot_amd.blocked.BlockedPlan); writes only the rows bp covers."""
+def spmm_blocked(bp, x, w, out, addend=None):
+    """L2-blocked SpMM over the tiles of `bp` (bot_amd.blocked.BlockedPlan); writes only the rows bp covers.  x / out /
+    addend: [n,H,D] with contiguous rows (any row stride)."""
     H, D = x.shape[1], x.shape[2]
     _check(_timed("spmm_blocked", (H, D, w is not None), lambda: _lib.bot_spmm_blocked_f32(
         bp.tile_rows.data_ptr(), bp.ptr.data_ptr(), bp.b_src.data_ptr(), bp.b_lrow.data_ptr(), bp.b_pos.data_ptr(), bp.n_tiles,
         bp.nblk, bp.block_rows, bp.T, bp.epi, bp.round_tiles, x.data_ptr(), x.stride(0), _ptr(w), H, D, out.data_ptr(), out.stride(0),
-        _stream())),
+        _ptr(addend), addend.stride(0) if addend is not None else 0, _stream())),
         "spmm_blocked")
     return out
+
+
+def _rows_contiguous(t):
+    """[n,H,D] whose rows are H*D contiguous floats (row stride free)."""
+    return t.stride(2) == 1 and (t.shape[1] == 1 or t.stride(1) == t.shape[2])
 
 
 def spmm(d, x, w=None, wperm=None, out=None, addend=None):
     """out[r,h,:] = sum_k w[wperm[k],h] * x[indices[k],h,:] (+ addend[r,h,:])   (w None: plain sum).  x: [n_src,H,D]."""
     _dev(x, w, d.indptr)
     x, ldx, hsx = _slab(x, "x")
-    if wperm is None and addend is None and out is None and x.is_contiguous():
+    if wperm is None and out is None and _rows_contiguous(x) and (
+            addend is None or (addend.dim() == 3 and addend.dtype == torch.float32 and _rows_contiguous(addend))):
         from . import blocked
         bp = blocked.plan_for(d, x.shape[0], x.shape[1], x.shape[2])
         if bp is not None:  # dense graph: L2-blocked sweep for the regular rows, row-per-group kernel for the hubs
             if w is not None:
                 w = _f32(w, "w").contiguous()
             out = torch.empty((d.n_rows, x.shape[1], x.shape[2]), dtype=torch.float32, device=x.device)
-            spmm_blocked(bp, x, w, out)
+            spmm_blocked(bp, x, w, out, addend)
             if bp.heavy is not None:
-                spmm(bp.heavy, x, w, None, out=out)
+                spmm(bp.heavy, x, w, None, out=out, addend=addend)
             return out
     lda = hsa = 0
     if addend is not None:

@@ -41,6 +41,8 @@ struct BlockedArgs {
     float* out;
     int64_t ldo;
     bool wstage;               // weighted, H <= 8 and 32 KB of LDS to spare: a batch's weights are staged in LDS
+    const float* addend;       // optional epilogue: out[r,:] += addend[r,:] (the layer's residual branch), row stride lda
+    int64_t lda;
 };
 
 constexpr int kBWaves = 16;             // wavefronts per workgroup (1024 threads): one workgroup per CU
@@ -212,6 +214,12 @@ __global__ __launch_bounds__(kBThreads) void spmm_blocked_kernel(BlockedArgs a) 
             if (act[c]) {
                 float o[VEC];
                 vload<VEC>(o, acc_lds + r * Fp + (c * G + li) * VEC);
+                if (a.addend) {
+                    float ad[VEC];
+                    vload<VEC>(ad, a.addend + (int64_t)row * a.lda + off[c]);
+#pragma unroll
+                    for (int t = 0; t < VEC; ++t) o[t] += ad[t];
+                }
                 vstore<VEC>(a.out + (int64_t)row * a.ldo + off[c], o);
             }
     }
@@ -245,7 +253,7 @@ extern "C" {
 int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int32_t* b_src, const uint8_t* b_lrow,
                          const int32_t* b_pos, int32_t n_tiles, int32_t nblk, int32_t block_rows, int32_t T, int32_t epi,
                          int32_t round_tiles, const float* x, int64_t ldx, const float* w, int32_t H, int32_t D, float* out,
-                         int64_t ldo, bot_stream_t stream) {
+                         int64_t ldo, const float* addend, int64_t lda, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n_tiles >= 0 && nblk >= 1 && round_tiles >= 1, BOT_E_RANGE, "spmm_blocked: n_tiles=%d nblk=%d round=%d", n_tiles, nblk, round_tiles);
     BOT_REQUIRE(T == 256 || T == 128 || T == 64 || T == 32, BOT_E_RANGE, "spmm_blocked: tile height %d (32, 64, 128 or 256)", T);
@@ -257,15 +265,15 @@ int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int
     if (n_tiles == 0) return 0;
     BOT_REQUIRE(tile_rows && ptr && b_src && b_lrow && x && out && (w == nullptr || b_pos), BOT_E_NULL, "spmm_blocked: NULL pointer");
     const int F = H * D;
-    BOT_REQUIRE(ldx >= F && ldo >= F, BOT_E_RANGE, "spmm_blocked: row stride smaller than H*D");
-    const int vec = pick_vec(D, {ldx, ldo}, {x, out});
+    BOT_REQUIRE(ldx >= F && ldo >= F && (addend == nullptr || lda >= F), BOT_E_RANGE, "spmm_blocked: row stride smaller than H*D");
+    const int vec = addend ? pick_vec(D, {ldx, ldo, lda}, {x, out, addend}) : pick_vec(D, {ldx, ldo}, {x, out});
     const int L = (F + vec - 1) / vec;
     const int G = 64 / epi;
     const int nchunk = (L + G - 1) / G;
     BOT_REQUIRE(epi == 1 || nchunk == 1, BOT_E_RANGE, "spmm_blocked: rows of %d x %d-float vectors do not fit the %d-lane groups of epi=%d (plan built for another row layout?)", L, vec, G, epi);
     BOT_REQUIRE(epi > 1 || T <= 128, BOT_E_RANGE, "spmm_blocked: T=256 only with lane groups (epi > 1)");
     BOT_REQUIRE(nchunk <= 4 && (size_t)T * nchunk * G * vec * 4 <= 160 * 1024, BOT_E_RANGE, "spmm_blocked: tile does not fit LDS");
-    BlockedArgs a{tile_rows, ptr, b_src, b_lrow, b_pos, 0, n_tiles, nblk, x, ldx, w, H, D, F, shift, out, ldo};
+    BlockedArgs a{tile_rows, ptr, b_src, b_lrow, b_pos, 0, n_tiles, nblk, x, ldx, w, H, D, F, shift, out, ldo, false, addend, lda};
     hipStream_t st = (hipStream_t)stream;
 #define BOT_BLK(V, NC)                                                        \
     do {                                                                      \

@@ -55,6 +55,8 @@ class GATConv(nn.Module):
     def set_allow_zero_in_degree(self, set_value):
         self._allow_zero_in_degree = set_value
 
+    merge_projections = True   # one GEMM for the four Linears on the layer input (full-graph / partitioned blocks alike)
+
     def forward(self, graph, feat_src, feat_edge=None, keep=None, edge_encoder=None):
         """`edge_encoder` (the stack's nn.Linear(8 -> 16)) given: `feat_edge` holds the RAW edge features and the
         encoder + ReLU + attn_edge_fc run fused per edge (bot_amd.ops.edge_mlp); otherwise `feat_edge` is the embedding."""
@@ -62,11 +64,34 @@ class GATConv(nn.Module):
             assert not has_zero_in_degree(graph), "0-in-degree nodes (ogbn-proteins/models.py:89-91)"
         H, D = self._n_heads, self._out_feats
         feat_dst = feat_src
-        if self._use_symmetric_norm:
-            feat_src = feat_src * _bcast(degree_norm(graph, "out", -0.5), feat_src)
-        ft = graph.extend(self.src_fc(feat_src).view(-1, H, D))
-        attn_src = graph.extend(self.attn_src_fc(feat_src).view(-1, H, 1))
-        attn_dst = self.attn_dst_fc(feat_dst).view(-1, H, 1) if self.attn_dst_fc is not None else None
+        res = None
+        if self._use_symmetric_norm or not self.merge_projections:
+            if self._use_symmetric_norm:
+                feat_src = feat_src * _bcast(degree_norm(graph, "out", -0.5), feat_src)
+            ft = self.src_fc(feat_src).view(-1, H, D)
+            attn_src = self.attn_src_fc(feat_src).view(-1, H, 1)
+            attn_dst = self.attn_dst_fc(feat_dst).view(-1, H, 1) if self.attn_dst_fc is not None else None
+        else:
+            # src_fc, dst_fc, attn_src_fc and attn_dst_fc all read the same input (ogbn-proteins/models.py:107-124): ONE GEMM on
+            # the concatenated weights.  Its backward is one dh GEMM, where four separate Linears leave autograd three
+            # [N, H*D]-sized gradient additions per layer (8.4 ms per layer at S-products); the residual goes into the SpMM epilogue.
+            parts, biases = [self.src_fc.weight], [None]
+            if self.dst_fc is not None:
+                parts.append(self.dst_fc.weight), biases.append(self.dst_fc.bias)
+            parts.append(self.attn_src_fc.weight), biases.append(None)
+            if self.attn_dst_fc is not None:
+                parts.append(self.attn_dst_fc.weight), biases.append(None)
+            bias = None
+            if any(b is not None for b in biases):
+                bias = torch.cat([b if b is not None else w.new_zeros(w.shape[0]) for w, b in zip(parts, biases)])
+            pieces = list(torch.split(F.linear(feat_src, torch.cat(parts), bias), [w.shape[0] for w in parts], dim=1))
+            ft = pieces.pop(0).unflatten(1, (H, D))
+            if self.dst_fc is not None:
+                res = pieces.pop(0).unflatten(1, (H, D))
+            attn_src = pieces.pop(0).unsqueeze(-1)
+            attn_dst = pieces.pop(0).unsqueeze(-1) if self.attn_dst_fc is not None else None
+        ft = graph.extend(ft)
+        attn_src = graph.extend(attn_src)
         ee, ee_order = None, "eid"
         if feat_edge is not None and edge_encoder is not None:
             ee = ops.edge_mlp(graph, feat_edge, edge_encoder.weight, edge_encoder.bias, self.attn_edge_fc.weight).view(-1, H, 1)
@@ -77,10 +102,12 @@ class GATConv(nn.Module):
             keep = ops.random_edge_keep(graph, self.edge_drop)
         a = ops.gat_attention(graph, attn_src, attn_dst, ee, keep=keep, negative_slope=self.leaky_relu.negative_slope,
                               order="csc", ee_order=ee_order)
-        rst = ops.u_mul_e_sum(graph, ft, self.attn_drop(a), order="csc")
+        rst = ops.u_mul_e_sum(graph, ft, self.attn_drop(a), order="csc", addend=res)
         if self._use_symmetric_norm:
             rst = rst * _bcast(degree_norm(graph, "in", 0.5), rst)
-        if self.dst_fc is not None:
+        if res is not None:
+            pass                                             # dst_fc(feat_dst) was added in the SpMM epilogue
+        elif self.dst_fc is not None:
             rst = rst + self.dst_fc(feat_dst).view(-1, H, D)
         else:
             rst = rst + self.bias.view(1, H, D)
@@ -132,7 +159,7 @@ class _EdgeGAT(nn.Module):
                 h = h + h_last[: h.shape[0], :]
             h_last = h
             h = _epilogue(h, self.norms[i], self.activation, self.dropout, self.training)  # BatchNorm + ReLU + dropout, fused
-        return self.pred_linear(h)
+        return ops.linear(h, self.pred_linear.weight, self.pred_linear.bias)
 
 
 class ProteinsGAT(_EdgeGAT):

@@ -84,12 +84,13 @@ def copy_u_sum(g, x):
 
 class _UMulESum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, g, x, a, order):
+    def forward(ctx, g, x, a, order, addend=None):
         x3, a2 = _as3(x), _edge2(a)
         ctx.g, ctx.order, ctx.xshape, ctx.ashape = g, order, x.shape, a.shape
         ctx.save_for_backward(x3, a2)
         wperm = g.csc.eid if order == "eid" else None
-        return _C.spmm(g.csc, x3, a2, wperm).view((g.number_of_dst_nodes(),) + tuple(x.shape[1:]))
+        ad3 = None if addend is None else _as3(addend)
+        return _C.spmm(g.csc, x3, a2, wperm, addend=ad3).view((g.number_of_dst_nodes(),) + tuple(x.shape[1:]))
 
     @staticmethod
     def backward(ctx, dout):
@@ -101,20 +102,22 @@ class _UMulESum(torch.autograd.Function):
             # one sweep over the out-edges yields both gradients: each gathered dout row is used twice
             wperm = g.csr.eid if ctx.order == "eid" else g.csr2csc
             dx, da = _C.spmm_dot(g.csr, d3, a2, wperm, x3)
-            return None, dx.view(ctx.xshape), da.view(ctx.ashape), None
+            return None, dx.view(ctx.xshape), da.view(ctx.ashape), None, (dout if ctx.needs_input_grad[4] else None)
         if ctx.needs_input_grad[1]:
             wperm = g.csr.eid if ctx.order == "eid" else g.csr2csc
             dx = _C.spmm(g.csr, d3, a2, wperm).view(ctx.xshape)
         if ctx.needs_input_grad[2]:
             operm = g.csc.eid if ctx.order == "eid" else None
             da = _C.sddmm_dot(g.csc, x3, d3, operm).view(ctx.ashape)
-        return None, dx, da, None
+        return None, dx, da, None, (dout if ctx.needs_input_grad[4] else None)
 
 
-def u_mul_e_sum(g, x, a, order="eid"):
+def u_mul_e_sum(g, x, a, order="eid", addend=None):
     """`update_all(fn.u_mul_e('ft','a','m'), fn.sum('m','ft'))` — models.py:547.
-    x: [N,H,D]; a: [E,H,1] (or [E,H]) in edge-id order, or in CSC position order with order="csc"."""
-    return _UMulESum.apply(g, x, a, order)
+    x: [N,H,D]; a: [E,H,1] (or [E,H]) in edge-id order, or in CSC position order with order="csc".
+    `addend` [N_dst,H,D]: added to the result in the kernel's epilogue (`rst + dst_fc(feat_dst)`, ogbn-proteins/models.py:159-160;
+    `rst + res_fc(h)`, models.py:558-560) instead of a separate pass; its gradient is the incoming one."""
+    return _UMulESum.apply(g, x, a, order, addend)
 
 
 class _CopyESum(torch.autograd.Function):
@@ -348,6 +351,27 @@ class _BNActDrop(torch.autograd.Function):
             else:
                 dx = _C.bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, None, None, total)
         return dx, dw, db, None, None, None, None
+
+
+class _AddBias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b):
+        return x + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        db = None
+        if ctx.needs_input_grad[1]:
+            mean, _ = _C.colstats(dy)          # column means by the tree-reduction kernel of the BatchNorm statistics
+            db = mean * dy.shape[0]
+        return dy, db
+
+
+def linear(x, weight, bias=None):
+    """`F.linear` whose bias gradient (a column sum over all N rows) runs on the colstats kernel: the stock reduction takes
+    19 ms for [2 449 029, 47] (S-products classifier, ogbn-products/models.py:262) — longer than the classifier GEMMs."""
+    y = torch.mm(x, weight.t())
+    return y if bias is None else _AddBias.apply(y, bias)
 
 
 def bn_relu_dropout(x, bn, *, relu=True, p=0.0, training=False):

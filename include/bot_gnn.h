@@ -109,12 +109,13 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
  * start at multiples of `epi`, and T may be 256.  epi = 1 otherwise.
  * One 1024-thread workgroup owns a tile and keeps its T output rows in LDS; its 16 waves cross the column blocks in
  * lockstep and all workgroups walk the blocks in the same order, so the block being gathered is resident in the XCD's L2; tiles are launched `round_tiles` at a time (one resident wave
- * of workgroups per launch).  H*D <= 1024 floats, T*H*D*4 <= 160 KB.  Deterministic, no atomics.
+ * of workgroups per launch).  H*D <= 1024 floats, T*H*D*4 <= 160 KB.  Rows are [H*D] contiguous with row strides ldx / ldo
+ * (/ lda); `addend` (may be NULL) is the same residual epilogue as in bot_spmm_f32.  Deterministic, no atomics.
  * ------------------------------------------------------------------------------------------- */
 int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int32_t* b_src, const uint8_t* b_lrow,
                          const int32_t* b_pos, int32_t n_tiles, int32_t nblk, int32_t block_rows, int32_t T, int32_t epi,
                          int32_t round_tiles, const float* x, int64_t ldx, const float* w, int32_t H, int32_t D, float* out,
-                         int64_t ldo, bot_stream_t stream);
+                         int64_t ldo, const float* addend, int64_t lda, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused backward of u_mul_e_sum (models.py:547) in ONE sweep over the transposed direction (rows = sources u,

@@ -422,6 +422,19 @@ def test_blocked_spmm_matches_row_kernel():
             assert torch.allclose(out_b, out_r, atol=2e-3, rtol=1e-4)
     bp = blocked.plan_for(csc, n, 1, 256)
     assert bp.heavy is not None  # the hub fallback is exercised
+    # residual epilogue and row-strided operands (slices of one GEMM output), blocked rows and hub rows alike
+    for H, D in ((6, 80), (1, 44), (2, 60)):
+        big = torch.randn(n, 2 * H * D + 8, generator=gen).to(DEV)
+        xs = big[:, :H * D].unflatten(1, (H, D))
+        res = big[:, H * D:2 * H * D].unflatten(1, (H, D))
+        w = torch.rand(csc.nnz, H, generator=gen).to(DEV)
+        blocked.ENABLED = True
+        out_b = _C.spmm(csc, xs, w, None, addend=res)
+        blocked.ENABLED = False
+        out_r = _C.spmm(csc, xs, w, None, addend=res)
+        blocked.ENABLED = True
+        ref = res + torch.zeros(n, H, D, device=DEV).index_add_(0, rows, xs[csc.indices.long()] * w.unsqueeze(-1))
+        assert torch.allclose(out_b, ref, atol=2e-3, rtol=1e-4) and torch.allclose(out_b, out_r, atol=2e-3, rtol=1e-4)
     xg = torch.randn(n, 64, generator=gen).to(DEV).requires_grad_()
     y = ops.copy_u_sum(g, xg)
     gy = torch.randn(n, 64, generator=gen).to(DEV)
