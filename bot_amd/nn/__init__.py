@@ -244,9 +244,11 @@ class GATConv(nn.Module):
             el = el * norm.unsqueeze(-1)
         ft = graph.extend(ft)  # identity on one GPU; appends the halo rows in partitioned mode
         el = graph.extend(el).unsqueeze(-1)
+        keep_order = "eid"
         if keep is None and self.training and self.edge_drop > 0:
-            keep = self._kept_edges(graph)
-        a = ops.gat_attention(graph, el, er, keep=keep, negative_slope=self.leaky_relu.negative_slope, order="csc")
+            keep, keep_order = self._kept_edges(graph), "csc"   # a uniform random subset: any fixed edge order will do
+        a = ops.gat_attention(graph, el, er, keep=keep, negative_slope=self.leaky_relu.negative_slope, order="csc",
+                              keep_order=keep_order)
         a = self.attn_drop(a)
         rst = ops.u_mul_e_sum(graph, ft, a, order="csc")
         if self._use_symmetric_norm:

@@ -98,10 +98,14 @@ class GATConv(nn.Module):
             ee_order = "csc"
         elif feat_edge is not None:
             ee = self.attn_edge_fc(feat_edge).view(-1, H, 1)
+        keep_order = "eid"
         if keep is None and self.training and self.edge_drop > 0:
+            # a uniformly random edge subset is uniformly random in any fixed edge order: use the mask as CSC-ordered whenever the
+            # edge logits are (or there are none), which saves permuting E bytes per layer
             keep = ops.random_edge_keep(graph, self.edge_drop)
+            keep_order = "csc" if (ee is None or ee_order == "csc") else "eid"
         a = ops.gat_attention(graph, attn_src, attn_dst, ee, keep=keep, negative_slope=self.leaky_relu.negative_slope,
-                              order="csc", ee_order=ee_order)
+                              order="csc", ee_order=ee_order, keep_order=keep_order)
         rst = ops.u_mul_e_sum(graph, ft, self.attn_drop(a), order="csc", addend=res)
         if self._use_symmetric_norm:
             rst = rst * _bcast(degree_norm(graph, "in", 0.5), rst)

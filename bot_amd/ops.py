@@ -199,16 +199,20 @@ def edge_mlp(g, efeat, W1, b1, W2):
 
 class _GatAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, g, el, er, ee, keep, slope, order, ee_csc=False):
+    def forward(ctx, g, el, er, ee, keep, slope, order, ee_csc=False, keep_csc=False):
         csc = g.csc
         H = _flat2(el if el is not None else ee).shape[1]
         el2 = None if el is None else el.reshape(-1, H)
         er2 = None if er is None else er.reshape(-1, H)
         ee2 = None if ee is None else ee.reshape(-1, H)
         aperm = csc.eid if order == "eid" else None
-        if ee_csc and keep is not None:  # one permutation serves both edge-indexed inputs: bring the mask to CSC order too
+        # one permutation (`eperm`) serves both edge-indexed inputs, so they must be in the same order
+        if keep is not None and ee is not None and keep_csc != ee_csc:
+            if keep_csc:
+                raise ValueError("gat_attention: a CSC-ordered keep mask needs CSC-ordered (or no) edge logits")
             keep = keep[csc.eid.long()].contiguous()
-        eperm = csc.eid if ((ee is not None or keep is not None) and not ee_csc) else None
+        in_csc = ee_csc if ee is not None else keep_csc
+        eperm = csc.eid if ((ee is not None or keep is not None) and not in_csc) else None
         a = _C.gat_attn_fwd(csc, el2, er2, ee2, eperm, keep, slope, H, aperm)
         ctx.g, ctx.slope, ctx.order, ctx.H, ctx.ee_csc = g, slope, order, H, ee_csc
         ctx.shapes = tuple(None if t is None else t.shape for t in (el, er, ee))
@@ -233,19 +237,20 @@ class _GatAttention(torch.autograd.Function):
             d_er = der.view(ctx.shapes[1])
         if ee2 is not None and ctx.needs_input_grad[3]:
             d_ee = dz.view(ctx.shapes[2])
-        return None, d_el, d_er, d_ee, None, None, None, None
+        return None, d_el, d_er, d_ee, None, None, None, None, None
 
 
-def gat_attention(g, el=None, er=None, ee=None, *, keep=None, negative_slope=0.2, order="eid", ee_order="eid"):
+def gat_attention(g, el=None, er=None, ee=None, *, keep=None, negative_slope=0.2, order="eid", ee_order="eid", keep_order="eid"):
     """Attention weights of one GAT layer in a single sweep over the in-edges (models.py:517-544):
 
         z_e = el[src] (+ er[dst]) (+ ee_e);  a = softmax over in-edges of leaky_relu(z, negative_slope)
 
     el, er: [N,H,1]; ee: [E,H,1] in edge-id order; keep: optional uint8 [E] in edge-id order — edges
     with keep == 0 are excluded from the softmax and get a == 0 (the edge-drop branch, models.py:528-539).
-    `ee_order="csc"`: `ee` is already in CSC position order (what `edge_mlp` returns).
+    `ee_order="csc"`: `ee` is already in CSC position order (what `edge_mlp` returns); `keep_order="csc"` likewise for the mask
+    (`random_edge_keep` draws a uniformly random subset, so a layer may use its mask in whichever order is cheapest).
     Returns a [E,H,1] in edge-id order (order="eid") or CSC position order (order="csc")."""
-    return _GatAttention.apply(g, el, er, ee, keep, float(negative_slope), order, ee_order == "csc")
+    return _GatAttention.apply(g, el, er, ee, keep, float(negative_slope), order, ee_order == "csc", keep_order == "csc")
 
 
 def edge_softmax(graph, logits, eids=None, norm_by="dst"):

@@ -440,3 +440,23 @@ def check_agg_first_against_oracle(golden, device):
         got = dict(model.named_parameters())
         for k, rg in zip(names, ref_grads):
             grad_close(got[k].grad, rg.numpy(), 3e-4)
+
+
+def check_keep_mask_orders(golden, device):
+    """A keep mask given in CSC position order (what the layers do with their own random draw) equals the same mask given in
+    edge-id order, with and without CSC-ordered edge logits."""
+    s_, d_, n = golden.graph("g300")
+    g = bot_amd.Graph(s_, d_, n).to(device)
+    E, H = g.number_of_edges(), 3
+    gen = torch.Generator().manual_seed(17)
+    el, er = torch.randn(n, H, 1, generator=gen).to(device), torch.randn(n, H, 1, generator=gen).to(device)
+    ee_csc = torch.randn(E, H, 1, generator=gen).to(device)
+    kc = (torch.rand(E, generator=gen) < 0.7).to(torch.uint8).to(device)
+    ke = torch.zeros_like(kc)
+    ke[g.csc.eid.long()] = kc
+    for ee in (None, ee_csc):
+        kw = dict(ee=ee, ee_order="csc") if ee is not None else {}
+        a1 = ops.gat_attention(g, el, er, keep=kc, keep_order="csc", order="csc", **kw)
+        a2 = ops.gat_attention(g, el, er, keep=ke, order="csc", **kw)
+        assert torch.equal(a1, a2)
+        assert torch.equal((a1.reshape(E, H)[:, 0] == 0), kc == 0)

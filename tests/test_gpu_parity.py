@@ -566,3 +566,7 @@ def test_full_size_properties_configs345(name):
         assert torch.equal(ops.copy_u_sum(g, ones)[:, 40].long(), g.in_degrees())
     del g
     torch.cuda.empty_cache()
+
+
+def test_keep_mask_orders(golden):
+    PC.check_keep_mask_orders(golden, DEV)

@@ -168,3 +168,7 @@ def test_blocked_plan_streams_cover_every_edge_once():
             assert torch.allclose(out[1:], ref[1:], rtol=1e-12, atol=1e-12) and float(out[0].abs().max()) == 0.0
     finally:
         blocked.L2_BLOCK_BYTES = old
+
+
+def test_keep_mask_orders(golden, cpu_backend):
+    PC.check_keep_mask_orders(golden, "cpu")

@@ -1,14 +1,24 @@
+"""Experiment: per-op device time (torch.profiler) of one S-products / S-proteins train step: what torch itself still runs."""
 import os, sys, torch, torch.nn.functional as F
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
 import scale_check as SC
 from bot_amd.nn import edge_gat
 from bot_amd import tuning
 tuning.enable()
-g, f, c, _ = SC.build("products")
-n = g.number_of_nodes()
-model = edge_gat.ProductsGAT(node_feats=f, edge_feats=0, n_classes=c, n_layers=3, n_heads=4, n_hidden=120, edge_emb=0,
-                             activation=F.relu, dropout=0.5, input_drop=0.1, attn_drop=0.0, edge_drop=0.1).to("cuda").train()
-g.ndata["feat"] = torch.randn(n, f, device="cuda")
+name = sys.argv[1] if len(sys.argv) > 1 else "products"
+g, f, c, _ = SC.build(name)
+n, E = g.number_of_nodes(), g.number_of_edges()
+if name == "products":
+    model = edge_gat.ProductsGAT(node_feats=f, edge_feats=0, n_classes=c, n_layers=3, n_heads=4, n_hidden=120, edge_emb=0,
+                                 activation=F.relu, dropout=0.5, input_drop=0.1, attn_drop=0.0, edge_drop=0.1).to("cuda").train()
+    g.ndata["feat"] = torch.randn(n, f, device="cuda")
+else:
+    from bot_amd import ops
+    model = edge_gat.ProteinsGAT(node_feats=f, edge_feats=8, n_classes=c, n_layers=6, n_heads=6, n_hidden=80, edge_emb=16,
+                                 activation=F.relu, dropout=0.25, input_drop=0.1, attn_drop=0.0, edge_drop=0.1,
+                                 allow_zero_in_degree=True).to("cuda").train()
+    g.edata["feat"] = torch.rand(E, 8, device="cuda")
+    g.ndata["feat"] = ops.copy_e_sum(g, g.edata["feat"])
 def step():
     model.zero_grad(set_to_none=True)
     out = model(g); out.square().mean().backward()
