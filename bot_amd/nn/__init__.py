@@ -156,7 +156,7 @@ class GraphConv(nn.Module):
         elif self._norm == "right":
             rst = rst * _bcast(degree_norm(graph, "in", -1.0), rst)
         if self.bias is not None:
-            rst = rst + self.bias
+            rst = ops.add_bias(rst, self.bias)   # bias gradient = a column sum over N rows: colstats kernel, not the stock reduction
         if self._activation is not None:
             rst = self._activation(rst)
         return rst

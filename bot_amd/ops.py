@@ -372,6 +372,11 @@ class _AddBias(torch.autograd.Function):
         return dy, db
 
 
+def add_bias(x, b):
+    """x [N,F] + b [F] with the bias gradient computed by the column-statistics kernel."""
+    return _AddBias.apply(x, b) if x.dim() == 2 and x.is_cuda == b.is_cuda else x + b
+
+
 def linear(x, weight, bias=None):
     """`F.linear` whose bias gradient (a column sum over all N rows) runs on the colstats kernel: the stock reduction takes
     19 ms for [2 449 029, 47] (S-products classifier, ogbn-products/models.py:262) — longer than the classifier GEMMs."""

@@ -8,7 +8,13 @@ tuning.enable()
 name = sys.argv[1] if len(sys.argv) > 1 else "products"
 g, f, c, _ = SC.build(name)
 n, E = g.number_of_nodes(), g.number_of_edges()
-if name == "products":
+if name == "reddit":
+    from bot_amd import nn as bnn
+    gcn = bnn.GCN(in_feats=f, n_classes=c, n_hidden=256, n_layers=3, activation=F.relu, norm="batch", dropout=0.5).to("cuda").train()
+    feat = torch.randn(n, f, device="cuda")
+    model = lambda graph: gcn(graph, feat)
+    model.zero_grad = lambda set_to_none=True: gcn.zero_grad(set_to_none=set_to_none)
+elif name == "products":
     model = edge_gat.ProductsGAT(node_feats=f, edge_feats=0, n_classes=c, n_layers=3, n_heads=4, n_hidden=120, edge_emb=0,
                                  activation=F.relu, dropout=0.5, input_drop=0.1, attn_drop=0.0, edge_drop=0.1).to("cuda").train()
     g.ndata["feat"] = torch.randn(n, f, device="cuda")
