@@ -210,7 +210,7 @@ class SyncBatchNorm1d(nn.BatchNorm1d):
     def forward(self, x):
         if not self.training or not (dist.is_available() and dist.is_initialized()):
             return super().forward(x)
-        stats = torch.cat([x.sum(0), (x * x).sum(0), x.new_tensor([float(x.shape[0])])])
+        stats = torch.cat([x.sum(0), (x * x).sum(0), x.new_full((1,), float(x.shape[0]))])
         stats = all_reduce_sum(stats, self.group)
         C = x.shape[1]
         cnt = stats[-1]
@@ -268,17 +268,23 @@ def forward_backward(model, part: Partition, *, use_labels=True, mask_rate=0.5, 
     tr = part.train_idx
     if mask is None:
         mask = torch.rand(tr.shape, device=tr.device) < mask_rate
+    # Fixed shapes throughout (no `tr[mask]`: boolean indexing makes the host wait for the device twice per step, which is
+    # what bounds a rank once its GPU work is a few ms): the label columns of the masked-out training nodes are written as
+    # zeros, and the loss runs over ALL owned training nodes with 0/1 weights.  Same sets, same mean as run.py:256-281.
     feat = part.feat
+    tr_labels = part.labels[tr, 0]
     if use_labels:
-        feat = T.add_labels(feat, part.labels, tr[mask], n_classes)
-        pred_idx = tr[~mask]
+        onehot = torch.zeros([feat.shape[0], n_classes], device=feat.device, dtype=feat.dtype)
+        onehot[tr, tr_labels] = mask.to(feat.dtype)
+        feat = torch.cat([feat, onehot], dim=-1)
+        w = (~mask).to(feat.dtype)
     else:
-        pred_idx = tr[mask]
+        w = mask.to(feat.dtype)
     pred = model(part.graph, feat)
-    y = T.per_node_loss(pred[pred_idx], part.labels[pred_idx], loss)
-    cnt = torch.tensor([float(pred_idx.numel())], device=feat.device)
+    y = T.per_node_loss(pred[tr], part.labels[tr], loss)
+    cnt = w.sum().reshape(1)
     dist.all_reduce(cnt, group=group)
-    local = y.sum() / cnt[0]
+    local = (y * w).sum() / cnt[0]
     local.backward()
     all_reduce_grads(model, group)
     total = local.detach().clone()

@@ -295,7 +295,7 @@ def bn_batch_stats(x, bn, bn_training):
         # host keeps running ahead of the GPU during the step
         totals = bn.__dict__.setdefault("_bot_total_rows", {})
         if n not in totals:
-            cnt = mean.new_tensor([float(n)])
+            cnt = mean.new_full((1,), float(n))
             dist.all_reduce(cnt, group=group)
             totals[n] = float(cnt.item())
         total = totals[n]

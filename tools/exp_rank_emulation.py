@@ -41,7 +41,12 @@ for _ in range(K): step()
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+if os.environ.get("BOT_CPROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(K): step()
+    pr.disable(); torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
 print(f"world {W}: rank 0 owns {part.n_owned} nodes, {part.n_edges} edges, halo {part.graph.halo.n_halo} rows, sends {part.graph.halo.n_send} rows")
 print(f"per step: wall {t_all / K * 1e3:.2f} ms, host enqueue {t_host / K * 1e3:.2f} ms")
 dist.destroy_process_group()
