@@ -182,7 +182,12 @@ def main():
         roof = {"bound": "hbm", "kernel": "bot::spmm_kernel<2,64,2,true> (u_mul_e_sum forward, H=3 D=250, hidden layers)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg * 1e3, 4),
-                "launches_timed": len(durs)}
+                "launches_timed": len(durs),
+                # measured L2<->fabric bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/spmm_traffic.json) over the same
+                # launch time: what the memory system actually delivered (Infinity-Cache hits included), next to the
+                # algorithmic-byte figure above
+                "traffic_GBs": round(traffic / avg / 1e9, 1) if traffic else None,
+                "traffic_frac_of_peak": round(traffic / avg / 1e9 / HBM_PEAK_GBS, 4) if traffic else None}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline != "off":
