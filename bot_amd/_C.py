@@ -47,9 +47,9 @@ _SIGS = {
                                          c_int32, c_int32, _P, _P, c_int32, _P]),
     "bot_sddmm_u_add_v_f32": (ctypes.c_int, [_P, _P, c_int64, _P, _P, c_int32, _P, _P]),
     "bot_gat_attn_fwd_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, _P, c_float,
-                                            c_int32, _P, _P, _P]),
+                                            c_int32, _P, _P, _P, _P]),
     "bot_gat_attn_bwd_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_int32,
-                                            _P, _P, _P, _P, _P, _P, _P]),
+                                            _P, _P, _P, _P, _P, _P, _P, _P]),
     "bot_segment_sum_f32": (ctypes.c_int, [_P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, c_int32, _P, _P]),
     "bot_gather_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
     "bot_scatter_add_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
@@ -332,8 +332,17 @@ def u_add_v(src, dst, x, y=None):
     return out
 
 
-def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm):
-    """Fused logits + leaky-ReLU + per-row softmax.  el/er: [n,H]; ee: [nnz,H] via eperm; -> a [nnz,H]."""
+def zsign_buffer(d, H, slope):
+    """uint8 [nnz] for the forward to record [z > 0] per head (H <= 8, slope != 1), else None: the backward then skips the
+    el[src] gather and the ee / edge-id reads."""
+    if os.environ.get("BOT_NO_ZSIGN"):  # measurements: the backward re-derives the signs from el / er / ee
+        return None
+    return torch.empty(d.nnz, dtype=torch.uint8, device=d.indptr.device) if (H <= 8 and slope != 1.0 and d.indptr.is_cuda) else None
+
+
+def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None):
+    """Fused logits + leaky-ReLU + per-row softmax.  el/er: [n,H]; ee: [nnz,H] via eperm; -> a [nnz,H].
+    `zsign`: optional uint8 [nnz] output (see zsign_buffer)."""
     _dev(el, er, ee, d.indptr)
     el = None if el is None else _f32(el, "el").contiguous()
     er = None if er is None else _f32(er, "er").contiguous()
@@ -343,12 +352,12 @@ def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm):
     a = torch.empty((d.nnz, H), dtype=torch.float32, device=d.indptr.device)
     _check(_lib.bot_gat_attn_fwd_f32(d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, _ptr(d.long_rows), d.n_long,
                                      d.chunk, _ptr(el), _ptr(er), _ptr(ee), _ptr(_i32(eperm, "eperm")), _ptr(keep),
-                                     float(slope), H, a.data_ptr(), _ptr(_i32(aperm, "aperm")), _stream()), "gat_attn_fwd")
+                                     float(slope), H, a.data_ptr(), _ptr(_i32(aperm, "aperm")), _ptr(zsign), _stream()), "gat_attn_fwd")
     return a
 
 
-def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der):
-    """Backward of gat_attn_fwd -> (dz [nnz,H] at zperm, der [n_rows,H] or None)."""
+def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der, zsign=None):
+    """Backward of gat_attn_fwd -> (dz [nnz,H] at zperm, der [n_rows,H] or None).  `zsign`: what the forward recorded."""
     _dev(a, da, d.indptr)
     el = None if el is None else _f32(el, "el").contiguous()
     er = None if er is None else _f32(er, "er").contiguous()
@@ -360,7 +369,7 @@ def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der):
     _check(_lib.bot_gat_attn_bwd_f32(d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, _ptr(d.long_rows), d.n_long,
                                      d.chunk, _ptr(el), _ptr(er), _ptr(ee), _ptr(_i32(eperm, "eperm")), float(slope), H,
                                      a.data_ptr(), da.data_ptr(), _ptr(_i32(aperm, "aperm")), dz.data_ptr(),
-                                     _ptr(_i32(zperm, "zperm")), _ptr(der), _stream()), "gat_attn_bwd")
+                                     _ptr(_i32(zperm, "zperm")), _ptr(der), _ptr(zsign), _stream()), "gat_attn_bwd")
     return dz, der
 
 

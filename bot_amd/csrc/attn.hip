@@ -104,6 +104,9 @@ struct AttnArgs {
     const int32_t* zperm;
     float* der;
     bool wide;  // el / ee / a / da / dz records may be moved as 8- / 16-byte vectors (see load_heads)
+    // optional (H <= 8): bit j of zsign[row of a] = [z_j > 0], written by the forward; with it the backward needs neither the
+    // el[src] gather nor ee nor the edge ids for the leaky-ReLU derivative (1 byte per edge instead of ~4*(2H+1))
+    uint8_t* zsign;
 };
 
 // HT consecutive floats at `q`.  `wide`: the record is 4*HT bytes at a multiple of 4*HT bytes from a 16-byte aligned base
@@ -185,15 +188,23 @@ __device__ __forceinline__ void attn_fwd_row(const AttnArgs& p, const Ctx& ctx, 
     }
     for (int k = beg + ctx.lane; k < end; k += Ctx::kStride) {
         const int ep = p.eperm ? p.eperm[k] : k;
-        float* ao = p.a + (int64_t)(p.aperm ? p.aperm[k] : k) * p.H + p.h0;
+        const int64_t arow = p.aperm ? p.aperm[k] : k;
+        float* ao = p.a + arow * p.H + p.h0;
         float e[HT];
         if (p.keep && p.keep[ep] == 0) {
 #pragma unroll
             for (int j = 0; j < HT; ++j) e[j] = NEG_INF;
             store_heads<HT>(ao, p.wide, e);
+            if (p.zsign) p.zsign[arow] = 0;
             continue;
         }
         edge_z<HT>(p, k, ep, erv, e);
+        if (p.zsign) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int j = 0; j < HT; ++j) bits |= (e[j] > 0.f ? 1u : 0u) << j;
+            p.zsign[arow] = (uint8_t)bits;
+        }
 #pragma unroll
         for (int j = 0; j < HT; ++j) {
             e[j] = e[j] > 0.f ? e[j] : e[j] * p.slope;
@@ -246,7 +257,15 @@ __device__ __forceinline__ void attn_bwd_row(const AttnArgs& p, const Ctx& ctx, 
         float av[HT], dv[HT], z[HT], g[HT];
         load_heads<HT>(p.a + o, p.wide, av);
         load_heads<HT>(p.da + o, p.wide, dv);
-        if (need_z) edge_z<HT>(p, k, p.eperm ? p.eperm[k] : k, erv, z);
+        if (need_z) {
+            if (p.zsign) {
+                const unsigned bits = p.zsign[p.aperm ? p.aperm[k] : k];
+#pragma unroll
+                for (int j = 0; j < HT; ++j) z[j] = (bits >> j) & 1u ? 1.f : 0.f;
+            } else {
+                edge_z<HT>(p, k, p.eperm ? p.eperm[k] : k, erv, z);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < HT; ++j) {
             g[j] = av[j] * (dv[j] - t[j]);
@@ -387,28 +406,31 @@ extern "C" {
 int bot_gat_attn_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
                          const int32_t* long_rows, int64_t n_long, int32_t chunk, const float* el, const float* er,
                          const float* ee, const int32_t* eperm, const uint8_t* keep, float slope, int32_t H, float* a,
-                         const int32_t* aperm, bot_stream_t stream) {
+                         const int32_t* aperm, uint8_t* zsign, bot_stream_t stream) {
     using namespace bot;
     if (int rc = attn_check("gat_attn_fwd", indptr, indices, n_rows, nnz, long_rows, n_long, chunk, el, H)) return rc;
     if (n_rows == 0 || nnz == 0) return 0;
     BOT_REQUIRE(a != nullptr, BOT_E_NULL, "gat_attn_fwd: a is NULL");
     BOT_REQUIRE(el || er || ee, BOT_E_NULL, "gat_attn_fwd: no logit source (el, er, ee all NULL)");
+    BOT_REQUIRE(zsign == nullptr || H <= 8, BOT_E_RANGE, "gat_attn_fwd: zsign holds 8 heads, H=%d", H);
     AttnArgs p{indptr, indices, n_rows, long_rows, chunk, el, er, ee, eperm, keep, slope, H, 0, a, nullptr, aperm, nullptr,
-               nullptr, nullptr};
+               nullptr, nullptr, false, zsign};
     return launch_attn<false>(p, n_long, (hipStream_t)stream);
 }
 
 int bot_gat_attn_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
                          const int32_t* long_rows, int64_t n_long, int32_t chunk, const float* el, const float* er,
                          const float* ee, const int32_t* eperm, float slope, int32_t H, const float* a, const float* da,
-                         const int32_t* aperm, float* dz, const int32_t* zperm, float* der, bot_stream_t stream) {
+                         const int32_t* aperm, float* dz, const int32_t* zperm, float* der, const uint8_t* zsign,
+                         bot_stream_t stream) {
     using namespace bot;
     if (int rc = attn_check("gat_attn_bwd", indptr, indices, n_rows, nnz, long_rows, n_long, chunk, el, H)) return rc;
     if (n_rows == 0) return 0;
     BOT_REQUIRE(nnz == 0 || (a && da && dz), BOT_E_NULL, "gat_attn_bwd: a/da/dz is NULL");
-    BOT_REQUIRE(slope == 1.f || el || er || ee, BOT_E_NULL, "gat_attn_bwd: slope != 1 needs el/er/ee to recompute the sign");
+    BOT_REQUIRE(slope == 1.f || zsign || el || er || ee, BOT_E_NULL, "gat_attn_bwd: slope != 1 needs zsign or el/er/ee for the sign");
+    BOT_REQUIRE(zsign == nullptr || H <= 8, BOT_E_RANGE, "gat_attn_bwd: zsign holds 8 heads, H=%d", H);
     AttnArgs p{indptr, indices, n_rows, long_rows, chunk, el, er, ee, eperm, nullptr, slope, H, 0, const_cast<float*>(a), da,
-               aperm, dz, zperm, der};
+               aperm, dz, zperm, der, false, const_cast<uint8_t*>(zsign)};
     return launch_attn<true>(p, n_long, (hipStream_t)stream);
 }
 

@@ -132,7 +132,8 @@ class _GATHidden(torch.autograd.Function):
         if sym:
             s_out, w_e = sym_scales(graph)
             el = el * s_out.unsqueeze(1)                                # logits see the scaled projection (models.py:505, :517)
-        a = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None)
+        ctx.zs = _C.zsign_buffer(csc, H, slope)
+        a = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None, ctx.zs)
         amask = None
         if attn_p > 0:                                                  # nn.Dropout on the attention weights (models.py:544)
             amask = (torch.rand_like(a) >= attn_p).to(a.dtype).mul_(1.0 / (1.0 - attn_p))
@@ -195,7 +196,7 @@ class _GATHidden(torch.autograd.Function):
             da = da * w_e
         if amask is not None:
             da = da * amask
-        dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er)
+        dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er, ctx.zs)
         d_el = _C.segment_sum(g.csr, dz, g.csr2csc)
         if ctx.sym:
             d_el = d_el * s_out.unsqueeze(1)
@@ -291,7 +292,8 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         if sym:
             s_out, w_e = sym_scales(graph)
             el = el * s_out.unsqueeze(1)
-        a = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None)
+        ctx.zs = _C.zsign_buffer(csc, H, slope)
+        a = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None, ctx.zs)
         amask = None
         if attn_p > 0:
             amask = (torch.rand_like(a) >= attn_p).to(a.dtype).mul_(1.0 / (1.0 - attn_p))
@@ -372,7 +374,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             da = da * w_e
         if amask is not None:
             da = da * amask
-        dz_e, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er)
+        dz_e, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er, ctx.zs)
         d_el = _C.segment_sum(g.csr, dz_e, g.csr2csc)
         if ctx.sym:
             d_el = d_el * s_out.unsqueeze(1)

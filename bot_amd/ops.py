@@ -213,9 +213,11 @@ class _GatAttention(torch.autograd.Function):
             keep = keep[csc.eid.long()].contiguous()
         in_csc = ee_csc if ee is not None else keep_csc
         eperm = csc.eid if ((ee is not None or keep is not None) and not in_csc) else None
-        a = _C.gat_attn_fwd(csc, el2, er2, ee2, eperm, keep, slope, H, aperm)
+        zs = _C.zsign_buffer(csc, H, slope)
+        a = _C.gat_attn_fwd(csc, el2, er2, ee2, eperm, keep, slope, H, aperm, zs)
         ctx.g, ctx.slope, ctx.order, ctx.H, ctx.ee_csc = g, slope, order, H, ee_csc
         ctx.shapes = tuple(None if t is None else t.shape for t in (el, er, ee))
+        ctx.zs = zs
         ctx.save_for_backward(el2, er2, ee2, a)
         return a.view(-1, H, 1)
 
@@ -229,7 +231,7 @@ class _GatAttention(torch.autograd.Function):
         # dz is written in edge-id order when something edge-indexed consumes it, else CSC position order
         z_eid = ee2 is not None and not ctx.ee_csc
         dz, der = _C.gat_attn_bwd(csc, el2, er2, ee2, eperm, ctx.slope, H, a, da.reshape(-1, H), aperm,
-                                  csc.eid if z_eid else None, er2 is not None)
+                                  csc.eid if z_eid else None, er2 is not None, ctx.zs)
         d_el = d_er = d_ee = None
         if el2 is not None and ctx.needs_input_grad[1]:
             d_el = _C.segment_sum(csr, dz, csr.eid if z_eid else g.csr2csc).view(ctx.shapes[0])

@@ -197,12 +197,14 @@ int bot_sddmm_u_add_v_f32(const int32_t* src, const int32_t* dst, int64_t n_edge
  * With el == er == NULL, slope == 1 this is dgl.ops.edge_softmax(graph, ee) (models.py:544) on
  * logits given in edge-id order.  `a` is written at aperm[k] (NULL: position order).
  * `long_rows` (rows longer than the plan's chunk) are handled by one workgroup each.
+ * `zsign` (may be NULL; H <= 8): uint8 [nnz], addressed like `a`; bit h receives [z > 0], so that the backward can take the
+ * leaky-ReLU derivative from one byte per edge instead of re-gathering el[src] and re-reading ee.
  * ------------------------------------------------------------------------------------------- */
 int bot_gat_attn_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
                          const int32_t* long_rows, int64_t n_long, int32_t chunk,
                          const float* el, const float* er, const float* ee, const int32_t* eperm,
                          const uint8_t* keep, float slope, int32_t H,
-                         float* a, const int32_t* aperm, bot_stream_t stream);
+                         float* a, const int32_t* aperm, uint8_t* zsign, bot_stream_t stream);
 
 /* Backward of the above.  Given a (forward output) and da (gradient w.r.t. a), both addressed
  * through aperm like the forward output:
@@ -213,14 +215,15 @@ int bot_gat_attn_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t 
  *            direction);
  *   der[r,h] = sum_k dz[k,h]       (written when der != NULL)
  *
- * With el == er == NULL, slope == 1 this is the backward of dgl.ops.edge_softmax.
+ * With el == er == NULL, slope == 1 this is the backward of dgl.ops.edge_softmax.  `zsign` (may be NULL): the sign bits the
+ * forward stored; when given, el / er / ee / eperm / indices are not read.
  */
 int bot_gat_attn_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
                          const int32_t* long_rows, int64_t n_long, int32_t chunk,
                          const float* el, const float* er, const float* ee, const int32_t* eperm,
                          float slope, int32_t H,
                          const float* a, const float* da, const int32_t* aperm,
-                         float* dz, const int32_t* zperm, float* der, bot_stream_t stream);
+                         float* dz, const int32_t* zperm, float* der, const uint8_t* zsign, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Segment sum of edge values.  Replaces update_all(fn.copy_e, fn.sum) — copy_e_sum

@@ -99,7 +99,7 @@ def _logits(d, el, er, ee, eperm, slope, H):
     return z, torch.where(z > 0, z, z * slope)
 
 
-def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm):
+def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None):  # zsign: never allocated on CPU (zsign_buffer)
     z, e = _logits(d, el, er, ee, eperm, slope, H)
     rows = _rows(d)
     a = torch.zeros_like(e)
@@ -114,7 +114,7 @@ def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm):
     return out
 
 
-def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der):
+def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der, zsign=None):
     rows = _rows(d)
     ap = _perm(aperm, d.nnz)
     a_, da_ = a[ap], da[ap]
