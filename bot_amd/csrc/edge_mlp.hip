@@ -72,9 +72,10 @@ __global__ __launch_bounds__(kBlock) void edge_mlp_fwd_kernel(const float* __res
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // part[wave][0][j][n] : dW2^T tile (n = head), part[wave][1][j][n] : [dW1 | db1] tile (n < 8: input i, n == 8: bias)
+template <int H>
 __global__ __launch_bounds__(kBlock) void edge_mlp_bwd_kernel(const float* __restrict__ ef, const float* __restrict__ W1,
                                                              const float* __restrict__ b1, const float* __restrict__ W2,
-                                                             const float* __restrict__ dz, int64_t E, int32_t H,
+                                                             const float* __restrict__ dz, int64_t E, bool wide,
                                                              float* __restrict__ part) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, k = lane >> 4;
@@ -101,11 +102,34 @@ __global__ __launch_bounds__(kBlock) void edge_mlp_bwd_kernel(const float* __res
             const int64_t ec = live[u] ? e : E - 1;  // tail: re-read a valid edge, contributions zeroed below
             vload<4>(*reinterpret_cast<float(*)[4]>(&f[u][0]), ef + ec * kI);
             vload<4>(*reinterpret_cast<float(*)[4]>(&f[u][4]), ef + ec * kI + 4);
+            // the H-float record of dz as 8- / 16-byte vectors where H allows (every 4-byte load touches the record's line again)
 #pragma unroll
-            for (int h = 0; h < 8; ++h) dzv[u][h] = h < H ? dz[ec * H + h] : 0.f;
-            // B operands: column n = lane & 15 of this lane's edge slot
-            bz[u] = (j < H) ? dz[ec * H + j] : 0.f;
-            bf[u] = (j < kI) ? ef[ec * kI + j] : (j == kI ? 1.f : 0.f);
+            for (int h = 0; h < 8; ++h) dzv[u][h] = 0.f;
+            const float* q = dz + ec * H;
+            if (wide && H % 4 == 0) {
+#pragma unroll
+                for (int h = 0; h + 3 < H; h += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(q + h);
+                    dzv[u][h] = t4.x, dzv[u][h + 1] = t4.y, dzv[u][h + 2] = t4.z, dzv[u][h + 3] = t4.w;
+                }
+            } else if (wide && H % 2 == 0) {
+#pragma unroll
+                for (int h = 0; h + 1 < H; h += 2) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(q + h);
+                    dzv[u][h] = t2.x, dzv[u][h + 1] = t2.y;
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < H; ++h) dzv[u][h] = q[h];
+            }
+            // B operands: column n = lane & 15 of this lane's edge slot — picked out of the registers just loaded
+            float zb = 0.f, fb = j == kI ? 1.f : 0.f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) zb = j == h ? dzv[u][h] : zb;
+#pragma unroll
+            for (int i = 0; i < kI; ++i) fb = j == i ? f[u][i] : fb;
+            bz[u] = zb;
+            bf[u] = fb;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -193,7 +217,19 @@ int bot_edge_mlp_bwd_f32(const float* ef, int32_t I, const float* W1, const floa
     BOT_REQUIRE(ef && W1 && b1 && W2 && dz && dW1 && db1 && dW2 && workspace, BOT_E_NULL, "edge_mlp_bwd: NULL pointer");
     BOT_REQUIRE(aligned(ef, 16), BOT_E_ALIGN, "edge_mlp_bwd: ef must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(kMlpBlocks), dim3(kBlock), 0, st, ef, W1, b1, W2, dz, n_edges, H, workspace);
+    const bool wide = aligned(dz, 16);
+#define BOT_MLP_BWD(HH) hipLaunchKernelGGL((edge_mlp_bwd_kernel<HH>), dim3(kMlpBlocks), dim3(kBlock), 0, st, ef, W1, b1, W2, dz, n_edges, wide, workspace)
+    switch (H) {
+        case 1: BOT_MLP_BWD(1); break;
+        case 2: BOT_MLP_BWD(2); break;
+        case 3: BOT_MLP_BWD(3); break;
+        case 4: BOT_MLP_BWD(4); break;
+        case 5: BOT_MLP_BWD(5); break;
+        case 6: BOT_MLP_BWD(6); break;
+        case 7: BOT_MLP_BWD(7); break;
+        default: BOT_MLP_BWD(8); break;
+    }
+#undef BOT_MLP_BWD
     hipLaunchKernelGGL(edge_mlp_bwd_final_kernel, dim3(512), dim3(kBlock), 0, st, workspace, (int64_t)kMlpBlocks * (kBlock / 64), H, dW1,
                        db1, dW2);
     return hip_status("edge_mlp_bwd launch");
