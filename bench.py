@@ -179,7 +179,7 @@ def main():
         tf = os.path.join(ROOT, "profiles", "spmm_traffic.json")
         if world == 1 and args.scale == 1.0 and os.path.exists(tf):
             traffic = json.load(open(tf)).get("bytes_per_launch")
-        roof = {"bound": "hbm", "kernel": "bot::spmm_kernel<2,64,2,true> (u_mul_e_sum forward, H=3 D=250, hidden layers)",
+        roof = {"bound": "hbm", "kernel": "bot::spmm_rows_kernel<2,64,6,2> (u_mul_e_sum forward, H=3 D=250, hidden layers)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg * 1e3, 4),
                 "launches_timed": len(durs),

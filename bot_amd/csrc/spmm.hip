@@ -237,6 +237,81 @@ __global__ __launch_bounds__(kBlock) void spmm_dot_rows_kernel(SpmmArgs a) {
         }
 }
 
+// The weighted forward SpMM in the same all-heads layout as spmm_dot_rows_kernel (one wavefront per work item, a head = HL
+// lanes or CPH whole chunks): a neighbour row is one contiguous H*D*4-byte read (see dispatch_spmm_rows); the head-major
+// kernel below keeps H = 1, unweighted sums and the shapes that do not fit.
+template <int VEC, int HL, int NCHUNK, int CPH>
+__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(SpmmArgs a) {
+    static_assert(CPH == 1 || HL == 64, "multi-chunk heads use whole waves");
+    constexpr int U = 4;
+    constexpr int HPC = 64 / HL;
+    constexpr int NSLOT = NCHUNK / CPH;
+    const int lane = threadIdx.x & 63;
+    const int64_t item = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (item >= a.n_items) return;
+    const int4 it = a.items[item];
+    const int row = __builtin_amdgcn_readfirstlane(it.x), beg = __builtin_amdgcn_readfirstlane(it.y);
+    const int end = __builtin_amdgcn_readfirstlane(it.z), slot = __builtin_amdgcn_readfirstlane(it.w);
+    const int hl = lane & (HL - 1);
+    int xoff[NCHUNK], hd[NCHUNK], el[NCHUNK];
+    bool act[NCHUNK];
+    float acc[NCHUNK][VEC];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int head = CPH > 1 ? c / CPH : c * HPC + lane / HL;
+        const int e = CPH > 1 ? ((c % CPH) * 64 + lane) * VEC : hl * VEC;
+        act[c] = head < a.H && e < a.D;
+        hd[c] = head < a.H ? head : 0;
+        el[c] = e;
+        xoff[c] = act[c] ? (int)(head * a.hsx) + e : 0;
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) acc[c][t] = 0.f;
+    }
+    for (int k0 = beg; k0 < end; k0 += 64) {
+        const int k = k0 + lane;
+        int idx = 0, wp = 0;
+        if (k < end) {
+            idx = a.indices[k];
+            wp = a.wperm ? a.wperm[k] : k;
+        }
+        const int cnt = min(64, end - k0);
+        for (int i = 0; i < cnt; i += U) {
+            float v[U][NCHUNK][VEC], ww[U][NSLOT];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = min(i + u, cnt - 1);
+                const int s = __builtin_amdgcn_readlane(idx, j);
+                const int ps = __builtin_amdgcn_readlane(wp, j);
+                const float* px = a.x + (int64_t)s * a.ldx;
+                const float* pw = a.w + (int64_t)ps * a.H;
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + xoff[c]);
+#pragma unroll
+                for (int q = 0; q < NSLOT; ++q) ww[u][q] = i + u < cnt ? pw[hd[q * CPH]] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                    for (int t = 0; t < VEC; ++t) acc[c][t] = fmaf(ww[u][c / CPH], v[u][c][t], acc[c][t]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+        if (act[c]) {
+            if (a.addend && slot < 0) {
+                float r[VEC];
+                vload<VEC>(r, a.addend + (int64_t)row * a.lda + (int64_t)hd[c] * a.hsa + el[c]);
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) acc[c][t] += r[t];
+            }
+            float* ob = slot < 0 ? a.out + (int64_t)row * a.ldo + (int64_t)hd[c] * a.hso + el[c]
+                                 : a.partial + (int64_t)slot * a.ldp + (int64_t)hd[c] * a.D + el[c];
+            vstore<VEC>(ob, acc[c]);
+        }
+}
+
 template <int VEC, int LANES, int NCHUNK, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs a) {
     constexpr int TILE = VEC * LANES * NCHUNK;
@@ -662,6 +737,48 @@ static bool dispatch_spmm_dot_rows(const SpmmArgs& a, hipStream_t st) {
     return true;
 }
 
+template <int VEC, int HL, int NCHUNK, int CPH>
+static void launch_spmm_rows(const SpmmArgs& a, hipStream_t st) {
+    const int64_t blocks = (a.n_items * 64 + kBlock - 1) / kBlock;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL((spmm_rows_kernel<VEC, HL, NCHUNK, CPH>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+}
+
+// All-heads layout for the weighted forward, taken whenever the shape fits (measured against the head-major kernel:
+// S-arxiv H=3 D=250 1.24 -> 1.12 ms, H=2 D=250 0.81 -> 0.76, H=4 D=64 and H=3 D=128 equal; S-products H=4 D=120 45.6 -> 42.3 ms;
+// S-proteins H=6 D=80 23.2 -> 19.3 ms).  BOT_SPMM_LAYOUT=heads forces the head-major kernel (measurements).
+template <int VEC>
+static bool dispatch_spmm_rows(const SpmmArgs& a, hipStream_t st) {
+    if (a.H < 2 || a.w == nullptr) return false;
+    const char* e = getenv("BOT_SPMM_LAYOUT");
+    if (e && !strcmp(e, "heads")) return false;
+    const int L = (a.D + VEC - 1) / VEC;
+    if (L <= 8) return false;
+    if (L > 64) {
+        if (L > 128 || VEC == 4 || a.H > 3) return false;
+        if constexpr (VEC != 4) {
+            if (a.H == 2) launch_spmm_rows<VEC, 64, 4, 2>(a, st);
+            else launch_spmm_rows<VEC, 64, 6, 2>(a, st);
+        }
+        return true;
+    }
+    const int HL = L <= 16 ? 16 : (L <= 32 ? 32 : 64);
+    const int nchunk = (a.H * HL + 63) / 64;
+    if (nchunk > 4) return false;
+#define BOT_ROWS(HLV)                                                  \
+    do {                                                               \
+        if (nchunk == 1) launch_spmm_rows<VEC, HLV, 1, 1>(a, st);      \
+        else if (nchunk == 2) launch_spmm_rows<VEC, HLV, 2, 1>(a, st); \
+        else if (nchunk == 3) launch_spmm_rows<VEC, HLV, 3, 1>(a, st); \
+        else launch_spmm_rows<VEC, HLV, 4, 1>(a, st);                  \
+    } while (0)
+    if (HL == 16) BOT_ROWS(16);
+    else if (HL == 32) BOT_ROWS(32);
+    else BOT_ROWS(64);
+#undef BOT_ROWS
+    return true;
+}
+
 template <int VEC>
 static void dispatch_spmm(SpmmArgs& a, hipStream_t st) {
     const int L = (a.D + VEC - 1) / VEC;  // lanes needed for one head slab
@@ -708,9 +825,12 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
     SpmmArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, hsx, w, wperm, H, D, 1, out, ldo, hso, partial,
                (int64_t)H * D, nullptr, 0, 0, nullptr, addend, lda, hsa};
     const int vec = addend ? pick_vec(D, {ldx, hsx, ldo, hso, lda, hsa}, {x, out, partial, addend}) : pick_vec(D, {ldx, hsx, ldo, hso}, {x, out, partial});
-    if (vec == 4) dispatch_spmm<4>(a, st);
-    else if (vec == 2) dispatch_spmm<2>(a, st);
-    else dispatch_spmm<1>(a, st);
+    const bool rows = vec == 4 ? dispatch_spmm_rows<4>(a, st) : (vec == 2 ? dispatch_spmm_rows<2>(a, st) : dispatch_spmm_rows<1>(a, st));
+    if (!rows) {
+        if (vec == 4) dispatch_spmm<4>(a, st);
+        else if (vec == 2) dispatch_spmm<2>(a, st);
+        else dispatch_spmm<1>(a, st);
+    }
     if (int rc = hip_status("spmm launch")) return rc;
     if (n_long > 0) {
         const int64_t n = n_long * H * D;
