@@ -28,6 +28,7 @@ _P = c_void_p
 _SIGS = {
     "bot_abi_version": (ctypes.c_int, []),
     "bot_last_error": (c_char_p, []),
+    "bot_last_kernel": (c_char_p, []),
     "bot_row_plan_default_chunk": (c_int32, [c_int64]),
     "bot_row_plan_size_host": (ctypes.c_int, [_P, c_int64, c_int32, _P, _P, _P]),
     "bot_row_plan_fill_host": (ctypes.c_int, [_P, c_int64, c_int32, _P, _P, _P]),
@@ -91,7 +92,7 @@ def _timed(name, key, launch):
     e0.record()
     rc = launch()
     e1.record()
-    PROFILE.append((name, key, e0, e1))
+    PROFILE.append((name, key, e0, e1, _lib.bot_last_kernel().decode()))
     return rc
 
 

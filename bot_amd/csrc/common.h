@@ -9,6 +9,7 @@
 namespace bot {
 
 void set_error(const char* fmt, ...);
+void set_kernel(const char* fmt, ...);  // name of the main device kernel a launch function dispatched (bot_last_kernel)
 
 inline int hip_status(const char* what) {
     hipError_t e = hipGetLastError();

@@ -23,13 +23,16 @@ constexpr int kTX = 64;   // lanes across columns (x VEC floats each)
 constexpr int kTY = 4;    // rows per block iteration
 constexpr int kRowBlocks = 256;
 
-// keep/(1-p) factors for the VEC elements of element-group `grp`
+// keep/(1-p) factors of the VEC elements starting at column c of row r.  The mask is a function of (seed, r, c) ONLY — never
+// of the load width a launch happens to pick: element (r, c) takes word c % 4 of the Philox block with counter
+// r * ceil(F/4) + c/4, so the forward and the two backward kernels agree even when their operands are aligned differently
+// (a VEC < 4 launch simply uses a part of each block).
 template <int VEC>
-__device__ __forceinline__ void drop_factors(uint64_t seed, uint64_t grp, float p, float scale, float (&f)[VEC]) {
-    uint32_t r[4];
-    Philox::gen(seed, grp, r);
+__device__ __forceinline__ void drop_factors(uint64_t seed, int64_t r, int c, int64_t nquad, float p, float scale, float (&f)[VEC]) {
+    uint32_t w[4];
+    Philox::gen(seed, (uint64_t)(r * nquad + (c >> 2)), w);
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) f[t] = ((r[t] >> 8) * (1.0f / 16777216.0f)) >= p ? scale : 0.f;
+    for (int t = 0; t < VEC; ++t) f[t] = ((w[(c & 3) + t] >> 8) * (1.0f / 16777216.0f)) >= p ? scale : 0.f;
 }
 
 struct BnArgs {
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
         sh[t] = a.b ? a.b[c + t] : 0.f;
     }
     const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
-    const int64_t ngrp = (a.F + VEC - 1) / VEC;
+    const int64_t nquad = (a.F + 3) / 4;
     constexpr int UR = 4;  // rows in flight per thread: loads first, then compute + store (x and y may alias for the compiler)
     const int64_t step = (int64_t)gridDim.y * kTY;
     for (int64_t r0 = (int64_t)blockIdx.y * kTY + ty; r0 < a.n; r0 += step * UR) {
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
             const int64_t r = r0 + u * step;
             if (r >= a.n) break;
             float f[VEC];
-            if (a.p > 0.f) drop_factors<VEC>(a.seed, (uint64_t)(r * ngrp + c / VEC), a.p, scale, f);
+            if (a.p > 0.f) drop_factors<VEC>(a.seed, r, c, nquad, a.p, scale, f);
 #pragma unroll
             for (int t = 0; t < VEC; ++t) {
                 float o = fmaf(v[u][t] - mu[t], sc[t], sh[t]);
@@ -185,13 +188,13 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_reduce_kernel(BnArgs a) {
             sh[t] = a.b ? a.b[c + t] : 0.f;
         }
         const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
-        const int64_t ngrp = (a.F + VEC - 1) / VEC;
+        const int64_t nquad = (a.F + 3) / 4;
 #pragma unroll 4
         for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < a.n; r += (int64_t)gridDim.y * kTY) {
             float v[VEC], g[VEC], f[VEC];
             vload<VEC>(v, a.x + r * a.ldx + c);
             vload<VEC>(g, a.dy + r * a.lddy + c);
-            if (a.p > 0.f) drop_factors<VEC>(a.seed, (uint64_t)(r * ngrp + c / VEC), a.p, scale, f);
+            if (a.p > 0.f) drop_factors<VEC>(a.seed, r, c, nquad, a.p, scale, f);
 #pragma unroll
             for (int t = 0; t < VEC; ++t) {
                 const float xh = (v[t] - mu[t]) * is[t];
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
         mgx[t] = a.sum_gx ? a.sum_gx[c + t] * a.inv_count : 0.f;
     }
     const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
-    const int64_t ngrp = (a.F + VEC - 1) / VEC;
+    const int64_t nquad = (a.F + 3) / 4;
     constexpr int UR = 4;
     const int64_t step = (int64_t)gridDim.y * kTY;
     for (int64_t r0 = (int64_t)blockIdx.y * kTY + ty; r0 < a.n; r0 += step * UR) {
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
             const int64_t r = r0 + u * step;
             if (r >= a.n) break;
             float f[VEC];
-            if (a.p > 0.f) drop_factors<VEC>(a.seed, (uint64_t)(r * ngrp + c / VEC), a.p, scale, f);
+            if (a.p > 0.f) drop_factors<VEC>(a.seed, r, c, nquad, a.p, scale, f);
 #pragma unroll
             for (int t = 0; t < VEC; ++t) {
                 const float xh = (v[u][t] - mu[t]) * is[t];

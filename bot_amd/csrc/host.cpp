@@ -14,12 +14,20 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+static thread_local char g_kernel[128] = "";
+void set_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
 }  // namespace bot
 
 extern "C" {
 
 int bot_abi_version(void) { return BOT_ABI_VERSION; }
 const char* bot_last_error(void) { return bot::g_err; }
+const char* bot_last_kernel(void) { return bot::g_kernel; }
 
 int32_t bot_row_plan_default_chunk(int64_t nnz) {
     // cdna_hip_programming.md Appendix B "Scatter / gather": split lists longer than a quarter of one

@@ -356,18 +356,10 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs a) {
         int idx = 0;
         float wv = 0.f;
         if (k < end) {
-#ifdef BOT_NT
-            idx = __builtin_nontemporal_load(a.indices + k);
-#else
             idx = a.indices[k];
-#endif
             if constexpr (WEIGHTED) {
                 const int wp = a.wperm ? a.wperm[k] : k;
-#ifdef BOT_NT
-                wv = __builtin_nontemporal_load(a.w + (int64_t)wp * a.H + head);
-#else
                 wv = a.w[(int64_t)wp * a.H + head];
-#endif
             }
         }
         const int cnt = min(LANES, end - k0);
@@ -423,11 +415,7 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs a) {
 #pragma unroll
                 for (int t = 0; t < VEC; ++t) acc[c][t] += r[t];
             }
-#ifdef BOT_NT
-            vstore_nt<VEC>(ob + off[c], acc[c]);
-#else
             vstore<VEC>(ob + off[c], acc[c]);
-#endif
         }
 }
 
@@ -637,6 +625,7 @@ static void dispatch_bcast(SpmmArgs& a, hipStream_t st) {
     do {                                                                                                                      \
         const int64_t blocks = (a.n_items * LN + kBlock - 1) / kBlock;                                                        \
         if (blocks == 0) break;                                                                                               \
+        set_kernel(DOT ? "bot::spmm_dot_bcast_kernel<%d,%d,%d,%d>" : "bot::spmm_bcast_kernel<%d,%d,%d,%d>", VEC, LN, NC, HB);        \
         if constexpr (DOT) hipLaunchKernelGGL((spmm_dot_bcast_kernel<VEC, LN, NC, HB>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a); \
         else hipLaunchKernelGGL((spmm_bcast_kernel<VEC, LN, NC, HB>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);        \
     } while (0)
@@ -667,6 +656,7 @@ static void launch_spmm(const SpmmArgs& a, hipStream_t st) {
     const int64_t groups = a.n_items * a.H * a.n_tiles;
     const int64_t blocks = (groups * LANES + kBlock - 1) / kBlock;
     if (blocks == 0) return;
+    set_kernel("bot::spmm_kernel<%d,%d,%d,%s>", VEC, LANES, NCHUNK, a.w ? "true" : "false");
     if (a.w) hipLaunchKernelGGL((spmm_kernel<VEC, LANES, NCHUNK, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
     else hipLaunchKernelGGL((spmm_kernel<VEC, LANES, NCHUNK, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
 }
@@ -676,6 +666,7 @@ static void launch_spmm_dot(const SpmmArgs& a, hipStream_t st) {
     const int64_t groups = a.n_items * a.H;
     const int64_t blocks = (groups * LANES + kBlock - 1) / kBlock;
     if (blocks == 0) return;
+    set_kernel("bot::spmm_dot_kernel<%d,%d,%d>", VEC, LANES, NCHUNK);
     hipLaunchKernelGGL((spmm_dot_kernel<VEC, LANES, NCHUNK>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
 }
 
@@ -694,14 +685,27 @@ static void dispatch_spmm_dot(SpmmArgs& a, hipStream_t st) {
 // "rows" layout of spmm_dot (one wave per item, all heads) is taken whenever the shape fits it; BOT_SPMM_DOT_LAYOUT=heads
 // forces the head-major kernel (measurements / debugging).
 static bool spmm_dot_rows_wanted() {
-    const char* e = getenv("BOT_SPMM_DOT_LAYOUT");
-    return !(e && !strcmp(e, "heads"));
+    static const bool wanted = [] {  // read once per process, not per launch
+        const char* e = getenv("BOT_SPMM_DOT_LAYOUT");
+        return !(e && !strcmp(e, "heads"));
+    }();
+    return wanted;
+}
+
+// BOT_SPMM_LAYOUT=heads forces the head-major forward kernel (measurements); read once per process.
+static bool spmm_rows_wanted() {
+    static const bool wanted = [] {
+        const char* e = getenv("BOT_SPMM_LAYOUT");
+        return !(e && !strcmp(e, "heads"));
+    }();
+    return wanted;
 }
 
 template <int VEC, int HL, int NCHUNK, int CPH>
 static void launch_spmm_dot_rows(const SpmmArgs& a, hipStream_t st) {
     const int64_t blocks = (a.n_items * 64 + kBlock - 1) / kBlock;
     if (blocks == 0) return;
+    set_kernel("bot::spmm_dot_rows_kernel<%d,%d,%d,%d>", VEC, HL, NCHUNK, CPH);
     hipLaunchKernelGGL((spmm_dot_rows_kernel<VEC, HL, NCHUNK, CPH>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
 }
 
@@ -741,6 +745,7 @@ template <int VEC, int HL, int NCHUNK, int CPH>
 static void launch_spmm_rows(const SpmmArgs& a, hipStream_t st) {
     const int64_t blocks = (a.n_items * 64 + kBlock - 1) / kBlock;
     if (blocks == 0) return;
+    set_kernel("bot::spmm_rows_kernel<%d,%d,%d,%d>", VEC, HL, NCHUNK, CPH);
     hipLaunchKernelGGL((spmm_rows_kernel<VEC, HL, NCHUNK, CPH>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
 }
 
@@ -749,9 +754,7 @@ static void launch_spmm_rows(const SpmmArgs& a, hipStream_t st) {
 // S-proteins H=6 D=80 23.2 -> 19.3 ms).  BOT_SPMM_LAYOUT=heads forces the head-major kernel (measurements).
 template <int VEC>
 static bool dispatch_spmm_rows(const SpmmArgs& a, hipStream_t st) {
-    if (a.H < 2 || a.w == nullptr) return false;
-    const char* e = getenv("BOT_SPMM_LAYOUT");
-    if (e && !strcmp(e, "heads")) return false;
+    if (a.H < 2 || a.w == nullptr || !spmm_rows_wanted()) return false;
     const int L = (a.D + VEC - 1) / VEC;
     if (L <= 8) return false;
     if (L > 64) {

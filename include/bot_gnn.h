@@ -46,6 +46,10 @@ typedef void* bot_stream_t; /* hipStream_t */
 
 int bot_abi_version(void);
 const char* bot_last_error(void);
+/* Name (as a profiler prints it) of the main device kernel the calling thread's most recent SpMM-family launch function
+ * dispatched — the template instance depends on H, D and the operands' alignment.  Diagnostic only (bench.py names the
+ * kernel of its roofline line from it); thread-local like bot_last_error. */
+const char* bot_last_kernel(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Row plan (host side, pure integer work; built once per graph direction).
@@ -259,8 +263,10 @@ int bot_scatter_add_rows_f32(float* x, int64_t ldx, const int32_t* rows, int64_t
  *   bwd_apply     dx = weight*invstd*( g - sum_g/count - xhat*sum_gx/count )
  *                 (sum_g == sum_gx == NULL: statistics were constants (eval mode): dx = weight*invstd*g)
  *
- * The dropout mask is a counter-based Philox4x32-10 stream keyed by (seed, element group): forward and
- * backward regenerate it from `seed`, nothing is stored.  p == 0 disables dropout.  `weight`/`bias` may be
+ * The dropout mask is a counter-based Philox4x32-10 stream: element (r, c) takes word c % 4 of the block with
+ * counter r * ceil(F/4) + c/4 under key `seed` — a function of (seed, r, c, F) only, independent of pointer
+ * alignment, strides or the vector width a launch picks, so forward and backward regenerate the same mask from
+ * `seed` for any operand layout; nothing is stored.  p == 0 disables dropout.  `weight`/`bias` may be
  * NULL.  `workspace` holds bot_bn_workspace_floats(F) floats.  In the vertex-partitioned mode the caller
  * all-reduces (mean, m2, count) and (sum_g, sum_gx) between the two halves; `total_count` is the global
  * row count.  The grad of weight is sum_gx, of bias sum_g.

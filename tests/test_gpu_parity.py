@@ -251,6 +251,41 @@ def test_fused_dropout_mask_consistency():
     assert not torch.equal(y2 != 0, y != 0)  # a fresh seed per call
 
 
+def test_fused_dropout_mask_independent_of_alignment():
+    """The Philox mask of element (r, c) must not depend on the vector width a launch picks (forward on 16-byte
+    aligned x/y, backward with dy / dx that are only 8- or 4-byte aligned used to regenerate ANOTHER mask).  The forward runs
+    at VEC=4; the backward kernels are driven through the raw wrappers with dy and dx shifted by 2 and by 1 floats."""
+    from bot_amd import _C
+    n, F, p, seed = 3000, 752, 0.6, 0x1234567890ABCDEF
+    x = torch.randn(n, F, device=DEV)
+    mean, m2 = _C.colstats(x)
+    invstd = torch.rsqrt(m2 / n + 1e-5)
+    w, b = torch.rand(F, device=DEV) + 0.5, torch.randn(F, device=DEV) * 0.1
+    y = _C.bn_act_fwd(x, mean, invstd, w, b, True, p, seed)
+    dy0 = torch.randn(n, F, device=DEV)
+    sg0, sgx0 = _C.bn_act_bwd_reduce(dy0, x, mean, invstd, w, b, True, p, seed)
+    dx0 = _C.bn_act_bwd_apply(dy0, x, mean, invstd, w, b, True, p, seed, sg0, sgx0, float(n))
+    # the mask the forward used, recovered from its output
+    kept = (y != 0)
+    pre = torch.relu((x - mean) * invstd * w + b)
+    assert torch.allclose(y[kept], (pre / (1 - p))[kept], rtol=1e-4, atol=1e-5)
+    g_ref = torch.where(kept, dy0 / (1 - p), torch.zeros_like(dy0))
+    assert torch.allclose(sg0, g_ref.sum(0), rtol=1e-4, atol=1e-2)
+    for shift in (2, 1):  # 8-byte, then 4-byte aligned rows (row stride F + 4 keeps 16 bytes, the base pointer does not)
+        buf = torch.zeros(n, F + 4, device=DEV)
+        dy = buf[:, shift:shift + F]
+        dy.copy_(dy0)
+        sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, w, b, True, p, seed)
+        assert torch.allclose(sg, sg0, rtol=1e-5, atol=1e-4) and torch.allclose(sgx, sgx0, rtol=1e-5, atol=1e-4)
+        obuf = torch.zeros(n, F + 4, device=DEV)
+        dx = _C.bn_act_bwd_apply(dy, x, mean, invstd, w, b, True, p, seed, sg0, sgx0, float(n), out=obuf[:, shift:shift + F])
+        assert torch.equal(dx, dx0)
+        xb = torch.zeros(n, F + 4, device=DEV)   # and a forward whose INPUT is misaligned writes the same mask
+        xs = xb[:, shift:shift + F]
+        xs.copy_(x)
+        assert torch.equal(_C.bn_act_fwd(xs, mean, invstd, w, b, True, p, seed) != 0, kept)
+
+
 def test_sddmm_dot_and_fused_backward_direct(golden):
     """The standalone SDDMM-dot kernel and the fused spmm_dot kernel against plain torch indexing."""
     s, d, n = golden.graph("g300")
@@ -570,3 +605,46 @@ def test_full_size_properties_configs345(name):
 
 def test_keep_mask_orders(golden):
     PC.check_keep_mask_orders(golden, DEV)
+
+
+# ---------------------------------------------------------------------------------------------- full-size logits + gradients
+_FULL = {}
+
+
+def _full_size_inputs():
+    """S-arxiv at BASELINE config 2's full size (169 343 nodes, 2.5 M edges after preprocess), config-2 weights, a fixed label mask."""
+    if not _FULL:
+        from bot_amd import synth
+        from tests import full_size as FS
+        ds = synth.make_dataset("arxiv", device="cpu", seed=0)
+        C = ds.n_classes
+        sd = FS.init_state(FS.GAT_ARXIV, ds.feat.shape[1] + C, C, seed=0)
+        mask = torch.rand(ds.train_idx.shape, generator=torch.Generator().manual_seed(7)) < 0.5
+        _FULL.update(ds=ds, sd=sd, mask=mask)
+    return _FULL
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_full_size_config2_logits_and_grads_against_c_oracle(fuse):
+    """at the size the headline number is quoted on, ONE whole train step (forward + loge loss + backward,
+    dropout 0, training-mode BatchNorm) on the HIP path — fused layer nodes AND the modular DGL-surface path — against the
+    oracle's C restatement of DGL's CPU kernels: every logit of the 169 343 nodes within 1e-4, every entry of every parameter
+    gradient within 1e-4 of that gradient's largest entry (tolerances of tests/parity_cases.py).  The oracle is evaluated at the
+    HIP run's ReLU gates (tests/full_size.py:GateAct explains why); the gates the oracle would have chosen itself may differ
+    only where the pre-activation is rounding noise, which is asserted too."""
+    from tests import full_size as FS
+    c = _full_size_inputs()
+    ds = c["ds"]
+    g = ds.graph.to(DEV)
+    g.create_formats_()
+    pred, grads, gates = FS.hip_step(g, ds.feat.to(DEV), ds.labels.to(DEV), ds.train_idx.to(DEV), c["mask"], c["sd"],
+                                     FS.GAT_ARXIV, ds.n_classes, fuse=fuse)
+    s, d = ds.graph.edges()
+    rp, rg, times, threads, gstats = FS.oracle_step(s, d, ds.graph.number_of_nodes(), ds.feat, ds.labels, ds.train_idx, c["mask"],
+                                                    c["sd"], FS.GAT_ARXIV, ds.n_classes, gates=gates)
+    r = FS.compare(pred, grads, rp, rg, gstats)
+    print("full-size parity", "fused" if fuse else "modular", r, "oracle step %.2f s on %d threads" % (times[0], threads))
+    assert r["n"] == 169343 and g.number_of_edges() > 2_000_000
+    assert r["max_abs_logit_diff"] <= PC.FWD_ATOL, r
+    assert r["max_rel_grad_err"] <= PC.GRAD_RTOL, r
+    assert r["max_abs_preact_at_differing_gate"] <= 1e-4 and r["relu_gates_differing"] <= 1e-5 * r["relu_gates"], r

@@ -172,3 +172,28 @@ def test_blocked_plan_streams_cover_every_edge_once():
 
 def test_keep_mask_orders(golden, cpu_backend):
     PC.check_keep_mask_orders(golden, "cpu")
+
+
+def test_whole_step_against_c_oracle_small(cpu_backend, monkeypatch):
+    """The full-size parity procedure of the GPU suite (tests/full_size.py) at 1/20 scale over the emulated backend: logits
+    and every parameter gradient of one config-2 train step against the oracle's C kernels, fused and modular.  Also shows
+    WHY the oracle is evaluated at the tested run's ReLU gates: with its own gates a few pre-activations of ~1e-7 land on the
+    other side of zero and whole rows of the weight gradients move by ~1 %; at equal gates everything agrees to 1e-5."""
+    from bot_amd import synth
+    from bot_amd.nn import fused
+    from tests import full_size as FS
+    monkeypatch.setattr(fused, "FORCE", True)
+    ds = synth.make_dataset("arxiv", device="cpu", seed=0, scale=0.05)
+    C = ds.n_classes
+    sd = FS.init_state(FS.GAT_ARXIV, ds.feat.shape[1] + C, C)
+    mask = torch.rand(ds.train_idx.shape, generator=torch.Generator().manual_seed(7)) < 0.5
+    s, d = ds.graph.edges()
+    n = ds.graph.number_of_nodes()
+    for fuse in (True, False):
+        calls = fused.CALLS
+        pred, grads, gates = FS.hip_step(ds.graph, ds.feat, ds.labels, ds.train_idx, mask, sd, FS.GAT_ARXIV, C, fuse=fuse)
+        assert (fused.CALLS > calls) == fuse
+        rp, rg, _, _, gs = FS.oracle_step(s, d, n, ds.feat, ds.labels, ds.train_idx, mask, sd, FS.GAT_ARXIV, C, gates=gates)
+        r = FS.compare(pred, grads, rp, rg, gs)
+        assert r["max_abs_logit_diff"] <= PC.FWD_ATOL and r["max_rel_grad_err"] <= PC.GRAD_RTOL, r
+        assert r["max_abs_preact_at_differing_gate"] <= 1e-4 and r["relu_gates_differing"] <= 1e-5 * r["relu_gates"], r
