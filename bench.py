@@ -95,7 +95,7 @@ def cpu_baseline_and_parity(ds, n_classes, steps, dev, fuse=True):
     g = ds.graph.to(dev)
     g.create_formats_()
     hp, hg, gates = FS.hip_step(g, ds.feat.to(dev), ds.labels.to(dev), ds.train_idx.to(dev), mask, sd, cfg, C, fuse=fuse)
-    # gradients are compared with the oracle evaluated at the HIP run's ReLU gates (tests/full_size.py:GateAct); the logits with
+    # gradients are compared with the oracle evaluated at the HIP run's ReLU gates (tests/full_size.py:KinkGates); the logits with
     # the oracle's own gates (the plain step timed above)
     gp, gg, _, _, gstats = FS.oracle_step(s, d, n, ds.feat, ds.labels, ds.train_idx, mask, sd, cfg, C, gates=gates)
     parity = FS.compare(hp, hg, gp, gg, gstats)

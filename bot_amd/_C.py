@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -51,6 +51,10 @@ _SIGS = {
                                             c_int32, _P, _P, _P, _P]),
     "bot_gat_attn_bwd_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_int32,
                                             _P, _P, _P, _P, _P, _P, _P, _P]),
+    "bot_gat_infer_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
+    "bot_gat_infer_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                         _P, c_int64, _P, c_int64, _P, _P, c_float, c_int32, c_int32, _P, c_int64, c_int64, _P, _P,
+                                         c_int32, _P, c_int64, c_int64, _P, _P]),
     "bot_segment_sum_f32": (ctypes.c_int, [_P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, c_int32, _P, _P]),
     "bot_gather_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
     "bot_scatter_add_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
@@ -372,6 +376,51 @@ def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der, 
                                      a.data_ptr(), da.data_ptr(), _ptr(_i32(aperm, "aperm")), dz.data_ptr(),
                                      _ptr(_i32(zperm, "zperm")), _ptr(der), _ptr(zsign), _stream()), "gat_attn_bwd")
     return dz, der
+
+
+def gat_infer(d, x, el=None, er=None, ee=None, ew=None, slope=0.2, addend=None, scale=None, shift=None, relu=False, out=None):
+    """Inference-only GAT layer in one sweep (include/bot_gnn.h bot_gat_infer_f32):
+        out[r,h,:] = act((sum_k softmax_k(leaky(el[src] + er[r] + ee[k]))[h] * ew[k] * x[src,h,:] + addend[r,h,:]) * scale + shift)
+    x: [n_src,H,D] (strided slab); el [n_src,H] / er [n_rows,H]: row-strided views allowed; ee [nnz,H], ew [nnz]: position order;
+    addend [n_rows,H,D]; scale / shift [H*D].  el None: plain ew-weighted sum (no softmax).  Returns [n_rows,H,D]."""
+    _dev(x, el, er, ee, ew, addend, scale, shift, d.indptr)
+    x, ldx, hsx = _slab(x, "x")
+    H, D = x.shape[1], x.shape[2]
+
+    def node2(t, name):
+        if t is None:
+            return None, 0
+        _f32(t, name)
+        t = t.reshape(t.shape[0], -1) if t.dim() != 2 else t
+        if t.shape[1] != H:
+            raise BotKernelError(f"{name} must be [n,{H}], got {tuple(t.shape)}")
+        if t.stride(1) != 1 and H > 1:
+            t = t.contiguous()
+        return t, (t.stride(0) if t.shape[0] > 1 else H)
+    el, ldel = node2(el, "el")
+    er, lder = node2(er, "er")
+    if ee is not None:
+        ee = _f32(ee, "ee").reshape(-1, H).contiguous()
+    if ew is not None:
+        ew = _f32(ew, "ew").reshape(-1).contiguous()
+    lda = hsa = 0
+    if addend is not None:
+        addend, lda, hsa = _slab(addend, "addend")
+    scale = None if scale is None else _f32(scale, "scale").reshape(-1).contiguous()
+    shift = None if shift is None else _f32(shift, "shift").reshape(-1).contiguous()
+    if out is None:
+        out = torch.empty((d.n_rows, H, D), dtype=torch.float32, device=x.device)
+    out_, ldo, hso = _slab(out, "out")
+    assert out_ is out
+    ws = None
+    if d.n_long:
+        ws = torch.empty(int(_lib.bot_gat_infer_workspace_floats(d.n_slots, H, D)), dtype=torch.float32, device=x.device)
+    _check(_timed("gat_infer", (H, D, el is not None), lambda: _lib.bot_gat_infer_f32(
+        d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
+        _ptr(d.long_ptr), d.n_long, d.n_slots, x.data_ptr(), ldx, hsx, _ptr(el), ldel, _ptr(er), lder, _ptr(ee), _ptr(ew),
+        float(slope), H, D, _ptr(addend), lda, hsa, _ptr(scale), _ptr(shift), int(bool(relu)), out.data_ptr(), ldo, hso, _ptr(ws),
+        _stream())), "gat_infer")
+    return out
 
 
 def segment_sum(d, vals, perm=None):

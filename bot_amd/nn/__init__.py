@@ -335,8 +335,16 @@ class GAT(nn.Module):
         from . import fused
         h = self.input_drop(feat)
         h_last = None
+        infer = self.fuse_layers and not self.training and not torch.is_grad_enabled() and (h.is_cuda or fused.FORCE)
         for i in range(self.n_layers):
             last = i == self.n_layers - 1
+            if infer:  # evaluate(): one GEMM + one fused sweep per layer, nothing kept for a backward (bot_amd/nn/fused.py, f3)
+                epi = self.biases[-1] if last else (self.norms[i] if len(self.norms) else self.biases[i])
+                if fused.can_infer(self.convs[i], epi, self.activation, graph, self.residual, last):
+                    h = fused.gat_infer_layer(self.convs[i], epi, graph, h, relu=not last, first=i == 0)
+                    if last:
+                        return h
+                    continue
             norm = None if last else (self.norms[i] if len(self.norms) else False)
             if (self.fuse_layers and norm is not False and (h.is_cuda or fused.FORCE)
                     and fused.can_fuse(self.convs[i], norm, self.activation, graph, self.training, self.residual)):

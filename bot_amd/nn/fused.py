@@ -430,3 +430,130 @@ def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
                             H, D, conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
                             conv.attn_drop.p if training else 0.0, dropout_p if training else 0.0, bn_training, WEIGHT_KP,
                             conv._use_symmetric_norm)
+
+
+# ------------------------------------------------------------------------------------------------ inference-only forward (f3)
+# `evaluate()` (run.py:290-322) runs the stack in eval mode under no_grad once per epoch, plus once per label-reuse iteration
+# (run.py:304-308).  Nothing is needed for a backward, eval-mode BatchNorm is a per-column affine and dropout is the identity, so
+# a whole layer is ONE GEMM + ONE sweep over the in-edges (bot_gat_infer_f32): no attention weights, no sign bytes and no
+# pre-BatchNorm [N, H*D] tensor reach HBM.
+
+def _versions(*ts):
+    return tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+
+
+def _cached(owner, slot, key, make):
+    """Value derived from parameters, recomputed when a parameter was modified in place (optimizer step) or replaced."""
+    c = owner.__dict__.setdefault("_bot_infer_cache", {})
+    hit = c.get(slot)
+    if hit is None or hit[0] != key:
+        hit = c[slot] = (key, make())
+    return hit[1]
+
+
+def infer_weight(conv):
+    """Merged projection weight of the layer in the layout the GEMM wants, cached across forward calls (evaluate() calls the
+    model 1 + n_label_iters times between two optimizer steps)."""
+    key = _versions(conv.fc.weight, conv.res_fc.weight if conv.res_fc is not None else None, conv.attn_l, conv.attn_r) + (WEIGHT_KP,)
+    return _cached(conv, "wcat", key, lambda: _kp(cat_weight(conv)).detach())
+
+
+def eval_affine(mod):
+    """(scale, shift) of the stack's eval-mode epilogue in front of the activation: nn.BatchNorm1d with running statistics
+    (models.py:726-727) or the bias-only ElementWiseLinear (models.py:728-729, :734)."""
+    if isinstance(mod, nn.BatchNorm1d):
+        key = _versions(mod.weight, mod.bias, mod.running_mean, mod.running_var)
+
+        def make():
+            scale = torch.rsqrt(mod.running_var + mod.eps)
+            if mod.affine:
+                scale = scale * mod.weight
+            shift = -mod.running_mean * scale
+            if mod.affine:
+                shift = shift + mod.bias
+            return scale.contiguous(), shift.contiguous()
+        return _cached(mod, "affine", key, make)
+    return (mod.weight.detach() if mod.weight is not None else None), (mod.bias.detach() if mod.bias is not None else None)
+
+
+def can_infer(conv, epi, activation, graph, stack_residual, last) -> bool:
+    """`epi`: the module applied behind the layer (BatchNorm1d in eval mode, or a bias-only ElementWiseLinear)."""
+    if torch.is_grad_enabled() or not hasattr(conv, "fc") or conv._activation is not None or conv.training:
+        return False
+    if isinstance(epi, nn.BatchNorm1d):
+        if epi.training or not epi.track_running_stats or epi.running_mean is None:
+            return False
+    elif not (type(epi).__name__ == "ElementWiseLinear" and not epi.inplace):
+        return False
+    if not last and (activation not in (F.relu, torch.relu) or stack_residual):
+        return False
+    if last and conv._num_heads != 1:
+        return False
+    return (not (conv._use_symmetric_norm and graph.halo is not None) and (graph.halo is not None or not graph.is_block)
+            and conv._out_feats <= 256)
+
+
+class _LabelReuse:
+    """Set by `label_reuse`: the first `static_cols` input columns do not change between the forward calls made inside the
+    context (only the label columns are rewritten, run.py:304-308), so their share of the first layer's projection is
+    computed once."""
+    active = None
+
+
+class label_reuse:
+    def __init__(self, static_cols):
+        self.static_cols, self.store = int(static_cols), {}
+
+    def __enter__(self):
+        self.prev, _LabelReuse.active = _LabelReuse.active, self
+        return self
+
+    def __exit__(self, *exc):
+        _LabelReuse.active = self.prev
+        self.store.clear()
+        return False
+
+
+INFER_CALLS = 0  # number of inference-layer invocations (tests assert the path was taken)
+
+
+@torch.no_grad()
+def gat_infer_layer(conv, epi, graph, h, relu, first=False):
+    """Eval-mode `act(epi(conv(graph, h).flatten(1)))` (models.py:716-731 with dropout off; for the output layer
+    `biases[-1](conv(graph, h).mean(1))`, models.py:733-734, one head) as one GEMM + one fused sweep.  h: [N, Fin] -> [N, H*D]."""
+    from . import has_zero_in_degree
+    if not conv._allow_zero_in_degree:
+        assert not has_zero_in_degree(graph), "0-in-degree nodes (models.py:477-479)"
+    global INFER_CALLS
+    INFER_CALLS += 1
+    H, D = conv._num_heads, conv._out_feats
+    HD, N = H * D, h.shape[0]
+    has_res, has_er = conv.res_fc is not None, conv.attn_r is not None
+    W = infer_weight(conv)                                              # [K, P] or [P, K]
+    ctx = _LabelReuse.active
+    F0 = ctx.static_cols if (ctx is not None and first and 0 < ctx.static_cols < h.shape[1]) else 0
+    if F0:
+        Wk = W if WEIGHT_KP else W.t()
+        key = (id(conv),) + _versions(W)
+        if ctx.store.get("key") != key:                                 # the static columns' share of the projection
+            ctx.store["key"], ctx.store["base"] = key, torch.mm(h[:, :F0], Wk[:F0])
+        out = torch.addmm(ctx.store["base"], h[:, F0:], Wk[F0:])
+    else:
+        out = torch.mm(h, W) if WEIGHT_KP else torch.mm(h, W.t())       # [N, P] = [ft | res | el | er | pad]
+    c = 2 * HD if has_res else HD
+    if graph.halo is not None:                                          # partitioned: owned + halo source rows [ft | el]
+        ext = _extend_forward(graph, out, HD, H, c)
+        ft, el = ext[:, :HD], ext[:, HD:HD + H]
+    else:
+        ft, el = out[:, :HD], out[:, c:c + H]
+    er = out[:, c + H:c + 2 * H] if has_er else None
+    ew = None
+    if conv._use_symmetric_norm:                                        # models.py:500-505, :550-555 folded into the edge weights
+        s_out, w_e = sym_scales(graph)
+        el = el * s_out.unsqueeze(1)
+        ew = w_e
+    scale, shift = eval_affine(epi)
+    res = out[:, HD:2 * HD].unflatten(1, (H, D)) if has_res else None
+    y = _C.gat_infer(graph.csc, ft.unflatten(1, (H, D)), el, er, None, ew, conv.leaky_relu.negative_slope, addend=res,
+                     scale=scale, shift=shift, relu=relu)
+    return y.view(N, HD)

@@ -83,15 +83,21 @@ def train_step(model, graph, feat, labels, train_idx, val_idx, test_idx, optimiz
 def evaluate(model, graph, feat, labels, train_idx, val_idx, test_idx, *, use_labels=True, n_label_iters=0, loss="logit",
              n_classes=None):
     """run.py:290-322 — eval-mode forward with every training label as input, optional label reuse."""
+    import contextlib
+    from .nn import fused
     model.eval()
+    n_static = feat.shape[1]
     if use_labels:
         feat = add_labels(feat, labels, train_idx, n_classes)
-    pred = model(graph, feat)
-    if n_label_iters > 0:
-        unlabel_idx = torch.cat([val_idx, test_idx])
-        for _ in range(n_label_iters):
-            feat[unlabel_idx, -n_classes:] = F.softmax(pred[unlabel_idx], dim=-1)
-            pred = model(graph, feat)
+    # between the 1 + n_label_iters forward calls only the label columns change (run.py:304-308): the inference path computes
+    # the feature columns' share of the first projection once
+    with (fused.label_reuse(n_static) if (use_labels and n_label_iters > 0) else contextlib.nullcontext()):
+        pred = model(graph, feat)
+        if n_label_iters > 0:
+            unlabel_idx = torch.cat([val_idx, test_idx])
+            for _ in range(n_label_iters):
+                feat[unlabel_idx, -n_classes:] = F.softmax(pred[unlabel_idx], dim=-1)
+                pred = model(graph, feat)
     losses = tuple(compute_loss(pred[i], labels[i], loss) for i in (train_idx, val_idx, test_idx))
     accs = tuple(compute_acc(pred[i], labels[i]) for i in (train_idx, val_idx, test_idx))
     return accs + losses + (pred,)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 2
+#define BOT_ABI_VERSION 3
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -228,6 +228,36 @@ int bot_gat_attn_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t 
                          float slope, int32_t H,
                          const float* a, const float* da, const int32_t* aperm,
                          float* dz, const int32_t* zperm, float* der, const uint8_t* zsign, bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Inference-only GAT layer: what `evaluate()` (src/no-sampling/run.py:290-322) needs from a layer — logits,
+ * leaky-ReLU, per-destination softmax (models.py:517-544), aggregation (models.py:547), residual (models.py:558-560), then the
+ * stack's eval-mode BatchNorm / bias and ReLU (models.py:726-734) — in ONE sweep over the in-edges, with nothing edge-sized
+ * and no pre-BatchNorm [n,H*D] tensor written:
+ *
+ *   z[k,h]     = el[indices[k]*ldel + h] (+ er[r*lder + h]) (+ ee[k*H + h]);   e = leaky_relu(z, slope)
+ *   a[k,h]     = softmax over the positions k of row r of e[k,h]
+ *   out[r,h,:] = act( (sum_k a[k,h] * ew[k] * x[indices[k],h,:] + addend[r,h,:]) * scale[h*D+:] + shift[h*D+:] )
+ *
+ * el / er are node arrays with a row stride (they may be columns of the projection GEMM's output); ee [nnz,H] and ew [nnz]
+ * are in position order; er, ee, ew, addend, scale, shift may each be NULL; relu != 0 applies max(.,0).  el == NULL (then er
+ * and ee must be NULL) drops the softmax: out = act((sum_k ew[k] x[indices[k]] + addend) * scale + shift), the GraphConv
+ * aggregation with its degree normalisation folded into ew (models.py:351-395).  Rows without in-edges give act(addend*scale
+ * + shift).  Long rows (row plan) take a (max, 1/sum) pass first and are combined in slot order; `workspace` holds
+ * bot_gat_infer_workspace_floats(n_slots, H, D) floats (may be NULL without long rows).  D <= 1024 / 512 / 256 by alignment.
+ * Deterministic, no atomics.  Same value as bot_gat_attn_fwd_f32 + bot_spmm_f32 up to fp32 rounding of the online softmax.
+ * ------------------------------------------------------------------------------------------- */
+int64_t bot_gat_infer_workspace_floats(int64_t n_slots, int32_t H, int32_t D);
+int bot_gat_infer_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                      const int32_t* items, int64_t n_items,
+                      const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, int64_t n_slots,
+                      const float* x, int64_t ldx, int64_t hsx,
+                      const float* el, int64_t ldel, const float* er, int64_t lder,
+                      const float* ee, const float* ew, float slope, int32_t H, int32_t D,
+                      const float* addend, int64_t lda, int64_t hsa,
+                      const float* scale, const float* shift, int32_t relu,
+                      float* out, int64_t ldo, int64_t hso,
+                      float* workspace, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Segment sum of edge values.  Replaces update_all(fn.copy_e, fn.sum) — copy_e_sum

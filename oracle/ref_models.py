@@ -109,11 +109,12 @@ def graphconv_forward(g: CooGraph, feat, weight, bias, norm="both", activation=N
 
 def gatconv_forward(g: CooGraph, feat, fc_weight, attn_l, attn_r=None, res_fc_weight=None, *,
                     num_heads, out_feats, negative_slope=0.2, use_symmetric_norm=False,
-                    keep_eids=None, allow_zero_in_degree=False, activation=None, return_attention=False):
+                    keep_eids=None, allow_zero_in_degree=False, activation=None, return_attention=False, leaky=None):
     """GATConv.forward (non-tuple, non-block branch) — src/no-sampling/models.py:475-566.
 
     `keep_eids` restates the training-time edge-drop branch :528-539 for a *given* kept-edge set
-    (the reference draws it with randperm)."""
+    (the reference draws it with randperm).  `leaky` (test infrastructure, default None = F.leaky_relu): a callable
+    (e, slope) -> leaky_relu(e) that may take the 0/1 side of every logit from outside (tests/full_size.py:KinkGates)."""
     n = g.num_nodes
     if not allow_zero_in_degree and bool((R.in_degrees(g.dst, n) == 0).any()):  # :477-479
         raise ZeroInDegreeError("0-in-degree nodes")
@@ -127,7 +128,7 @@ def gatconv_forward(g: CooGraph, feat, fc_weight, attn_l, attn_r=None, res_fc_we
         e = _u_add_v(g, el, er)
     else:  # :525
         e = _u_add_v(g, el, None)
-    e = F.leaky_relu(e, negative_slope)  # :526
+    e = F.leaky_relu(e, negative_slope) if leaky is None else leaky(e, negative_slope)  # :526
     a = _edge_softmax(g, e, keep_eids)  # :528-539 (edge drop) / :544
     rst = _u_mul_e_sum(g, ft, a)  # :547-548
     if use_symmetric_norm:  # :550-555  (+0.5)
@@ -167,7 +168,7 @@ def gcn_forward(g: CooGraph, feat, sd: dict, *, n_layers, norm="none", norm_adj=
 
 def gat_forward(g: CooGraph, feat, sd: dict, *, n_layers, n_heads, n_hidden, n_classes, norm="none",
                 non_interactive_attn=False, use_symmetric_norm=False, linear=False, residual=False,
-                activation=F.relu, training=False, keep_eids=None):
+                activation=F.relu, training=False, keep_eids=None, leaky=None):
     """GAT.forward — src/no-sampling/models.py:709-736 (dropout rates 0)."""
     h, h_last = feat, None
     for i in range(n_layers):
@@ -178,7 +179,7 @@ def gat_forward(g: CooGraph, feat, sd: dict, *, n_layers, n_heads, n_hidden, n_c
             sd[f"convs.{i}.attn_r"] if non_interactive_attn else None,
             sd[f"convs.{i}.res_fc.weight"] if linear else None,
             num_heads=heads, out_feats=out, use_symmetric_norm=use_symmetric_norm,
-            keep_eids=None if keep_eids is None else keep_eids[i])
+            keep_eids=None if keep_eids is None else keep_eids[i], leaky=leaky)
         if i < n_layers - 1:
             if residual and h_last is not None:  # :721-723
                 h = h + h_last

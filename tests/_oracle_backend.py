@@ -129,6 +129,35 @@ def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der, 
     return dz, der
 
 
+def gat_infer(d, x, el=None, er=None, ee=None, ew=None, slope=0.2, addend=None, scale=None, shift=None, relu=False, out=None):
+    """include/bot_gnn.h bot_gat_infer_f32, restated with plain torch ops."""
+    H, D = x.shape[1], x.shape[2]
+    rows = _rows(d)
+    if el is not None:
+        _, e = _logits(d, el.reshape(-1, H), None if er is None else er.reshape(-1, H), None if ee is None else ee.reshape(-1, H),
+                       None, slope, H)
+        a = R.edge_softmax(rows, d.n_rows, e)
+    else:
+        a = torch.ones(d.nnz, H)
+    if ew is not None:
+        a = a * ew.reshape(-1, 1)
+    r = torch.zeros(d.n_rows, H, D).index_add(0, rows, x[d.indices.long()] * a.unsqueeze(-1))
+    if addend is not None:
+        r = r + addend
+    r = r.reshape(d.n_rows, H * D)
+    if scale is not None:
+        r = r * scale
+    if shift is not None:
+        r = r + shift
+    if relu:
+        r = torch.relu(r)
+    r = r.view(d.n_rows, H, D)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
 def segment_sum(d, vals, perm=None):
     return torch.zeros(d.n_rows, vals.shape[1]).index_add(0, _rows(d), vals[_perm(perm, d.nnz)])
 
@@ -203,7 +232,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

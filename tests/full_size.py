@@ -28,32 +28,48 @@ def init_state(cfg, fin, n_classes, seed=0):
     return {k: v.detach().clone() for k, v in model.state_dict().items()}
 
 
-class GateAct:
-    """ReLU with the 0/1 gates GIVEN (one uint8/bool [N, F] tensor per hidden layer, taken from the HIP run) instead of derived
-    from the oracle's own pre-activations.  The stack has a ReLU behind every hidden BatchNorm (models.py:726-730); a
-    pre-activation within fp32 rounding of zero can fall on either side in two fp32 implementations that sum in different
-    orders, and the node's whole contribution then enters or leaves one row of the layer's weight gradients (~1/sqrt(N) of the
-    row, far above 1e-4: two CPU restatements of this same step, oracle/ref_ops.py vs oracle/c_ops.py, differ by 0.75 % on such
-    a row and by 1e-6 elsewhere).  Evaluating the oracle AT THE HIP RUN'S GATES removes exactly that ambiguity and nothing
-    else: the forward changes only where |pre-activation| is rounding noise (recorded in `stats` and bounded by the caller),
-    and the gradients of the two implementations become comparable entry by entry."""
+class KinkGates:
+    """The piecewise-linear activations of the stack evaluated with the 0/1 side of every kink GIVEN (taken from the HIP run)
+    instead of derived from the oracle's own pre-activations: `relu` for the ReLU behind every hidden BatchNorm
+    (models.py:726-730), `leaky` for the leaky-ReLU of the attention logits (models.py:526).
 
-    def __init__(self, gates):
-        self.gates, self.i, self.stats = gates, 0, []
+    Why: a pre-activation within fp32 rounding of zero can fall on either side in two fp32 implementations that sum in
+    different orders.  The forward value barely moves (it is ~0 either way) but the derivative jumps: a hidden unit's whole
+    contribution enters or leaves one row of the layer's weight gradients (~1/sqrt(N) of the row, far above 1e-4), and an
+    attention logit of the reference's default scoring depends on the SOURCE node only (models.py:525), so one node's sign
+    flips the derivative on all its out-edges at once.  Two CPU restatements of this step (oracle/ref_ops.py vs
+    oracle/c_ops.py) differ by 0.75 % on such a row and agree to 2.6e-6 at equal gates; both are within 4e-6 of an fp64 run
+    at equal gates.  Evaluating the oracle AT THE TESTED RUN'S GATES removes exactly that ambiguity and nothing else: the
+    forward changes only where |pre-activation| is rounding noise (recorded in `stats`, bounded by the caller), and the
+    gradients of the two implementations become comparable entry by entry."""
 
-    def __call__(self, h):
-        g = self.gates[self.i % len(self.gates)]
-        self.i += 1
-        own = h.detach() > 0
-        diff = own != g.bool()
-        self.stats.append({"differ": int(diff.sum()), "of": diff.numel(),
+    def __init__(self, relu_gates, leaky_gates=None):
+        self.rg, self.lg, self.ri, self.li, self.stats = relu_gates, leaky_gates, 0, 0, []
+
+    def _note(self, kind, h, g):
+        diff = (h.detach() > 0) != g
+        self.stats.append({"kind": kind, "differ": int(diff.sum()), "of": diff.numel(),
                            "max_abs_preact_where_differ": float(h.detach().abs()[diff].max()) if bool(diff.any()) else 0.0})
+
+    def relu(self, h):
+        g = self.rg[self.ri % len(self.rg)].bool()
+        self.ri += 1
+        self._note("relu", h, g)
         return h * g.to(h.dtype)
+
+    def leaky(self, e, slope):
+        if self.lg is None:
+            return F.leaky_relu(e, slope)
+        g = self.lg[self.li % len(self.lg)].bool().view(e.shape)
+        self.li += 1
+        self._note("leaky", e, g)
+        return torch.where(g, e, e * slope)
 
 
 def oracle_step(src, dst, n, feat, labels, train_idx, mask, sd, cfg, n_classes, loss="loge", threads=None, steps=1, gates=None):
     """One train step (forward + loss + backward, training-mode BatchNorm, no dropout) on the oracle's C kernels.
-    `gates`: see GateAct (None: plain ReLU).  Returns (pred [N,C], {param name: grad}, [seconds per step], threads, gate stats)."""
+    `gates`: (relu gates, leaky gates) as returned by hip_step, see KinkGates (None: the oracle's own).
+    Returns (pred [N,C], {param name: grad}, [seconds per step], threads, gate stats)."""
     from oracle import c_ops
     from oracle import ref_models as RM
     if threads is None:
@@ -63,52 +79,70 @@ def oracle_step(src, dst, n, feat, labels, train_idx, mask, sd, cfg, n_classes, 
     g = c_ops.CGraph(src, dst, n)
     sdg = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
     names = [k for k, v in sdg.items() if v.requires_grad]
-    times, pred, grads, act = [], None, None, F.relu
+    times, pred, grads, kg = [], None, None, None
     for _ in range(steps):
         t0 = time.perf_counter()
-        act = F.relu if gates is None else GateAct(gates)
+        kg = None if gates is None else KinkGates(*gates)
         x = RM.add_labels(feat, labels, train_idx[mask], n_classes)
         pred = RM.gat_forward(g, x, sdg, n_layers=cfg["n_layers"], n_heads=cfg["n_heads"], n_hidden=cfg["n_hidden"],
                               n_classes=n_classes, norm=cfg["norm"], non_interactive_attn=cfg["non_interactive_attn"],
                               use_symmetric_norm=cfg["use_symmetric_norm"], linear=cfg["linear"], residual=cfg["residual"],
-                              activation=act, training=True)
+                              activation=F.relu if kg is None else kg.relu, leaky=None if kg is None else kg.leaky, training=True)
         out = RM.compute_loss(pred[train_idx[~mask]], labels[train_idx[~mask]], loss)
         grads = torch.autograd.grad(out, [sdg[k] for k in names])
         times.append(time.perf_counter() - t0)
-    return pred.detach(), dict(zip(names, grads)), times, int(c_ops.num_threads()), (act.stats if gates is not None else None)
+    return pred.detach(), dict(zip(names, grads)), times, int(c_ops.num_threads()), (kg.stats if kg is not None else None)
 
 
 @contextlib.contextmanager
-def tap_hidden():
-    """Records the output of every hidden layer's BatchNorm+ReLU(+dropout) epilogue of a bot_amd.nn stack while active — the
-    fused layer node (bot_amd.nn.fused.gat_hidden_layer) and the modular epilogue (bot_amd.nn._epilogue) alike — by wrapping
-    those two functions from the outside (test code; the product has no hook)."""
+def tap_kinks():
+    """While active, records from a bot_amd.nn stack (a) the output of every hidden layer's BatchNorm+ReLU(+dropout) epilogue
+    — the fused layer node (bot_amd.nn.fused.gat_hidden_layer) and the modular epilogue (bot_amd.nn._epilogue) alike — and (b)
+    the sign of every attention logit handed to the fused attention kernel (bot_amd._C.gat_attn_fwd), recomputed from the
+    kernel's own operands in the kernel's order of additions, in edge-id order.  Wraps those three functions from the outside
+    (test code; the product has no hook)."""
     import bot_amd.nn as bnn
+    from bot_amd import _C
     from bot_amd.nn import fused
-    taps = []
-    orig_e, orig_f = bnn._epilogue, fused.gat_hidden_layer
+    relu_taps, leaky_taps = [], []
+    orig_e, orig_f, orig_a = bnn._epilogue, fused.gat_hidden_layer, _C.gat_attn_fwd
 
     def epi(h, norm, activation, dropout, training):
         y = orig_e(h, norm, activation, dropout, training)
-        taps.append(y.detach())
+        relu_taps.append((y.detach() > 0).to(torch.uint8).cpu())
         return y
 
     def hid(conv, bn, graph, h, dropout_p, training):
         y = orig_f(conv, bn, graph, h, dropout_p, training)
         if bn is not None:
-            taps.append(y.detach())
+            relu_taps.append((y.detach() > 0).to(torch.uint8).cpu())
         return y
 
-    bnn._epilogue, fused.gat_hidden_layer = epi, hid
+    def attn(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None):
+        with torch.no_grad():
+            deg = (d.indptr[1:] - d.indptr[:-1]).long()
+            z = torch.zeros((d.nnz, H), dtype=torch.float32, device=d.indptr.device)
+            if er is not None:
+                z = z + er.reshape(-1, H)[torch.repeat_interleave(torch.arange(d.n_rows, device=deg.device), deg)]
+            if el is not None:
+                z = z + el.reshape(-1, H)[d.indices.long()]
+            if ee is not None:
+                z = z + (ee.reshape(-1, H) if eperm is None else ee.reshape(-1, H)[eperm.long()])
+            gate = torch.empty((d.nnz, H), dtype=torch.uint8, device=z.device)
+            gate[d.eid.long()] = (z > 0).to(torch.uint8)
+            leaky_taps.append(gate.cpu())
+        return orig_a(d, el, er, ee, eperm, keep, slope, H, aperm, zsign)
+
+    bnn._epilogue, fused.gat_hidden_layer, _C.gat_attn_fwd = epi, hid, attn
     try:
-        yield taps
+        yield relu_taps, leaky_taps
     finally:
-        bnn._epilogue, fused.gat_hidden_layer = orig_e, orig_f
+        bnn._epilogue, fused.gat_hidden_layer, _C.gat_attn_fwd = orig_e, orig_f, orig_a
 
 
 def hip_step(g, feat, labels, train_idx, mask, sd, cfg, n_classes, loss="loge", fuse=True):
     """The same step on the HIP path: bot_amd.nn.GAT + bot_amd.train.forward_backward on the device of `g`.
-    Returns (pred, {param: grad}, [ReLU gates of the hidden layers as CPU uint8 tensors])."""
+    Returns (pred, {param: grad}, (ReLU gates per hidden layer, leaky-ReLU gates per layer [E,H] in edge-id order))."""
     from bot_amd import nn as bnn
     from bot_amd import train as T
     dev = feat.device
@@ -117,18 +151,17 @@ def hip_step(g, feat, labels, train_idx, mask, sd, cfg, n_classes, loss="loge", 
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).train()
     model.fuse_layers = fuse
-    with tap_hidden() as taps:
+    with tap_kinks() as (relu_gates, leaky_gates):
         _, pred, _ = T.forward_backward(model, g, feat, labels, train_idx, train_idx[:0], train_idx[:0], use_labels=True,
                                         loss=loss, n_classes=n_classes, mask=mask.to(dev))
-    assert len(taps) == cfg["n_layers"] - 1
-    gates = [(t > 0).to(torch.uint8).cpu() for t in taps]
-    return pred.detach(), {k: p.grad.detach() for k, p in model.named_parameters()}, gates
+    assert len(relu_gates) == cfg["n_layers"] - 1 and len(leaky_gates) == cfg["n_layers"]
+    return pred.detach(), {k: p.grad.detach() for k, p in model.named_parameters()}, (relu_gates, leaky_gates)
 
 
 def compare(pred_hip, grads_hip, pred_ref, grads_ref, gate_stats=None, tol=1e-4):
     """max |logit diff| over all nodes; the worst parameter-gradient error relative to that gradient's largest entry; the
-    number of gradient entries beyond `tol` of it; and (with gates given to the oracle) how many ReLU gates the two runs
-    would have set differently and how large the pre-activation was there."""
+    number of gradient entries beyond `tol` of it; and (with gates given to the oracle) how many ReLU / leaky-ReLU gates the two
+    runs would have set differently and how large the pre-activation was there."""
     d = float((pred_hip.detach().cpu().double() - pred_ref.double()).abs().max())
     worst, which, over, total = 0.0, None, 0, 0
     for k, gr in grads_ref.items():
@@ -142,7 +175,9 @@ def compare(pred_hip, grads_hip, pred_ref, grads_ref, gate_stats=None, tol=1e-4)
     r = {"max_abs_logit_diff": d, "max_rel_grad_err": worst, "worst_grad": which, "grad_entries_over_1e-4": over,
          "grad_entries": total, "n": int(pred_ref.shape[0]), "logit_scale": float(pred_ref.abs().max())}
     if gate_stats is not None:
-        r["relu_gates_differing"] = sum(s["differ"] for s in gate_stats)
-        r["relu_gates"] = sum(s["of"] for s in gate_stats)
+        for kind in ("relu", "leaky"):
+            st = [s for s in gate_stats if s["kind"] == kind]
+            r[f"{kind}_gates_differing"] = sum(s["differ"] for s in st)
+            r[f"{kind}_gates"] = sum(s["of"] for s in st)
         r["max_abs_preact_at_differing_gate"] = max(s["max_abs_preact_where_differ"] for s in gate_stats)
     return r

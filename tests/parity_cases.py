@@ -401,8 +401,12 @@ def check_train_step_golden(golden, device):
                 np.testing.assert_allclose(v.cpu().numpy(), c[f"p1.{k}"], rtol=2e-3, atol=2e-4, err_msg=k)
         # evaluate() — run.py:290-322 — on exactly the reference's post-step state (removes the optimizer's rounding)
         model = load_params(model, c, device, prefix="p1.")
+        from bot_amd.nn import fused
+        calls = fused.INFER_CALLS
         ev = T.evaluate(model, g, feat, labels, tr, va, te, use_labels=True, n_label_iters=int(n_label_iters), loss=loss_name,
                         n_classes=C)
+        if kind == "gat" and (str(device) != "cpu" or fused.FORCE):  # evaluate() takes the inference-only layers (f3)
+            assert fused.INFER_CALLS - calls == 2 * (1 + int(n_label_iters)), (fused.INFER_CALLS, calls)
         np.testing.assert_allclose(np.array(ev[:3]), c["eval_accs"], atol=1e-6)
         np.testing.assert_allclose(np.array([float(v) for v in ev[3:6]]), c["eval_losses"], rtol=1e-4, atol=1e-5)
         fwd_close(ev[6], c["eval_pred"])

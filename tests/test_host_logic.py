@@ -196,4 +196,4 @@ def test_whole_step_against_c_oracle_small(cpu_backend, monkeypatch):
         rp, rg, _, _, gs = FS.oracle_step(s, d, n, ds.feat, ds.labels, ds.train_idx, mask, sd, FS.GAT_ARXIV, C, gates=gates)
         r = FS.compare(pred, grads, rp, rg, gs)
         assert r["max_abs_logit_diff"] <= PC.FWD_ATOL and r["max_rel_grad_err"] <= PC.GRAD_RTOL, r
-        assert r["max_abs_preact_at_differing_gate"] <= 1e-4 and r["relu_gates_differing"] <= 1e-5 * r["relu_gates"], r
+        assert r["max_abs_preact_at_differing_gate"] <= 1e-4 and r["relu_gates_differing"] <= 1e-5 * r["relu_gates"] and r["leaky_gates_differing"] <= 1e-5 * r["leaky_gates"], r
