@@ -148,6 +148,8 @@ def main():
     np.savez_compressed(os.path.join(args.out, "graphconv.npz"), **out)
 
     # ------------------------------------------------------------------ GATConv (models.py:416-566)
+    # every section draws its inputs from its OWN generator: adding or reordering sections never changes another file
+    gen = torch.Generator().manual_seed(200)
     out = {}
     case = 0
     real_randperm = torch.randperm
@@ -201,6 +203,7 @@ def main():
     np.savez_compressed(os.path.join(args.out, "gatconv.npz"), **out)
 
     # ------------------------------------------------------------------ stacks GCN / GAT (models.py:569-736)
+    gen = torch.Generator().manual_seed(300)
     out = {}
     case = 0
     stack_cfgs = [
@@ -260,6 +263,7 @@ def main():
     np.savez_compressed(os.path.join(args.out, "stacks.npz"), **out)
 
     # ------------------------------------------------------------------ proteins GATConv / GAT
+    gen = torch.Generator().manual_seed(400)
     out = {}
     case = 0
     for gname in ("g64", "g300"):
@@ -328,6 +332,7 @@ def main():
     # ------------------------------------------------------------------ products GAT stack (src/ogbn-products/models.py:170-265)
     if args.only in ("", "products"):
         PR = _import_ref("ogbn-products", "models", "ref_products_models")
+        gen = torch.Generator().manual_seed(420)
         out = {}
         case = 0
         for residual, edge_emb, training in ((False, 0, True), (True, 0, True), (True, 16, True), (False, 0, False)):
@@ -359,18 +364,23 @@ def main():
             return
 
     # ------------------------------------------------------------------ callers: run.py add_labels/compute_loss/train
+    gen = torch.Generator().manual_seed(500)
     out = {}
     RUN.device = torch.device("cpu")
-    for ci, (gname, kind, optim_name, loss_name, epoch) in enumerate((
-            ("g64", "gat", "rmsprop", "loge", 25), ("g300", "gcn", "adam", "savage", 1),
-            ("g64", "gat", "rmsprop", "logit", 51))):
+    # RMSprop warm-up (run.py:246-249, 351-352) at epochs 1 / 25 / 50 (last warm-up epoch) / 51 (first epoch past it);
+    # label reuse (run.py:274-279, 304-308) once on a GCN and once on a GAT
+    train_cases = (("g64", "gat", "rmsprop", "loge", 25, 0), ("g300", "gcn", "adam", "savage", 1, 1),
+                   ("g64", "gat", "rmsprop", "logit", 51, 0), ("g300", "gat", "rmsprop", "loge", 50, 1),
+                   ("g64", "gcn", "rmsprop", "logit", 1, 0))
+    out["n_cases"] = np.int64(len(train_cases))
+    for ci, (gname, kind, optim_name, loss_name, epoch, label_iters) in enumerate(train_cases):
         g = G(gname)
         n, fin, C = g.number_of_nodes(), 7, 4
         RUN.n_node_feats, RUN.n_classes, RUN.n_edge_feats = fin, C, 0
         a = types.SimpleNamespace(labels=True, activation="relu", model=kind, n_hidden=6, n_layers=2, n_heads=2,
                                   norm="batch", dropout=0.0, input_drop=0.0, attn_drop=0.0, edge_drop=0.0,
                                   non_interactive_attn=False, norm_adj="symm" if kind == "gcn" else "rw",
-                                  linear=True, residual=False, mask_rate=0.5, n_label_iters=1 if ci == 1 else 0,
+                                  linear=True, residual=False, mask_rate=0.5, n_label_iters=label_iters,
                                   loss=loss_name, optimizer=optim_name, lr=0.01, wd=0.0)
         torch.manual_seed(5000 + ci)
         model = RUN.build_model(a)
@@ -402,6 +412,7 @@ def main():
         out[k + "eval_losses"] = np.array([float(v) for v in ev[3:6]])
         out[k + "eval_pred"] = t2n(ev[6])
     RUN.n_classes = 5
+    gen = torch.Generator().manual_seed(510)
     x = torch.randn(40, 5, generator=gen)
     y = torch.randint(0, 5, (40, 1), generator=gen)
     out["loss.x"], out["loss.y"] = t2n(x), t2n(y)

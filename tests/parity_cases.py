@@ -254,7 +254,7 @@ def check_stacks_golden(golden, device, fuse=True):
     """`fuse=True`: hidden GAT layers run as the single fused autograd node where their options allow
     (bot_amd/nn/fused.py); `fuse=False`: the modular path everywhere.  Both must reproduce the reference."""
     from bot_amd.nn import fused
-    calls0 = fused.CALLS
+    calls0, infer_seen = fused.CALLS, [0]
     for c in golden.cases("stacks"):
         gname, kind, training, cfg = (str(x) for x in c["meta"])
         cfg = ast.literal_eval(cfg)
@@ -273,7 +273,21 @@ def check_stacks_golden(golden, device, fuse=True):
         grad_close(feat.grad, c["dfeat"], 3e-4)
         for k, p in model.named_parameters():
             grad_close(p.grad, c[f"g.{k}"], 3e-4)
+        if not bool(int(training)):
+            # f3: the same eval-mode logits from the inference-only path (`evaluate()` runs the stack under no_grad, run.py:291):
+            # one GEMM + one fused sweep per layer where the stack's options allow, the generic path otherwise
+            n0 = fused.INFER_CALLS
+            with torch.no_grad():
+                fwd_close(model(g, feat.detach()), c["logits"])
+            took = fused.INFER_CALLS - n0
+            if kind == "gat" and fuse and (str(device) != "cpu" or fused.FORCE):
+                assert took == (cfg["n_layers"] if not cfg["residual"] else 1), (took, cfg)   # stack residual: output layer only
+                infer_seen[0] += took
+            else:
+                assert took == 0
     assert (fused.CALLS - calls0 >= 8) if fuse else (fused.CALLS == calls0)
+    if fuse and (str(device) != "cpu" or fused.FORCE):
+        assert infer_seen[0] >= 6
 
 
 # ---------------------------------------------------------------------------------------------- edge-feature GAT (config 4/5)
@@ -368,7 +382,7 @@ def check_train_step_golden(golden, device):
     from bot_amd import train as T
     f = golden.file("train")
     from tests._golden import Case
-    for ci in range(3):
+    for ci in range(int(f["n_cases"])):
         pre = f"t{ci}."
         c = Case({k[len(pre):]: v for k, v in f.items() if k.startswith(pre)})
         gname, kind, optim_name, loss_name, epoch, n_label_iters = (str(x) for x in c["meta"])

@@ -648,3 +648,111 @@ def test_full_size_config2_logits_and_grads_against_c_oracle(fuse):
     assert r["max_abs_logit_diff"] <= PC.FWD_ATOL, r
     assert r["max_rel_grad_err"] <= PC.GRAD_RTOL, r
     assert r["max_abs_preact_at_differing_gate"] <= 1e-4 and r["relu_gates_differing"] <= 1e-5 * r["relu_gates"] and r["leaky_gates_differing"] <= 1e-5 * r["leaky_gates"], r
+
+
+# ---------------------------------------------------------------------------------------------- f3: inference-only GAT layer
+def test_gat_infer_kernel_against_unfused_kernels_and_oracle(golden):
+    """bot_gat_infer_f32 (logits + softmax + aggregation + residual + affine + ReLU in one sweep, nothing edge-sized written)
+    against (a) the training kernels it replaces in eval mode — bot_gat_attn_fwd_f32 + bot_spmm_f32 + torch epilogue — on a
+    power-law graph with long rows at the default chunk and on a small graph with chunk 8 (multi-slot rows everywhere), over
+    head / width shapes that select every layout (all-heads with 1, 2, 4 heads per chunk and 2 chunks per head; head-major
+    groups of 8..64 lanes and up to 4 chunks), aligned and misaligned strides; and (b) the oracle's restatement of the header
+    contract (tests/_oracle_backend.gat_infer, plain torch ops on the CPU)."""
+    from tests import _oracle_backend as OB
+    n = 20000
+    rs, rd = _powerlaw(n, 150000, 5)
+    s, d = R.preprocess_edges(rs, rd, n)
+    big = bot_amd.Graph(s, d, n).to(DEV)
+    s2, d2, n2 = golden.graph("g300")
+    small_cpu = bot_amd.Graph(s2, d2, n2, chunk=8)
+    small = small_cpu.to(DEV)
+    assert big.csc.n_long > 0 and small.csc.n_long > 10
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(3, 250), (1, 40), (4, 120), (6, 80), (2, 64), (8, 16), (1, 128), (3, 7), (2, 250), (5, 33), (1, 1000), (4, 30), (1, 3)]
+    kernels = set()
+    for g, gc in ((big, None), (small, small_cpu)):
+        N, E = g.number_of_nodes(), g.number_of_edges()
+        for i, (H, D) in enumerate(shapes):
+            F = H * D
+            # even cases: row stride a multiple of 4 floats (16-byte lanes); odd cases: an odd stride forces the 4-byte instances
+            pad = (-(F + H)) % 4 if i % 2 == 0 else (3 if (F + H + 3) % 2 else 4)
+            buf = torch.randn(N, F + H + pad, generator=gen).to(DEV)
+            x = buf[:, :F].unflatten(1, (H, D))                 # strided slab, as in the merged GEMM output
+            el = buf[:, F:F + H]                                 # a column view, row stride F + H + pad
+            er = torch.randn(N, H, generator=gen).to(DEV) if i % 3 != 1 else None
+            ee = torch.randn(E, H, generator=gen).to(DEV) if i % 4 == 2 else None
+            ew = (torch.rand(E, generator=gen) + 0.5).to(DEV) if i % 3 == 0 else None
+            addend = torch.randn(N, H, D, generator=gen).to(DEV) if i % 2 == 0 else None
+            scale = (torch.rand(F, generator=gen) + 0.5).to(DEV) if i % 5 != 4 else None
+            shift = torch.randn(F, generator=gen).to(DEV) if i % 3 != 2 else None
+            relu = i % 2 == 1
+            out = _C.gat_infer(g.csc, x, el, er, ee, ew, 0.2, addend=addend, scale=scale, shift=shift, relu=relu)
+            kernels.add(_C._lib.bot_last_kernel().decode())
+            a = _C.gat_attn_fwd(g.csc, el.contiguous(), er, ee, None, None, 0.2, H, None)
+            if ew is not None:
+                a = a * ew.unsqueeze(1)
+            ref = _C.spmm(g.csc, x, a, None, addend=addend).reshape(N, F)
+            if scale is not None:
+                ref = ref * scale
+            if shift is not None:
+                ref = ref + shift
+            if relu:
+                ref = torch.relu(ref)
+            assert torch.allclose(out.reshape(N, F), ref, rtol=1e-4, atol=3e-5), (H, D, float((out.reshape(N, F) - ref).abs().max()))
+            if gc is not None:                                   # the oracle, independent of every HIP kernel
+                cpu = lambda t: None if t is None else t.cpu()
+                oref = OB.gat_infer(gc.csc, x.cpu(), cpu(el), cpu(er), cpu(ee), cpu(ew), 0.2, addend=cpu(addend), scale=cpu(scale),
+                                    shift=cpu(shift), relu=relu)
+                PC.fwd_close(out, oref.numpy(), 1e-4)
+            # el None: plain (ew-weighted) sum, the GraphConv aggregation
+            out2 = _C.gat_infer(g.csc, x, None, None, None, ew, addend=addend, scale=scale, shift=shift, relu=relu)
+            w1 = (ew if ew is not None else torch.ones(E, device=DEV)).unsqueeze(1).expand(E, H).contiguous()
+            ref2 = _C.spmm(g.csc, x, w1, None, addend=addend).reshape(N, F)
+            ref2 = ref2 * scale if scale is not None else ref2
+            ref2 = ref2 + shift if shift is not None else ref2
+            ref2 = torch.relu(ref2) if relu else ref2
+            assert torch.allclose(out2.reshape(N, F), ref2, rtol=1e-4, atol=3e-5), (H, D)
+    assert any("rows_kernel" in k for k in kernels) and any("heads_kernel" in k for k in kernels), kernels
+    # isolated destination: no in-edges -> act(addend * scale + shift)
+    g0 = bot_amd.Graph(torch.tensor([0, 1]), torch.tensor([1, 1]), 3).to(DEV)
+    x = torch.randn(3, 2, 8, device=DEV)
+    ad = torch.randn(3, 2, 8, device=DEV)
+    o = _C.gat_infer(g0.csc, x, torch.randn(3, 2, device=DEV), None, None, None, addend=ad)
+    assert torch.equal(o[0], ad[0]) and torch.equal(o[2], ad[2])
+    # determinism
+    xb, lb = torch.randn(n, 3, 250, device=DEV), torch.randn(n, 3, device=DEV)
+    assert torch.equal(_C.gat_infer(big.csc, xb, lb), _C.gat_infer(big.csc, xb, lb))
+
+
+def test_evaluate_inference_path_full_size():
+    """f3 at BASELINE config 2's size: `evaluate()` (run.py:290-322) with 1 label-reuse iteration through the inference-only
+    layers against the generic eval-mode forward of the same model (fuse_layers off: modular layers + fused BN kernel), and the
+    label-reuse cache of the first projection against recomputation."""
+    from bot_amd import nn as bnn, synth, train as T
+    from bot_amd.nn import fused
+    import torch.nn.functional as F
+    ds = synth.make_dataset("arxiv", device="cpu", seed=0)
+    g = ds.graph.to(DEV)
+    g.create_formats_()
+    C = ds.n_classes
+    torch.manual_seed(0)
+    model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, n_layers=3, n_heads=3, n_hidden=250,
+                    norm="batch", dropout=0.75, input_drop=0.25, attn_drop=0.1, linear=True).to(DEV)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+    feat, labels = ds.feat.to(DEV), ds.labels.to(DEV)
+    tr, va, te = ds.train_idx.to(DEV), ds.val_idx.to(DEV), ds.test_idx.to(DEV)
+    n0 = fused.INFER_CALLS
+    ev = T.evaluate(model, g, feat, labels, tr, va, te, use_labels=True, n_label_iters=1, loss="loge", n_classes=C)
+    assert fused.INFER_CALLS - n0 == 6
+    model.fuse_layers = False
+    ev_ref = T.evaluate(model, g, feat, labels, tr, va, te, use_labels=True, n_label_iters=1, loss="loge", n_classes=C)
+    assert fused.INFER_CALLS - n0 == 6
+    assert float((ev[6] - ev_ref[6]).abs().max()) <= 1e-4
+    assert all(abs(float(a) - float(b)) <= 1e-4 for a, b in zip(ev[3:6], ev_ref[3:6]))
+    assert all(abs(a - b) <= 2e-4 for a, b in zip(ev[:3], ev_ref[:3]))  # accuracies: a tie in an argmax may flip a node
