@@ -8,9 +8,9 @@ loads bot_amd/lib/libbot_gnn.so and fails if it has not been built — there is 
 from . import _C  # noqa: F401  (fails loudly when the HIP library is missing)
 from . import function, ops
 from .errors import DGLError
-from .graph import Graph, add_self_loop, graph, preprocess, remove_self_loop, to_bidirected
+from .graph import Graph, add_self_loop, graph, preprocess, remove_self_loop, reorder_graph, to_bidirected
 from .ops import edge_softmax
 
-__all__ = ["Graph", "graph", "to_bidirected", "add_self_loop", "remove_self_loop", "preprocess", "function", "ops",
+__all__ = ["Graph", "graph", "to_bidirected", "add_self_loop", "remove_self_loop", "preprocess", "reorder_graph", "function", "ops",
            "edge_softmax", "DGLError"]
 __version__ = "0.1.0"

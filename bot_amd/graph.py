@@ -43,10 +43,32 @@ class Direction:
                          mv(self.long_ptr), self.n_rows, self.nnz, self.n_items, self.n_long, self.n_slots, self.chunk)
 
 
-def build_direction(rows: torch.Tensor, cols: torch.Tensor, n_rows: int, chunk: int | None = None) -> Direction:
+def xcd_item_order(items: torch.Tensor) -> torch.Tensor:
+    """Row-plan items re-ordered for graphs whose NUMBERING carries locality (after `reorder_graph`): workgroups are dealt
+    round-robin over the 8 XCDs (block b and b + 8 share an L2, MI355X_MICROARCH.md "Workgroup dispatch"), a workgroup is 4
+    wavefronts = 4 items, so the whole-row items are cut into 8 contiguous row ranges and dealt 4 at a time, range x to the
+    blocks with b % 8 == x.  Each XCD then sweeps ITS range of rows in order, and rows that share sources (a community) are
+    gathered through one L2 at about the same time.  The chunks of long rows stay in front (they start first).  A pure
+    re-ordering: every item appears exactly once, results are unchanged.  Placement is a speed heuristic only."""
+    whole = items[:, 3] < 0
+    longs, rest = items[~whole], items[whole]
+    rest = rest[torch.argsort(rest[:, 0], stable=True)]                      # natural row order
+    lead = (-longs.shape[0]) % 4                                             # keep 4-item groups aligned with workgroups
+    head, rest = rest[:lead], rest[lead:]
+    n = rest.shape[0]
+    if n:
+        seg = ((n + 7) // 8 + 3) // 4 * 4                                    # rows per XCD range, a multiple of 4
+        q = torch.arange(n, device=items.device)
+        x, o = q // seg, q % seg
+        rest = rest[torch.argsort((o // 4) * 32 + x * 4 + o % 4, stable=True)]
+    return torch.cat([longs, head, rest]).contiguous()
+
+
+def build_direction(rows: torch.Tensor, cols: torch.Tensor, n_rows: int, chunk: int | None = None, order: str = "degree") -> Direction:
     """Compress the COO list (edge e: row rows[e], neighbour cols[e]) by row, stable in edge id.
 
     Integer work done with torch on whatever device the edge list lives on; the row plan is host-side C.
+    `order`: "degree" = the plan's longest-first item order; "xcd" = `xcd_item_order`.
     """
     dev = rows.device
     nnz = int(rows.numel())
@@ -60,6 +82,8 @@ def build_direction(rows: torch.Tensor, cols: torch.Tensor, n_rows: int, chunk: 
     if chunk is None:
         chunk = _C.default_chunk(nnz)
     items, long_rows, long_ptr, n_slots = _C.row_plan(indptr32.cpu().contiguous(), chunk)
+    if order == "xcd":
+        items = xcd_item_order(items)
     n_long = int(long_rows.numel())
     return Direction(indptr32.contiguous(), cols[eid].to(torch.int32).contiguous(), eid.to(torch.int32).contiguous(),
                      items.to(dev), long_rows.to(dev) if n_long else None, long_ptr.to(dev) if n_long else None,
@@ -90,6 +114,11 @@ class Graph:
             raise ValueError("node id out of range")
         self._src, self._dst, self._n, self._n_dst = src, dst, int(num_nodes), n_dst
         self._chunk = chunk
+        self.plan_order = "degree"       # item order of the row plans (build_direction)
+        # set by `reorder_graph`: this graph's ids are INTERNAL ids; node_perm[new] = original id, node_inv[original] = new.
+        # The stacks (bot_amd.nn.GCN / GAT / edge GATs) take and return node tensors in ORIGINAL order and convert at their
+        # boundary (to_internal / to_original); the operator-level surface (update_all, ops.*) works in the graph's own ids.
+        self.node_perm = self.node_inv = None
         self.halo = None                 # bot_amd.dist.HaloPlan in partitioned mode
         self.global_out_degrees = None   # int64 [num_dst_nodes]: out-degrees in the WHOLE graph (partitioned mode)
         self._csc = self._csr = self._csr2csc = self._csc2csr = None
@@ -113,6 +142,14 @@ class Graph:
         if self.is_block:
             raise ValueError("a block without a halo plan needs source features supplied by the caller")
         return x_dst
+
+    def to_internal(self, x):
+        """Node tensor in original order -> the order of this graph's ids (identity unless `reorder_graph` made this graph)."""
+        return x if self.node_perm is None else x.index_select(0, self.node_perm)
+
+    def to_original(self, y):
+        """Node tensor in this graph's ids -> original order."""
+        return y if self.node_inv is None else y.index_select(0, self.node_inv)
 
     @property
     def srcdata(self):
@@ -163,7 +200,8 @@ class Graph:
         if device == self.device:
             return self
         g = Graph(self._src.to(device), self._dst.to(device), self._n, num_dst_nodes=self._n_dst, chunk=self._chunk)
-        for name in ("_csc", "_csr", "_csr2csc", "_csc2csr", "_src32", "_dst32", "global_out_degrees", "halo"):
+        g.plan_order = self.plan_order
+        for name in ("_csc", "_csr", "_csr2csc", "_csc2csr", "_src32", "_dst32", "global_out_degrees", "halo", "node_perm", "node_inv"):
             v = getattr(self, name)
             setattr(g, name, None if v is None else v.to(device))
         g.ndata = _Frame({k: v.to(device) for k, v in self.ndata.items()})
@@ -195,14 +233,14 @@ class Graph:
     def csc(self) -> Direction:
         """In-edges grouped by destination: rows = dst, indices = src."""
         if self._csc is None:
-            self._csc = build_direction(self._dst, self._src, self._n_dst, self._chunk)
+            self._csc = build_direction(self._dst, self._src, self._n_dst, self._chunk, self.plan_order)
         return self._csc
 
     @property
     def csr(self) -> Direction:
         """Out-edges grouped by source: rows = src, indices = dst."""
         if self._csr is None:
-            self._csr = build_direction(self._src, self._dst, self._n, self._chunk)
+            self._csr = build_direction(self._src, self._dst, self._n, self._chunk, self.plan_order)
         return self._csr
 
     def _inverse(self, perm):
@@ -281,12 +319,74 @@ def remove_self_loop(g: Graph) -> Graph:
     return g.remove_self_loop()
 
 
-def preprocess(g: Graph) -> Graph:
-    """The graph half of `preprocess(graph)` — run.py:133-148."""
+def label_propagation(src, dst, n: int, iters: int = 10) -> torch.Tensor:
+    """A cheap community pass, entirely with device-side integer ops (sort / unique / scatter-reduce): every vertex starts
+    in its own community and repeatedly adopts the label most frequent among its in-neighbours (ties: the smallest label);
+    half of the vertices (a hash of the id, alternating) move per sweep, which keeps the synchronous form from oscillating.
+    O(E log E) per sweep.  On a graph with planted blocks it recovers them within ~10 sweeps (87 % of the edges inside a
+    label at p_in = 0.9); on a structureless power-law graph the labels flood into one giant community — harmless for the use
+    made of them here (an ORDER: vertices grouped by label, hubs first inside a label)."""
+    dev = src.device
+    labels = torch.arange(n, dtype=torch.int64, device=dev)
+    ids = torch.arange(n, dtype=torch.int64, device=dev)
+    for it in range(iters):
+        key = torch.sort(dst * n + labels[src]).values
+        uniq, counts = torch.unique_consecutive(key, return_counts=True)
+        du, lu = torch.div(uniq, n, rounding_mode="floor"), uniq % n
+        best = torch.zeros(n, dtype=counts.dtype, device=dev).scatter_reduce(0, du, counts, "amax")
+        cand = torch.where(counts == best[du], lu, torch.full_like(lu, n))
+        new = torch.full((n,), n, dtype=torch.int64, device=dev).scatter_reduce(0, du, cand, "amin")
+        new = torch.where(new == n, labels, new)                       # no in-edges: keep
+        move = (((ids * 2654435761) >> 7) + it) % 2 == 0
+        labels = torch.where(move, new, labels)
+    return labels
+
+
+def reorder_permutation(g: Graph, method: str = "community"):
+    """(perm [N] int64: new id -> old id, labels or None).  "degree": in-degree descending (stable in the old id);
+    "community": grouped by `label_propagation` label (communities in order of their smallest member), in-degree descending
+    inside a community."""
+    n = g.number_of_nodes()
+    src, dst = g.edges()
+    deg = torch.bincount(dst, minlength=n)
+    if method == "degree":
+        return torch.argsort(deg, descending=True, stable=True), None
+    if method != "community":
+        raise ValueError(f"unknown reorder method {method!r}")
+    labels = label_propagation(src, dst, n)
+    by_deg = torch.argsort(deg, descending=True, stable=True)
+    return by_deg[torch.argsort(labels[by_deg], stable=True)], labels
+
+
+def reorder_graph(g: Graph, method: str = "community") -> Graph:
+    """The same graph under a locality-friendly vertex numbering.  Edge e keeps its id and its endpoints
+    (relabelled), so per-destination sums run over the same edges in the same order and every integer property (degrees,
+    edge ids, CSC/CSR contents) maps back through `node_perm` exactly; node tensors handed to / returned by the stacks stay
+    in ORIGINAL order (`to_internal` / `to_original`).  With method="community" and a real community structure (no label
+    holding over a quarter of the vertices) the row plans use the XCD-aware item order."""
+    assert not g.is_block, "reorder applies to whole graphs"
+    perm, labels = reorder_permutation(g, method)
+    n = g.number_of_nodes()
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n, dtype=perm.dtype, device=perm.device)
+    s, d = g.edges()
+    h = Graph(inv[s], inv[d], n, chunk=g._chunk)
+    h.node_perm, h.node_inv = perm, inv
+    h.ndata, h.edata = _Frame(g.ndata), _Frame(g.edata)                 # frames stay in original node / edge order
+    if labels is not None and int(torch.bincount(labels).max()) * 4 <= n:
+        h.plan_order = "xcd"
+    return h
+
+
+def preprocess(g: Graph, reorder: str | None = None) -> Graph:
+    """The graph half of `preprocess(graph)` — run.py:133-148.  `reorder` ("degree" | "community", default None): renumber
+    the vertices for locality afterwards (see `reorder_graph`); results of the stacks are unchanged and stay in original order."""
     feat = g.ndata.get("feat")
     g = to_bidirected(g)
     if feat is not None:
         g.ndata["feat"] = feat
     g = g.remove_self_loop().add_self_loop()
+    if reorder:
+        g = reorder_graph(g, reorder)
     g.create_formats_()
     return g

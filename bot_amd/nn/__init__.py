@@ -285,7 +285,7 @@ class GCN(nn.Module):
         self.activation = activation
 
     def forward(self, graph, feat):
-        h = self.input_drop(feat)
+        h = self.input_drop(graph.to_internal(feat))  # identity unless the graph was renumbered (bot_amd.reorder_graph)
         h_last = None
         for i in range(self.n_layers):
             conv = self.convs[i](graph, h)
@@ -298,7 +298,7 @@ class GCN(nn.Module):
                     h = _epilogue(h, self.norms[i], self.activation, self.dropout, self.training)
                 else:
                     h = self.dropout(self.activation(h))
-        return h
+        return graph.to_original(h)
 
 
 class GAT(nn.Module):
@@ -333,7 +333,7 @@ class GAT(nn.Module):
 
     def forward(self, graph, feat):
         from . import fused
-        h = self.input_drop(feat)
+        h = self.input_drop(graph.to_internal(feat))  # identity unless the graph was renumbered (bot_amd.reorder_graph)
         h_last = None
         infer = self.fuse_layers and not self.training and not torch.is_grad_enabled() and (h.is_cuda or fused.FORCE)
         for i in range(self.n_layers):
@@ -343,7 +343,7 @@ class GAT(nn.Module):
                 if fused.can_infer(self.convs[i], epi, self.activation, graph, self.residual, last):
                     h = fused.gat_infer_layer(self.convs[i], epi, graph, h, relu=not last, first=i == 0)
                     if last:
-                        return h
+                        return graph.to_original(h)
                     continue
             norm = None if last else (self.norms[i] if len(self.norms) else False)
             if (self.fuse_layers and norm is not False and (h.is_cuda or fused.FORCE)
@@ -364,4 +364,4 @@ class GAT(nn.Module):
                     h = _epilogue(h, self.norms[i], self.activation, self.dropout, self.training)
                 else:
                     h = self.dropout(self.activation(self.biases[i](h)))
-        return self.biases[-1](h.mean(1))
+        return graph.to_original(self.biases[-1](h.mean(1)))

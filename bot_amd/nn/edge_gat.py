@@ -150,7 +150,7 @@ class _EdgeGAT(nn.Module):
                 and _C.edge_mlp_supported(enc.in_features, enc.out_features, conv._n_heads))
 
     def _body(self, g, h, residual):
-        h = self.input_drop(h)
+        h = self.input_drop(g.to_internal(h))   # node features arrive in original order; edge features are in edge-id order
         h_last = None
         efeat = g.edata.get("feat") if self.edge_encoder is not None else None
         for i in range(self.n_layers):
@@ -163,7 +163,7 @@ class _EdgeGAT(nn.Module):
                 h = h + h_last[: h.shape[0], :]
             h_last = h
             h = _epilogue(h, self.norms[i], self.activation, self.dropout, self.training)  # BatchNorm + ReLU + dropout, fused
-        return ops.linear(h, self.pred_linear.weight, self.pred_linear.bias)
+        return g.to_original(ops.linear(h, self.pred_linear.weight, self.pred_linear.bias))
 
 
 class ProteinsGAT(_EdgeGAT):

@@ -197,3 +197,118 @@ def test_whole_step_against_c_oracle_small(cpu_backend, monkeypatch):
         r = FS.compare(pred, grads, rp, rg, gs)
         assert r["max_abs_logit_diff"] <= PC.FWD_ATOL and r["max_rel_grad_err"] <= PC.GRAD_RTOL, r
         assert r["max_abs_preact_at_differing_gate"] <= 1e-4 and r["relu_gates_differing"] <= 1e-5 * r["relu_gates"] and r["leaky_gates_differing"] <= 1e-5 * r["leaky_gates"], r
+
+
+# ---------------------------------------------------------------------------------------------- f4: reordering / locality
+def _reorder_cases(golden):
+    from bot_amd import synth
+    from oracle import ref_ops as R
+    s, d, n = golden.graph("g300")
+    yield "g300", bot_amd.Graph(s, d, n)
+    n2 = 6000
+    cs, cd = synth.community_edges(n2, 40000, 3, n_blocks=12, p_in=0.9)
+    ps, pd = R.preprocess_edges(cs, cd, n2)
+    yield "comm", bot_amd.Graph(ps, pd, n2)
+
+
+@pytest.mark.parametrize("method", ["degree", "community"])
+def test_reorder_integer_invariants(golden, cpu_backend, method):
+    """`reorder_graph` is a pure renumbering (integer work, bit-exact): node_perm is a permutation, every edge
+    keeps its id and its endpoints, degrees and the per-destination edge lists (edge ids in order) map back through node_perm,
+    node tensors round-trip through to_internal / to_original, and the XCD-aware item order is a permutation of the plan."""
+    from bot_amd.graph import build_direction, reorder_graph, xcd_item_order
+    for name, g in _reorder_cases(golden):
+        n = g.number_of_nodes()
+        h = reorder_graph(g, method)
+        perm, inv = h.node_perm, h.node_inv
+        assert torch.equal(torch.sort(perm).values, torch.arange(n)) and torch.equal(perm[inv], torch.arange(n))
+        s, d = g.edges()
+        hs, hd = h.edges()
+        assert torch.equal(perm[hs], s) and torch.equal(perm[hd], d)                # edge e: same endpoints, same id
+        assert torch.equal(h.to_original(h.in_degrees()), g.in_degrees())
+        assert torch.equal(h.to_original(h.out_degrees()), g.out_degrees())
+        x = torch.arange(n * 3).view(n, 3)
+        assert torch.equal(h.to_original(h.to_internal(x)), x) and torch.equal(h.to_internal(x)[inv], x)
+        for v in (0, 1, n // 2, n - 1):                                               # in-edge lists: same edge ids, same order
+            a, b = g.csc, h.csc
+            ra = a.eid[a.indptr[v]:a.indptr[v + 1]]
+            rb = b.eid[b.indptr[inv[v]]:b.indptr[inv[v] + 1]]
+            assert torch.equal(ra, rb)
+            assert torch.equal(perm[b.indices[b.indptr[inv[v]]:b.indptr[inv[v] + 1]].long()], a.indices[a.indptr[v]:a.indptr[v + 1]].long())
+        if method == "degree":
+            deg = h.in_degrees()
+            assert bool((deg[:-1] >= deg[1:]).all())
+        for chunk in (4, 64):                                                         # with and without long rows
+            d0 = build_direction(hd, hs, n, chunk)
+            items = xcd_item_order(d0.items)
+            key = lambda t: sorted(map(tuple, t.tolist()))
+            assert items.shape == d0.items.shape and key(items) == key(d0.items)
+            n_long_items = int((d0.items[:, 3] >= 0).sum())
+            assert torch.equal(items[:n_long_items], d0.items[:n_long_items])
+
+
+def test_label_propagation_finds_planted_blocks(golden):
+    from bot_amd import synth
+    from bot_amd.graph import label_propagation, reorder_graph
+    from oracle import ref_ops as R
+    n, B = 6000, 12
+    cs, cd = synth.community_edges(n, 40000, 3, n_blocks=B, p_in=0.9)
+    s, d = R.preprocess_edges(cs, cd, n)
+    labels = label_propagation(s, d, n)
+    inside = float((labels[s] == labels[d]).double().mean())
+    assert inside > 0.8 and 6 <= torch.unique(labels).numel() <= 80, (inside, torch.unique(labels).numel())
+    h = reorder_graph(bot_amd.Graph(s, d, n), "community")
+    assert h.plan_order == "xcd"
+    hs, hd = h.edges()
+    # locality of the numbering: half of the edges now span fewer than n/B ids (before: a uniformly random numbering)
+    assert float(((hs - hd).abs() < n // B).double().mean()) > 0.6 > 0.3 > float(((s - d).abs() < n // B).double().mean())
+    rs, rd = synth.powerlaw_edges(n, 40000, 3)
+    s2, d2 = R.preprocess_edges(rs, rd, n)
+    assert reorder_graph(bot_amd.Graph(s2, d2, n), "community").plan_order == "degree"   # no structure: labels flood
+
+
+@pytest.mark.parametrize("method", ["degree", "community"])
+def test_stacks_unchanged_by_reordering(golden, cpu_backend, monkeypatch, method):
+    """Logits and gradients of GCN / GAT stacks on a renumbered graph equal those on the original graph, in ORIGINAL node
+    order (train mode with batch statistics, eval mode, the inference-only path)."""
+    from bot_amd.graph import reorder_graph
+    from bot_amd.nn import fused
+    monkeypatch.setattr(fused, "FORCE", True)
+    for name, g in _reorder_cases(golden):
+        n = g.number_of_nodes()
+        h = reorder_graph(g, method)
+        gen = torch.Generator().manual_seed(5)
+        feat = torch.randn(n, 11, generator=gen)
+        gout = torch.randn(n, 5, generator=gen)
+        for kind, cfg in (("gat", dict(n_layers=3, n_heads=3, n_hidden=6, norm="batch", linear=True)),
+                          ("gcn", dict(n_layers=2, n_hidden=8, norm="batch", norm_adj="symm", use_linear=True))):
+            torch.manual_seed(1)
+            model = PC.build_stack(kind, cfg)
+            with torch.no_grad():
+                for m in model.modules():
+                    if isinstance(m, torch.nn.BatchNorm1d):
+                        m.running_mean.normal_(0, 0.3, generator=gen)
+                        m.running_var.uniform_(0.5, 1.5, generator=gen)
+            outs, state = [], {k: v.clone() for k, v in model.state_dict().items()}
+            for graph in (g, h):
+                model.load_state_dict(state)   # the train-mode forward below updates the running statistics
+                # train mode (batch statistics): logits only — the column sums of BatchNorm run over the rows in another order,
+                # and a ReLU input within rounding of zero may then take the other side (tests/full_size.py:KinkGates)
+                model.train()
+                with torch.no_grad():
+                    yt = model(graph, feat)
+                # eval mode: every row's arithmetic is independent of the numbering, so gradients are comparable too
+                model.eval()
+                model.zero_grad()
+                f = feat.clone().requires_grad_()
+                y = model(graph, f)
+                (y * gout).sum().backward()
+                grads = [p.grad.clone() for p in model.parameters()]
+                with torch.no_grad():
+                    yi = model(graph, feat)   # inference-only layers
+                outs.append((yt, y.detach(), f.grad, grads, yi))
+            (t0, y0, df0, g0, i0), (t1, y1, df1, g1, i1) = outs
+            for a, b in ((t0, t1), (y0, y1), (df0, df1), (i0, i1), (y0, i0)):
+                assert torch.allclose(a, b, rtol=1e-4, atol=2e-5)
+            for a, b in zip(g0, g1):
+                assert torch.allclose(a, b, atol=1e-4 * max(1.0, float(a.abs().max())))
