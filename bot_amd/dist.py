@@ -88,6 +88,7 @@ class HaloPlan:
     send_splits: list            # rows per destination rank
     recv_splits: list            # halo rows per owner rank (sum = n_halo)
     group: object = None
+    n_global: int = 0            # vertices of the whole graph (the row count BatchNorm normalises over, models.py:698,727)
 
     @property
     def n_send(self):
@@ -101,7 +102,7 @@ class HaloPlan:
         return _HaloExchange.apply(x_own, self)
 
     def to(self, device):
-        return HaloPlan(self.send_rows.to(device), self.send_splits, self.recv_splits, self.group)
+        return HaloPlan(self.send_rows.to(device), self.send_splits, self.recv_splits, self.group, self.n_global)
 
 
 # ------------------------------------------------------------------------------------------------ partitioning (host, integer)
@@ -138,6 +139,8 @@ class Partition:
     n_edges: int
     edge_ids: torch.Tensor = None    # int64 [n_edges] global ids of the local edges, ascending = local edge-id order
                                      # (edge features of the block: efeat[edge_ids]; configs 4/5, src/ogbn-proteins/models.py:244)
+    node_ids: torch.Tensor = None    # int64 [n_owned]: ORIGINAL ids of the owned vertices when the partitioner renumbered them
+                                     # (None: lo + arange(n_owned))
     feat: torch.Tensor = None
     labels: torch.Tensor = None
     train_idx: torch.Tensor = None   # LOCAL ids of owned training nodes (same for val/test)
@@ -149,53 +152,96 @@ class Partition:
         return self.hi - self.lo
 
 
-def build_partition(src, dst, num_nodes: int, rank: int, world: int, device="cpu", group=None, bounds=None,
+def build_partition(src, dst, num_nodes: int, rank: int, world: int, device=None, group=None, bounds=None,
                     chunk=None) -> Partition:
-    """Cut rank's block out of the whole graph (edge list in edge-id order, on the host).  Pure integer
-    work, no communication: every rank derives the same halo lists from the same edge list."""
-    src, dst = src.cpu(), dst.cpu()
+    """Cut rank's block out of the whole graph (edge list in edge-id order).  Pure integer work with torch ops on the device
+    the edge list lives on — on the GPU box every rank holds the (identically seeded) edge list in its OWN HBM, so no host ever
+    holds `world` copies — and no communication: ranks derive matching halo / send lists from the same edge list.  Only the
+    edges that touch this rank are processed beyond the two owner look-ups: its in-edges (the local block and the halo it
+    receives) and the out-edges of its vertices that end elsewhere (what it sends)."""
+    dev = src.device
+    device = dev if device is None else torch.device(device)
     if bounds is None:
-        bounds = partition_bounds(torch.bincount(dst, minlength=num_nodes), world)
-    bt = torch.tensor(bounds[1:], dtype=torch.int64)
+        bounds = partition_bounds(torch.bincount(dst, minlength=num_nodes).cpu(), world)
+    bt = torch.tensor(bounds[1:], dtype=torch.int64, device=dev)
     own_src = torch.searchsorted(bt, src, right=True)   # owner rank of every edge's source
     own_dst = torch.searchsorted(bt, dst, right=True)
     lo, hi = bounds[rank], bounds[rank + 1]
     n_own = hi - lo
-    # all cross-partition (destination owner, source vertex) pairs, deduplicated and sorted
-    cross = own_src != own_dst
-    key = torch.unique(own_dst[cross] * num_nodes + src[cross])
-    k_dst, k_src = torch.div(key, num_nodes, rounding_mode="floor"), key % num_nodes
-    k_own = torch.searchsorted(bt, k_src, right=True)
-    mine = k_dst == rank                                  # what I receive: sorted by global id = grouped by owner
-    halo_global = k_src[mine]
-    recv_splits = torch.bincount(k_own[mine], minlength=world).tolist()
-    out = k_own == rank                                   # what I send: sorted by (destination rank, global id)
-    send_rows = (k_src[out] - lo).to(torch.int32)
-    send_splits = torch.bincount(k_dst[out], minlength=world).tolist()
-    # local block
+    # local block: all in-edges of my vertices, in global edge-id order
     m = own_dst == rank
     ls, ld = src[m], dst[m] - lo
-    local_src = torch.where((ls >= lo) & (ls < hi), ls - lo, n_own + torch.searchsorted(halo_global, ls))
+    remote = own_src[m] != rank
+    halo_global = torch.unique(ls[remote])                # sorted by global id = grouped by owner rank
+    recv_splits = torch.bincount(torch.searchsorted(bt, halo_global, right=True), minlength=world).tolist()
+    # what I send: my vertices that are sources of edges ending on another rank, per destination rank, sorted by id
+    out = (own_src == rank) & ~m
+    key = torch.unique(own_dst[out] * num_nodes + src[out])
+    send_rows = (key % num_nodes - lo).to(torch.int32)
+    send_splits = torch.bincount(torch.div(key, num_nodes, rounding_mode="floor"), minlength=world).tolist()
+    local_src = torch.where(remote, n_own + torch.searchsorted(halo_global, ls), ls - lo)
     g = Graph(local_src, ld, n_own + halo_global.numel(), num_dst_nodes=n_own, chunk=chunk)
-    g.global_out_degrees = torch.bincount(src, minlength=num_nodes)[lo:hi].to(torch.int64)
-    g.halo = HaloPlan(send_rows.contiguous(), send_splits, recv_splits, group)
+    g.global_out_degrees = torch.bincount(src[own_src == rank] - lo, minlength=n_own).to(torch.int64)
+    g.halo = HaloPlan(send_rows.contiguous(), send_splits, recv_splits, group, n_global=int(num_nodes))
     g = g.to(device)
     g.create_formats_()
-    return Partition(g, rank, world, lo, hi, halo_global, int(ls.numel()), edge_ids=torch.nonzero(m).squeeze(1))
+    return Partition(g, rank, world, lo, hi, halo_global.to(device), int(ls.numel()), edge_ids=torch.nonzero(m).squeeze(1).to(device))
 
 
-def partition_dataset(ds, rank: int, world: int, device, group=None) -> Partition:
-    """Partition a `bot_amd.synth.Dataset` (whole graph on the host) and move rank's slice to `device`."""
-    s, d = ds.graph.edges()
-    n = ds.graph.number_of_nodes()
+def partition_dataset(ds, rank: int, world: int, device, group=None, partitioner: str = "contiguous") -> Partition:
+    """Partition a `bot_amd.synth.Dataset` and move rank's slice to `device`.
+
+    partitioner="contiguous": ranges of the graph's own ids (for the benchmark graphs these are random: ~ (P-1)/P of every
+    rank's sources are remote).  "community": an edge-cut-aware 1-D partition — the vertices are first
+    renumbered by `bot_amd.graph.reorder_permutation(…, "community")` (label propagation on the device, communities
+    contiguous, hubs first inside a community) and the ranges are cut in THAT order, so most edges of a community stay inside
+    one rank; `Partition.node_ids` keeps the original ids of the owned rows.  A graph that was already renumbered by
+    `preprocess(reorder=...)` is partitioned in its internal order."""
+    from .graph import reorder_permutation
+    g = ds.graph
+    s, d = g.edges()
+    n = g.number_of_nodes()
+    perm = g.node_perm                                   # internal -> original (None: identity)
+    if partitioner == "community":
+        p2, _ = reorder_permutation(g, "community")      # new -> current
+        inv2 = torch.empty_like(p2)
+        inv2[p2] = torch.arange(n, dtype=p2.dtype, device=p2.device)
+        s, d = inv2[s], inv2[d]
+        perm = p2 if perm is None else perm[p2]
+    elif partitioner != "contiguous":
+        raise ValueError(f"unknown partitioner {partitioner!r}")
     p = build_partition(s, d, n, rank, world, device, group)
-    p.feat = ds.feat[p.lo:p.hi].to(device)
-    p.labels = ds.labels[p.lo:p.hi].to(device)
+    if perm is None:
+        rows = slice(p.lo, p.hi)
+        to_new = None
+    else:
+        perm = perm.to(ds.feat.device)
+        rows = perm[p.lo:p.hi]
+        p.node_ids = rows.to(device)
+        to_new = torch.empty_like(perm)
+        to_new[perm] = torch.arange(n, dtype=perm.dtype, device=perm.device)
+    p.feat = ds.feat[rows].to(device)
+    p.labels = ds.labels[rows].to(device)
     for name in ("train_idx", "val_idx", "test_idx"):
-        idx = getattr(ds, name).cpu()
+        idx = getattr(ds, name)
+        if to_new is not None:
+            idx = to_new[idx.to(to_new.device)]
         idx = idx[(idx >= p.lo) & (idx < p.hi)] - p.lo
-        setattr(p, name, idx.to(device))
+        setattr(p, name, torch.sort(idx).values.to(device))
     return p
+
+
+def halo_statistics(src, dst, num_nodes: int, world: int, bounds=None) -> dict:
+    """Halo rows every rank would receive under contiguous ranges of the given numbering (host-side planning aid)."""
+    if bounds is None:
+        bounds = partition_bounds(torch.bincount(dst, minlength=num_nodes).cpu(), world)
+    bt = torch.tensor(bounds[1:], dtype=torch.int64, device=src.device)
+    od, os_ = torch.searchsorted(bt, dst, right=True), torch.searchsorted(bt, src, right=True)
+    cross = od != os_
+    key = torch.unique(od[cross] * num_nodes + src[cross])
+    halo = torch.bincount(torch.div(key, num_nodes, rounding_mode="floor"), minlength=world)
+    return {"halo_rows_per_rank": halo.tolist(), "cut_edges": int(cross.sum()), "edges": int(src.numel()),
+            "owned_rows_per_rank": [bounds[k + 1] - bounds[k] for k in range(world)]}
 
 
 # ------------------------------------------------------------------------------------------------ model pieces
@@ -218,10 +264,10 @@ class SyncBatchNorm1d(nn.BatchNorm1d):
         var = stats[C:2 * C] / cnt - mean * mean
         if self.track_running_stats:
             with torch.no_grad():
-                mom = self.momentum if self.momentum is not None else 0.1
+                self.num_batches_tracked += 1
+                mom = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
                 self.running_mean.mul_(1 - mom).add_(mean.detach(), alpha=mom)
                 self.running_var.mul_(1 - mom).add_(var.detach() * (cnt / (cnt - 1)), alpha=mom)
-                self.num_batches_tracked += 1
         y = (x - mean) * torch.rsqrt(var + self.eps)
         return y * self.weight + self.bias if self.affine else y
 
@@ -261,8 +307,22 @@ def all_reduce_grads(model: nn.Module, group=None):
         off += n
 
 
-def forward_backward(model, part: Partition, *, use_labels=True, mask_rate=0.5, loss="logit", n_classes=None, mask=None,
-                     group=None):
+def seed_rank_streams(base_seed: int, rank: int):
+    """Give every rank its own dropout / edge-drop / label-mask stream (call AFTER the replicated model was built from the
+    common seed): the fused kernels draw their Philox seeds from torch's CPU generator and count elements from 0 on every
+    rank, so identically seeded ranks would drop the same local positions."""
+    torch.manual_seed((int(base_seed) * 1000003 + 7919 * (int(rank) + 1)) & 0x7FFFFFFFFFFFFFFF)
+
+
+def _global_mean(y, w, group):
+    """sum(y * w) / global sum(w) as this rank's additive share of the global mean (its backward gives the right scale)."""
+    cnt = w.sum().reshape(1)
+    dist.all_reduce(cnt, group=group)
+    return (y * w).sum() / cnt[0]
+
+
+def forward_backward(model, part: Partition, *, use_labels=True, mask_rate=0.5, n_label_iters=0, loss="logit", n_classes=None,
+                     mask=None, group=None):
     """Partitioned counterpart of `bot_amd.train.forward_backward` (run.py:252-284): same step, the loss is the
     mean over the prediction nodes of ALL ranks, parameter gradients are summed over ranks."""
     tr = part.train_idx
@@ -281,10 +341,19 @@ def forward_backward(model, part: Partition, *, use_labels=True, mask_rate=0.5, 
     else:
         w = mask.to(feat.dtype)
     pred = model(part.graph, feat)
+    if n_label_iters > 0 and use_labels:
+        # label reuse (run.py:274-279): the label columns of every node WITHOUT an input label — the masked-out training nodes,
+        # validation and test nodes — are overwritten with the previous prediction's softmax, then the model runs again
+        m = mask.unsqueeze(1)
+        for _ in range(n_label_iters):
+            pred = pred.detach()
+            prob = torch.softmax(pred, dim=-1)
+            feat[tr, -n_classes:] = torch.where(m, feat[tr, -n_classes:], prob[tr])
+            for idx in (part.val_idx, part.test_idx):
+                feat[idx, -n_classes:] = prob[idx]
+            pred = model(part.graph, feat)
     y = T.per_node_loss(pred[tr], part.labels[tr], loss)
-    cnt = w.sum().reshape(1)
-    dist.all_reduce(cnt, group=group)
-    local = (y * w).sum() / cnt[0]
+    local = _global_mean(y, w, group)
     local.backward()
     all_reduce_grads(model, group)
     total = local.detach().clone()
@@ -298,3 +367,58 @@ def train_step(model, part: Partition, optimizer, **kw):
     loss, pred = forward_backward(model, part, **kw)
     optimizer.step()
     return loss, pred
+
+
+@torch.no_grad()
+def evaluate(model, part: Partition, *, use_labels=True, n_label_iters=0, loss="logit", n_classes=None, group=None):
+    """Partitioned counterpart of `bot_amd.train.evaluate` (run.py:290-322): eval-mode forward with every training label as
+    input, optional label reuse; returns (train_acc, val_acc, test_acc, train_loss, val_loss, test_loss, pred of the owned rows),
+    accuracies and losses being GLOBAL means (all-reduced sums and counts)."""
+    import contextlib
+    from .nn import fused
+    model.eval()
+    feat = part.feat
+    n_static = feat.shape[1]
+    if use_labels:
+        feat = T.add_labels(feat, part.labels, part.train_idx, n_classes)
+    with (fused.label_reuse(n_static) if (use_labels and n_label_iters > 0) else contextlib.nullcontext()):
+        pred = model(part.graph, feat)
+        for _ in range(n_label_iters if use_labels else 0):
+            prob = torch.softmax(pred, dim=-1)
+            for idx in (part.val_idx, part.test_idx):
+                feat[idx, -n_classes:] = prob[idx]
+            pred = model(part.graph, feat)
+    stats = []
+    for idx in (part.train_idx, part.val_idx, part.test_idx):
+        y = T.per_node_loss(pred[idx], part.labels[idx], loss)
+        hit = (torch.argmax(pred[idx], dim=1) == part.labels[idx, 0]).to(pred.dtype)
+        stats += [y.sum(), hit.sum(), y.new_tensor(float(idx.numel()))]
+    stats = torch.stack(stats)
+    dist.all_reduce(stats, group=group)
+    st = stats.tolist()
+    losses = tuple(st[3 * i] / max(st[3 * i + 2], 1.0) for i in range(3))
+    accs = tuple(st[3 * i + 1] / max(st[3 * i + 2], 1.0) for i in range(3))
+    return accs + losses + (pred,)
+
+
+def step_generic(model_call, part: Partition, node_loss, idx=None, weights=None, model=None, optimizer=None, group=None):
+    """One partitioned train step for stacks with their own calling convention (the edge-feature GATs of configs 4 / 5:
+    `model(graph)` reading `graph.ndata['feat']` / `graph.edata['feat']`, src/ogbn-proteins/gat.py:123-140).  `model_call()`
+    returns the predictions of the owned rows; `node_loss(pred[idx], labels[idx])` a per-node loss [len(idx)]; the loss is the
+    global mean over `idx` (default: the owned training nodes) with optional 0/1 `weights`."""
+    idx = part.train_idx if idx is None else idx
+    if optimizer is not None:
+        model.train()
+        optimizer.zero_grad()
+    pred = model_call()
+    y = node_loss(pred[idx], part.labels[idx])
+    w = torch.ones_like(y) if weights is None else weights
+    local = _global_mean(y, w, group)
+    local.backward()
+    if model is not None:
+        all_reduce_grads(model, group)
+    if optimizer is not None:
+        optimizer.step()
+    total = local.detach().clone()
+    dist.all_reduce(total, group=group)
+    return total, pred

@@ -296,11 +296,12 @@ def bn_batch_stats(x, bn, bn_training):
         # the global row count is a constant of the partition: ask for it once (one host sync), then never again, so the
         # host keeps running ahead of the GPU during the step
         totals = bn.__dict__.setdefault("_bot_total_rows", {})
-        if n not in totals:
+        key = (id(group), dist.get_rank(group), n)   # per process group and local row count (one partition per rank and group)
+        if key not in totals:
             cnt = mean.new_full((1,), float(n))
             dist.all_reduce(cnt, group=group)
-            totals[n] = float(cnt.item())
-        total = totals[n]
+            totals[key] = float(cnt.item())
+        total = totals[key]
         gmean = mean * (n / total)
         dist.all_reduce(gmean, group=group)
         m2 = m2 + n * (mean - gmean) ** 2
@@ -309,10 +310,12 @@ def bn_batch_stats(x, bn, bn_training):
     invstd = torch.rsqrt(m2 / total + bn.eps)
     if bn.track_running_stats:
         with torch.no_grad():
-            mom = 0.1 if bn.momentum is None else bn.momentum
+            bn.num_batches_tracked += 1
+            # nn.BatchNorm1d: momentum None = cumulative moving average, factor 1 / num_batches_tracked (one host read per
+            # step in that rarely used mode)
+            mom = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
             bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
             bn.running_var.mul_(1 - mom).add_(m2 / max(total - 1.0, 1.0), alpha=mom)
-            bn.num_batches_tracked += 1
     return mean, invstd, total, sync, group
 
 

@@ -182,3 +182,81 @@ def _worker_edge(rank, world, port, kind, tmp):
 def test_partitioned_edge_gat_matches_single_process(kind, world, tmp_path):
     mp.spawn(_worker_edge, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _worker_extras(rank, world, port, partitioner, tmp):
+    """Label reuse in the partitioned train step (run.py:274-279), partitioned evaluate() (run.py:290-322) and the
+    community partitioner (renumbered ranges, results mapped back through Partition.node_ids) against one process."""
+    import types
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from tests import _oracle_backend
+        _oracle_backend.install_direct()
+        import bot_amd
+        from bot_amd.nn import fused
+        fused.FORCE = True
+        from bot_amd import dist as bdist, synth
+        from bot_amd import nn as bnn
+        from bot_amd import train as T
+        from oracle import ref_ops as R
+        n, C, fin = 1500, 5, 9
+        cs, cd = synth.community_edges(n, 9000, 3, n_blocks=6, p_in=0.9)
+        s, d = R.preprocess_edges(cs, cd, n)
+        gen = torch.Generator().manual_seed(7)
+        feat = torch.randn(n, fin, generator=gen)
+        labels = torch.randint(0, C, (n, 1), generator=gen)
+        perm = torch.randperm(n, generator=gen)
+        tr, va, te = perm[: n // 2], perm[n // 2: 3 * n // 4], perm[3 * n // 4:]
+        mask_full = torch.rand(n, generator=gen) < 0.5
+
+        def make():
+            torch.manual_seed(3)
+            return bnn.GAT(dim_node=fin + C, dim_edge=0, dim_output=C, n_hidden=16, n_layers=3, n_heads=3, activation=F.relu,
+                           norm="batch", linear=True)
+
+        g = bot_amd.Graph(s, d, n)
+        ref = make().train()
+        loss_ref, pred_ref, _ = T.forward_backward(ref, g, feat, labels, tr, va, te, use_labels=True, n_label_iters=1, loss="loge",
+                                                   n_classes=C, mask=mask_full[tr])
+        ds = types.SimpleNamespace(graph=g, feat=feat, labels=labels, train_idx=tr, val_idx=va, test_idx=te)
+        part = bdist.partition_dataset(ds, rank, world, "cpu", partitioner=partitioner)
+        ids = part.node_ids if part.node_ids is not None else torch.arange(part.lo, part.hi)
+        assert (part.node_ids is not None) == (partitioner == "community")
+        assert torch.equal(part.feat, feat[ids]) and torch.equal(part.labels, labels[ids])
+        model = bdist.wrap_model(make().train())
+        own_tr = ids[part.train_idx]                      # original ids of the owned training nodes, in local order
+        loss, pred = bdist.forward_backward(model, part, use_labels=True, n_label_iters=1, loss="loge", n_classes=C,
+                                            mask=mask_full[own_tr])
+        assert abs(loss.item() - loss_ref.item()) < 1e-5, (loss.item(), loss_ref.item())
+        np.testing.assert_allclose(pred.detach().numpy(), pred_ref.detach()[ids].numpy(), rtol=1e-4, atol=2e-5)
+        for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            np.testing.assert_allclose(p.grad.numpy(), q.grad.numpy(), rtol=2e-4, atol=2e-5 * max(1.0, q.grad.abs().max().item()), err_msg=k)
+        # evaluate(): same post-forward state on both sides (running statistics were updated identically above)
+        ev_ref = T.evaluate(ref, g, feat, labels, tr, va, te, use_labels=True, n_label_iters=1, loss="loge", n_classes=C)
+        n0 = fused.INFER_CALLS
+        ev = bdist.evaluate(model, part, use_labels=True, n_label_iters=1, loss="loge", n_classes=C)
+        assert fused.INFER_CALLS - n0 == 6                # the inference-only layers run partitioned too
+        np.testing.assert_allclose(np.array(ev[:6], dtype=np.float64), np.array([float(v) for v in ev_ref[:6]]), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ev[6].numpy(), ev_ref[6][ids].numpy(), rtol=1e-4, atol=2e-5)
+        if rank == 0:  # the edge-cut-aware partitioner: far fewer halo rows than contiguous ranges of the random numbering
+            from bot_amd.graph import reorder_permutation
+            before = bdist.halo_statistics(s, d, n, world)
+            p2, _ = reorder_permutation(g, "community")
+            inv = torch.empty_like(p2)
+            inv[p2] = torch.arange(n)
+            after = bdist.halo_statistics(inv[s], inv[d], n, world)
+            assert sum(after["halo_rows_per_rank"]) < 0.6 * sum(before["halo_rows_per_rank"]), (before, after)
+            assert after["cut_edges"] < 0.5 * before["cut_edges"]
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("partitioner,world", [("contiguous", 2), ("community", 2), ("community", 3)])
+def test_partitioned_label_reuse_evaluate_and_partitioner(partitioner, world, tmp_path):
+    mp.spawn(_worker_extras, args=(world, _free_port(), partitioner, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
