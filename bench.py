@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
-"""Headline benchmark: edges/sec of one full-batch GAT train step (forward + loss + backward + optimizer
-step) on an ogbn-arxiv-shaped synthetic graph (BASELINE.json config 2), plus the HBM roofline of the
-dominant kernel (the CSR/CSC SpMM of the 3x250 GAT aggregation) and a CPU baseline timed in the same run.
+"""Headline benchmark: edges/sec of one full-batch train step (forward + loss + backward + optimizer step) of a BASELINE.json
+configuration on a synthetic graph of its shape — by default config 2, the ogbn-arxiv-shaped 3 x 3 x 250 GAT — plus the HBM
+roofline of the step's dominant SpMM, a CPU baseline timed in the same run and (config 2) full-size parity against the oracle.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5 [--workload cora|arxiv|reddit|proteins|products]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--workload ...]
 
-Prints ONE JSON line on rank 0.  `value` = preprocessed edges of the whole graph / wall time per step
-(max over ranks), inputs resident in HBM.  For N > 1 the same graph is 1-D vertex-partitioned over the
-ranks with a halo all-to-all per layer on RCCL ("scaling": "strong").
+Prints ONE JSON line on rank 0.  `value` = preprocessed edges of the whole graph / wall time per step (max over ranks), inputs
+resident in HBM.  For N > 1 the same graph is 1-D vertex-partitioned over the ranks with a halo all-to-all per layer on RCCL
+("scaling": "strong"); every rank builds the seeded dataset in its own HBM and cuts its block out there.
 """
 from __future__ import annotations
 
@@ -20,7 +20,6 @@ import sys
 import time
 
 import torch
-import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -28,19 +27,14 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md "Chip-level parameters"
 
-# reference command for config 2 (src/no-sampling/run.py:1011-1013):
-#   run.py --optimizer=rmsprop --lr=0.002 --loss=loge --labels --mask-rate=0.5 --model=gat --linear
-#          --n-heads=3 --n-hidden=250 --dropout=0.75 --input-drop=0.25 --attn-drop=0.1
-CFG = dict(n_layers=3, n_heads=3, n_hidden=250, norm="batch", dropout=0.75, input_drop=0.25, attn_drop=0.1,
-           edge_drop=0.0, non_interactive_attn=False, use_symmetric_norm=False, linear=True, residual=False)
-
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="arxiv", choices=["arxiv", "cora", "products", "reddit"])
+    ap.add_argument("--workload", default="arxiv", choices=["arxiv", "cora", "products", "reddit", "proteins"],
+                    help="BASELINE.json configs 2 (default: the one `metric` is quoted on), 1, 5, 3, 4")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; reported in config)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -48,8 +42,10 @@ def parse():
                     help="file: hipBLASLt/rocBLAS kernel selections from bot_amd/tuning (TunableOp, read-only); "
                          "tune: also time shapes missing from the file and write them to gpurun_out/ (maintenance)")
     ap.add_argument("--norm-adj", default="rw", choices=["rw", "symm"],
-                    help="rw: BASELINE config 2 (run.py:1011-1013); symm: the --norm-adj=symm variant of the same command "
-                         "(run.py:1023-1025), reported in config")
+                    help="arxiv only. rw: BASELINE config 2 (run.py:1011-1013); symm: the --norm-adj=symm variant of the same "
+                         "command (run.py:1023-1025), reported in config")
+    ap.add_argument("--partitioner", default="contiguous", choices=["contiguous", "community"],
+                    help="N > 1: contiguous id ranges, or ranges of the label-propagation community order (bot_amd/dist.py)")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the 1-D partitioned code path even with one rank (exercises the RCCL plumbing on a 1-GPU box)")
     return ap.parse_args()
@@ -71,20 +67,22 @@ def cpu_model_name():
 
 
 def cpu_baseline_and_parity(ds, n_classes, steps, dev, fuse=True):
-    """`cpu_baseline`: the oracle's C restatement of DGL's CPU kernels (oracle/c_ops.py + oracle/ref_models.py) driving the same
-    3-layer GAT train step (forward + loge loss + backward; dropout 0, fixed label mask) on the host cores of this box: 1 warm-up
-    + `steps` timed steps, median.  `parity`: the SAME step (same weights, same mask, dropout 0) on the HIP path, every logit and
-    every parameter gradient compared with what the oracle just computed (tests/full_size.py) — outside the timed region."""
+    """Config 2.  `cpu_baseline`: the oracle's C restatement of DGL's CPU kernels (oracle/c_ops.py + oracle/ref_models.py) driving
+    the same 3-layer GAT train step (forward + loge loss + backward; dropout 0, fixed label mask) on the host cores of this box:
+    1 warm-up + `steps` timed steps, median.  `parity`: the SAME step (same weights, same mask, dropout 0) on the HIP path, every
+    logit and every parameter gradient compared with the oracle's (tests/full_size.py) — outside the timed region."""
+    from bot_amd import workloads
     from tests import full_size as FS
-    cfg = {k: CFG[k] for k in FS.GAT_ARXIV}
+    cfg = {k: workloads.ARXIV_GAT[k] for k in FS.GAT_ARXIV}
     C = n_classes
-    sd = FS.init_state(cfg, ds.feat.shape[1] + C, C, seed=0)
-    mask = torch.rand(ds.train_idx.shape, generator=torch.Generator().manual_seed(7)) < 0.5
-    s, d = ds.graph.edges()
+    feat, labels, train_idx = ds.feat.cpu(), ds.labels.cpu(), ds.train_idx.cpu()
+    sd = FS.init_state(cfg, feat.shape[1] + C, C, seed=0)
+    mask = torch.rand(train_idx.shape, generator=torch.Generator().manual_seed(7)) < 0.5
+    s, d = (t.cpu() for t in ds.graph.edges())
     n = ds.graph.number_of_nodes()
     # 32 threads: measured best on the 256-thread host of the GPU box (tools/exp_cpu_threads.py, 1/4-scale step:
     # 8/16/32/64/128/256 threads -> 1.56/1.21/1.07/1.53/2.90/19.5 s); more threads only add contention.
-    pred, grads, times, threads, _ = FS.oracle_step(s, d, n, ds.feat, ds.labels, ds.train_idx, mask, sd, cfg, C, steps=steps + 1)
+    pred, grads, times, threads, _ = FS.oracle_step(s, d, n, feat, labels, train_idx, mask, sd, cfg, C, steps=steps + 1)
     timed = sorted(times[1:])
     t = timed[len(timed) // 2]
     cpu = {"value": s.numel() / t, "unit": "edges/s", "cores": threads, "kind": "port",
@@ -95,13 +93,13 @@ def cpu_baseline_and_parity(ds, n_classes, steps, dev, fuse=True):
     g = ds.graph.to(dev)
     g.create_formats_()
     hp, hg, gates = FS.hip_step(g, ds.feat.to(dev), ds.labels.to(dev), ds.train_idx.to(dev), mask, sd, cfg, C, fuse=fuse)
-    # gradients are compared with the oracle evaluated at the HIP run's ReLU gates (tests/full_size.py:KinkGates); the logits with
-    # the oracle's own gates (the plain step timed above)
-    gp, gg, _, _, gstats = FS.oracle_step(s, d, n, ds.feat, ds.labels, ds.train_idx, mask, sd, cfg, C, gates=gates)
+    # gradients are compared with the oracle evaluated at the HIP run's ReLU / leaky-ReLU gates (tests/full_size.py:KinkGates);
+    # the logits with the oracle's own gates (the plain step timed above) as well
+    gp, gg, _, _, gstats = FS.oracle_step(s, d, n, feat, labels, train_idx, mask, sd, cfg, C, gates=gates)
     parity = FS.compare(hp, hg, gp, gg, gstats)
     parity["max_abs_logit_diff"] = max(parity["max_abs_logit_diff"], float((hp.cpu().double() - pred.double()).abs().max()))
     parity["against"] = ("oracle/c_ops.py (C restatement of DGL's CPU kernels): same weights + label mask, dropout 0, training-mode "
-                         "BatchNorm; logits vs the plain oracle step, gradients vs the oracle at the HIP run's ReLU gates")
+                         "BatchNorm; logits vs the plain oracle step, gradients vs the oracle at the HIP run's ReLU / leaky-ReLU gates")
     return cpu, parity
 
 
@@ -121,50 +119,25 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from bot_amd import _C, synth, train, tuning
-    from bot_amd import nn as bnn
+    from bot_amd import _C, tuning, workloads
     tuned = tuning.enable(tune_missing=args.gemm_tuning == "tune") if args.gemm_tuning != "off" else False
     if args.gemm_tuning == "tune":
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         torch.cuda.tunable.set_filename(os.path.join(ROOT, "gpurun_out", f"tunableop_new_rank{rank}.csv"))
 
-    ds = synth.make_dataset(args.workload, device="cpu", seed=0, scale=args.scale)
-    n, C = ds.graph.number_of_nodes(), ds.n_classes
-    E = ds.graph.number_of_edges()
-    src_cpu, dst_cpu = ds.graph.edges()
-    torch.manual_seed(0)
-    cfg = dict(CFG, use_symmetric_norm=args.norm_adj == "symm")
-    model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **cfg).to(dev)
-    opt = torch.optim.RMSprop(model.parameters(), lr=0.002)
-
-    if not partitioned:
-        g = ds.graph.to(dev)
-        g.create_formats_()
-        feat, labels = ds.feat.to(dev), ds.labels.to(dev)
-        tr, va, te = ds.train_idx.to(dev), ds.val_idx.to(dev), ds.test_idx.to(dev)
-
-        def step():
-            return train.train_step(model, g, feat, labels, tr, va, te, opt, use_labels=True, mask_rate=0.5, loss="loge",
-                                    n_classes=C)
-        barrier = lambda: None
-    else:
-        from bot_amd import dist as bdist
-        part = bdist.partition_dataset(ds, rank, world, dev)
-        model = bdist.wrap_model(model)
-
-        def step():
-            return bdist.train_step(model, part, opt, use_labels=True, mask_rate=0.5, loss="loge", n_classes=C)
-        barrier = torch.distributed.barrier
+    wl = workloads.build(args.workload, dev, rank=rank, world=world, partitioned=partitioned, seed=0, scale=args.scale,
+                         norm_adj=args.norm_adj, partitioner=args.partitioner)
+    barrier = torch.distributed.barrier if partitioned else (lambda: None)
 
     for _ in range(args.warmup):
-        step()
+        wl.step()
     # ---- timed region: exactly K steps between barrier + synchronize
     _C.PROFILE = prof = []
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        wl.step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -175,52 +148,46 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
 
-    # ---- roofline of the dominant kernel: the weighted SpMM of the hidden layers (H=3, D=250; the CSC sweep of the
-    # forward pass), HIP events recorded around each launch on the launch stream inside the timed region.
-    H, D = CFG["n_heads"], CFG["n_hidden"]
-    sel = [r for r in prof if r[0] == "spmm" and r[1] == (H, D, True)]
-    durs = [r[2].elapsed_time(r[3]) * 1e-3 for r in sel]
-    kernel = sel[0][4] if sel else None   # the template instance bot_spmm_f32 dispatched for this shape (bot_last_kernel)
+    # ---- roofline of the dominant kernel: the SpMM of the hidden layers' shape (forward CSC sweep; for the dense graphs the
+    # L2-blocked form), HIP events recorded around each launch on the launch stream inside the timed region.
+    H, D, weighted = wl.dominant_shape
+    sel = [r for r in prof if r[0] in ("spmm", "spmm_blocked") and r[1] == (H, D, weighted)]
+    fam = max({r[0] for r in sel}, key=lambda f: sum(r[2].elapsed_time(r[3]) for r in sel if r[0] == f)) if sel else None
+    sel = [r for r in sel if r[0] == fam]
     roof = None
-    if durs:
-        n_loc = part.n_owned if partitioned else n
-        e_loc = part.n_edges if partitioned else E
-        alg = spmm_alg_bytes(n_loc, e_loc, H, D, True)
+    if sel:
+        durs = [r[2].elapsed_time(r[3]) * 1e-3 for r in sel]
+        kernel = sel[0][4]   # the template instance the launch function dispatched for this shape (bot_last_kernel)
+        alg = spmm_alg_bytes(wl.n_local, wl.e_local, H, D, weighted)
         avg = sum(durs) / len(durs)
         ach = alg / avg / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "spmm_traffic.json")
-        if world == 1 and args.scale == 1.0 and os.path.exists(tf):
-            traffic = json.load(open(tf)).get("bytes_per_launch")
         tj = json.load(open(tf)) if os.path.exists(tf) else {}
-        if traffic is not None and tj.get("kernel") != kernel:
-            traffic = None   # the committed PMC summary belongs to another kernel instance: do not attach it
-        roof = {"bound": "hbm", "kernel": f"{kernel} (u_mul_e_sum forward, H={H} D={D}, hidden layers)",
+        if world == 1 and args.scale == 1.0 and args.workload == "arxiv" and tj.get("kernel") == kernel:
+            traffic = tj.get("bytes_per_launch")   # PMC passes of the same kernel instance on the same graph (tools/f4_pmc.sh)
+        roof = {"bound": "hbm", "kernel": f"{kernel} (SpMM forward, H={H} D={D}{', weighted' if weighted else ''}, hidden layers)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg * 1e3, 4),
                 "launches_timed": len(durs),
                 # measured L2<->fabric bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/spmm_traffic.json) over the same
-                # launch time: what the memory system actually delivered (Infinity-Cache hits included), next to the
-                # algorithmic-byte figure above
+                # launch time: what the memory system actually delivered (Infinity-Cache hits included)
                 "traffic_GBs": round(traffic / avg / 1e9, 1) if traffic else None,
                 "traffic_frac_of_peak": round(traffic / avg / 1e9 / HBM_PEAK_GBS, 4) if traffic else None}
 
     cpu = parity = None
-    if rank == 0 and world == 1 and args.cpu_baseline != "off":
-        cpu, parity = cpu_baseline_and_parity(ds, C, args.cpu_steps, dev)
+    if rank == 0 and world == 1 and args.cpu_baseline != "off" and args.workload == "arxiv" and args.norm_adj == "rw":
+        cpu, parity = cpu_baseline_and_parity(wl.dataset, wl.dataset.n_classes, args.cpu_steps, dev)
 
     if rank == 0:
         out = {
             "metric": "edges/sec full-batch GAT fwd+bwd on ogbn-arxiv; achieved HBM GB/s vs peak",
-            "value": E / (ms * 1e-3), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": wl.n_edges / (ms * 1e-3), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"S-{args.workload}: power-law graph N={n} E={E} (raw {ds.raw_edges}), F={ds.feat.shape[1]}, "
-                                   f"C={C}; GAT 3 layers x 3 heads x 250, --labels --loss=loge --linear --norm=batch"
-                                   f"{' --norm-adj=symm' if args.norm_adj == 'symm' else ''}, "
-                                   f"dropout 0.75/0.25/0.1, RMSprop step included",
-                       "gemm_kernel_selection": "TunableOp file" if tuned else "library default",
-                       "scale": args.scale, "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world}"},
+            "config": {"workload": wl.describe, "gemm_kernel_selection": "TunableOp file" if tuned else "library default",
+                       "scale": args.scale,
+                       "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world} ({args.partitioner} ranges)"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(out))

@@ -237,6 +237,7 @@ static int launch_blocked(const BlockedArgs& a0, int round_tiles, hipStream_t st
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
+    set_kernel("bot::spmm_blocked_kernel<%d,%d,%s,%d,%d>", VEC, NCHUNK, a.w ? "true" : "false", T, EPI);
     for (int t0 = 0; t0 < a.n_tiles; t0 += round_tiles) {  // one resident wave of workgroups per launch keeps the sweeps aligned
         a.tile0 = t0;
         const int n = a.n_tiles - t0 < round_tiles ? a.n_tiles - t0 : round_tiles;

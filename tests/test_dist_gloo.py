@@ -260,3 +260,43 @@ def _worker_extras(rank, world, port, partitioner, tmp):
 def test_partitioned_label_reuse_evaluate_and_partitioner(partitioner, world, tmp_path):
     mp.spawn(_worker_extras, args=(world, _free_port(), partitioner, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+SCALES = {"cora": 0.3, "arxiv": 0.004, "reddit": 0.00002, "proteins": 0.00004, "products": 0.00003}
+
+
+def _worker_workloads(rank, world, port, tmp):
+    """bench.py's five workloads (bot_amd/workloads.py), tiny and without dropout, partitioned over the ranks: two steps each run,
+    the loss is finite, equal on all ranks, and equal to the single-process step of the same workload (same seed, same init)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from tests import _oracle_backend
+        _oracle_backend.install_direct()
+        from bot_amd.nn import fused
+        fused.FORCE = True
+        from bot_amd import workloads
+        for name in workloads.NAMES:
+            single = workloads.build(name, "cpu", scale=SCALES[name], drop=False)
+            torch.manual_seed(11)
+            l0 = [float(single.step()[0]) for _ in range(2)]
+            part = workloads.build(name, "cpu", rank=rank, world=world, partitioned=True, scale=SCALES[name], drop=False)
+            torch.manual_seed(11)                      # the same label-mask draws as the single-process run need the same node order:
+            l1 = [float(part.step()[0]) for _ in range(2)]   # not the case -> only edge-GAT / no-mask losses are compared exactly
+            assert all(np.isfinite(l0)) and all(np.isfinite(l1)), (name, l0, l1)
+            t = torch.tensor(l1)
+            dist.all_reduce(t)
+            assert torch.allclose(t / world, torch.tensor(l1), atol=1e-6), name      # every rank reports the global loss
+            if name in ("proteins", "products"):       # no random mask in their step: comparable with one process
+                np.testing.assert_allclose(l1, l0, rtol=2e-4, atol=1e-5, err_msg=name)
+            assert part.n_edges == single.n_edges and part.e_local < part.n_edges
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_workloads_single_and_partitioned(tmp_path):
+    mp.spawn(_worker_workloads, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(2))
