@@ -65,11 +65,11 @@ _SIGS = {
     "bot_random_keep_u8": (ctypes.c_int, [c_int64, c_int64, c_uint64, _P, _P, _P]),
     "bot_bn_workspace_floats": (c_int64, [c_int32]),
     "bot_colstats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
-    "bot_bn_act_fwd_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, c_int64, _P]),
+    "bot_bn_act_fwd_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, _P, c_int64, _P]),
     "bot_bn_act_bwd_reduce_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
-                                                 c_uint64, _P, _P, _P, _P]),
+                                                 c_uint64, _P, _P, _P, _P, _P]),
     "bot_bn_act_bwd_apply_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
-                                                c_uint64, _P, _P, c_double, _P, c_int64, _P]),
+                                                c_uint64, _P, _P, _P, c_double, _P, c_int64, _P]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(_lib, _name)  # AttributeError here = header and library disagree
@@ -460,6 +460,15 @@ def scatter_add_rows(x, rows, vals):
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm + ReLU + dropout
+# Device word mixed into every fused-dropout Philox key (include/bot_gnn.h `seed_offset`).  None = not used.  A hipGraph-captured
+# train step (bot_amd.train.CapturedTrainStep) allocates it and bumps it once per replay, so that replays draw fresh masks.
+SEED_OFFSET = None
+
+
+def _seed_off(p):
+    return SEED_OFFSET.data_ptr() if (SEED_OFFSET is not None and p > 0) else None
+
+
 def _mat(x, name):
     _f32(x, name)
     if x.dim() != 2:
@@ -491,7 +500,7 @@ def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed):
     y = torch.empty((n, F), dtype=torch.float32, device=x.device)
     _check(_timed("bn_act_fwd", (F,), lambda: _lib.bot_bn_act_fwd_f32(
         x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p),
-        int(seed), y.data_ptr(), y.stride(0), _stream())), "bn_act_fwd")
+        int(seed), _seed_off(p), y.data_ptr(), y.stride(0), _stream())), "bn_act_fwd")
     return y
 
 
@@ -503,7 +512,7 @@ def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed):
     sg = torch.empty(F, dtype=torch.float32, device=x.device)
     sgx = torch.empty(F, dtype=torch.float32, device=x.device)
     _check(_lib.bot_bn_act_bwd_reduce_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, F, mean.data_ptr(),
-                                          invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p), int(seed),
+                                          invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p), int(seed), _seed_off(p),
                                           sg.data_ptr(), sgx.data_ptr(), _bn_ws(F, x.device).data_ptr(), _stream()),
            "bn_act_bwd_reduce")
     return sg, sgx
@@ -518,7 +527,7 @@ def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, su
     dx = out if out is not None else torch.empty((n, F), dtype=torch.float32, device=x.device)
     assert dx.stride(1) == 1 and dx.dtype == torch.float32
     _check(_lib.bot_bn_act_bwd_apply_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, F, mean.data_ptr(),
-                                         invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p), int(seed),
+                                         invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p), int(seed), _seed_off(p),
                                          _ptr(sum_g), _ptr(sum_gx), float(total_count), dx.data_ptr(), dx.stride(0), _stream()),
            "bn_act_bwd_apply")
     return dx

@@ -35,6 +35,13 @@ __device__ __forceinline__ void drop_factors(uint64_t seed, int64_t r, int c, in
     for (int t = 0; t < VEC; ++t) f[t] = ((w[(c & 3) + t] >> 8) * (1.0f / 16777216.0f)) >= p ? scale : 0.f;
 }
 
+// The Philox key of a launch: the host-side `seed`, plus — when the caller passes a device word — that word times an odd
+// constant.  A captured hipGraph bakes `seed` into the launch; bumping the device word between replays (one tiny captured add)
+// gives every replay a fresh mask while forward and backward of the SAME replay still regenerate the same one.
+__device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const uint64_t* off) {
+    return off ? seed + off[0] * 0x9E3779B97F4A7C15ull : seed;
+}
+
 struct BnArgs {
     const float* x;
     int64_t ldx;
@@ -47,6 +54,7 @@ struct BnArgs {
     int32_t relu;
     float p;
     uint64_t seed;
+    const uint64_t* seed_offset;  // optional device word mixed into the seed at run time (hipGraph replays: see eff_seed)
     // fwd
     float* y;
     int64_t ldy;
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
     }
     const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
     const int64_t nquad = (a.F + 3) / 4;
+    const uint64_t seed = eff_seed(a.seed, a.seed_offset);
     constexpr int UR = 4;  // rows in flight per thread: loads first, then compute + store (x and y may alias for the compiler)
     const int64_t step = (int64_t)gridDim.y * kTY;
     for (int64_t r0 = (int64_t)blockIdx.y * kTY + ty; r0 < a.n; r0 += step * UR) {
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
             const int64_t r = r0 + u * step;
             if (r >= a.n) break;
             float f[VEC];
-            if (a.p > 0.f) drop_factors<VEC>(a.seed, r, c, nquad, a.p, scale, f);
+            if (a.p > 0.f) drop_factors<VEC>(seed, r, c, nquad, a.p, scale, f);
 #pragma unroll
             for (int t = 0; t < VEC; ++t) {
                 float o = fmaf(v[u][t] - mu[t], sc[t], sh[t]);
@@ -189,12 +198,13 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_reduce_kernel(BnArgs a) {
         }
         const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
         const int64_t nquad = (a.F + 3) / 4;
+        const uint64_t seed = eff_seed(a.seed, a.seed_offset);
 #pragma unroll 4
         for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < a.n; r += (int64_t)gridDim.y * kTY) {
             float v[VEC], g[VEC], f[VEC];
             vload<VEC>(v, a.x + r * a.ldx + c);
             vload<VEC>(g, a.dy + r * a.lddy + c);
-            if (a.p > 0.f) drop_factors<VEC>(a.seed, r, c, nquad, a.p, scale, f);
+            if (a.p > 0.f) drop_factors<VEC>(seed, r, c, nquad, a.p, scale, f);
 #pragma unroll
             for (int t = 0; t < VEC; ++t) {
                 const float xh = (v[t] - mu[t]) * is[t];
@@ -249,6 +259,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
     }
     const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
     const int64_t nquad = (a.F + 3) / 4;
+    const uint64_t seed = eff_seed(a.seed, a.seed_offset);
     constexpr int UR = 4;
     const int64_t step = (int64_t)gridDim.y * kTY;
     for (int64_t r0 = (int64_t)blockIdx.y * kTY + ty; r0 < a.n; r0 += step * UR) {
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
             const int64_t r = r0 + u * step;
             if (r >= a.n) break;
             float f[VEC];
-            if (a.p > 0.f) drop_factors<VEC>(a.seed, r, c, nquad, a.p, scale, f);
+            if (a.p > 0.f) drop_factors<VEC>(seed, r, c, nquad, a.p, scale, f);
 #pragma unroll
             for (int t = 0; t < VEC; ++t) {
                 const float xh = (v[u][t] - mu[t]) * is[t];
@@ -308,8 +319,8 @@ int bot_colstats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* m
 }
 
 int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
-                       const float* weight, const float* bias, int32_t relu, float p, uint64_t seed, float* y, int64_t ldy,
-                       bot_stream_t stream) {
+                       const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
+                       const uint64_t* seed_offset, float* y, int64_t ldy, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && ldy >= F, BOT_E_RANGE, "bn_act_fwd: n=%lld F=%d", (long long)n, F);
     BOT_REQUIRE(p >= 0.f && p < 1.f, BOT_E_RANGE, "bn_act_fwd: dropout p=%f must be in [0,1)", (double)p);
@@ -317,7 +328,7 @@ int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const 
     BOT_REQUIRE(x && mean && invstd && y, BOT_E_NULL, "bn_act_fwd: NULL pointer");
     BnArgs a{};
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
-    a.seed = seed, a.y = y, a.ldy = ldy;
+    a.seed = seed, a.seed_offset = seed_offset, a.y = y, a.ldy = ldy;
     const int vec = pick_vec(F, {ldx, ldy}, {x, y, mean, invstd});
     const dim3 grid = bn_grid(F, vec, n);
     hipStream_t st = (hipStream_t)stream;
@@ -329,13 +340,14 @@ int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const 
 
 int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
                               const float* mean, const float* invstd, const float* weight, const float* bias, int32_t relu,
-                              float p, uint64_t seed, float* sum_g, float* sum_gx, float* workspace, bot_stream_t stream) {
+                              float p, uint64_t seed, const uint64_t* seed_offset, float* sum_g, float* sum_gx, float* workspace,
+                              bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n >= 1 && F >= 1 && ldx >= F && lddy >= F, BOT_E_RANGE, "bn_act_bwd_reduce: n=%lld F=%d", (long long)n, F);
     BOT_REQUIRE(dy && x && mean && invstd && sum_g && sum_gx && workspace, BOT_E_NULL, "bn_act_bwd_reduce: NULL pointer");
     BnArgs a{};
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
-    a.seed = seed, a.dy = dy, a.lddy = lddy, a.part = workspace;
+    a.seed = seed, a.seed_offset = seed_offset, a.dy = dy, a.lddy = lddy, a.part = workspace;
     const int vec = pick_vec(F, {ldx, lddy}, {x, dy, mean, invstd});
     const dim3 grid = bn_grid(F, vec, n);
     hipStream_t st = (hipStream_t)stream;
@@ -349,8 +361,8 @@ int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int
 
 int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
                              const float* mean, const float* invstd, const float* weight, const float* bias, int32_t relu,
-                             float p, uint64_t seed, const float* sum_g, const float* sum_gx, double total_count, float* dx,
-                             int64_t lddx, bot_stream_t stream) {
+                             float p, uint64_t seed, const uint64_t* seed_offset, const float* sum_g, const float* sum_gx,
+                             double total_count, float* dx, int64_t lddx, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && lddy >= F && lddx >= F, BOT_E_RANGE, "bn_act_bwd_apply: n=%lld F=%d", (long long)n, F);
     if (n == 0) return 0;
@@ -359,7 +371,7 @@ int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int6
     BOT_REQUIRE(sum_g == nullptr || total_count >= 1.0, BOT_E_RANGE, "bn_act_bwd_apply: total_count=%f", total_count);
     BnArgs a{};
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
-    a.seed = seed, a.dy = dy, a.lddy = lddy, a.sum_g = sum_g, a.sum_gx = sum_gx, a.inv_count = sum_g ? (float)(1.0 / total_count) : 0.f;
+    a.seed = seed, a.seed_offset = seed_offset, a.dy = dy, a.lddy = lddy, a.sum_g = sum_g, a.sum_gx = sum_gx, a.inv_count = sum_g ? (float)(1.0 / total_count) : 0.f;
     a.dx = dx, a.lddx = lddx;
     const int vec = pick_vec(F, {ldx, lddy, lddx}, {x, dy, dx, mean, invstd, sum_g, sum_gx});
     const dim3 grid = bn_grid(F, vec, n);

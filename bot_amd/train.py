@@ -50,24 +50,38 @@ def compute_acc(pred, labels):
 def forward_backward(model, graph, feat, labels, train_idx, val_idx, test_idx, *, use_labels=True, mask_rate=0.5,
                      n_label_iters=0, loss="logit", n_classes=None, mask=None):
     """Forward + loss + backward of `train()` — run.py:252-284 without the optimizer step.
-    Returns (loss tensor, pred, train_pred_idx).  `mask` overrides the random split of run.py:258."""
+    Returns (loss tensor, pred, w) with w the 0/1 weight of every training node in the loss (1 = a prediction node of this
+    step, run.py:259-261 / :267).  `mask` overrides the random split of run.py:258.
+
+    Written with FIXED shapes: the reference's `train_idx[mask]` / `train_idx[~mask]` (boolean indexing) makes the host wait
+    for the device and gives tensors whose size changes from step to step; here the one-hot label block is written with the
+    mask as its values and the loss is the weighted mean over ALL training nodes — the same sets, the same numbers (up to the
+    summation order of a mean), no synchronisation, and a launch sequence a hipGraph can capture (CapturedTrainStep)."""
     if mask is None:
         mask = torch.rand(train_idx.shape, device=train_idx.device) < mask_rate
     if use_labels:
-        train_labels_idx, train_pred_idx = train_idx[mask], train_idx[~mask]
-        feat = add_labels(feat, labels, train_labels_idx, n_classes)
+        onehot = torch.zeros([feat.shape[0], n_classes], device=feat.device, dtype=feat.dtype)
+        onehot[train_idx, labels[train_idx, 0]] = mask.to(feat.dtype)          # run.py:240-243 for idx = train_idx[mask]
+        feat = torch.cat([feat, onehot], dim=-1)
+        w = (~mask).to(feat.dtype)                                              # train_pred_idx = train_idx[~mask]
     else:
-        train_pred_idx = train_idx[mask]
+        w = mask.to(feat.dtype)                                                 # run.py:265-267
     pred = model(graph, feat)
-    if n_label_iters > 0:
-        unlabel_idx = torch.cat([train_pred_idx, val_idx, test_idx])
+    if n_label_iters > 0 and use_labels:
+        # label reuse (run.py:274-279): nodes without an input label — masked-out training, validation and test nodes — get
+        # the previous prediction's softmax in their label columns, then the model runs again
+        m = mask.unsqueeze(1)
         for _ in range(n_label_iters):
             pred = pred.detach()
-            feat[unlabel_idx, -n_classes:] = F.softmax(pred[unlabel_idx], dim=-1)
+            prob = F.softmax(pred, dim=-1)
+            feat[train_idx, -n_classes:] = torch.where(m, feat[train_idx, -n_classes:], prob[train_idx])
+            for idx in (val_idx, test_idx):
+                feat[idx, -n_classes:] = prob[idx]
             pred = model(graph, feat)
-    out = compute_loss(pred[train_pred_idx], labels[train_pred_idx], loss)
+    y = per_node_loss(pred[train_idx], labels[train_idx], loss)
+    out = (y * w).sum() / w.sum()
     out.backward()
-    return out, pred, train_pred_idx
+    return out, pred, w
 
 
 def train_step(model, graph, feat, labels, train_idx, val_idx, test_idx, optimizer, **kw):
@@ -101,3 +115,56 @@ def evaluate(model, graph, feat, labels, train_idx, val_idx, test_idx, *, use_la
     losses = tuple(compute_loss(pred[i], labels[i], loss) for i in (train_idx, val_idx, test_idx))
     accs = tuple(compute_acc(pred[i], labels[i]) for i in (train_idx, val_idx, test_idx))
     return accs + losses + (pred,)
+
+
+class CapturedTrainStep:
+    """One `train()` call (run.py:252-287: forward, loss, backward, optimizer step) captured ONCE into a hipGraph and replayed:
+    ~300 launches per step cost one graph launch on the host, which is what bounds a rank once its GPU work drops to a few ms
+    (8-way partitions).  Works because the step has fixed shapes and no host synchronisation (forward_backward), the C ABI
+    never allocates or synchronises (include/bot_gnn.h), and the optimizer is constructed with `capturable=True`.
+
+    Fresh randomness per replay: torch's own generators are graph-safe (mask split, input / attention dropout); the fused
+    BatchNorm+ReLU+dropout kernels bake their Philox seed into the launch, so they additionally read a device word
+    (`bot_amd._C.SEED_OFFSET`) that the captured step bumps first — forward and backward of one replay see the same value.
+    Training-time edge drop (`edge_drop > 0`, the edge-feature GATs) draws its mask seed on the host and is not supported here.
+
+    `step_fn()` -> (loss, pred) must run the WHOLE step (model.train(), zero_grad(set_to_none=True), ..., optimizer.step())."""
+
+    def __init__(self, step_fn, device, warmup: int = 3):
+        from . import _C
+        self.device = torch.device(device)
+        if _C.SEED_OFFSET is None or _C.SEED_OFFSET.device != self.device:
+            _C.SEED_OFFSET = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._off = _C.SEED_OFFSET
+
+        def body():
+            self._off.add_(1)
+            return step_fn()
+
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):                       # warm-up off the default stream: lazy plans, autotuned GEMMs, caches
+            for _ in range(warmup):
+                body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.pred = body()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.loss, self.pred
+
+
+def captured_train_step(model, graph, feat, labels, train_idx, val_idx, test_idx, optimizer, warmup=3, **kw) -> CapturedTrainStep:
+    """`train_step` as a replayable hipGraph; `optimizer` must have been built with capturable=True."""
+    if not all(g.get("capturable", False) for g in optimizer.param_groups):
+        raise ValueError("captured_train_step needs an optimizer constructed with capturable=True")
+
+    def step():
+        model.train()
+        optimizer.zero_grad(set_to_none=True)
+        loss, pred, _ = forward_backward(model, graph, feat, labels, train_idx, val_idx, test_idx, **kw)
+        optimizer.step()
+        return loss, pred
+    return CapturedTrainStep(step, feat.device, warmup)

@@ -296,7 +296,9 @@ int bot_scatter_add_rows_f32(float* x, int64_t ldx, const int32_t* rows, int64_t
  * The dropout mask is a counter-based Philox4x32-10 stream: element (r, c) takes word c % 4 of the block with
  * counter r * ceil(F/4) + c/4 under key `seed` — a function of (seed, r, c, F) only, independent of pointer
  * alignment, strides or the vector width a launch picks, so forward and backward regenerate the same mask from
- * `seed` for any operand layout; nothing is stored.  p == 0 disables dropout.  `weight`/`bias` may be
+ * `seed` for any operand layout; nothing is stored.  `seed_offset` (device pointer, may be NULL): one 64-bit word read by
+ * the kernel and mixed into the key (seed + word * 0x9E3779B97F4A7C15): a captured hipGraph bakes `seed` in, the caller
+ * bumps the word between replays.  p == 0 disables dropout.  `weight`/`bias` may be
  * NULL.  `workspace` holds bot_bn_workspace_floats(F) floats.  In the vertex-partitioned mode the caller
  * all-reduces (mean, m2, count) and (sum_g, sum_gx) between the two halves; `total_count` is the global
  * row count.  The grad of weight is sum_gx, of bias sum_g.
@@ -306,15 +308,15 @@ int bot_colstats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* m
                      bot_stream_t stream);
 int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
                        const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
-                       float* y, int64_t ldy, bot_stream_t stream);
+                       const uint64_t* seed_offset, float* y, int64_t ldy, bot_stream_t stream);
 int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
                               const float* mean, const float* invstd, const float* weight, const float* bias,
-                              int32_t relu, float p, uint64_t seed, float* sum_g, float* sum_gx, float* workspace,
-                              bot_stream_t stream);
+                              int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, float* sum_g, float* sum_gx,
+                              float* workspace, bot_stream_t stream);
 int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
                              const float* mean, const float* invstd, const float* weight, const float* bias,
-                             int32_t relu, float p, uint64_t seed, const float* sum_g, const float* sum_gx,
-                             double total_count, float* dx, int64_t lddx, bot_stream_t stream);
+                             int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, const float* sum_g,
+                             const float* sum_gx, double total_count, float* dx, int64_t lddx, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Edge-feature attention term of the ogbn-proteins GAT, fused.  Replaces, per layer,

@@ -159,7 +159,7 @@ def test_block_graphs_reproduce_full_graph(golden):
     dl, dr = torch.zeros_like(el), torch.zeros_like(er)
     for rank in range(2):
         p = bdist.build_partition(s, d, n, rank, 2, device=DEV)
-        glob = torch.cat([torch.arange(p.lo, p.hi), p.halo_global]).to(DEV)
+        glob = torch.cat([torch.arange(p.lo, p.hi, device=DEV), p.halo_global.to(DEV)])
         xe, le = x[glob].clone().requires_grad_(), el[glob].clone().requires_grad_()
         re = er[p.lo:p.hi].clone().requires_grad_()
         out = ops.u_mul_e_sum(p.graph, xe, ops.gat_attention(p.graph, le, re, order="csc"), order="csc")
@@ -756,3 +756,56 @@ def test_evaluate_inference_path_full_size():
     assert float((ev[6] - ev_ref[6]).abs().max()) <= 1e-4
     assert all(abs(float(a) - float(b)) <= 1e-4 for a, b in zip(ev[3:6], ev_ref[3:6]))
     assert all(abs(a - b) <= 2e-4 for a, b in zip(ev[:3], ev_ref[:3]))  # accuracies: a tie in an argmax may flip a node
+
+
+# ---------------------------------------------------------------------------------------------- hipGraph-captured train step
+def test_captured_train_step_bit_identical_and_fresh_masks():
+    """the whole train step (forward, loge loss, backward, RMSprop) captured into a hipGraph.  (a) With every drop
+    rate 0 the replayed step is BIT-identical to the eager step from the same state (same kernels, same order, no atomics):
+    parameters, BatchNorm buffers and logits after 3 steps.  (b) With the reference's drop rates every replay draws fresh
+    masks (torch's graph-safe generators + the device seed word of the fused dropout kernels) and training proceeds."""
+    import copy
+    import torch.nn.functional as F
+    from bot_amd import nn as bnn, synth, train as T
+    ds = synth.make_dataset("arxiv", device=DEV, seed=0, scale=0.2)
+    g, C = ds.graph, ds.n_classes
+    g.create_formats_()
+    mask = torch.rand(ds.train_idx.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(3)) < 0.5
+    kw = dict(use_labels=True, loss="loge", n_classes=C)
+
+    def make(drop):
+        torch.manual_seed(0)
+        k = 1.0 if drop else 0.0
+        m = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, n_layers=3, n_heads=3, n_hidden=64,
+                    norm="batch", dropout=0.75 * k, input_drop=0.25 * k, attn_drop=0.1 * k, linear=True).to(DEV)
+        return m, torch.optim.RMSprop(m.parameters(), lr=0.002, capturable=True)
+
+    # (a) bit-identity without dropout, fixed mask
+    m1, o1 = make(False)
+    m2, o2 = make(False)
+    m2.load_state_dict(copy.deepcopy(m1.state_dict()))
+    cap = T.captured_train_step(m2, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o2, warmup=3, mask=mask, **kw)
+    for _ in range(3 + 1):          # the capture ran 3 warm-up steps + 1 capture pass (capture itself does not execute)
+        pass
+    for _ in range(3):               # eager: the same number of optimizer steps as warm-up, then 3 more
+        T.train_step(m1, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o1, mask=mask, **kw)
+    for _ in range(3):
+        le, pe = T.train_step(m1, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o1, mask=mask, **kw)
+        lc, pc = cap()
+    torch.cuda.synchronize()
+    assert torch.equal(lc, le) and torch.equal(pc, pe)
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    # (b) dropout on: fresh masks per replay, finite decreasing-ish loss
+    m3, o3 = make(True)
+    cap3 = T.captured_train_step(m3, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o3, warmup=3, mask_rate=0.5, **kw)
+    losses, preds = [], []
+    for _ in range(4):
+        l, p = cap3()
+        losses.append(float(l))
+        preds.append(p.clone())
+    assert all(torch.isfinite(torch.tensor(losses))) and len(set(losses)) == 4, losses
+    assert not torch.equal(preds[0], preds[1])
+    from bot_amd import _C
+    assert int(_C.SEED_OFFSET) >= 4
+    _C.SEED_OFFSET = None
