@@ -46,6 +46,9 @@ def parse():
                          "command (run.py:1023-1025), reported in config")
     ap.add_argument("--partitioner", default="contiguous", choices=["contiguous", "community"],
                     help="N > 1: contiguous id ranges, or ranges of the label-propagation community order (bot_amd/dist.py)")
+    ap.add_argument("--capture", default="auto", choices=["auto", "on", "off"],
+                    help="replay the train step as ONE hipGraph (bot_amd.train.CapturedTrainStep) instead of ~300 eager launches. "
+                         "auto: on for single-GPU runs of the GCN / GAT stacks (configs 1-3), off otherwise; on: also partitioned")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the 1-D partitioned code path even with one rank (exercises the RCCL plumbing on a 1-GPU box)")
     return ap.parse_args()
@@ -125,8 +128,9 @@ def main():
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         torch.cuda.tunable.set_filename(os.path.join(ROOT, "gpurun_out", f"tunableop_new_rank{rank}.csv"))
 
+    capture = args.capture == "on" or (args.capture == "auto" and not partitioned)
     wl = workloads.build(args.workload, dev, rank=rank, world=world, partitioned=partitioned, seed=0, scale=args.scale,
-                         norm_adj=args.norm_adj, partitioner=args.partitioner)
+                         norm_adj=args.norm_adj, partitioner=args.partitioner, capture=capture)
     barrier = torch.distributed.barrier if partitioned else (lambda: None)
 
     for _ in range(args.warmup):
@@ -186,7 +190,7 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl.describe, "gemm_kernel_selection": "TunableOp file" if tuned else "library default",
-                       "scale": args.scale,
+                       "scale": args.scale, "launch": "one hipGraph replay per step" if wl.captured else "eager",
                        "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world} ({args.partitioner} ranges)"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }

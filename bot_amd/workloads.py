@@ -83,10 +83,12 @@ def _edge_dataset(name, device, seed, scale):
 
 
 def build(name: str, device, *, rank=0, world=1, partitioned=False, seed=0, scale=1.0, norm_adj="rw", partitioner="contiguous",
-          group=None, drop=True) -> Workload:
+          group=None, drop=True, capture=False) -> Workload:
     """Dataset + model + optimizer + step of one configuration.  Every rank builds the same (seeded) whole dataset on its own
     device and cuts its block out of it there (bot_amd.dist.build_partition).  `drop=False` zeroes every drop rate (parity
-    and CPU tests; the benchmark keeps the reference's rates)."""
+    and CPU tests; the benchmark keeps the reference's rates).  `capture=True`: the step is captured into a hipGraph after 3 eager
+    warm-up steps and replayed (bot_amd.train.CapturedTrainStep; the GCN / GAT stacks of configs 1-3, whose step draws no
+    host-side seeds per step — the edge-drop mask of configs 4 / 5 does, those stay eager)."""
     k = 1.0 if drop else 0.0
     if name not in NAMES:
         raise ValueError(f"unknown workload {name!r}: {NAMES}")
@@ -102,7 +104,7 @@ def build(name: str, device, *, rank=0, world=1, partitioned=False, seed=0, scal
         cfg = dict(ARXIV_GAT, use_symmetric_norm=norm_adj == "symm")
         cfg.update(dropout=0.75 * k, input_drop=0.25 * k, attn_drop=0.1 * k)
         model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **cfg).to(dev)
-        opt = torch.optim.RMSprop(model.parameters(), lr=0.002)
+        opt = torch.optim.RMSprop(model.parameters(), lr=0.002, capturable=capture)
         kw = dict(use_labels=True, mask_rate=0.5, loss="loge", n_classes=C)
         shape, desc = (3, 250, True), (f"GAT 3 layers x 3 heads x 250, --labels --loss=loge --linear --norm=batch"
                                        f"{' --norm-adj=symm' if norm_adj == 'symm' else ''}, dropout 0.75/0.25/0.1, RMSprop step included")
@@ -110,7 +112,7 @@ def build(name: str, device, *, rank=0, world=1, partitioned=False, seed=0, scal
         hid, layers = (16, 2) if name == "cora" else (256, 3)
         model = bnn.GCN(in_feats=ds.feat.shape[1], n_classes=C, n_hidden=hid, n_layers=layers, activation=F.relu,
                         norm="none" if name == "cora" else "batch", norm_adj="symm", dropout=0.5 * k).to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=0.01)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=capture)
         kw = dict(use_labels=False, mask_rate=0.5, loss="logit", n_classes=C)   # run.py:265-267: the mask split also without --labels
         shape, desc = (1, hid, False), f"GCN {layers} layers x {hid}, norm_adj=symm, dropout 0.5, logit loss, Adam step included"
     elif name == "proteins":
@@ -169,6 +171,12 @@ def build(name: str, device, *, rank=0, world=1, partitioned=False, seed=0, scal
             def step():
                 return bdist.train_step(model, part, opt, group=group, **dkw)
         ds.part = part
+    captured = False
+    if capture and not edge:
+        eager, captured = step, True
+        step = T.CapturedTrainStep(lambda: eager()[:2], dev)
     H, D, weighted = shape
     describe = (f"S-{name}: power-law graph N={n} E={E} (raw {ds.raw_edges}), F={0 if ds.feat is None else ds.feat.shape[1]}, C={C}; {desc}")
-    return Workload(name, describe, n, E, ds.raw_edges, step, model, ("spmm", shape), shape, n_local, e_local, ds, g)
+    wl = Workload(name, describe, n, E, ds.raw_edges, step, model, ("spmm", shape), shape, n_local, e_local, ds, g)
+    wl.captured = captured
+    return wl
