@@ -46,9 +46,11 @@ def parse():
                          "command (run.py:1023-1025), reported in config")
     ap.add_argument("--partitioner", default="contiguous", choices=["contiguous", "community"],
                     help="N > 1: contiguous id ranges, or ranges of the label-propagation community order (bot_amd/dist.py)")
-    ap.add_argument("--capture", default="auto", choices=["auto", "on", "off"],
-                    help="replay the train step as ONE hipGraph (bot_amd.train.CapturedTrainStep) instead of ~300 eager launches. "
-                         "auto: on for single-GPU runs of the GCN / GAT stacks (configs 1-3), off otherwise; on: also partitioned")
+    ap.add_argument("--capture", default="off", choices=["on", "off"],
+                    help="on: replay the train step as ONE hipGraph (bot_amd.train.CapturedTrainStep) instead of ~300 eager launches "
+                         "(configs 1-3; works partitioned too, RCCL collectives are captured).  Default off: the roofline object "
+                         "needs HIP events around individual launches inside the timed region, which a replay has none of; "
+                         "measured at config 2 on one GPU: 19.74 ms captured vs 19.80 ms eager (the step is GPU-bound)")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the 1-D partitioned code path even with one rank (exercises the RCCL plumbing on a 1-GPU box)")
     return ap.parse_args()
@@ -128,7 +130,7 @@ def main():
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         torch.cuda.tunable.set_filename(os.path.join(ROOT, "gpurun_out", f"tunableop_new_rank{rank}.csv"))
 
-    capture = args.capture == "on" or (args.capture == "auto" and not partitioned)
+    capture = args.capture == "on"
     wl = workloads.build(args.workload, dev, rank=rank, world=world, partitioned=partitioned, seed=0, scale=args.scale,
                          norm_adj=args.norm_adj, partitioner=args.partitioner, capture=capture)
     barrier = torch.distributed.barrier if partitioned else (lambda: None)
