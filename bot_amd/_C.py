@@ -46,6 +46,8 @@ _SIGS = {
                                               _P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     "bot_sddmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                          c_int32, c_int32, _P, _P, c_int32, _P]),
+    "bot_sddmm_dot_bcast_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32,
+                                               c_int32, _P, _P, _P]),
     "bot_sddmm_u_add_v_f32": (ctypes.c_int, [_P, _P, c_int64, _P, _P, c_int32, _P, _P]),
     "bot_gat_attn_fwd_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, _P, c_float,
                                             c_int32, _P, _P, _P, _P]),
@@ -322,6 +324,21 @@ def sddmm_dot(d, x, y, operm=None, out=None):
     _check(_timed("sddmm_dot", (H, D), lambda: _lib.bot_sddmm_dot_f32(
         d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, x.data_ptr(), ldx, hsx,
         y.data_ptr(), ldy, hsy, H, D, out.data_ptr(), _ptr(_i32(operm, "operm")), 0, _stream())), "sddmm_dot")
+    return out
+
+
+def sddmm_dot_bcast(d, x, y, operm=None):
+    """out[operm[k],h] = <x[indices[k],:], y[h,r,:]> — x [n_src, D] (row stride allowed), y [H, n_rows, D] head-outer.  -> [nnz,H]"""
+    _dev(x, y, d.indptr)
+    _f32(x, "x"), _f32(y, "y")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    assert y.dim() == 3 and y.is_contiguous()
+    H, n, D = y.shape
+    out = torch.empty((d.nnz, H), dtype=torch.float32, device=x.device)
+    _check(_timed("sddmm_dot_bcast", (H, D), lambda: _lib.bot_sddmm_dot_bcast_f32(
+        d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, x.data_ptr(), x.stride(0),
+        y.data_ptr(), D, n * D, H, D, out.data_ptr(), _ptr(_i32(operm, "operm")), _stream())), "sddmm_dot_bcast")
     return out
 
 

@@ -94,6 +94,23 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// Reduce 16 values per lane across a LANES-wide group (LANES >= 16); on return lane l holds the total of value l % 16.
+template <int LANES>
+__device__ __forceinline__ float transpose_reduce16(float (&p)[16], int lane) {
+    float q[8], r[4], s2[2];
+    const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = (b8 ? p[i + 8] : p[i]) + __shfl_xor(b8 ? p[i] : p[i + 8], 8, LANES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (b4 ? q[i + 4] : q[i]) + __shfl_xor(b4 ? q[i] : q[i + 4], 4, LANES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) s2[i] = (b2 ? r[i + 2] : r[i]) + __shfl_xor(b2 ? r[i] : r[i + 2], 2, LANES);
+    float s = (b1 ? s2[1] : s2[0]) + __shfl_xor(b1 ? s2[0] : s2[1], 1, LANES);
+#pragma unroll
+    for (int m = 16; m < LANES; m <<= 1) s += __shfl_xor(s, m, LANES);
+    return s;  // value index = 8*b8 + 4*b4 + 2*b2 + b1 = lane % 16
+}
+
 struct Philox {
     // Philox4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0,k1)
     static __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {

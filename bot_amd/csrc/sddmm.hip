@@ -158,6 +158,95 @@ static void dispatch_dot(const DotArgs& a, hipStream_t st) {
     else launch_dot<VEC, 64, 4>(a, st);
 }
 
+// sddmm_dot_bcast: out[k,h] = < x[indices[k],:] , y[r,h,:] > — the source row has NO head axis and is gathered ONCE per edge
+// for all HB <= 4 heads; the H destination slabs y[r,h,:] sit in registers.  This is the weight gradient of the
+// aggregate-before-project layer (spmm_bcast, spmm.hip) when the layer INPUT needs no gradient (the first layer of a stack:
+// its input is data): 4*D bytes gathered per edge instead of the 4*H*D of spmm_dot_bcast, and no transposed sweep at all.
+// 4 edges x 4 head slots are reduced together by the 16-value transposing butterfly.
+template <int VEC, int LANES, int NCHUNK, int HB>
+__global__ __launch_bounds__(kBlock) void sddmm_dot_bcast_kernel(DotArgs a) {
+    static_assert(LANES >= 16 && HB <= 4, "butterfly layout");
+    constexpr int U = 4;
+    const int lane = threadIdx.x % LANES;
+    const int64_t item = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+    if (item >= a.n_items) return;
+    const int4 it = a.items[item];
+    int row = it.x, beg = it.y, end = it.z;
+    if constexpr (LANES == 64) {
+        row = __builtin_amdgcn_readfirstlane(row);
+        beg = __builtin_amdgcn_readfirstlane(beg);
+        end = __builtin_amdgcn_readfirstlane(end);
+    }
+    int off[NCHUNK];
+    float yv[HB][NCHUNK][VEC];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int e = (c * LANES + lane) * VEC;
+        const bool act = e < a.D;
+        off[c] = act ? e : 0;
+#pragma unroll
+        for (int h = 0; h < HB; ++h) {
+            vload<VEC>(yv[h][c], a.y + (int64_t)row * a.ldy + (int64_t)h * a.hsy + off[c]);
+            if (!act) {
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) yv[h][c][t] = 0.f;
+            }
+        }
+    }
+    for (int k0 = beg; k0 < end; k0 += LANES) {
+        const int k = k0 + lane;
+        const int idx = k < end ? a.indices[k] : 0;
+        const int cnt = min(LANES, end - k0);
+        for (int i = 0; i < cnt; i += U) {
+            float p[16], v[U][NCHUNK][VEC];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) p[q] = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = group_bcast<LANES>(idx, min(i + u, cnt - 1));  // past the end: a valid row again, result not stored
+                const float* px = a.x + (int64_t)s * a.ldx;
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + off[c]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                        for (int t = 0; t < VEC; ++t) d = fmaf(v[u][c][t], yv[h][c][t], d);
+                    p[u * 4 + h] = d;  // value slot = 4*u + h
+                }
+            const float tot = transpose_reduce16<LANES>(p, lane);
+            const int slot16 = lane & 15, u = slot16 >> 2, h = slot16 & 3;
+            if (lane < 16 && h < HB && i + u < cnt) {
+                const int pos = k0 + i + u;
+                a.out[(int64_t)(a.operm ? a.operm[pos] : pos) * HB + h] = tot;
+            }
+        }
+    }
+}
+
+template <int VEC, int HB>
+static void dispatch_dot_bcast(const DotArgs& a, hipStream_t st) {
+    const int L = (a.D + VEC - 1) / VEC;
+#define BOT_DOTB(LN, NC)                                                                                                    \
+    do {                                                                                                                    \
+        const int64_t blocks = (a.n_items * LN + kBlock - 1) / kBlock;                                                      \
+        if (blocks == 0) break;                                                                                             \
+        set_kernel("bot::sddmm_dot_bcast_kernel<%d,%d,%d,%d>", VEC, LN, NC, HB);                                           \
+        hipLaunchKernelGGL((sddmm_dot_bcast_kernel<VEC, LN, NC, HB>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);      \
+    } while (0)
+    if (L <= 16) BOT_DOTB(16, 1);
+    else if (L <= 32) BOT_DOTB(32, 1);
+    else if (L <= 64) BOT_DOTB(64, 1);
+    else if (L <= 128) BOT_DOTB(64, 2);
+    else BOT_DOTB(64, 4);
+#undef BOT_DOTB
+}
+
 // e[i,:] = x[src[i],:] (+ y[dst[i],:])
 __global__ __launch_bounds__(kBlock) void u_add_v_kernel(const int32_t* src, const int32_t* dst, int64_t n_edges,
                                                         const float* x, const float* y, int32_t W, float* out) {
@@ -199,6 +288,32 @@ int bot_sddmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_r
         else dispatch_dot<1>(a, st);
     }
     return hip_status("sddmm_dot launch");
+}
+
+int bot_sddmm_dot_bcast_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz, const int32_t* items,
+                            int64_t n_items, const float* x, int64_t ldx, const float* y, int64_t ldy, int64_t hsy, int32_t H,
+                            int32_t D, float* out, const int32_t* operm, bot_stream_t stream) {
+    using namespace bot;
+    (void)indptr;
+    BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_items >= 0 && nnz < INT32_MAX && n_rows < INT32_MAX, BOT_E_RANGE, "sddmm_dot_bcast: bad size");
+    BOT_REQUIRE(H >= 1 && H <= 4 && D >= 1 && D <= 1024, BOT_E_RANGE, "sddmm_dot_bcast: H=%d (1..4) D=%d (1..1024)", H, D);
+    if (nnz == 0 || n_rows == 0) return 0;
+    BOT_REQUIRE(indices && items && x && y && out, BOT_E_NULL, "sddmm_dot_bcast: NULL pointer");
+    BOT_REQUIRE(ldx >= D && ldy >= D && (hsy >= D || H == 1), BOT_E_RANGE, "sddmm_dot_bcast: strides smaller than the slab");
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = pick_vec(D, {ldx, ldy, H > 1 ? hsy : 0}, {x, y});
+    BOT_REQUIRE(D <= vec * 256, BOT_E_RANGE, "sddmm_dot_bcast: D=%d exceeds one launch tile", D);
+    DotArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, 0, y, ldy, hsy, H, D, out, operm, 0};
+#define BOT_DOTB_H(V)                                       \
+    switch (H) {                                            \
+        case 1: dispatch_dot_bcast<V, 1>(a, st); break;     \
+        case 2: dispatch_dot_bcast<V, 2>(a, st); break;     \
+        case 3: dispatch_dot_bcast<V, 3>(a, st); break;     \
+        default: dispatch_dot_bcast<V, 4>(a, st); break;    \
+    }
+    if (vec == 4) { BOT_DOTB_H(4) } else if (vec == 2) { BOT_DOTB_H(2) } else { BOT_DOTB_H(1) }
+#undef BOT_DOTB_H
+    return hip_status("sddmm_dot_bcast launch");
 }
 
 int bot_sddmm_u_add_v_f32(const int32_t* src, const int32_t* dst, int64_t n_edges, const float* x, const float* y,

@@ -364,7 +364,16 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         dW = dW3.view(HD, Fin) if dW3 is not None else None
         halo = g.halo is not None
         c = HD if has_res else 0
-        if halo:
+        need_dh = ctx.needs_input_grad[0]
+        if not need_dh:
+            # The layer input is DATA (the first layer of a stack: features + label columns, run.py:256-263): only the gradient
+            # of the attention weights is wanted from the sparse sweep.  d a[e,h] = <x[u], dz[v,h,:]> by ONE sweep over the
+            # in-edges that gathers the Fin-wide source row once for all heads (4*Fin bytes per edge) — instead of the transposed
+            # sweep that gathers the [H, Fin] gradient slab per edge (4*H*Fin) and also produces the unused d x.
+            xsrc = table[:, :Fin] if halo else h
+            da = _C.sddmm_dot_bcast(g.csc, xsrc, dz)
+            dh_g = None
+        elif halo:
             dext = torch.empty_like(table)
             _, da = _C.spmm_dot_bcast(g.csr, dz, a_d, g.csr2csc, table[:, :Fin], out=dext[:, :Fin])
         else:
@@ -378,7 +387,11 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         d_el = _C.segment_sum(g.csr, dz_e, g.csr2csc)
         if ctx.sym:
             d_el = d_el * s_out.unsqueeze(1)
-        if halo:
+        if halo and not need_dh:                                        # only d el travels back: [n_ext, H] rows, not [n_ext, Fin + H]
+            dsm = d_el.new_zeros((d_el.shape[0], (H + 3) // 4 * 4))
+            dsm[:, :H] = d_el
+            dout2[:, c:c + H] = _extend_backward(g, dsm, N)[:, :H]
+        elif halo:
             dext[:, Fin:Fin + H] = d_el
             if dext.shape[1] > Fin + H:
                 dext[:, Fin + H:].zero_()
@@ -396,7 +409,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             dWr = torch.mm(h.t(), dout2) if kp else torch.mm(dout2.t(), h)
         dh = None
-        if ctx.needs_input_grad[0]:
+        if need_dh:
             dh = torch.addmm(dh_g, dout2, Wr.t() if kp else Wr)
         return (dh, dW, dWr, d_bn_w if ctx.needs_input_grad[3] else None, d_bn_b if ctx.needs_input_grad[4] else None,
                 None, None, None, None, None, None, None, None, None, None, None, None)

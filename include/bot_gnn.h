@@ -181,6 +181,19 @@ int bot_sddmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_r
                       int32_t H, int32_t D,
                       float* out, const int32_t* operm, int32_t accumulate, bot_stream_t stream);
 
+/* The same gradient for the aggregate-before-project layer (bot_spmm_bcast_f32) when its input needs no gradient (the first
+ * layer of a stack): the source row has no head axis and is gathered once per edge for all H <= 4 heads,
+ *
+ *   out[operm[k], h] = < x[indices[k],:] , y[r,h,:] >          x: [n_src, D] (ldx);  y: [n_rows, H, D] (ldy, hsy; may be head-outer)
+ *
+ * 4*D gathered bytes per edge instead of the 4*H*D of bot_spmm_dot_bcast_f32, and no transposed sweep.  D <= 1024 / 512 / 256. */
+int bot_sddmm_dot_bcast_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                            const int32_t* items, int64_t n_items,
+                            const float* x, int64_t ldx,
+                            const float* y, int64_t ldy, int64_t hsy,
+                            int32_t H, int32_t D,
+                            float* out, const int32_t* operm, bot_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * SDDMM copy_u / u_add_v.  Replaces apply_edges(fn.copy_u) / apply_edges(fn.u_add_v)
  * (models.py:525 / :523; proteins models.py:127 / :125) on the COO list in edge-id order:

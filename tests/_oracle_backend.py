@@ -81,6 +81,14 @@ def sddmm_dot(d, x, y, operm=None, out=None):
     return res
 
 
+def sddmm_dot_bcast(d, x, y, operm=None):
+    rows = _rows(d)
+    dots = (x[d.indices.long()].unsqueeze(0) * y[:, rows]).sum(-1).t()      # [nnz, H]
+    out = torch.empty_like(dots)
+    out[_perm(operm, d.nnz)] = dots
+    return out
+
+
 def u_add_v(src, dst, x, y=None):
     out = x[src.long()]
     if y is not None:
@@ -232,7 +240,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

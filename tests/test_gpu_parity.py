@@ -416,6 +416,15 @@ def test_bcast_kernels_direct(golden):
         o, dot = _C.spmm_dot_bcast(csr, dz, w, g.csr2csc, x)
         assert torch.allclose(o, ref_out, atol=2e-4, rtol=1e-4)
         assert torch.allclose(dot, ref_dot, atol=1e-3 * D ** 0.5, rtol=1e-4)
+        # the weight gradient alone, by the in-edge sweep that gathers the source row once for all heads (sddmm_dot_bcast):
+        # same numbers as the dot output of spmm_dot_bcast; also from a row-strided x and through an output permutation
+        dot2 = _C.sddmm_dot_bcast(csc, x, dz)
+        assert torch.allclose(dot2, ref_dot, atol=1e-3 * D ** 0.5, rtol=1e-4)
+        xb = torch.zeros(n, D + 4, device=DEV)
+        xb[:, :D] = x
+        assert torch.equal(_C.sddmm_dot_bcast(csc, xb[:, :D], dz), dot2)
+        dot3 = _C.sddmm_dot_bcast(csc, x, dz, operm=csc.eid)
+        assert torch.equal(dot3[csc.eid.long()], dot2)
 
 
 def test_blocked_spmm_matches_row_kernel():
