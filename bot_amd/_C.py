@@ -50,9 +50,9 @@ _SIGS = {
                                                c_int32, _P, _P, _P]),
     "bot_sddmm_u_add_v_f32": (ctypes.c_int, [_P, _P, c_int64, _P, _P, c_int32, _P, _P]),
     "bot_gat_attn_fwd_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, _P, c_float,
-                                            c_int32, _P, _P, _P, _P]),
+                                            c_int32, _P, _P, _P, c_float, c_uint64, _P, _P, _P]),
     "bot_gat_attn_bwd_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_int32,
-                                            _P, _P, _P, _P, _P, _P, _P, _P]),
+                                            _P, _P, _P, _P, _P, _P, _P, c_float, c_uint64, _P, _P]),
     "bot_gat_infer_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "bot_gat_infer_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                          _P, c_int64, _P, c_int64, _P, _P, c_float, c_int32, c_int32, _P, c_int64, c_int64, _P, _P,
@@ -362,9 +362,10 @@ def zsign_buffer(d, H, slope):
     return torch.empty(d.nnz, dtype=torch.uint8, device=d.indptr.device) if (H <= 8 and slope != 1.0 and d.indptr.is_cuda) else None
 
 
-def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None):
+def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None, drop=None):
     """Fused logits + leaky-ReLU + per-row softmax.  el/er: [n,H]; ee: [nnz,H] via eperm; -> a [nnz,H].
-    `zsign`: optional uint8 [nnz] output (see zsign_buffer)."""
+    `zsign`: optional uint8 [nnz] output (see zsign_buffer).  `drop` = (p, seed) with p > 0: also returns
+    a_drop = a * keep / (1 - p) (the attention dropout of models.py:544, Philox mask) -> (a, a_drop)."""
     _dev(el, er, ee, d.indptr)
     el = None if el is None else _f32(el, "el").contiguous()
     er = None if er is None else _f32(er, "er").contiguous()
@@ -372,14 +373,18 @@ def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None):
     if keep is not None and (keep.dtype != torch.uint8 or not keep.is_contiguous()):
         raise BotKernelError("keep must be contiguous uint8")
     a = torch.empty((d.nnz, H), dtype=torch.float32, device=d.indptr.device)
+    p, seed = drop if drop is not None else (0.0, 0)
+    a_drop = torch.empty_like(a) if p > 0 else None
     _check(_lib.bot_gat_attn_fwd_f32(d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, _ptr(d.long_rows), d.n_long,
                                      d.chunk, _ptr(el), _ptr(er), _ptr(ee), _ptr(_i32(eperm, "eperm")), _ptr(keep),
-                                     float(slope), H, a.data_ptr(), _ptr(_i32(aperm, "aperm")), _ptr(zsign), _stream()), "gat_attn_fwd")
-    return a
+                                     float(slope), H, a.data_ptr(), _ptr(_i32(aperm, "aperm")), _ptr(zsign), float(p),
+                                     int(seed) & 0xFFFFFFFFFFFFFFFF, _seed_off(p), _ptr(a_drop), _stream()), "gat_attn_fwd")
+    return a if drop is None else (a, a_drop if a_drop is not None else a)
 
 
-def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der, zsign=None):
-    """Backward of gat_attn_fwd -> (dz [nnz,H] at zperm, der [n_rows,H] or None).  `zsign`: what the forward recorded."""
+def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der, zsign=None, drop=None):
+    """Backward of gat_attn_fwd -> (dz [nnz,H] at zperm, der [n_rows,H] or None).  `zsign`: what the forward recorded.
+    `drop` = the forward's (p, seed): `da` is then the gradient of a_drop."""
     _dev(a, da, d.indptr)
     el = None if el is None else _f32(el, "el").contiguous()
     er = None if er is None else _f32(er, "er").contiguous()
@@ -391,7 +396,9 @@ def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der, 
     _check(_lib.bot_gat_attn_bwd_f32(d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, _ptr(d.long_rows), d.n_long,
                                      d.chunk, _ptr(el), _ptr(er), _ptr(ee), _ptr(_i32(eperm, "eperm")), float(slope), H,
                                      a.data_ptr(), da.data_ptr(), _ptr(_i32(aperm, "aperm")), dz.data_ptr(),
-                                     _ptr(_i32(zperm, "zperm")), _ptr(der), _ptr(zsign), _stream()), "gat_attn_bwd")
+                                     _ptr(_i32(zperm, "zperm")), _ptr(der), _ptr(zsign), float(drop[0]) if drop else 0.0,
+                                     (int(drop[1]) & 0xFFFFFFFFFFFFFFFF) if drop else 0, _seed_off(drop[0]) if drop else None,
+                                     _stream()), "gat_attn_bwd")
     return dz, der
 
 

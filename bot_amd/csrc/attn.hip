@@ -107,7 +107,29 @@ struct AttnArgs {
     // optional (H <= 8): bit j of zsign[row of a] = [z_j > 0], written by the forward; with it the backward needs neither the
     // el[src] gather nor ee nor the edge ids for the leaky-ReLU derivative (1 byte per edge instead of ~4*(2H+1))
     uint8_t* zsign;
+    // optional dropout on the attention weights (nn.Dropout(attn_drop) behind edge_softmax, models.py:544): the forward also
+    // writes a_drop = a * keep / (1 - p); the backward takes d(a_drop) in `da` and applies the same factor first.  The keep
+    // mask is a Philox4x32-10 stream keyed by (seed [+ device word], record index, head / 4): regenerated, never stored.
+    float drop_p;
+    uint64_t drop_seed;
+    const uint64_t* seed_offset;
+    float* a_drop;
 };
+
+// keep/(1-p) factors of the HT heads [h0, h0+HT) of the edge record `arow`
+template <int HT>
+__device__ __forceinline__ void attn_drop_factors(const AttnArgs& p, uint64_t seed, int64_t arow, float (&f)[HT]) {
+    const float scale = 1.f / (1.f - p.drop_p);
+    const int64_t nq = (p.H + 3) / 4;
+#pragma unroll
+    for (int q = 0; q < (HT + 3) / 4; ++q) {
+        uint32_t w[4];
+        Philox::gen(seed, (uint64_t)(arow * nq + (p.h0 >> 2) + q), w);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (q * 4 + t < HT) f[q * 4 + t] = ((w[t] >> 8) * (1.0f / 16777216.0f)) >= p.drop_p ? scale : 0.f;
+    }
+}
 
 // HT consecutive floats at `q`.  `wide`: the record is 4*HT bytes at a multiple of 4*HT bytes from a 16-byte aligned base
 // (H == HT, one head tile), so even HT moves as 8- or 16-byte vectors: one memory instruction touches each record's cache
@@ -223,13 +245,22 @@ __device__ __forceinline__ void attn_fwd_row(const AttnArgs& p, const Ctx& ctx, 
     ctx.sum_n(inv);
 #pragma unroll
     for (int j = 0; j < HT; ++j) inv[j] = inv[j] > 0.f ? 1.f / inv[j] : 0.f;
+    const uint64_t dseed = p.a_drop ? (p.seed_offset ? p.drop_seed + p.seed_offset[0] * 0x9E3779B97F4A7C15ull : p.drop_seed) : 0;
     for (int k = beg + ctx.lane; k < end; k += Ctx::kStride) {
-        float* ao = p.a + (int64_t)(p.aperm ? p.aperm[k] : k) * p.H + p.h0;
+        const int64_t arow = p.aperm ? p.aperm[k] : k;
+        float* ao = p.a + arow * p.H + p.h0;
         float e[HT];
         load_heads<HT>(ao, p.wide, e);
 #pragma unroll
         for (int j = 0; j < HT; ++j) e[j] = e[j] > NEG_INF ? expf(e[j] - M[j]) * inv[j] : 0.f;
         store_heads<HT>(ao, p.wide, e);
+        if (p.a_drop) {
+            float f[HT];
+            attn_drop_factors<HT>(p, dseed, arow, f);
+#pragma unroll
+            for (int j = 0; j < HT; ++j) e[j] *= f[j];
+            store_heads<HT>(p.a_drop + arow * p.H + p.h0, p.wide, e);
+        }
     }
 }
 
@@ -242,21 +273,37 @@ __device__ __forceinline__ void attn_bwd_row(const AttnArgs& p, const Ctx& ctx, 
         t[j] = 0.f;
         dacc[j] = 0.f;
     }
+    const bool dropped = p.drop_p > 0.f;
+    const uint64_t dseed = dropped ? (p.seed_offset ? p.drop_seed + p.seed_offset[0] * 0x9E3779B97F4A7C15ull : p.drop_seed) : 0;
     for (int k = beg + ctx.lane; k < end; k += Ctx::kStride) {
-        const int64_t o = (int64_t)(p.aperm ? p.aperm[k] : k) * p.H + p.h0;
+        const int64_t arow = p.aperm ? p.aperm[k] : k;
+        const int64_t o = arow * p.H + p.h0;
         float av[HT], dv[HT];
         load_heads<HT>(p.a + o, p.wide, av);
         load_heads<HT>(p.da + o, p.wide, dv);
+        if (dropped) {
+            float f[HT];
+            attn_drop_factors<HT>(p, dseed, arow, f);
+#pragma unroll
+            for (int j = 0; j < HT; ++j) dv[j] *= f[j];
+        }
 #pragma unroll
         for (int j = 0; j < HT; ++j) t[j] = fmaf(av[j], dv[j], t[j]);
     }
     ctx.sum_n(t);
     const bool need_z = p.slope != 1.f;
     for (int k = beg + ctx.lane; k < end; k += Ctx::kStride) {
-        const int64_t o = (int64_t)(p.aperm ? p.aperm[k] : k) * p.H + p.h0;
+        const int64_t arow = p.aperm ? p.aperm[k] : k;
+        const int64_t o = arow * p.H + p.h0;
         float av[HT], dv[HT], z[HT], g[HT];
         load_heads<HT>(p.a + o, p.wide, av);
         load_heads<HT>(p.da + o, p.wide, dv);
+        if (dropped) {
+            float f[HT];
+            attn_drop_factors<HT>(p, dseed, arow, f);
+#pragma unroll
+            for (int j = 0; j < HT; ++j) dv[j] *= f[j];
+        }
         if (need_z) {
             if (p.zsign) {
                 const unsigned bits = p.zsign[p.aperm ? p.aperm[k] : k];
@@ -307,7 +354,8 @@ __global__ __launch_bounds__(kBlock) void attn_long_kernel(AttnArgs p) {
 template <bool BWD>
 static int launch_attn(AttnArgs p, int64_t n_long, hipStream_t st) {
     const int64_t blocks = (p.n_rows * kRowLanes + kBlock - 1) / kBlock;
-    p.wide = p.H <= 8 && aligned(p.el, 16) && aligned(p.ee, 16) && aligned(p.a, 16) && aligned(p.da, 16) && aligned(p.dz, 16);
+    p.wide = p.H <= 8 && aligned(p.el, 16) && aligned(p.ee, 16) && aligned(p.a, 16) && aligned(p.da, 16) && aligned(p.dz, 16) &&
+             aligned(p.a_drop, 16);
     for (int h0 = 0; h0 < p.H;) {  // heads in register tiles of up to 8 (one sweep over the edges for H <= 8)
         const int ht = p.H - h0 >= 8 ? 8 : p.H - h0;
         p.h0 = h0;
@@ -406,15 +454,18 @@ extern "C" {
 int bot_gat_attn_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
                          const int32_t* long_rows, int64_t n_long, int32_t chunk, const float* el, const float* er,
                          const float* ee, const int32_t* eperm, const uint8_t* keep, float slope, int32_t H, float* a,
-                         const int32_t* aperm, uint8_t* zsign, bot_stream_t stream) {
+                         const int32_t* aperm, uint8_t* zsign, float attn_drop, uint64_t drop_seed, const uint64_t* seed_offset,
+                         float* a_drop, bot_stream_t stream) {
     using namespace bot;
     if (int rc = attn_check("gat_attn_fwd", indptr, indices, n_rows, nnz, long_rows, n_long, chunk, el, H)) return rc;
     if (n_rows == 0 || nnz == 0) return 0;
     BOT_REQUIRE(a != nullptr, BOT_E_NULL, "gat_attn_fwd: a is NULL");
     BOT_REQUIRE(el || er || ee, BOT_E_NULL, "gat_attn_fwd: no logit source (el, er, ee all NULL)");
     BOT_REQUIRE(zsign == nullptr || H <= 8, BOT_E_RANGE, "gat_attn_fwd: zsign holds 8 heads, H=%d", H);
+    BOT_REQUIRE(attn_drop >= 0.f && attn_drop < 1.f, BOT_E_RANGE, "gat_attn_fwd: attn_drop=%f must be in [0,1)", (double)attn_drop);
+    BOT_REQUIRE((attn_drop > 0.f) == (a_drop != nullptr), BOT_E_NULL, "gat_attn_fwd: a_drop goes with attn_drop > 0");
     AttnArgs p{indptr, indices, n_rows, long_rows, chunk, el, er, ee, eperm, keep, slope, H, 0, a, nullptr, aperm, nullptr,
-               nullptr, nullptr, false, zsign};
+               nullptr, nullptr, false, zsign, attn_drop, drop_seed, seed_offset, a_drop};
     return launch_attn<false>(p, n_long, (hipStream_t)stream);
 }
 
@@ -422,15 +473,16 @@ int bot_gat_attn_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t 
                          const int32_t* long_rows, int64_t n_long, int32_t chunk, const float* el, const float* er,
                          const float* ee, const int32_t* eperm, float slope, int32_t H, const float* a, const float* da,
                          const int32_t* aperm, float* dz, const int32_t* zperm, float* der, const uint8_t* zsign,
-                         bot_stream_t stream) {
+                         float attn_drop, uint64_t drop_seed, const uint64_t* seed_offset, bot_stream_t stream) {
     using namespace bot;
     if (int rc = attn_check("gat_attn_bwd", indptr, indices, n_rows, nnz, long_rows, n_long, chunk, el, H)) return rc;
     if (n_rows == 0) return 0;
     BOT_REQUIRE(nnz == 0 || (a && da && dz), BOT_E_NULL, "gat_attn_bwd: a/da/dz is NULL");
     BOT_REQUIRE(slope == 1.f || zsign || el || er || ee, BOT_E_NULL, "gat_attn_bwd: slope != 1 needs zsign or el/er/ee for the sign");
     BOT_REQUIRE(zsign == nullptr || H <= 8, BOT_E_RANGE, "gat_attn_bwd: zsign holds 8 heads, H=%d", H);
+    BOT_REQUIRE(attn_drop >= 0.f && attn_drop < 1.f, BOT_E_RANGE, "gat_attn_bwd: attn_drop=%f must be in [0,1)", (double)attn_drop);
     AttnArgs p{indptr, indices, n_rows, long_rows, chunk, el, er, ee, eperm, nullptr, slope, H, 0, const_cast<float*>(a), da,
-               aperm, dz, zperm, der, false, const_cast<uint8_t*>(zsign)};
+               aperm, dz, zperm, der, false, const_cast<uint8_t*>(zsign), attn_drop, drop_seed, seed_offset, nullptr};
     return launch_attn<true>(p, n_long, (hipStream_t)stream);
 }
 

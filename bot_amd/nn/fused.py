@@ -133,17 +133,15 @@ class _GATHidden(torch.autograd.Function):
             s_out, w_e = sym_scales(graph)
             el = el * s_out.unsqueeze(1)                                # logits see the scaled projection (models.py:505, :517)
         ctx.zs = _C.zsign_buffer(csc, H, slope)
-        a = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None, ctx.zs)
-        amask = None
-        if attn_p > 0:                                                  # nn.Dropout on the attention weights (models.py:544)
-            amask = (torch.rand_like(a) >= attn_p).to(a.dtype).mul_(1.0 / (1.0 - attn_p))
-        a_d = a * amask if amask is not None else a
+        # nn.Dropout on the attention weights (models.py:544) inside the attention kernel: a_d = a * keep / (1 - p), Philox mask
+        ctx.adrop = (attn_p, new_dropout_seed(attn_p)) if attn_p > 0 else None
+        a, a_d = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None, ctx.zs, drop=ctx.adrop or (0.0, 0))
         if sym:
             a_d = a_d * w_e                                             # the SpMM weights; d a below is scaled back by w_e
         res = out[:, HD:2 * HD].unflatten(1, (H, D)) if has_res else None
         x = _C.spmm(csc, ft, a_d, None, addend=res).view(N, HD)         # aggregation + residual (models.py:547-560)
         ctx.graph = graph
-        keep = (h, Wcat, ext if ext is not None else out, el, er, a, amask, a_d)
+        keep = (h, Wcat, ext if ext is not None else out, el, er, a, a_d)
         if bn is None:                                                  # output layer: no epilogue
             ctx.save_for_backward(*keep)
             ctx.cfg = (H, D, has_res, has_er, slope, None)
@@ -163,9 +161,9 @@ class _GATHidden(torch.autograd.Function):
         dy = dy.contiguous()
         d_bn_w = d_bn_b = None
         if epi is None:
-            h, Wcat, table, el, er, a, amask, a_d = ctx.saved_tensors
+            h, Wcat, table, el, er, a, a_d = ctx.saved_tensors
         else:
-            h, Wcat, table, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
+            h, Wcat, table, el, er, a, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
             drop_p, seed, bn_training, sync, group, total = epi
         kp = ctx.kp
         N, HD, P = h.shape[0], H * D, Wcat.shape[1 if kp else 0]
@@ -194,9 +192,7 @@ class _GATHidden(torch.autograd.Function):
         if ctx.sym:
             s_out, w_e = sym_scales(g)
             da = da * w_e
-        if amask is not None:
-            da = da * amask
-        dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er, ctx.zs)
+        dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er, ctx.zs, drop=ctx.adrop)
         d_el = _C.segment_sum(g.csr, dz, g.csr2csc)
         if ctx.sym:
             d_el = d_el * s_out.unsqueeze(1)
@@ -293,11 +289,8 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             s_out, w_e = sym_scales(graph)
             el = el * s_out.unsqueeze(1)
         ctx.zs = _C.zsign_buffer(csc, H, slope)
-        a = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None, ctx.zs)
-        amask = None
-        if attn_p > 0:
-            amask = (torch.rand_like(a) >= attn_p).to(a.dtype).mul_(1.0 / (1.0 - attn_p))
-        a_d = a * amask if amask is not None else a
+        ctx.adrop = (attn_p, new_dropout_seed(attn_p)) if attn_p > 0 else None
+        a, a_d = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None, ctx.zs, drop=ctx.adrop or (0.0, 0))
         if sym:
             a_d = a_d * w_e
         z = _C.spmm_bcast(csc, xsrc, a_d, None, head_outer=True)        # [H, N, Fin]
@@ -314,7 +307,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
                 torch.mm(z[i], Wh[i].t(), out=agg[i])
             x = agg.permute(1, 0, 2).reshape(N, HD)
         ctx.graph = graph
-        keep = (h, W, Wr, z, ext if ext is not None else h, el, er, a, amask, a_d)
+        keep = (h, W, Wr, z, ext if ext is not None else h, el, er, a, a_d)
         if bn is None:
             ctx.save_for_backward(*keep)
             ctx.cfg = (H, D, has_res, has_er, slope, None)
@@ -334,9 +327,9 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         dy = dy.contiguous()
         d_bn_w = d_bn_b = None
         if epi is None:
-            h, W, Wr, z, table, el, er, a, amask, a_d = ctx.saved_tensors
+            h, W, Wr, z, table, el, er, a, a_d = ctx.saved_tensors
         else:
-            h, W, Wr, z, table, el, er, a, amask, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
+            h, W, Wr, z, table, el, er, a, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
             drop_p, seed, bn_training, sync, group, total = epi
         kp = ctx.kp
         N, Fin, HD, P2 = h.shape[0], h.shape[1], H * D, Wr.shape[1 if kp else 0]
@@ -381,9 +374,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         if ctx.sym:
             s_out, w_e = sym_scales(g)
             da = da * w_e
-        if amask is not None:
-            da = da * amask
-        dz_e, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er, ctx.zs)
+        dz_e, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er, ctx.zs, drop=ctx.adrop)
         d_el = _C.segment_sum(g.csr, dz_e, g.csr2csc)
         if ctx.sym:
             d_el = d_el * s_out.unsqueeze(1)

@@ -216,12 +216,18 @@ int bot_sddmm_u_add_v_f32(const int32_t* src, const int32_t* dst, int64_t n_edge
  * `long_rows` (rows longer than the plan's chunk) are handled by one workgroup each.
  * `zsign` (may be NULL; H <= 8): uint8 [nnz], addressed like `a`; bit h receives [z > 0], so that the backward can take the
  * leaky-ReLU derivative from one byte per edge instead of re-gathering el[src] and re-reading ee.
+ * `attn_drop` > 0 with `a_drop` [nnz,H] (addressed like `a`): the dropout behind the softmax (`self.attn_drop(...)`, models.py:544)
+ * fused in — a_drop = a * keep / (1 - attn_drop), keep from a Philox4x32-10 stream keyed by (drop_seed [+ *seed_offset *
+ * 0x9E3779B97F4A7C15], record index, head / 4); `a` itself stays the plain softmax (the backward needs it).  The backward
+ * takes the gradient of a_drop in `da` with the same (attn_drop, drop_seed, seed_offset) and regenerates the mask.
  * ------------------------------------------------------------------------------------------- */
 int bot_gat_attn_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
                          const int32_t* long_rows, int64_t n_long, int32_t chunk,
                          const float* el, const float* er, const float* ee, const int32_t* eperm,
                          const uint8_t* keep, float slope, int32_t H,
-                         float* a, const int32_t* aperm, uint8_t* zsign, bot_stream_t stream);
+                         float* a, const int32_t* aperm, uint8_t* zsign,
+                         float attn_drop, uint64_t drop_seed, const uint64_t* seed_offset, float* a_drop,
+                         bot_stream_t stream);
 
 /* Backward of the above.  Given a (forward output) and da (gradient w.r.t. a), both addressed
  * through aperm like the forward output:
@@ -240,7 +246,8 @@ int bot_gat_attn_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t 
                          const float* el, const float* er, const float* ee, const int32_t* eperm,
                          float slope, int32_t H,
                          const float* a, const float* da, const int32_t* aperm,
-                         float* dz, const int32_t* zperm, float* der, const uint8_t* zsign, bot_stream_t stream);
+                         float* dz, const int32_t* zperm, float* der, const uint8_t* zsign,
+                         float attn_drop, uint64_t drop_seed, const uint64_t* seed_offset, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Inference-only GAT layer: what `evaluate()` (src/no-sampling/run.py:290-322) needs from a layer — logits,

@@ -107,7 +107,8 @@ def _logits(d, el, er, ee, eperm, slope, H):
     return z, torch.where(z > 0, z, z * slope)
 
 
-def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None):  # zsign: never allocated on CPU (zsign_buffer)
+def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None, drop=None):  # zsign: never allocated on CPU (zsign_buffer)
+    assert drop is None or drop[0] == 0.0, "the CPU emulation has no Philox stream: attention-dropout parity is checked on the GPU only"
     z, e = _logits(d, el, er, ee, eperm, slope, H)
     rows = _rows(d)
     a = torch.zeros_like(e)
@@ -119,10 +120,11 @@ def gat_attn_fwd(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None):  # zs
         a = R.edge_softmax(rows, d.n_rows, e)
     out = torch.empty_like(a)
     out[_perm(aperm, d.nnz)] = a
-    return out
+    return out if drop is None else (out, out)
 
 
-def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der, zsign=None):
+def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der, zsign=None, drop=None):
+    assert drop is None or drop[0] == 0.0
     rows = _rows(d)
     ap = _perm(aperm, d.nnz)
     a_, da_ = a[ap], da[ap]

@@ -118,7 +118,7 @@ def tap_kinks():
             relu_taps.append((y.detach() > 0).to(torch.uint8).cpu())
         return y
 
-    def attn(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None):
+    def attn(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None, **kw):
         with torch.no_grad():
             deg = (d.indptr[1:] - d.indptr[:-1]).long()
             z = torch.zeros((d.nnz, H), dtype=torch.float32, device=d.indptr.device)
@@ -131,7 +131,7 @@ def tap_kinks():
             gate = torch.empty((d.nnz, H), dtype=torch.uint8, device=z.device)
             gate[d.eid.long()] = (z > 0).to(torch.uint8)
             leaky_taps.append(gate.cpu())
-        return orig_a(d, el, er, ee, eperm, keep, slope, H, aperm, zsign)
+        return orig_a(d, el, er, ee, eperm, keep, slope, H, aperm, zsign, **kw)
 
     bnn._epilogue, fused.gat_hidden_layer, _C.gat_attn_fwd = epi, hid, attn
     try:

@@ -38,7 +38,7 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"NULL" in lib.bot_last_error()
     rc = lib.bot_segment_sum_f32(None, 3, 0, None, 0, 0, None, None, 1, None, None)
     assert rc == -2
-    rc = lib.bot_gat_attn_bwd_f32(None, None, -1, 0, None, 0, 8, None, None, None, None, 0.2, 1, None, None, None, None, None, None, None, None)
+    rc = lib.bot_gat_attn_bwd_f32(None, None, -1, 0, None, 0, 8, None, None, None, None, 0.2, 1, None, None, None, None, None, None, None, 0.0, 0, None, None)
     assert rc == -2
     # empty problems are no-ops
     assert lib.bot_degrees_i64(None, 0, None, None) == 0

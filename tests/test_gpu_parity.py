@@ -818,3 +818,39 @@ def test_captured_train_step_bit_identical_and_fresh_masks():
     from bot_amd import _C
     assert int(_C.SEED_OFFSET) >= 4
     _C.SEED_OFFSET = None
+
+
+def test_attention_dropout_in_kernel(golden):
+    """nn.Dropout on the attention weights (models.py:544) fused into the attention kernels: a_drop = a * keep / (1 - p) with a
+    Philox mask that the backward regenerates.  Keep rate ~ 1 - p, kept entries scaled exactly, `a` itself untouched, a fresh
+    mask per seed, the device seed word changes it, and the backward equals autograd of softmax * (the forward's mask)."""
+    n = 20000
+    rs, rd = _powerlaw(n, 150000, 5)
+    s, d = R.preprocess_edges(rs, rd, n)
+    g = bot_amd.Graph(s, d, n).to(DEV)
+    E = g.number_of_edges()
+    for H in (3, 1, 6):
+        el, er = torch.randn(n, H, device=DEV), torch.randn(n, H, device=DEV)
+        p, seed = 0.3, 0x0123456789ABCDEF + H
+        a0 = _C.gat_attn_fwd(g.csc, el, er, None, None, None, 0.2, H, None)
+        a, ad = _C.gat_attn_fwd(g.csc, el, er, None, None, None, 0.2, H, None, drop=(p, seed))
+        assert torch.equal(a, a0)
+        kept = ad != 0
+        rate = float(kept.sum()) / float((a0 != 0).sum())
+        assert abs(rate - (1 - p)) < 5e-3, rate
+        assert torch.allclose(ad[kept], (a0 / (1 - p))[kept], rtol=1e-6, atol=0)
+        _, ad2 = _C.gat_attn_fwd(g.csc, el, er, None, None, None, 0.2, H, None, drop=(p, seed))
+        _, ad3 = _C.gat_attn_fwd(g.csc, el, er, None, None, None, 0.2, H, None, drop=(p, seed + 1))
+        assert torch.equal(ad, ad2) and not torch.equal(ad3 != 0, kept)
+        _C.SEED_OFFSET = torch.ones(1, dtype=torch.int64, device=DEV)
+        try:
+            _, ad4 = _C.gat_attn_fwd(g.csc, el, er, None, None, None, 0.2, H, None, drop=(p, seed))
+            assert not torch.equal(ad4 != 0, kept)
+        finally:
+            _C.SEED_OFFSET = None
+        # backward: d(a_drop) in, dz out == autograd through softmax(leaky(z)) * factor with the forward's mask
+        gd = torch.randn(E, H, device=DEV)
+        dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, 0.2, H, a, gd, None, None, True, None, drop=(p, seed))
+        factor = torch.where(kept, torch.full_like(ad, 1 / (1 - p)), torch.zeros_like(ad))
+        dz_ref, der_ref = _C.gat_attn_bwd(g.csc, el, er, None, None, 0.2, H, a, gd * factor, None, None, True, None)
+        assert torch.allclose(dz, dz_ref, rtol=1e-5, atol=1e-7) and torch.allclose(der, der_ref, rtol=1e-4, atol=1e-6)
