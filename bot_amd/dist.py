@@ -352,8 +352,10 @@ def forward_backward(model, part: Partition, *, use_labels=True, mask_rate=0.5, 
             for idx in (part.val_idx, part.test_idx):
                 feat[idx, -n_classes:] = prob[idx]
             pred = model(part.graph, feat)
-    y = T.per_node_loss(pred[tr], part.labels[tr], loss)
-    local = _global_mean(y, w, group)
+    wn = torch.zeros(pred.shape[0], device=pred.device, dtype=pred.dtype)   # weighted mean over all owned rows: see bot_amd.train
+    wn[tr] = w
+    y = T.per_node_loss(pred, part.labels, loss)
+    local = _global_mean(y, wn, group)
     local.backward()
     all_reduce_grads(model, group)
     total = local.detach().clone()

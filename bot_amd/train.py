@@ -78,8 +78,12 @@ def forward_backward(model, graph, feat, labels, train_idx, val_idx, test_idx, *
             for idx in (val_idx, test_idx):
                 feat[idx, -n_classes:] = prob[idx]
             pred = model(graph, feat)
-    y = per_node_loss(pred[train_idx], labels[train_idx], loss)
-    out = (y * w).sum() / w.sum()
+    # weighted mean over ALL nodes (weight 0 outside the prediction set) instead of `pred[train_pred_idx]`: the backward of an
+    # index gather is an index_put with accumulation, which sorts its indices on the device every step
+    wn = torch.zeros(pred.shape[0], device=pred.device, dtype=pred.dtype)
+    wn[train_idx] = w
+    y = per_node_loss(pred, labels, loss)
+    out = (y * wn).sum() / w.sum()
     out.backward()
     return out, pred, w
 

@@ -181,3 +181,40 @@ def compare(pred_hip, grads_hip, pred_ref, grads_ref, gate_stats=None, tol=1e-4)
             r[f"{kind}_gates"] = sum(s["of"] for s in st)
         r["max_abs_preact_at_differing_gate"] = max(s["max_abs_preact_where_differ"] for s in gate_stats)
     return r
+
+
+# ---------------------------------------------------------------------------------------------- GCN (BASELINE configs 1 / 3)
+def gcn_oracle_step(src, dst, n, feat, labels, train_idx, sd, cfg, loss="logit", threads=None, gates=None):
+    """One GCN train step (run.py:252-284 without --labels: the loss over `train_idx`) on the oracle's C kernels."""
+    from oracle import c_ops
+    from oracle import ref_models as RM
+    if threads is None:
+        threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    c_ops.set_num_threads(threads)
+    g = c_ops.CGraph(src, dst, n)
+    sdg = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    names = [k for k, v in sdg.items() if v.requires_grad]
+    kg = None if gates is None else KinkGates(gates[0], None)
+    t0 = time.perf_counter()
+    pred = RM.gcn_forward(g, feat, sdg, n_layers=cfg["n_layers"], norm=cfg["norm"], norm_adj=cfg["norm_adj"],
+                          use_linear=cfg["use_linear"], residual=cfg["residual"], activation=F.relu if kg is None else kg.relu,
+                          training=True)
+    out = RM.compute_loss(pred[train_idx], labels[train_idx], loss)
+    grads = torch.autograd.grad(out, [sdg[k] for k in names])
+    return pred.detach(), dict(zip(names, grads)), time.perf_counter() - t0, (kg.stats if kg is not None else None)
+
+
+def gcn_hip_step(g, feat, labels, train_idx, sd, cfg, n_classes, loss="logit"):
+    from bot_amd import nn as bnn
+    from bot_amd import train as T
+    dev = feat.device
+    model = bnn.GCN(in_feats=feat.shape[1], n_classes=n_classes, activation=F.relu, dropout=0.0, input_drop=0.0, **cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    with tap_kinks() as (relu_gates, leaky_gates):
+        pred = model(g, feat)
+        out = T.compute_loss(pred[train_idx], labels[train_idx], loss)
+        out.backward()
+    assert len(relu_gates) == cfg["n_layers"] - 1
+    return pred.detach(), {k: p.grad.detach() for k, p in model.named_parameters()}, (relu_gates, None)

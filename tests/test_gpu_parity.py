@@ -854,3 +854,31 @@ def test_attention_dropout_in_kernel(golden):
         factor = torch.where(kept, torch.full_like(ad, 1 / (1 - p)), torch.zeros_like(ad))
         dz_ref, der_ref = _C.gat_attn_bwd(g.csc, el, er, None, None, 0.2, H, a, gd * factor, None, None, True, None)
         assert torch.allclose(dz, dz_ref, rtol=1e-5, atol=1e-7) and torch.allclose(der, der_ref, rtol=1e-4, atol=1e-6)
+
+
+def test_full_size_config3_reddit_gcn_against_c_oracle():
+    """BASELINE config 3 at its full synthetic size — S-reddit, 232 965 nodes / 113.7 M edges, GCN 3 x 256
+    with BatchNorm — one train step (dropout 0) on the HIP path (L2-blocked SpMM + hub rows, W-first and aggregate-first
+    GraphConv) against the oracle's C kernels on the host cores: every logit within 1e-4, every gradient entry within 1e-4 of
+    its gradient's largest entry (oracle at the HIP run's ReLU gates, tests/full_size.py:KinkGates)."""
+    import torch.nn.functional as F
+    from bot_amd import nn as bnn, synth
+    from tests import full_size as FS
+    ds = synth.make_dataset("reddit", device=DEV, seed=0)
+    g, C = ds.graph, ds.n_classes
+    g.create_formats_()
+    cfg = dict(n_layers=3, n_hidden=256, norm="batch", norm_adj="symm", use_linear=False, residual=False)
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in bnn.GCN(in_feats=ds.feat.shape[1], n_classes=C, activation=F.relu, **cfg).state_dict().items()}
+    pred, grads, gates = FS.gcn_hip_step(g, ds.feat, ds.labels, ds.train_idx, sd, cfg, C)
+    s, d = (t.cpu() for t in g.edges())
+    rp, rg, secs, gstats = FS.gcn_oracle_step(s, d, g.number_of_nodes(), ds.feat.cpu(), ds.labels.cpu(), ds.train_idx.cpu(), sd, cfg,
+                                              gates=gates)
+    r = FS.compare(pred, grads, rp, rg, None)
+    r["relu_gates_differing"] = sum(x["differ"] for x in gstats)
+    r["max_abs_preact_at_differing_gate"] = max(x["max_abs_preact_where_differ"] for x in gstats)
+    print("full-size parity S-reddit GCN", r, "oracle step %.1f s" % secs)
+    assert r["n"] == 232965 and g.number_of_edges() > 100_000_000
+    assert r["max_abs_logit_diff"] <= PC.FWD_ATOL * max(1.0, r["logit_scale"] / 10), r
+    assert r["max_rel_grad_err"] <= PC.GRAD_RTOL, r
+    assert r["max_abs_preact_at_differing_gate"] <= 1e-4, r
