@@ -18,7 +18,7 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 from bot_amd import synth, tuning, dist as bdist
 from bot_amd import nn as bnn
-import bench
+from bot_amd import workloads, train as T
 tuning.enable()
 real_a2a = dist.all_to_all_single
 def fake_a2a(out, inp, out_splits=None, in_splits=None, group=None):
@@ -27,8 +27,8 @@ dist.all_to_all_single = fake_a2a
 ds = synth.make_dataset("arxiv", device="cpu", seed=0)
 C = ds.n_classes
 torch.manual_seed(0)
-model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **bench.CFG).to(dev)
-opt = torch.optim.RMSprop(model.parameters(), lr=0.002)
+model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **workloads.ARXIV_GAT).to(dev)
+opt = torch.optim.RMSprop(model.parameters(), lr=0.002, capturable=True)
 part = bdist.partition_dataset(ds, 0, W, dev)
 model = bdist.wrap_model(model)
 def step():
@@ -48,5 +48,14 @@ if os.environ.get("BOT_CPROFILE"):
     pr.disable(); torch.cuda.synchronize()
     pstats.Stats(pr).sort_stats("tottime").print_stats(28)
 print(f"world {W}: rank 0 owns {part.n_owned} nodes, {part.n_edges} edges, halo {part.graph.halo.n_halo} rows, sends {part.graph.halo.n_send} rows")
-print(f"per step: wall {t_all / K * 1e3:.2f} ms, host enqueue {t_host / K * 1e3:.2f} ms")
+print(f"per step (eager): wall {t_all / K * 1e3:.2f} ms, host enqueue {t_host / K * 1e3:.2f} ms")
+cap = T.CapturedTrainStep(lambda: step(), dev)          # the same step as ONE hipGraph replay (RCCL all-reduces captured)
+for _ in range(3): cap()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(K): cap()
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print(f"per step (hipGraph replay): wall {t_all / K * 1e3:.2f} ms, host enqueue {t_host / K * 1e3:.2f} ms")
 dist.destroy_process_group()
