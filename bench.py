@@ -181,6 +181,29 @@ def main():
                 "traffic_GBs": round(traffic / avg / 1e9, 1) if traffic else None,
                 "traffic_frac_of_peak": round(traffic / avg / 1e9 / HBM_PEAK_GBS, 4) if traffic else None}
 
+    # the other HIP sweeps of the step, same live events, same byte accounting (SURVEY §8d formulas), for context
+    others = []
+    fam_bytes = {
+        "spmm": lambda h, d, w: spmm_alg_bytes(wl.n_local, wl.e_local, h, d, w),
+        "spmm_blocked": lambda h, d, w: spmm_alg_bytes(wl.n_local, wl.e_local, h, d, w),
+        "spmm_dot": lambda h, d: 4 * (3 * wl.n_local * h * d + wl.e_local + wl.n_local + 1 + 2 * wl.e_local * h),
+        "spmm_bcast": lambda h, d: 4 * (wl.n_local * d * (1 + h) + wl.e_local + wl.e_local * h),
+        "spmm_dot_bcast": lambda h, d: 4 * (wl.n_local * d * (2 + h) + wl.e_local + 2 * wl.e_local * h),
+        "sddmm_dot_bcast": lambda h, d: 4 * (wl.n_local * d * (1 + h) + wl.e_local + wl.e_local * h),
+    }
+    groups = {}
+    for r in prof:
+        groups.setdefault((r[0], r[1]), []).append(r)
+    for (fam_, key), rs in sorted(groups.items(), key=lambda kv: -sum(r[2].elapsed_time(r[3]) for r in kv[1])):
+        if fam_ not in fam_bytes:
+            continue
+        avg_ms = sum(r[2].elapsed_time(r[3]) for r in rs) / len(rs)
+        b = fam_bytes[fam_](*key)
+        others.append({"op": fam_, "shape": list(key), "kernel": rs[0][4], "launches": len(rs), "avg_launch_ms": round(avg_ms, 4),
+                       "algorithmic_GBs": round(b / avg_ms / 1e6, 1), "frac": round(b / avg_ms / 1e6 / HBM_PEAK_GBS, 4)})
+    if roof is not None:
+        roof["all_sparse_sweeps"] = others
+
     cpu = parity = None
     if rank == 0 and world == 1 and args.cpu_baseline != "off" and args.workload == "arxiv" and args.norm_adj == "rw":
         cpu, parity = cpu_baseline_and_parity(wl.dataset, wl.dataset.n_classes, args.cpu_steps, dev)

@@ -116,11 +116,19 @@ def _stream():
 
 
 def _dev(*ts):
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise BotKernelError(
                 "bot_amd kernels run on MI355X only: got a CPU tensor and there is no CPU fallback "
                 "(move the graph and features to the GPU)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise BotKernelError(f"operands live on different devices ({dev} and {t.device}): graph structures and features "
+                                 "must be on the same GPU")
 
 
 def _f32(t, name):
@@ -204,6 +212,13 @@ def spmm(d, x, w=None, wperm=None, out=None, addend=None):
             addend is None or (addend.dim() == 3 and addend.dtype == torch.float32 and _rows_contiguous(addend))):
         from . import blocked
         bp = blocked.plan_for(d, x.shape[0], x.shape[1], x.shape[2])
+        if bp is not None:
+            # the plan's LDS layout assumes the vector width blocked.layout() derives from D alone; the C side re-derives it
+            # from the operands' alignment too — a slab whose base or row stride is not a multiple of it takes the row kernel
+            vec = blocked.layout(x.shape[1], x.shape[2])[0]
+            ok = lambda t: t is None or (t.data_ptr() % (4 * vec) == 0 and t.stride(0) % vec == 0)
+            if not (ok(x) and ok(addend)):
+                bp = None
         if bp is not None:  # dense graph: L2-blocked sweep for the regular rows, row-per-group kernel for the hubs
             if w is not None:
                 w = _f32(w, "w").contiguous()
