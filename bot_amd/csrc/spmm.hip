@@ -40,24 +40,6 @@ struct SpmmArgs {
     int64_t lda, hsa;
 };
 
-// Reduce 4 values per lane across a LANES-wide group; on return lane l holds the total of value number l % 4.
-template <int LANES>
-__device__ __forceinline__ float transpose_reduce4(float (&p)[4], int lane) {
-    const bool h2 = lane & 2;
-    float r[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float keep = h2 ? p[i + 2] : p[i];
-        const float send = h2 ? p[i] : p[i + 2];
-        r[i] = keep + __shfl_xor(send, 2, LANES);
-    }
-    const bool h1 = lane & 1;
-    float s = (h1 ? r[1] : r[0]) + __shfl_xor(h1 ? r[0] : r[1], 1, LANES);
-#pragma unroll
-    for (int m = 4; m < LANES; m <<= 1) s += __shfl_xor(s, m, LANES);
-    return s;
-}
-
 // Backward of u_mul_e_sum in ONE sweep over the out-edges (CSR direction) — each gathered row dx[v,h,:] is used twice:
 //   out[u,h,:]           = sum_k w[wperm[k],h] * x[indices[k],h,:]        (d ft: transposed SpMM)
 //   dot_out[wperm[k],h]  = < y[u,h,:] , x[indices[k],h,:] >               (d a : SDDMM dot)

@@ -550,6 +550,39 @@ def test_blocked_spmm_matches_row_kernel():
     (y * gy).sum().backward()
     ref_g = torch.zeros(n, 64, device=DEV).index_add_(0, s.to(DEV), gy[d.to(DEV)])
     assert torch.allclose(xg.grad, ref_g, atol=2e-3, rtol=1e-4)
+    # the fused backward (spmm_dot: d ft and d a from one sweep of the transposed direction) in its L2-blocked form against the
+    # row kernel and plain torch: every head-segment layout (16 / 32 / 64 lanes, 1-4 chunks), slabs of a wider buffer, hub rows
+    csr, c2c = g.csr, g.csr2csc
+    rows_r = torch.repeat_interleave(torch.arange(n, device=DEV), (csr.indptr[1:] - csr.indptr[:-1]).long())
+    seen = set()
+    for H, D in ((6, 80), (4, 120), (2, 64), (8, 16), (1, 128), (3, 40), (4, 250), (3, 7), (1, 20)):
+        F = H * D
+        big = torch.randn(n, 3 * F + 4, generator=gen).to(DEV)
+        dx = big[:, :F].unflatten(1, (H, D))                      # upstream gradient (gathered)
+        ft = big[:, F:2 * F].unflatten(1, (H, D))                 # the rows' own features
+        w = torch.rand(csr.nnz, H, generator=gen).to(DEV)         # in CSC position order, reached through csr2csc
+        outb = big[:, 2 * F:3 * F].unflatten(1, (H, D))
+        blocked.ENABLED = True
+        bp = blocked.plan_for_dot(csr, n, H, D, c2c)
+        o_b, dot_b = _C.spmm_dot(csr, dx, w, c2c, ft, out=outb)
+        seen.add(_C._lib.bot_last_kernel().decode().split("<")[0] if bp is not None else "row")
+        o_b, dot_b = o_b.clone(), dot_b.clone()
+        blocked.ENABLED = False
+        o_r, dot_r = _C.spmm_dot(csr, dx, w, c2c, ft)
+        blocked.ENABLED = True
+        wr = w[c2c.long()]
+        xs = dx[csr.indices.long()]
+        ref_o = torch.zeros(n, H, D, device=DEV).index_add_(0, rows_r, xs * wr.unsqueeze(-1))
+        ref_dot = torch.empty(csr.nnz, H, device=DEV)
+        ref_dot[c2c.long()] = (xs * ft[rows_r]).sum(-1)
+        assert (bp is not None) == (blocked.dot_tile_rows(H, D) > 0 and F >= blocked.MIN_ROW_FLOATS), (H, D)
+        assert torch.allclose(o_b, ref_o, atol=2e-3, rtol=1e-4) and torch.allclose(o_b, o_r, atol=2e-3, rtol=1e-4), (H, D)
+        assert torch.allclose(dot_b, ref_dot, atol=1e-3 * D ** 0.5, rtol=1e-4) and torch.allclose(dot_b, dot_r, atol=1e-3 * D ** 0.5, rtol=1e-4), (H, D)
+        if bp is not None:
+            assert bp.heavy is not None and bp.T in (16, 32, 64, 128) and bp.epi == 1
+            o2, dot2 = _C.spmm_dot(csr, dx, w, c2c, ft)          # bitwise reproducible
+            assert torch.equal(o2, o_b) and torch.equal(dot2, dot_b)
+    assert "row" in seen and any("blocked" in k for k in seen), seen
 
 
 def test_config1_cora_shape_gcn():
