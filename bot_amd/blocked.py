@@ -11,6 +11,13 @@ import torch
 ENABLED = True
 MIN_MEAN_DEGREE = 96       # below this a (row, block) visit holds < 1 edge: nothing to reuse
 L2_BLOCK_BYTES = 2 << 20   # source rows per column block * row bytes (half of the 4 MiB L2 of an XCD; 1 / 2 / 4 / 8 MiB: 7.80 / 6.54 / 6.44 / 7.95 ms on S-reddit)
+DOT_L2_BLOCK_BYTES = 2 << 20   # the same for the fused backward's plan (half-height tiles: fewer edges per (tile, block))
+# The L2-blocked fused backward is correct and tested but NOT faster than the all-heads row kernel, so it is off by default.
+# Measured at S-proteins (H=6, D=80, tools/exp_blocked_dot.py): row kernel 21.9 ms; blocked with 1 / 2 / 4 / 8 / 16 MiB column
+# blocks 34.4 / 28.6 / 25.3 / 23.5 / 22.7 ms.  Two [T, H*D] tiles in LDS leave T = 32 rows, i.e. ~9 edges per wave between two
+# workgroup barriers (130 column blocks): every phase is a couple of dependent gather groups plus a barrier tail, so the sweep is
+# latency-bound long before L2 residency pays; larger blocks trade the residency away and converge to the row kernel's time.
+DOT_ENABLED = False
 TILE_ROWS = 128            # destination rows per workgroup (32 / 64 / 128; 256 when rows are gathered by lane groups)
 TILE_LDS_BYTES = 128 * 1024  # LDS per workgroup: one 16-wave workgroup per CU
 WAVES = 16                 # wavefronts per workgroup (bot_amd/csrc/blocked.hip kBWaves)
@@ -93,7 +100,7 @@ def build(d, n_src: int, H: int, D: int, dot_wperm=None, dot=False) -> BlockedPl
         T = 256 if epi > 1 else TILE_ROWS
         while T > 32 and Fp * 4 * T > TILE_LDS_BYTES:
             T //= 2
-    cb = max(64, L2_BLOCK_BYTES // (F * 4))
+    cb = max(64, (DOT_L2_BLOCK_BYTES if dot else L2_BLOCK_BYTES) // (F * 4))
     cb = 1 << (cb.bit_length() - 1)
     nblk = (n_src + cb - 1) // cb
     regular = deg <= hub_thr
@@ -185,7 +192,7 @@ def plan_for(d, n_src: int, H: int, D: int):
 def plan_for_dot(d, n_src: int, H: int, D: int, wperm):
     """BlockedPlan of the fused backward (bot_spmm_dot_blocked_f32) for direction `d`, or None when the row kernel is the right
     one.  `wperm` (position -> row of the weight / dot arrays, or None) is baked into the plan."""
-    if (not ENABLED or d.n_rows == 0 or d.nnz < MIN_MEAN_DEGREE * d.n_rows or not d.indptr.is_cuda or H * D < MIN_ROW_FLOATS
+    if (not ENABLED or not DOT_ENABLED or d.n_rows == 0 or d.nnz < MIN_MEAN_DEGREE * d.n_rows or not d.indptr.is_cuda or H * D < MIN_ROW_FLOATS
             or dot_tile_rows(H, D) == 0):
         return None
     key = (H, D, "dot", None if wperm is None else wperm.data_ptr())
