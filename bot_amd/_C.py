@@ -69,6 +69,7 @@ _SIGS = {
     "bot_random_keep_u8": (ctypes.c_int, [c_int64, c_int64, c_uint64, _P, _P, _P]),
     "bot_bn_workspace_floats": (c_int64, [c_int32]),
     "bot_colstats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
+    "bot_bn_stats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "bot_bn_act_fwd_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, _P, c_int64, _P]),
     "bot_bn_act_bwd_reduce_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
                                                  c_uint64, _P, _P, _P, _P, _P]),
@@ -554,6 +555,20 @@ def colstats(x):
     _check(_lib.bot_colstats_f32(x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), m2.data_ptr(), _bn_ws(F, x.device).data_ptr(),
                                  _stream()), "colstats")
     return mean, m2
+
+
+def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
+    """Training-mode statistics step of nn.BatchNorm1d over the rows of x [n,F] in one call: returns (mean, invstd) and updates
+    the running statistics / step counter in place (include/bot_gnn.h bot_bn_stats_f32)."""
+    _dev(x, running_mean, running_var)
+    x = _mat(x, "x")
+    n, F = x.shape
+    mean = torch.empty(F, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(F, dtype=torch.float32, device=x.device)
+    _check(_lib.bot_bn_stats_f32(x.data_ptr(), x.stride(0), n, F, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
+                                 _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _bn_ws(F, x.device).data_ptr(),
+                                 _stream()), "bn_stats")
+    return mean, invstd
 
 
 def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed):

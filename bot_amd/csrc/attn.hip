@@ -5,7 +5,7 @@
 // than the SpMM/SDDMM gathers; the node-side operands el/er ([n,H], 2 MB at ogbn-arxiv) stay
 // resident in the 4 MiB XCD L2.  Lanes run ACROSS THE EDGES of a row: a 16-lane group per short
 // row (4 rows per wavefront; mean in-degree of the target graphs is ~15), one 256-thread workgroup
-// per long row (rows above the row plan's chunk), both through the same per-row routine.  Softmax is
+// per long row (rows above the row plan's chunk), both through the same per-row routine and in ONE launch.  Softmax is
 // the online (running max / running sum) form: two passes over the row, not three; heads are held
 // in registers HT at a time.  No atomics; fixed reduction order.
 //
@@ -330,25 +330,28 @@ __device__ __forceinline__ void attn_bwd_row(const AttnArgs& p, const Ctx& ctx, 
     }
 }
 
+// ONE launch for both row classes: the first `n_long` workgroups take one long row each (all 256 threads on the row, they
+// start first: they are the longest pieces of work), the others take 16 short rows each (a 16-lane group per row).  As two
+// launches the long-row kernel (a few hundred small workgroups, latency-bound by the longest row) ran alone on an empty chip
+// behind the short-row kernel: 73 + 47 us per forward at S-arxiv; merged they overlap.
 template <int HT, bool BWD>
-__global__ __launch_bounds__(kBlock) void attn_short_kernel(AttnArgs p) {
-    const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kRowLanes;
+__global__ __launch_bounds__(kBlock) void attn_kernel(AttnArgs p, int n_long) {
+    __shared__ float lds[(kBlock / 64) * 8];
+    if ((int)blockIdx.x < n_long) {  // workgroup-uniform
+        const int row = p.long_rows[blockIdx.x];
+        const int beg = p.indptr[row], end = p.indptr[row + 1];
+        BlockCtx ctx{(int)threadIdx.x, lds};
+        if constexpr (BWD) attn_bwd_row<HT>(p, ctx, row, beg, end);
+        else attn_fwd_row<HT>(p, ctx, row, beg, end);
+        return;
+    }
+    const int64_t row = ((int64_t)(blockIdx.x - n_long) * kBlock + threadIdx.x) / kRowLanes;
     if (row >= p.n_rows) return;
     const int beg = p.indptr[row], end = p.indptr[row + 1];
-    if (end - beg > p.chunk) return;  // the workgroup-per-row kernel owns it
+    if (end - beg > p.chunk) return;  // a long row: owned by one of the first workgroups
     GroupCtx<kRowLanes> ctx{(int)(threadIdx.x % kRowLanes)};
     if constexpr (BWD) attn_bwd_row<HT>(p, ctx, (int)row, beg, end);
     else attn_fwd_row<HT>(p, ctx, (int)row, beg, end);
-}
-
-template <int HT, bool BWD>
-__global__ __launch_bounds__(kBlock) void attn_long_kernel(AttnArgs p) {
-    __shared__ float lds[(kBlock / 64) * 8];
-    const int row = p.long_rows[blockIdx.x];
-    const int beg = p.indptr[row], end = p.indptr[row + 1];
-    BlockCtx ctx{(int)threadIdx.x, lds};
-    if constexpr (BWD) attn_bwd_row<HT>(p, ctx, row, beg, end);
-    else attn_fwd_row<HT>(p, ctx, row, beg, end);
 }
 
 template <bool BWD>
@@ -359,11 +362,8 @@ static int launch_attn(AttnArgs p, int64_t n_long, hipStream_t st) {
     for (int h0 = 0; h0 < p.H;) {  // heads in register tiles of up to 8 (one sweep over the edges for H <= 8)
         const int ht = p.H - h0 >= 8 ? 8 : p.H - h0;
         p.h0 = h0;
-#define BOT_LAUNCH_ATTN(HT)                                                                                             \
-    do {                                                                                                                \
-        hipLaunchKernelGGL((attn_short_kernel<HT, BWD>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);                \
-        if (n_long > 0) hipLaunchKernelGGL((attn_long_kernel<HT, BWD>), dim3((unsigned)n_long), dim3(kBlock), 0, st, p); \
-    } while (0)
+#define BOT_LAUNCH_ATTN(HT) \
+    hipLaunchKernelGGL((attn_kernel<HT, BWD>), dim3((unsigned)(blocks + n_long)), dim3(kBlock), 0, st, p, (int)n_long)
         switch (ht) {
             case 8: BOT_LAUNCH_ATTN(8); break;
             case 7: BOT_LAUNCH_ATTN(7); break;
@@ -414,21 +414,20 @@ __device__ __forceinline__ void seg_row(const SegArgs& p, const Ctx& ctx, int ro
 }
 
 template <int WT>
-__global__ __launch_bounds__(kBlock) void seg_short_kernel(SegArgs p) {
-    const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kRowLanes;
+__global__ __launch_bounds__(kBlock) void seg_kernel(SegArgs p, int n_long) {  // long rows first, as in attn_kernel
+    __shared__ float lds[(kBlock / 64) * 8];
+    if ((int)blockIdx.x < n_long) {
+        const int row = p.long_rows[blockIdx.x];
+        BlockCtx ctx{(int)threadIdx.x, lds};
+        seg_row<WT>(p, ctx, row, p.indptr[row], p.indptr[row + 1]);
+        return;
+    }
+    const int64_t row = ((int64_t)(blockIdx.x - n_long) * kBlock + threadIdx.x) / kRowLanes;
     if (row >= p.n_rows) return;
     const int beg = p.indptr[row], end = p.indptr[row + 1];
     if (end - beg > p.chunk) return;
     GroupCtx<kRowLanes> ctx{(int)(threadIdx.x % kRowLanes)};
     seg_row<WT>(p, ctx, (int)row, beg, end);
-}
-
-template <int WT>
-__global__ __launch_bounds__(kBlock) void seg_long_kernel(SegArgs p) {
-    __shared__ float lds[(kBlock / 64) * 8];
-    const int row = p.long_rows[blockIdx.x];
-    BlockCtx ctx{(int)threadIdx.x, lds};
-    seg_row<WT>(p, ctx, row, p.indptr[row], p.indptr[row + 1]);
 }
 
 __global__ __launch_bounds__(kBlock) void degrees_kernel(const int32_t* indptr, int64_t n_rows, int64_t* deg) {
@@ -501,11 +500,7 @@ int bot_segment_sum_f32(const int32_t* indptr, int64_t n_rows, int64_t nnz, cons
     for (int w0 = 0; w0 < W;) {  // record columns in register tiles of up to 8 (one sweep for W <= 8)
         const int wt = W - w0 >= 8 ? 8 : W - w0;
         p.w0 = w0;
-#define BOT_LAUNCH_SEG(WT)                                                                                    \
-    do {                                                                                                      \
-        hipLaunchKernelGGL((seg_short_kernel<WT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p);            \
-        if (n_long > 0) hipLaunchKernelGGL((seg_long_kernel<WT>), dim3((unsigned)n_long), dim3(kBlock), 0, st, p); \
-    } while (0)
+#define BOT_LAUNCH_SEG(WT) hipLaunchKernelGGL((seg_kernel<WT>), dim3((unsigned)(blocks + n_long)), dim3(kBlock), 0, st, p, (int)n_long)
         switch (wt) {
             case 8: BOT_LAUNCH_SEG(8); break;
             case 7: BOT_LAUNCH_SEG(7); break;

@@ -122,17 +122,30 @@ __device__ __forceinline__ void pair_reduce(const float* part, int nblk, int32_t
     for (int g = 0; g < 4; ++g) S += lds[0][g][threadIdx.x & 63], Q += lds[1][g][threadIdx.x & 63];
 }
 
-// mean[c] = pivot + S/n ; m2[c] = Q - S^2/n
+// mean[c] = pivot + S/n ; m2[c] = Q - S^2/n.  With `invstd` given this is the whole training-mode statistics step of
+// nn.BatchNorm1d in one launch (it replaced nine elementwise launches per layer): invstd = rsqrt(m2/n + eps), and the running
+// statistics move by `momentum` towards the batch mean / the UNBIASED batch variance; the step counter is bumped by one.
 __global__ __launch_bounds__(kBlock) void colstats_final_kernel(const float* x, int64_t n, int32_t F, const float* part, int nblk,
-                                                               float* mean, float* m2) {
+                                                               float* mean, float* m2, float* invstd, float eps, float momentum,
+                                                               float* running_mean, float* running_var, int64_t* num_batches) {
     __shared__ double lds[2][4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     double S, Q;
     pair_reduce(part, nblk, F, c, grp, lds, S, Q);
     if (grp == 0 && c < F) {
-        mean[c] = (float)((double)x[c] + S / (double)n);
-        m2[c] = (float)fmax(Q - S * S / (double)n, 0.0);
+        const float mu = (float)((double)x[c] + S / (double)n);
+        const float q = (float)fmax(Q - S * S / (double)n, 0.0);
+        mean[c] = mu;
+        if (m2) m2[c] = q;
+        if (invstd) {
+            invstd[c] = rsqrtf(q / (float)n + eps);
+            if (running_mean) {
+                running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mu;
+                running_var[c] = running_var[c] * (1.f - momentum) + momentum * (q / (float)(n > 1 ? n - 1 : 1));
+            }
+        }
     }
+    if (num_batches && blockIdx.x == 0 && threadIdx.x == 0) num_batches[0] += 1;
 }
 
 template <int VEC>
@@ -314,8 +327,27 @@ int bot_colstats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* m
     else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
     else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
     hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
-                       mean, m2);
+                       mean, m2, (float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (int64_t*)nullptr);
     return hip_status("colstats launch");
+}
+
+int bot_bn_stats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float eps, float momentum, float* mean, float* invstd,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float* workspace,
+                     bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 1 && F >= 1 && ldx >= F, BOT_E_RANGE, "bn_stats: n=%lld F=%d ldx=%lld", (long long)n, F, (long long)ldx);
+    BOT_REQUIRE(x && mean && invstd && workspace, BOT_E_NULL, "bn_stats: NULL pointer");
+    BOT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), BOT_E_NULL, "bn_stats: running_mean and running_var go together");
+    BOT_REQUIRE(eps >= 0.f && momentum >= 0.f && momentum <= 1.f, BOT_E_RANGE, "bn_stats: eps=%f momentum=%f", (double)eps, (double)momentum);
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = pick_vec(F, {ldx}, {x});
+    const dim3 grid = bn_grid(F, vec, n);
+    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
+    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
+    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
+    hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
+                       mean, (float*)nullptr, invstd, eps, momentum, running_mean, running_var, num_batches_tracked);
+    return hip_status("bn_stats launch");
 }
 
 int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,

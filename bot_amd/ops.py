@@ -291,6 +291,13 @@ def bn_batch_stats(x, bn, bn_training):
     total = float(n)
     if not bn_training:
         return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps), total, sync, group
+    if not sync and (bn.momentum is not None or not bn.track_running_stats):
+        # one GPU: statistics, invstd and the running-statistics update in ONE call (nine elementwise launches per layer before)
+        track = bn.track_running_stats
+        with torch.no_grad():
+            mean, invstd = _C.bn_stats(x, bn.eps, bn.momentum if track else 0.0, bn.running_mean if track else None,
+                                       bn.running_var if track else None, bn.num_batches_tracked if track else None)
+        return mean, invstd, total, sync, group
     mean, m2 = _C.colstats(x)
     if sync:
         # the global row count is a constant of the partition: ask for it once (one host sync), then never again, so the

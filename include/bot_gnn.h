@@ -338,6 +338,12 @@ int bot_scatter_add_rows_f32(float* x, int64_t ldx, const int32_t* rows, int64_t
 int64_t bot_bn_workspace_floats(int32_t F);
 int bot_colstats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* mean, float* m2, float* workspace,
                      bot_stream_t stream);
+/* colstats + everything nn.BatchNorm1d does with them in training mode, in one call: mean, invstd = rsqrt(m2/n + eps),
+ * running_mean / running_var (may both be NULL) moved by `momentum` towards the batch mean / unbiased batch variance,
+ * *num_batches_tracked (may be NULL) += 1.  Single-GPU form; the partitioned mode all-reduces between the two halves. */
+int bot_bn_stats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float eps, float momentum, float* mean, float* invstd,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float* workspace,
+                     bot_stream_t stream);
 int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
                        const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
                        const uint64_t* seed_offset, float* y, int64_t ldy, bot_stream_t stream);

@@ -190,6 +190,19 @@ def colstats(x):
     return mean, ((x - mean) ** 2).sum(0)
 
 
+def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
+    n = x.shape[0]
+    mean = x.mean(0)
+    m2 = ((x - mean) ** 2).sum(0)
+    invstd = torch.rsqrt(m2 / n + eps)
+    if running_mean is not None:
+        running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+        running_var.mul_(1 - momentum).add_(m2 / max(n - 1, 1), alpha=momentum)
+    if num_batches_tracked is not None:
+        num_batches_tracked += 1
+    return mean, invstd
+
+
 def _bn_gate(x, mean, invstd, weight, bias, relu, p):
     assert p == 0.0, "the CPU emulation has no Philox stream: dropout parity is checked on the GPU only"
     xh = (x - mean) * invstd
@@ -242,7 +255,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 
