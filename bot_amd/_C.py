@@ -62,6 +62,8 @@ _SIGS = {
     "bot_segment_sum_f32": (ctypes.c_int, [_P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, c_int32, _P, _P]),
     "bot_gather_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
     "bot_scatter_add_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
+    "bot_merge_weight_fwd_f32": (ctypes.c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "bot_merge_weight_bwd_f32": (ctypes.c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     "bot_edge_mlp_workspace_floats": (c_int64, []),
     "bot_edge_mlp_fwd_f32": (ctypes.c_int, [_P, c_int32, _P, _P, c_int32, _P, c_int32, c_int64, _P, _P]),
     "bot_edge_mlp_bwd_f32": (ctypes.c_int, [_P, c_int32, _P, _P, c_int32, _P, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
@@ -652,3 +654,32 @@ def edge_mlp_bwd(ef, W1, b1, W2, dz):
                                      dz.data_ptr(), E, dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), ws.data_ptr(), _stream()),
            "edge_mlp_bwd")
     return dW1, db1, dW2
+
+
+# ------------------------------------------------------------------------------------------------ merged projection weight
+def merge_weight_fwd(W, Wres, attn_l, attn_r, H, D, P, with_fc):
+    """[K, P] = [W^T (with_fc) | Wres^T | wl | wr | 0] (include/bot_gnn.h bot_merge_weight_fwd_f32)."""
+    _dev(W, Wres, attn_l, attn_r)
+    W = _f32(W, "W").contiguous()
+    Wres = None if Wres is None else _f32(Wres, "Wres").contiguous()
+    al = _f32(attn_l, "attn_l").contiguous()
+    ar = None if attn_r is None else _f32(attn_r, "attn_r").contiguous()
+    K = W.shape[1]
+    out = torch.empty((K, P), dtype=torch.float32, device=W.device)
+    _check(_lib.bot_merge_weight_fwd_f32(W.data_ptr(), _ptr(Wres), al.data_ptr(), _ptr(ar), H, D, K, P, int(with_fc), out.data_ptr(),
+                                         _stream()), "merge_weight_fwd")
+    return out
+
+
+def merge_weight_bwd(W, attn_l, attn_r, H, D, P, with_fc, has_res, dm):
+    _dev(W, attn_l, attn_r, dm)
+    W, al, dm = W.contiguous(), attn_l.contiguous(), _f32(dm, "d_merged").contiguous()
+    ar = None if attn_r is None else attn_r.contiguous()
+    K = W.shape[1]
+    dW = torch.empty_like(W)
+    dWres = torch.empty_like(W) if has_res else None
+    dal = torch.empty_like(al)
+    dar = None if ar is None else torch.empty_like(ar)
+    _check(_lib.bot_merge_weight_bwd_f32(W.data_ptr(), al.data_ptr(), _ptr(ar), H, D, K, P, int(with_fc), dm.data_ptr(), dW.data_ptr(),
+                                         _ptr(dWres), dal.data_ptr(), _ptr(dar), _stream()), "merge_weight_bwd")
+    return dW, dWres, dal, dar

@@ -1,0 +1,120 @@
+// Merged projection weight of a GAT layer and its gradient (gfx950) — tiny tensors, few launches.
+//
+// bot_amd.nn.fused runs a layer's four linear maps on the layer input — fc (models.py:490-492), res_fc (:558-560) and the two
+// attention scores folded through fc, el = h . (W_h^T attn_l[h]) (:517), er likewise (:521) — as ONE GEMM against
+//     Wm [K, P] = [ W_fc^T | W_res^T | wl | wr | 0 ]        wl[k,h] = sum_d W_fc[h*D+d, k] * attn_l[h,d]
+// (the aggregate-before-project layer leaves W_fc^T out).  Built with stock tensor ops that is ~11 launches per layer forward
+// and as many backward, every step; here it is one launch forward and two backward.
+#include "common.h"
+
+namespace bot {
+
+struct MergeArgs {
+    const float* W;     // [H*D, K]
+    const float* Wres;  // [H*D, K] or NULL
+    const float* al;    // [H*D]
+    const float* ar;    // [H*D] or NULL
+    int32_t H, D, K, P, with_fc;
+    float* out;         // forward: Wm [K, P]
+    const float* dm;    // backward: d Wm [K, P]
+    float* dW;          // [H*D, K]
+    float* dWres;       // [H*D, K] or NULL
+    float* dal;         // [H*D]
+    float* dar;         // [H*D] or NULL
+};
+
+__global__ __launch_bounds__(kBlock) void merge_fwd_kernel(MergeArgs a) {
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (int64_t)a.K * a.P) return;
+    const int k = (int)(gid / a.P), p = (int)(gid - (int64_t)k * a.P);
+    const int HD = a.H * a.D;
+    const int c0 = a.with_fc ? HD : 0, c1 = c0 + (a.Wres ? HD : 0), c2 = c1 + a.H, c3 = c2 + (a.ar ? a.H : 0);
+    float v = 0.f;
+    if (p < c0) v = a.W[(int64_t)p * a.K + k];
+    else if (p < c1) v = a.Wres[(int64_t)(p - c0) * a.K + k];
+    else if (p < c3) {
+        const bool left = p < c2;
+        const int h = left ? p - c1 : p - c2;
+        const float* at = left ? a.al : a.ar;
+        for (int d = 0; d < a.D; ++d) v = fmaf(a.W[(int64_t)(h * a.D + d) * a.K + k], at[h * a.D + d], v);
+    }
+    a.out[gid] = v;
+}
+
+// dW[p,k] = [with_fc] dm[k,p] + attn_l[p] * dm[k, c1+h] (+ attn_r[p] * dm[k, c2+h]);  dWres[p,k] = dm[k, c0+p]
+__global__ __launch_bounds__(kBlock) void merge_bwd_w_kernel(MergeArgs a) {
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int HD = a.H * a.D;
+    if (gid >= (int64_t)HD * a.K) return;
+    const int p = (int)(gid / a.K), k = (int)(gid - (int64_t)p * a.K);
+    const int h = p / a.D;
+    const int c0 = a.with_fc ? HD : 0, c1 = c0 + (a.Wres ? HD : 0), c2 = c1 + a.H;
+    const float* row = a.dm + (int64_t)k * a.P;
+    float g = a.with_fc ? row[p] : 0.f;
+    g = fmaf(a.al[p], row[c1 + h], g);
+    if (a.ar) g = fmaf(a.ar[p], row[c2 + h], g);
+    a.dW[gid] = g;
+    if (a.dWres) a.dWres[gid] = row[c0 + p];
+}
+
+// dal[p] = sum_k W[p,k] * dm[k, c1+h];  dar[p] likewise with c2.  One 64-lane group per p.
+__global__ __launch_bounds__(kBlock) void merge_bwd_a_kernel(MergeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int p = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const int HD = a.H * a.D;
+    if (p >= HD) return;
+    const int h = p / a.D;
+    const int c0 = a.with_fc ? HD : 0, c1 = c0 + (a.Wres ? HD : 0), c2 = c1 + a.H;
+    float sl = 0.f, sr = 0.f;
+    for (int k = lane; k < a.K; k += 64) {
+        const float w = a.W[(int64_t)p * a.K + k];
+        sl = fmaf(w, a.dm[(int64_t)k * a.P + c1 + h], sl);
+        if (a.ar) sr = fmaf(w, a.dm[(int64_t)k * a.P + c2 + h], sr);
+    }
+    sl = group_sum<64>(sl);
+    sr = group_sum<64>(sr);
+    if (lane == 0) {
+        a.dal[p] = sl;
+        if (a.dar) a.dar[p] = sr;
+    }
+}
+
+static int merge_check(const char* who, const float* W, const float* al, int32_t H, int32_t D, int32_t K, int32_t P, const float* Wres,
+                       const float* ar, int32_t with_fc) {
+    BOT_REQUIRE(H >= 1 && D >= 1 && K >= 1, BOT_E_RANGE, "%s: H=%d D=%d K=%d", who, H, D, K);
+    BOT_REQUIRE(W && al, BOT_E_NULL, "%s: W / attn_l is NULL", who);
+    const int64_t used = (int64_t)(with_fc ? H * D : 0) + (Wres ? H * D : 0) + H + (ar ? H : 0);
+    BOT_REQUIRE(P >= used, BOT_E_RANGE, "%s: P=%d smaller than the %lld merged columns", who, P, (long long)used);
+    return 0;
+}
+
+}  // namespace bot
+
+extern "C" {
+
+int bot_merge_weight_fwd_f32(const float* W, const float* Wres, const float* attn_l, const float* attn_r, int32_t H, int32_t D,
+                             int32_t K, int32_t P, int32_t with_fc, float* out, bot_stream_t stream) {
+    using namespace bot;
+    if (int rc = merge_check("merge_weight_fwd", W, attn_l, H, D, K, P, Wres, attn_r, with_fc)) return rc;
+    BOT_REQUIRE(out != nullptr, BOT_E_NULL, "merge_weight_fwd: out is NULL");
+    MergeArgs a{W, Wres, attn_l, attn_r, H, D, K, P, with_fc, out, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int64_t n = (int64_t)K * P;
+    hipLaunchKernelGGL(merge_fwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    return hip_status("merge_weight_fwd launch");
+}
+
+int bot_merge_weight_bwd_f32(const float* W, const float* attn_l, const float* attn_r, int32_t H, int32_t D, int32_t K, int32_t P,
+                             int32_t with_fc, const float* d_merged, float* dW, float* dWres, float* d_attn_l, float* d_attn_r,
+                             bot_stream_t stream) {
+    using namespace bot;
+    if (int rc = merge_check("merge_weight_bwd", W, attn_l, H, D, K, P, dWres, attn_r, with_fc)) return rc;
+    BOT_REQUIRE(d_merged && dW && d_attn_l && ((attn_r == nullptr) == (d_attn_r == nullptr)), BOT_E_NULL, "merge_weight_bwd: NULL pointer");
+    MergeArgs a{W, dWres, attn_l, attn_r, H, D, K, P, with_fc, nullptr, d_merged, dW, dWres, d_attn_l, d_attn_r};
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)H * D * K;
+    hipLaunchKernelGGL(merge_bwd_w_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(merge_bwd_a_kernel, dim3((unsigned)(((int64_t)H * D * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, a);
+    return hip_status("merge_weight_bwd launch");
+}
+
+}  // extern "C"

@@ -73,6 +73,38 @@ def cat_weight(conv):
     return torch.cat(rows)
 
 
+class _MergeWeight(torch.autograd.Function):
+    """`_kp(cat_weight(conv))` / `_kp(cat_weight_aggfirst(conv))` in one launch forward and two backward (merge.hip) instead of
+    ~11 + ~11 stock launches per layer and step.  Same columns, [K, P] layout."""
+
+    @staticmethod
+    def forward(ctx, W, Wres, attn_l, attn_r, H, D, with_fc):
+        used = (H * D if with_fc else 0) + (H * D if Wres is not None else 0) + H + (H if attn_r is not None else 0)
+        P = used + (-used) % 128
+        ctx.save_for_backward(W, attn_l, attn_r)
+        ctx.cfg = (H, D, P, with_fc, Wres is not None)
+        return _C.merge_weight_fwd(W, Wres, attn_l.reshape(-1), None if attn_r is None else attn_r.reshape(-1), H, D, P, with_fc)
+
+    @staticmethod
+    def backward(ctx, dm):
+        W, attn_l, attn_r = ctx.saved_tensors
+        H, D, P, with_fc, has_res = ctx.cfg
+        dW, dWres, dal, dar = _C.merge_weight_bwd(W, attn_l.reshape(-1), None if attn_r is None else attn_r.reshape(-1), H, D, P,
+                                                  with_fc, has_res, dm)
+        return dW, dWres, dal.view_as(attn_l), (None if dar is None else dar.view_as(attn_r)), None, None, None
+
+
+def merged_weight(conv, with_fc=True):
+    """The layer's merged projection weight in the layout the GEMMs want.  On the GPU (and [K, P] layout) by the merge kernels;
+    otherwise (CPU test backend) by the tensor-op definition `cat_weight` / `cat_weight_aggfirst`."""
+    W = conv.fc.weight
+    if W.is_cuda and WEIGHT_KP:
+        return _MergeWeight.apply(W, conv.res_fc.weight if conv.res_fc is not None else None, conv.attn_l,
+                                  conv.attn_r if isinstance(conv.attn_r, torch.Tensor) else None, conv._num_heads, conv._out_feats,
+                                  with_fc)
+    return _kp(cat_weight(conv) if with_fc else cat_weight_aggfirst(conv))
+
+
 def _ext_width(HD, H):
     """Row width of the halo-extended table [ft | el | pad]: keeps the slab's vector alignment."""
     return HD + (H + 3) // 4 * 4
@@ -422,15 +454,15 @@ def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
     if use_agg_first(conv):
         global AGG_CALLS
         AGG_CALLS += 1
-        return _GATHiddenAggFirst.apply(h, conv.fc.weight, _kp(cat_weight_aggfirst(conv)), bn_w, bn_b, graph, bn, H, D,
+        return _GATHiddenAggFirst.apply(h, conv.fc.weight, merged_weight(conv, with_fc=False), bn_w, bn_b, graph, bn, H, D,
                                         conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
                                         attn_p, dropout_p if training and bn is not None else 0.0, bn_training, WEIGHT_KP,
                                         conv._use_symmetric_norm)
     if bn is None:
-        return _GATHidden.apply(h, _kp(cat_weight(conv)), None, None, graph, None, H, D, conv.res_fc is not None,
+        return _GATHidden.apply(h, merged_weight(conv), None, None, graph, None, H, D, conv.res_fc is not None,
                                 conv.attn_r is not None, conv.leaky_relu.negative_slope, attn_p, 0.0, False, WEIGHT_KP,
                                 conv._use_symmetric_norm)
-    return _GATHidden.apply(h, _kp(cat_weight(conv)), bn.weight if bn.affine else None, bn.bias if bn.affine else None, graph, bn,
+    return _GATHidden.apply(h, merged_weight(conv), bn.weight if bn.affine else None, bn.bias if bn.affine else None, graph, bn,
                             H, D, conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
                             conv.attn_drop.p if training else 0.0, dropout_p if training else 0.0, bn_training, WEIGHT_KP,
                             conv._use_symmetric_norm)
@@ -459,7 +491,7 @@ def infer_weight(conv):
     """Merged projection weight of the layer in the layout the GEMM wants, cached across forward calls (evaluate() calls the
     model 1 + n_label_iters times between two optimizer steps)."""
     key = _versions(conv.fc.weight, conv.res_fc.weight if conv.res_fc is not None else None, conv.attn_l, conv.attn_r) + (WEIGHT_KP,)
-    return _cached(conv, "wcat", key, lambda: _kp(cat_weight(conv)).detach())
+    return _cached(conv, "wcat", key, lambda: merged_weight(conv).detach())
 
 
 def eval_affine(mod):

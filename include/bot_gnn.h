@@ -357,6 +357,20 @@ int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int6
                              const float* sum_gx, double total_count, float* dx, int64_t lddx, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Merged projection weight of a GAT layer (host-side convenience of the fused layer node, not a DGL operator): the layer's
+ * linear maps on its input — fc (models.py:490-492), res_fc (:558-560), and the attention scores folded through fc,
+ * el = h . (W_h^T attn_l[h]) (:517), er likewise (:521) — become ONE GEMM against
+ *     merged [K, P] = [ W_fc^T (with_fc) | W_res^T (Wres != NULL) | wl | wr (attn_r != NULL) | 0 ... ]
+ * with wl[k,h] = sum_d W_fc[h*D+d, k] * attn_l[h*D+d].  W, Wres: [H*D, K] row-major; attn_l, attn_r: [H*D].  The backward
+ * takes d merged and returns the gradients of the four parameters (dWres / d_attn_r NULL when absent).
+ * ------------------------------------------------------------------------------------------- */
+int bot_merge_weight_fwd_f32(const float* W, const float* Wres, const float* attn_l, const float* attn_r, int32_t H, int32_t D,
+                             int32_t K, int32_t P, int32_t with_fc, float* merged, bot_stream_t stream);
+int bot_merge_weight_bwd_f32(const float* W, const float* attn_l, const float* attn_r, int32_t H, int32_t D, int32_t K,
+                             int32_t P, int32_t with_fc, const float* d_merged, float* dW, float* dWres, float* d_attn_l,
+                             float* d_attn_r, bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Edge-feature attention term of the ogbn-proteins GAT, fused.  Replaces, per layer,
  *   efeat_emb = relu(edge_encoder[i](efeat))                 src/ogbn-proteins/models.py:244-248
  *   attn_edge = attn_edge_fc(efeat_emb)                      src/ogbn-proteins/models.py:130-131

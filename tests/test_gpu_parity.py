@@ -982,3 +982,26 @@ def test_full_size_config3_reddit_gcn_against_c_oracle():
     assert r["max_abs_logit_diff"] <= PC.FWD_ATOL * max(1.0, r["logit_scale"] / 10), r
     assert r["max_rel_grad_err"] <= PC.GRAD_RTOL, r
     assert r["max_abs_preact_at_differing_gate"] <= 1e-4, r
+
+
+def test_merged_weight_kernels_match_tensor_ops():
+    """merge.hip: the layer's merged projection weight [W_fc^T | W_res^T | wl | wr | 0] and the gradients of fc.weight,
+    res_fc.weight, attn_l, attn_r through it, against the tensor-op definition (fused.cat_weight / cat_weight_aggfirst + autograd)."""
+    from bot_amd import nn as bnn
+    from bot_amd.nn import fused
+    gen = torch.Generator().manual_seed(12)
+    for fin, H, D, linear, attn_r in ((168, 3, 250, True, False), (750, 3, 250, True, True), (750, 1, 40, True, False), (33, 2, 7, False, True)):
+        for with_fc in (True, False):
+            conv = bnn.GATConv(fin, D, num_heads=H, linear=linear, non_interactive_attn=attn_r).to(DEV)
+            ref = fused._kp(fused.cat_weight(conv) if with_fc else fused.cat_weight_aggfirst(conv))
+            g = torch.randn(ref.shape, generator=gen).to(DEV)
+            params = [p for p in conv.parameters()]
+            ref_grads = torch.autograd.grad((ref * g).sum(), params, allow_unused=True)
+            out = fused.merged_weight(conv, with_fc=with_fc)
+            assert out.shape == ref.shape and torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+            grads = torch.autograd.grad((out * g).sum(), params, allow_unused=True)
+            for p, a, b in zip(conv.named_parameters(), grads, ref_grads):
+                if b is None:
+                    assert a is None or float(a.abs().max()) == 0.0, p[0]
+                else:
+                    assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max())), p[0]
