@@ -23,22 +23,43 @@ struct MergeArgs {
     float* dar;         // [H*D] or NULL
 };
 
-__global__ __launch_bounds__(kBlock) void merge_fwd_kernel(MergeArgs a) {
-    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= (int64_t)a.K * a.P) return;
-    const int k = (int)(gid / a.P), p = (int)(gid - (int64_t)k * a.P);
+// Two workgroup ranges in one launch, both with coalesced reads AND writes:
+//   [0, n_tiles)   32 x 32 tiles of the transposed copies W_fc^T / W_res^T through LDS;
+//   [n_tiles, ..)  the score columns wl / wr (threads run along k, so the D rows of W they walk are read contiguously) and the pad.
+__global__ __launch_bounds__(kBlock) void merge_fwd_kernel(MergeArgs a, int n_tiles, int tiles_k) {
+    __shared__ float tile[32][33];
     const int HD = a.H * a.D;
     const int c0 = a.with_fc ? HD : 0, c1 = c0 + (a.Wres ? HD : 0), c2 = c1 + a.H, c3 = c2 + (a.ar ? a.H : 0);
+    if ((int)blockIdx.x < n_tiles) {
+        const int tk = blockIdx.x % tiles_k, tp = blockIdx.x / tiles_k;   // tp runs over the c1 copied columns
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8 threads
+#pragma unroll
+        for (int j = 0; j < 32; j += 8) {
+            const int p = tp * 32 + ty + j, k = tk * 32 + tx;
+            float v = 0.f;
+            if (p < c1 && k < a.K) v = p < c0 ? a.W[(int64_t)p * a.K + k] : a.Wres[(int64_t)(p - c0) * a.K + k];
+            tile[ty + j][tx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; j += 8) {
+            const int k = tk * 32 + ty + j, p = tp * 32 + tx;
+            if (p < c1 && k < a.K) a.out[(int64_t)k * a.P + p] = tile[tx][ty + j];
+        }
+        return;
+    }
+    const int64_t gid = (int64_t)(blockIdx.x - n_tiles) * kBlock + threadIdx.x;
+    const int nq = a.P - c1;
+    if (gid >= (int64_t)nq * a.K) return;
+    const int q = (int)(gid / a.K), k = (int)(gid - (int64_t)q * a.K), p = c1 + q;
     float v = 0.f;
-    if (p < c0) v = a.W[(int64_t)p * a.K + k];
-    else if (p < c1) v = a.Wres[(int64_t)(p - c0) * a.K + k];
-    else if (p < c3) {
+    if (p < c3) {
         const bool left = p < c2;
         const int h = left ? p - c1 : p - c2;
         const float* at = left ? a.al : a.ar;
         for (int d = 0; d < a.D; ++d) v = fmaf(a.W[(int64_t)(h * a.D + d) * a.K + k], at[h * a.D + d], v);
     }
-    a.out[gid] = v;
+    a.out[(int64_t)k * a.P + p] = v;
 }
 
 // dW[p,k] = [with_fc] dm[k,p] + attn_l[p] * dm[k, c1+h] (+ attn_r[p] * dm[k, c2+h]);  dWres[p,k] = dm[k, c0+p]
@@ -98,8 +119,12 @@ int bot_merge_weight_fwd_f32(const float* W, const float* Wres, const float* att
     if (int rc = merge_check("merge_weight_fwd", W, attn_l, H, D, K, P, Wres, attn_r, with_fc)) return rc;
     BOT_REQUIRE(out != nullptr, BOT_E_NULL, "merge_weight_fwd: out is NULL");
     MergeArgs a{W, Wres, attn_l, attn_r, H, D, K, P, with_fc, out, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const int64_t n = (int64_t)K * P;
-    hipLaunchKernelGGL(merge_fwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a);
+    const int HD = H * D;
+    const int c1 = (with_fc ? HD : 0) + (Wres ? HD : 0);
+    const int tiles_k = (K + 31) / 32, n_tiles = tiles_k * ((c1 + 31) / 32);
+    const int64_t rest = (int64_t)(P - c1) * K;
+    hipLaunchKernelGGL(merge_fwd_kernel, dim3((unsigned)(n_tiles + (rest + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a,
+                       n_tiles, tiles_k);
     return hip_status("merge_weight_fwd launch");
 }
 
