@@ -57,7 +57,20 @@ __global__ __launch_bounds__(kBlock) void merge_fwd_kernel(MergeArgs a, int n_ti
         const bool left = p < c2;
         const int h = left ? p - c1 : p - c2;
         const float* at = left ? a.al : a.ar;
-        for (int d = 0; d < a.D; ++d) v = fmaf(a.W[(int64_t)(h * a.D + d) * a.K + k], at[h * a.D + d], v);
+        // D independent loads per thread and only a few thousand threads: keep 8 in flight (4 partial sums)
+        const float* wc = a.W + (int64_t)h * a.D * a.K + k;
+        const float* ah = at + h * a.D;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int d = 0;
+        for (; d + 8 <= a.D; d += 8) {
+            float w[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) w[t] = wc[(int64_t)(d + t) * a.K];
+            s0 = fmaf(w[0], ah[d], s0), s1 = fmaf(w[1], ah[d + 1], s1), s2 = fmaf(w[2], ah[d + 2], s2), s3 = fmaf(w[3], ah[d + 3], s3);
+            s0 = fmaf(w[4], ah[d + 4], s0), s1 = fmaf(w[5], ah[d + 5], s1), s2 = fmaf(w[6], ah[d + 6], s2), s3 = fmaf(w[7], ah[d + 7], s3);
+        }
+        for (; d < a.D; ++d) s0 = fmaf(wc[(int64_t)d * a.K], ah[d], s0);
+        v = (s0 + s1) + (s2 + s3);
     }
     a.out[(int64_t)k * a.P + p] = v;
 }
