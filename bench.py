@@ -219,9 +219,17 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world} ({args.partitioner} ranges)"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
-        print(json.dumps(out))
     if partitioned:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
