@@ -3,13 +3,13 @@ config-2 model on S-arxiv with library-default GEMM kernels vs with bot_amd/tuni
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
-import bench
+from bot_amd import workloads
 from bot_amd import synth, tuning, nn as bnn
 dev = torch.device("cuda:0")
 ds = synth.make_dataset("arxiv", device="cpu")
 C = ds.n_classes
 g = ds.graph.to(dev); g.create_formats_()
-cfg = dict(bench.CFG, dropout=0.0, input_drop=0.0, attn_drop=0.0)
+cfg = dict(workloads.ARXIV_GAT, dropout=0.0, input_drop=0.0, attn_drop=0.0)
 torch.manual_seed(0)
 model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **cfg).to(dev).train()
 x = torch.cat([ds.feat, torch.zeros(ds.feat.shape[0], C)], 1).to(dev)

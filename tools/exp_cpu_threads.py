@@ -4,12 +4,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
 from oracle import c_ops, ref_models as RM
 from bot_amd import synth, nn as bnn
-import bench
+from bot_amd import workloads
 ds = synth.make_dataset("arxiv", device="cpu", scale=0.25)
 s, d = ds.graph.edges(); n = ds.graph.number_of_nodes(); C = ds.n_classes
 g = c_ops.CGraph(s, d, n)
 torch.manual_seed(0)
-model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **bench.CFG)
+model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **workloads.ARXIV_GAT)
 sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in model.state_dict().items()}
 params = [v for v in sd.values() if v.requires_grad]
 x = RM.add_labels(ds.feat, ds.labels, ds.train_idx[:1000], C)

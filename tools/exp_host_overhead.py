@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
-import bench
+from bot_amd import workloads
 from bot_amd import synth, train, tuning, nn as bnn
 tuning.enable()
 dev = torch.device("cuda:0")
@@ -10,7 +10,7 @@ for scale in (1.0, 0.125):
     ds = synth.make_dataset("arxiv", device="cpu", scale=scale)
     C = ds.n_classes
     torch.manual_seed(0)
-    model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **bench.CFG).to(dev)
+    model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **workloads.ARXIV_GAT).to(dev)
     opt = torch.optim.RMSprop(model.parameters(), lr=0.002)
     g = ds.graph.to(dev); g.create_formats_()
     feat, labels = ds.feat.to(dev), ds.labels.to(dev)

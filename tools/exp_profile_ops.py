@@ -2,7 +2,7 @@
 outside the GEMMs and the HIP kernels."""
 import os, sys, torch, torch.nn.functional as F
 sys.path.insert(0, "/root/repo")
-import bench
+from bot_amd import workloads
 from bot_amd import synth, train, tuning
 from bot_amd import nn as bnn
 tuning.enable()
@@ -10,7 +10,7 @@ dev = torch.device("cuda", 0)
 ds = synth.make_dataset("arxiv", device="cpu", seed=0)
 n, C = ds.graph.number_of_nodes(), ds.n_classes
 torch.manual_seed(0)
-model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **bench.CFG).to(dev)
+model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **workloads.ARXIV_GAT).to(dev)
 opt = torch.optim.RMSprop(model.parameters(), lr=0.002)
 g = ds.graph.to(dev); g.create_formats_()
 feat, labels = ds.feat.to(dev), ds.labels.to(dev)
