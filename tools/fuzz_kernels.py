@@ -100,4 +100,38 @@ for t in range(trials):
     (oc * gw.float()).sum().backward()
     assert close(oc, rc, 1e-4), ("copy_u_sum", t, n, E, W)
     assert close(f.grad, f64.grad, 1e-4), ("copy_u_sum bwd", t, n, E, W)
+    # --- inference-only fused layer (round 2): logits + softmax + aggregation + residual + affine + ReLU in one sweep
+    Hi = ri(1, 8)
+    Di = ri(1, 300) if ri(0, 2) else 4 * ri(1, 64)
+    if E and Di <= (1024 if Di % 4 == 0 else 512 if Di % 2 == 0 else 256):
+        csc = g.csc
+        xi = torch.randn(n, Hi, Di, generator=gen, dtype=torch.float64).to(DEV)
+        eli = torch.randn(n, Hi, generator=gen, dtype=torch.float64).to(DEV)
+        eri = torch.randn(n, Hi, generator=gen, dtype=torch.float64).to(DEV) if ri(0, 1) else None
+        ewi = (torch.rand(E, generator=gen, dtype=torch.float64) + 0.5).to(DEV) if ri(0, 1) else None
+        adi = torch.randn(n, Hi, Di, generator=gen, dtype=torch.float64).to(DEV) if ri(0, 1) else None
+        sci = (torch.rand(Hi * Di, generator=gen, dtype=torch.float64) + 0.5).to(DEV) if ri(0, 1) else None
+        shi = torch.randn(Hi * Di, generator=gen, dtype=torch.float64).to(DEV) if ri(0, 1) else None
+        relu = bool(ri(0, 1))
+        srcp = csc.indices.long()
+        dstp = torch.repeat_interleave(torch.arange(n, device=DEV), (csc.indptr[1:] - csc.indptr[:-1]).long())
+        ai = ref_attention(srcp, dstp, n, eli.unsqueeze(-1), None if eri is None else eri.unsqueeze(-1), None, None, 0.2)
+        if ewi is not None:
+            ai = ai * ewi.view(-1, 1, 1)
+        refi = torch.zeros(n, Hi, Di, device=DEV, dtype=torch.float64).index_add_(0, dstp, xi[srcp] * ai)
+        if adi is not None:
+            refi = refi + adi
+        refi = refi.reshape(n, -1)
+        refi = refi * sci if sci is not None else refi
+        refi = refi + shi if shi is not None else refi
+        refi = torch.relu(refi) if relu else refi
+        f32 = lambda t: None if t is None else t.float()
+        outi = _C.gat_infer(csc, f32(xi), f32(eli), f32(eri), None, f32(ewi), 0.2, addend=f32(adi), scale=f32(sci), shift=f32(shi), relu=relu)
+        assert close(outi.reshape(n, -1), refi, 1e-4), ("gat_infer", t, n, E, Hi, Di)
+        # --- first-layer weight gradient: one in-edge sweep, the source row gathered once for all heads
+        if Hi <= 4:
+            xs = torch.randn(n, Di, generator=gen, dtype=torch.float64).to(DEV)
+            ys = torch.randn(Hi, n, Di, generator=gen, dtype=torch.float64).to(DEV)
+            refd = (xs[srcp].unsqueeze(1) * ys[:, dstp].permute(1, 0, 2)).sum(-1)
+            assert close(_C.sddmm_dot_bcast(csc, xs.float(), ys.float()), refd, 1e-4), ("sddmm_dot_bcast", t, n, E, Hi, Di)
 print(f"fuzz ok: {trials} trials (seed {seed}), {blocked_hits} of them on the L2-blocked path")
