@@ -570,7 +570,7 @@ def gat_infer_layer(conv, epi, graph, h, relu, first=False):
     F0 = ctx.static_cols if (ctx is not None and first and 0 < ctx.static_cols < h.shape[1]) else 0
     if F0:
         Wk = W if WEIGHT_KP else W.t()
-        key = (id(conv),) + _versions(W)
+        key = (id(conv), h.data_ptr(), tuple(h.shape)) + _versions(W)   # same layer, same input buffer, same weights
         if ctx.store.get("key") != key:                                 # the static columns' share of the projection
             ctx.store["key"], ctx.store["base"] = key, torch.mm(h[:, :F0], Wk[:F0])
         out = torch.addmm(ctx.store["base"], h[:, F0:], Wk[F0:])
