@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from . import _bcast, _epilogue, _pair, degree_norm, has_zero_in_degree
+from . import fused as _fused
 
 __all__ = ["GATConv", "ProteinsGAT", "ProductsGAT"]
 
@@ -57,7 +58,21 @@ class GATConv(nn.Module):
 
     merge_projections = True   # one GEMM for the four Linears on the layer input (full-graph / partitioned blocks alike)
 
-    def forward(self, graph, feat_src, feat_edge=None, keep=None, edge_encoder=None):
+    def _infer(self, graph, ft, attn_src, attn_dst, res, feat_edge, edge_encoder, epilogue):
+        from .. import _C
+        H = self._n_heads
+        csc = graph.csc
+        ee = None
+        if feat_edge is not None and edge_encoder is not None:
+            ee = _C.edge_mlp_fwd(ops.edge_features_csc(graph, feat_edge), edge_encoder.weight, edge_encoder.bias, self.attn_edge_fc.weight)
+        elif feat_edge is not None:
+            ee = self.attn_edge_fc(feat_edge).view(-1, H)[csc.eid.long()]          # edge-id order -> position order
+        scale, shift, relu = epilogue if epilogue is not None else (None, None, False)
+        _fused.count_infer()
+        return _C.gat_infer(csc, ft, attn_src.reshape(-1, H), None if attn_dst is None else attn_dst.reshape(-1, H), ee, None,
+                            self.leaky_relu.negative_slope, addend=res, scale=scale, shift=shift, relu=relu)
+
+    def forward(self, graph, feat_src, feat_edge=None, keep=None, edge_encoder=None, epilogue=None):
         """`edge_encoder` (the stack's nn.Linear(8 -> 16)) given: `feat_edge` holds the RAW edge features and the
         encoder + ReLU + attn_edge_fc run fused per edge (bot_amd.ops.edge_mlp); otherwise `feat_edge` is the embedding."""
         if not self._allow_zero_in_degree:
@@ -92,6 +107,12 @@ class GATConv(nn.Module):
             attn_dst = pieces.pop(0).unsqueeze(-1) if self.attn_dst_fc is not None else None
         ft = graph.extend(ft)
         attn_src = graph.extend(attn_src)
+        if (not torch.is_grad_enabled() and not self.training and res is not None and (ft.is_cuda or _fused.FORCE) and H <= 8
+                and self.activation is None):
+            # inference (evaluate(): eval mode under no_grad, ogbn-proteins/gat.py:136-160): logits + softmax + aggregation +
+            # dst_fc residual (+ the stack's eval-mode BatchNorm and ReLU when it hands them in) in ONE sweep, nothing
+            # edge-sized written beyond the edge logits of the edge-feature term (bot_gat_infer_f32)
+            return self._infer(graph, ft, attn_src, attn_dst, res, feat_edge, edge_encoder, epilogue)
         ee, ee_order = None, "eid"
         if feat_edge is not None and edge_encoder is not None:
             ee = ops.edge_mlp(graph, feat_edge, edge_encoder.weight, edge_encoder.bias, self.attn_edge_fc.weight).view(-1, H, 1)
@@ -117,6 +138,10 @@ class GATConv(nn.Module):
             rst = rst + self.bias.view(1, H, D)
         if self.activation is not None:
             rst = self.activation(rst, inplace=True)
+        if epilogue is not None:   # the stack handed its eval-mode BatchNorm + ReLU in, but this call took the generic path
+            scale, shift, relu = epilogue
+            rst = rst.flatten(1) * scale + shift
+            rst = (torch.relu(rst) if relu else rst).view(-1, H, D)
         return rst
 
 
@@ -153,12 +178,20 @@ class _EdgeGAT(nn.Module):
         h = self.input_drop(g.to_internal(h))   # node features arrive in original order; edge features are in edge-id order
         h_last = None
         efeat = g.edata.get("feat") if self.edge_encoder is not None else None
+        infer = (not torch.is_grad_enabled() and not self.training and (h.is_cuda or _fused.FORCE)
+                 and self.activation in (F.relu, torch.relu))
         for i in range(self.n_layers):
+            # evaluate(): without an inter-layer residual the eval-mode BatchNorm + ReLU ride in the layer's fused sweep too
+            epi = None
+            if infer and not residual and not self.norms[i].training and self.norms[i].track_running_stats and self.convs[i].dst_fc is not None:
+                epi = _fused.eval_affine(self.norms[i]) + (True,)
             if efeat is not None and self._fusable_edge_mlp(i, efeat):
-                h = self.convs[i](g, h, efeat, edge_encoder=self.edge_encoder[i]).flatten(1, -1)  # f2: no [E,16] tensor exists
+                h = self.convs[i](g, h, efeat, edge_encoder=self.edge_encoder[i], epilogue=epi).flatten(1, -1)  # f2: no [E,16] tensor exists
             else:
                 emb = F.relu(self.edge_encoder[i](efeat), inplace=True) if efeat is not None else None
-                h = self.convs[i](g, h, emb).flatten(1, -1)
+                h = self.convs[i](g, h, emb, epilogue=epi).flatten(1, -1)
+            if epi is not None:
+                continue
             if residual and h_last is not None:
                 h = h + h_last[: h.shape[0], :]
             h_last = h

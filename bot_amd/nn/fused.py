@@ -553,6 +553,11 @@ class label_reuse:
 INFER_CALLS = 0  # number of inference-layer invocations (tests assert the path was taken)
 
 
+def count_infer():
+    global INFER_CALLS
+    INFER_CALLS += 1
+
+
 @torch.no_grad()
 def gat_infer_layer(conv, epi, graph, h, relu, first=False):
     """Eval-mode `act(epi(conv(graph, h).flatten(1)))` (models.py:716-731 with dropout off; for the output layer

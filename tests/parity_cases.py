@@ -332,6 +332,13 @@ def check_proteins_golden(golden, device):
         for k, p in model.named_parameters():
             if f"g.{k}" in c:
                 grad_close(p.grad, c[f"g.{k}"], 3e-4)
+        if not training:   # evaluate()'s forward: the layers' inference-only sweep (inter-layer residual: BatchNorm stays outside)
+            from bot_amd.nn import fused
+            n0 = fused.INFER_CALLS
+            with torch.no_grad():
+                fwd_close(model(g), c["logits"])
+            if str(device) != "cpu" or fused.FORCE:
+                assert fused.INFER_CALLS - n0 == 2
 
 
 def check_products_golden(golden, device):
@@ -364,6 +371,13 @@ def check_products_golden(golden, device):
             for k, p in model.named_parameters():
                 if f"g.{k}" in c and p.grad is not None:
                     grad_close(p.grad, c[f"g.{k}"], 3e-4)
+            if not training:   # evaluate()'s forward (eval mode, no_grad): the inference-only sweep, BatchNorm + ReLU folded in
+                from bot_amd.nn import fused
+                n0 = fused.INFER_CALLS
+                with torch.no_grad():
+                    fwd_close(model(g), c["logits"])
+                if str(device) != "cpu" or fused.FORCE:
+                    assert fused.INFER_CALLS - n0 == 3
 
 
 def check_copy_e_sum_preprocess(golden, device):

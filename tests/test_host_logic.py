@@ -88,11 +88,15 @@ def test_empty_and_isolated(cpu_backend):
     assert torch.all(out == 0)
 
 
-def test_proteins_golden(golden, cpu_backend):
+def test_proteins_golden(golden, cpu_backend, monkeypatch):
+    from bot_amd.nn import fused
+    monkeypatch.setattr(fused, "FORCE", True)   # the eval-mode cases also run through the inference-only sweep (emulated)
     PC.check_proteins_golden(golden, "cpu")
 
 
-def test_products_golden(golden, cpu_backend):
+def test_products_golden(golden, cpu_backend, monkeypatch):
+    from bot_amd.nn import fused
+    monkeypatch.setattr(fused, "FORCE", True)
     PC.check_products_golden(golden, "cpu")
 
 
