@@ -108,7 +108,7 @@ class GATConv(nn.Module):
         ft = graph.extend(ft)
         attn_src = graph.extend(attn_src)
         if (not torch.is_grad_enabled() and not self.training and res is not None and (ft.is_cuda or _fused.FORCE) and H <= 8
-                and self.activation is None):
+                and self.activation is None and _fused.sweep_is_row_kernel(graph, H, D)):
             # inference (evaluate(): eval mode under no_grad, ogbn-proteins/gat.py:136-160): logits + softmax + aggregation +
             # dst_fc residual (+ the stack's eval-mode BatchNorm and ReLU when it hands them in) in ONE sweep, nothing
             # edge-sized written beyond the edge logits of the edge-feature term (bot_gat_infer_f32)

@@ -512,6 +512,15 @@ def eval_affine(mod):
     return (mod.weight.detach() if mod.weight is not None else None), (mod.bias.detach() if mod.bias is not None else None)
 
 
+def sweep_is_row_kernel(graph, H, D) -> bool:
+    """True when the aggregation of this graph runs on the row-per-wavefront kernels — the family the fused inference sweep
+    belongs to.  Dense graphs (mean degree >= 96: S-reddit, S-proteins) aggregate with the L2-blocked SpMM, which is ~2x faster
+    than any row kernel there (10.6 vs 19 ms at S-proteins), so their eval-mode forward keeps the attention kernel + blocked SpMM."""
+    from .. import blocked
+    csc = graph.csc
+    return not csc.indptr.is_cuda or blocked.plan_for(csc, graph.number_of_nodes(), H, D) is None
+
+
 def can_infer(conv, epi, activation, graph, stack_residual, last) -> bool:
     """`epi`: the module applied behind the layer (BatchNorm1d in eval mode, or a bias-only ElementWiseLinear)."""
     if torch.is_grad_enabled() or not hasattr(conv, "fc") or conv._activation is not None or conv.training:
@@ -526,7 +535,7 @@ def can_infer(conv, epi, activation, graph, stack_residual, last) -> bool:
     if last and conv._num_heads != 1:
         return False
     return (not (conv._use_symmetric_norm and graph.halo is not None) and (graph.halo is not None or not graph.is_block)
-            and conv._out_feats <= 256)
+            and conv._out_feats <= 256 and sweep_is_row_kernel(graph, conv._num_heads, conv._out_feats))
 
 
 class _LabelReuse:
