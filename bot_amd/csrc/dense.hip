@@ -35,6 +35,47 @@ __device__ __forceinline__ void drop_factors(uint64_t seed, int64_t r, int c, in
     for (int t = 0; t < VEC; ++t) f[t] = ((w[(c & 3) + t] >> 8) * (1.0f / 16777216.0f)) >= p ? scale : 0.f;
 }
 
+// ---- quad access (round 2).  A VEC = 4 launch may run on rows whose length is 4k + 2 and on operands that are only 8-byte
+// aligned: `nv` of the 4 columns at c exist (4, or 2 in the tail quad); an operand whose base and row stride are 16-byte
+// multiples (`wide`) moves a full quad as one float4, any other as two float2 — so e.g. F = 750 runs its 16-byte-aligned
+// operands (the SpMM / GEMM-slab outputs) at full width and one Philox block per 4 elements instead of per 2.
+template <int VEC>
+__device__ __forceinline__ void load_cols(float (&v)[VEC], const float* p, bool wide, int nv) {
+    if constexpr (VEC == 4) {
+        if (wide && nv == 4) {
+            vload<4>(v, p);
+        } else {
+            const float2 a = *reinterpret_cast<const float2*>(p);
+            v[0] = a.x, v[1] = a.y, v[2] = 0.f, v[3] = 0.f;
+            if (nv == 4) {
+                const float2 b = *reinterpret_cast<const float2*>(p + 2);
+                v[2] = b.x, v[3] = b.y;
+            }
+        }
+    } else {
+        vload<VEC>(v, p);
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void store_cols(float* p, const float (&v)[VEC], bool wide, int nv) {
+    if constexpr (VEC == 4) {
+        if (wide && nv == 4) {
+            vstore<4>(p, v);
+        } else {
+            *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+            if (nv == 4) *reinterpret_cast<float2*>(p + 2) = make_float2(v[2], v[3]);
+        }
+    } else {
+        vstore<VEC>(p, v);
+    }
+}
+// per-column parameter vector (length F, any alignment): element c + t, `dflt` past the end or when the vector is absent
+template <int VEC>
+__device__ __forceinline__ void load_param(float (&v)[VEC], const float* a, int c, int F, float dflt) {
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) v[t] = (a && c + t < F) ? a[c + t] : dflt;
+}
+
 // The Philox key of a launch: the host-side `seed`, plus — when the caller passes a device word — that word times an odd
 // constant.  A captured hipGraph bakes `seed` into the launch; bumping the device word between replays (one tiny captured add)
 // gives every replay a fresh mask while forward and backward of the SAME replay still regenerate the same one.
@@ -67,23 +108,26 @@ struct BnArgs {
     float* dx;
     int64_t lddx;
     float* part;  // [kRowBlocks][2][F]
+    bool wx, wy, wdy, wdx;  // quad launches: which operands have 16-byte aligned rows (load_cols / store_cols)
 };
 
 // part[rb][0][c] = sum_{rows of block rb} (x - pivot_c),  part[rb][1][c] = sum (x - pivot_c)^2,  pivot = x[0,c]
 template <int VEC>
-__global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float* x, int64_t ldx, int64_t n, int32_t F, float* part) {
+__global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float* x, int64_t ldx, int64_t n, int32_t F, float* part,
+                                                                   bool wx) {
     __shared__ float lds[2][kTY][kTX * VEC];
     const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
     const int c = (blockIdx.x * kTX + tx) * VEC;
+    const int nv = min(VEC, F - c);
     float s[VEC], q[VEC], piv[VEC];
 #pragma unroll
     for (int t = 0; t < VEC; ++t) s[t] = q[t] = 0.f;
     if (c < F) {
-        vload<VEC>(piv, x + c);
+        load_cols<VEC>(piv, x + c, wx, nv);
 #pragma unroll 4
         for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < n; r += (int64_t)gridDim.y * kTY) {
             float v[VEC];
-            vload<VEC>(v, x + r * ldx + c);
+            load_cols<VEC>(v, x + r * ldx + c, wx, nv);
 #pragma unroll
             for (int t = 0; t < VEC; ++t) {
                 const float d = v[t] - piv[t];
@@ -98,6 +142,7 @@ __global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float*
     if (ty == 0 && c < F) {
 #pragma unroll
         for (int t = 0; t < VEC; ++t) {
+            if (t >= nv) break;
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int j = 0; j < kTY; ++j) a += lds[0][j][tx * VEC + t], b += lds[1][j][tx * VEC + t];
@@ -153,14 +198,14 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
     const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
     const int c = (blockIdx.x * kTX + tx) * VEC;
     if (c >= a.F) return;
-    float mu[VEC], sc[VEC], sh[VEC];
-    vload<VEC>(mu, a.mean + c);
-    vload<VEC>(sc, a.invstd + c);
+    const int nv = min(VEC, a.F - c);
+    float mu[VEC], sc[VEC], sh[VEC], wv[VEC];
+    load_param<VEC>(mu, a.mean, c, a.F, 0.f);
+    load_param<VEC>(sc, a.invstd, c, a.F, 0.f);
+    load_param<VEC>(wv, a.w, c, a.F, 1.f);
+    load_param<VEC>(sh, a.b, c, a.F, 0.f);
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) {
-        sc[t] *= a.w ? a.w[c + t] : 1.f;
-        sh[t] = a.b ? a.b[c + t] : 0.f;
-    }
+    for (int t = 0; t < VEC; ++t) sc[t] *= wv[t];
     const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
     const int64_t nquad = (a.F + 3) / 4;
     const uint64_t seed = eff_seed(a.seed, a.seed_offset);
@@ -171,7 +216,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
             const int64_t r = r0 + u * step;
-            if (r < a.n) vload<VEC>(v[u], a.x + r * a.ldx + c);
+            if (r < a.n) load_cols<VEC>(v[u], a.x + r * a.ldx + c, a.wx, nv);
         }
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
@@ -186,7 +231,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
                 if (a.p > 0.f) o *= f[t];
                 v[u][t] = o;
             }
-            vstore<VEC>(a.y + r * a.ldy + c, v[u]);
+            store_cols<VEC>(a.y + r * a.ldy + c, v[u], a.wy, nv);
         }
     }
 }
@@ -200,23 +245,21 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_reduce_kernel(BnArgs a) {
     float s[VEC], q[VEC];
 #pragma unroll
     for (int t = 0; t < VEC; ++t) s[t] = q[t] = 0.f;
+    const int nv = min(VEC, a.F - c);
     if (c < a.F) {
         float mu[VEC], is[VEC], sc[VEC], sh[VEC];
-        vload<VEC>(mu, a.mean + c);
-        vload<VEC>(is, a.invstd + c);
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) {
-            sc[t] = a.w ? a.w[c + t] : 1.f;
-            sh[t] = a.b ? a.b[c + t] : 0.f;
-        }
+        load_param<VEC>(mu, a.mean, c, a.F, 0.f);
+        load_param<VEC>(is, a.invstd, c, a.F, 0.f);
+        load_param<VEC>(sc, a.w, c, a.F, 1.f);
+        load_param<VEC>(sh, a.b, c, a.F, 0.f);
         const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
         const int64_t nquad = (a.F + 3) / 4;
         const uint64_t seed = eff_seed(a.seed, a.seed_offset);
 #pragma unroll 4
         for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < a.n; r += (int64_t)gridDim.y * kTY) {
             float v[VEC], g[VEC], f[VEC];
-            vload<VEC>(v, a.x + r * a.ldx + c);
-            vload<VEC>(g, a.dy + r * a.lddy + c);
+            load_cols<VEC>(v, a.x + r * a.ldx + c, a.wx, nv);
+            load_cols<VEC>(g, a.dy + r * a.lddy + c, a.wdy, nv);
             if (a.p > 0.f) drop_factors<VEC>(seed, r, c, nquad, a.p, scale, f);
 #pragma unroll
             for (int t = 0; t < VEC; ++t) {
@@ -235,6 +278,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_reduce_kernel(BnArgs a) {
     if (ty == 0 && c < a.F) {
 #pragma unroll
         for (int t = 0; t < VEC; ++t) {
+            if (t >= nv) break;
             float u = 0.f, w = 0.f;
 #pragma unroll
             for (int j = 0; j < kTY; ++j) u += lds[0][j][tx * VEC + t], w += lds[1][j][tx * VEC + t];
@@ -260,16 +304,16 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
     const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
     const int c = (blockIdx.x * kTX + tx) * VEC;
     if (c >= a.F) return;
+    const int nv = min(VEC, a.F - c);
     float mu[VEC], is[VEC], sc[VEC], sh[VEC], mg[VEC], mgx[VEC];
-    vload<VEC>(mu, a.mean + c);
-    vload<VEC>(is, a.invstd + c);
+    load_param<VEC>(mu, a.mean, c, a.F, 0.f);
+    load_param<VEC>(is, a.invstd, c, a.F, 0.f);
+    load_param<VEC>(sc, a.w, c, a.F, 1.f);
+    load_param<VEC>(sh, a.b, c, a.F, 0.f);
+    load_param<VEC>(mg, a.sum_g, c, a.F, 0.f);                    // NULL sums: eval mode (running statistics are constants)
+    load_param<VEC>(mgx, a.sum_gx, c, a.F, 0.f);
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) {
-        sc[t] = a.w ? a.w[c + t] : 1.f;
-        sh[t] = a.b ? a.b[c + t] : 0.f;
-        mg[t] = a.sum_g ? a.sum_g[c + t] * a.inv_count : 0.f;     // NULL sums: eval mode (running statistics are constants)
-        mgx[t] = a.sum_gx ? a.sum_gx[c + t] * a.inv_count : 0.f;
-    }
+    for (int t = 0; t < VEC; ++t) mg[t] *= a.inv_count, mgx[t] *= a.inv_count;
     const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
     const int64_t nquad = (a.F + 3) / 4;
     const uint64_t seed = eff_seed(a.seed, a.seed_offset);
@@ -281,8 +325,8 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
         for (int u = 0; u < UR; ++u) {
             const int64_t r = r0 + u * step;
             if (r < a.n) {
-                vload<VEC>(v[u], a.x + r * a.ldx + c);
-                vload<VEC>(g[u], a.dy + r * a.lddy + c);
+                load_cols<VEC>(v[u], a.x + r * a.ldx + c, a.wx, nv);
+                load_cols<VEC>(g[u], a.dy + r * a.lddy + c, a.wdy, nv);
             }
         }
 #pragma unroll
@@ -299,9 +343,24 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
                 if (a.relu && !(fmaf(xh, sc[t], sh[t]) > 0.f)) gg = 0.f;
                 v[u][t] = sc[t] * is[t] * (gg - mg[t] - xh * mgx[t]);
             }
-            vstore<VEC>(a.dx + r * a.lddx + c, v[u]);
+            store_cols<VEC>(a.dx + r * a.lddx + c, v[u], a.wdx, nv);
         }
     }
+}
+
+// Launch width of the BatchNorm kernels.  16 / 8 / 4-byte lanes when EVERY operand allows them (pick_vec); otherwise, for even
+// F with 8-byte aligned operands, the quad form: VEC = 4 lanes whose operands are moved per `wide` flag (load_cols).
+static inline bool rows16(const void* p, int64_t ld) { return p != nullptr && aligned(p, 16) && ld % 4 == 0; }
+static int bn_vec(int32_t F, std::initializer_list<int64_t> strides, std::initializer_list<const void*> ptrs, bool* quad) {
+    const int v = pick_vec(F, strides, ptrs);
+    *quad = false;
+    if (v == 4 || F % 2 != 0) return v;
+    for (int64_t st : strides)
+        if (st % 2 != 0) return v;
+    for (const void* p : ptrs)
+        if (p != nullptr && !aligned(p, 8)) return v;
+    *quad = true;
+    return 4;
 }
 
 static dim3 bn_grid(int32_t F, int vec, int64_t n) {
@@ -321,11 +380,13 @@ int bot_colstats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* m
     BOT_REQUIRE(n >= 1 && F >= 1 && ldx >= F, BOT_E_RANGE, "colstats: n=%lld F=%d ldx=%lld", (long long)n, F, (long long)ldx);
     BOT_REQUIRE(x && mean && m2 && workspace, BOT_E_NULL, "colstats: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int vec = pick_vec(F, {ldx}, {x});
+    bool quad;
+    const int vec = bn_vec(F, {ldx}, {x}, &quad);
+    const bool wx = !quad || rows16(x, ldx);
     const dim3 grid = bn_grid(F, vec, n);
-    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
-    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
-    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
+    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, wx);
+    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true);
+    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true);
     hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
                        mean, m2, (float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (int64_t*)nullptr);
     return hip_status("colstats launch");
@@ -340,11 +401,13 @@ int bot_bn_stats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float ep
     BOT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), BOT_E_NULL, "bn_stats: running_mean and running_var go together");
     BOT_REQUIRE(eps >= 0.f && momentum >= 0.f && momentum <= 1.f, BOT_E_RANGE, "bn_stats: eps=%f momentum=%f", (double)eps, (double)momentum);
     hipStream_t st = (hipStream_t)stream;
-    const int vec = pick_vec(F, {ldx}, {x});
+    bool quad;
+    const int vec = bn_vec(F, {ldx}, {x}, &quad);
+    const bool wx = !quad || rows16(x, ldx);
     const dim3 grid = bn_grid(F, vec, n);
-    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
-    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
-    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace);
+    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, wx);
+    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true);
+    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true);
     hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
                        mean, (float*)nullptr, invstd, eps, momentum, running_mean, running_var, num_batches_tracked);
     return hip_status("bn_stats launch");
@@ -361,7 +424,9 @@ int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const 
     BnArgs a{};
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
     a.seed = seed, a.seed_offset = seed_offset, a.y = y, a.ldy = ldy;
-    const int vec = pick_vec(F, {ldx, ldy}, {x, y, mean, invstd});
+    bool quad;
+    const int vec = bn_vec(F, {ldx, ldy}, {x, y}, &quad);
+    a.wx = !quad || rows16(x, ldx), a.wy = !quad || rows16(y, ldy);
     const dim3 grid = bn_grid(F, vec, n);
     hipStream_t st = (hipStream_t)stream;
     if (vec == 4) hipLaunchKernelGGL((bn_act_fwd_kernel<4>), grid, dim3(kTX * kTY), 0, st, a);
@@ -380,7 +445,9 @@ int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int
     BnArgs a{};
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
     a.seed = seed, a.seed_offset = seed_offset, a.dy = dy, a.lddy = lddy, a.part = workspace;
-    const int vec = pick_vec(F, {ldx, lddy}, {x, dy, mean, invstd});
+    bool quad;
+    const int vec = bn_vec(F, {ldx, lddy}, {x, dy}, &quad);
+    a.wx = !quad || rows16(x, ldx), a.wdy = !quad || rows16(dy, lddy);
     const dim3 grid = bn_grid(F, vec, n);
     hipStream_t st = (hipStream_t)stream;
     if (vec == 4) hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<4>), grid, dim3(kTX * kTY), 0, st, a);
@@ -405,7 +472,9 @@ int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int6
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
     a.seed = seed, a.seed_offset = seed_offset, a.dy = dy, a.lddy = lddy, a.sum_g = sum_g, a.sum_gx = sum_gx, a.inv_count = sum_g ? (float)(1.0 / total_count) : 0.f;
     a.dx = dx, a.lddx = lddx;
-    const int vec = pick_vec(F, {ldx, lddy, lddx}, {x, dy, dx, mean, invstd, sum_g, sum_gx});
+    bool quad;
+    const int vec = bn_vec(F, {ldx, lddy, lddx}, {x, dy, dx}, &quad);
+    a.wx = !quad || rows16(x, ldx), a.wdy = !quad || rows16(dy, lddy), a.wdx = !quad || rows16(dx, lddx);
     const dim3 grid = bn_grid(F, vec, n);
     hipStream_t st = (hipStream_t)stream;
     if (vec == 4) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<4>), grid, dim3(kTX * kTY), 0, st, a);

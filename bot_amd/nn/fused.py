@@ -171,7 +171,14 @@ class _GATHidden(torch.autograd.Function):
         if sym:
             a_d = a_d * w_e                                             # the SpMM weights; d a below is scaled back by w_e
         res = out[:, HD:2 * HD].unflatten(1, (H, D)) if has_res else None
-        x = _C.spmm(csc, ft, a_d, None, addend=res).view(N, HD)         # aggregation + residual (models.py:547-560)
+        if HD % 4 and bn is not None and sweep_is_row_kernel(graph, H, D):
+            # rows of 750 floats: give the pre-BatchNorm tensor a row pitch of 752 so that its rows are 16-byte aligned — the
+            # BatchNorm kernels read it four times per step and move 16-byte aligned operands at full width (dense.hip)
+            xbuf = torch.empty((N, (HD + 3) // 4 * 4), dtype=out.dtype, device=out.device)
+            x = xbuf[:, :HD]
+            _C.spmm(csc, ft, a_d, None, out=x.unflatten(1, (H, D)), addend=res)
+        else:
+            x = _C.spmm(csc, ft, a_d, None, addend=res).view(N, HD)     # aggregation + residual (models.py:547-560)
         ctx.graph = graph
         keep = (h, Wcat, ext if ext is not None else out, el, er, a, a_d)
         if bn is None:                                                  # output layer: no epilogue
