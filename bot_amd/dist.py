@@ -203,11 +203,14 @@ def partition_dataset(ds, rank: int, world: int, device, group=None, partitioner
     n = g.number_of_nodes()
     perm = g.node_perm                                   # internal -> original (None: identity)
     if partitioner == "community":
-        p2, _ = reorder_permutation(g, "community")      # new -> current
-        inv2 = torch.empty_like(p2)
-        inv2[p2] = torch.arange(n, dtype=p2.dtype, device=p2.device)
-        s, d = inv2[s], inv2[d]
-        perm = p2 if perm is None else perm[p2]
+        p2, labels = reorder_permutation(g, "community")  # new -> current
+        if int(torch.bincount(labels).max()) * 4 <= n:    # a real community structure (same criterion as reorder_graph) ...
+            inv2 = torch.empty_like(p2)
+            inv2[p2] = torch.arange(n, dtype=p2.dtype, device=p2.device)
+            s, d = inv2[s], inv2[d]
+            perm = p2 if perm is None else perm[p2]
+        # ... otherwise the labels flooded into one community and the order is just degree-descending: ranges of it are badly
+        # unbalanced in vertices (hubs first) and cut as many edges as the given numbering, so that one is kept
     elif partitioner != "contiguous":
         raise ValueError(f"unknown partitioner {partitioner!r}")
     p = build_partition(s, d, n, rank, world, device, group)
