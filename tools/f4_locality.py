@@ -85,6 +85,29 @@ def main():
             ms = timeit(lambda: _C.spmm(dd, x, a, None, out=out))
             print("sources folded into %6d rows (%6.1f MB): %.3f ms -> %.2f TB/s gathered, alg frac of 8 TB/s %.3f" % (
                 win, win * 3000 / 1e6, ms, E * 3000 / ms / 1e9, 4 * (2 * n * H * D + E + n + 1 + E * H) / ms / 1e6 / 8000))
+    elif mode == "step":   # the whole config-2 train step on the community graph, as generated vs renumbered by preprocess(reorder=...)
+        import torch.nn.functional as F
+        from bot_amd import nn as bnn, train as T, tuning, workloads
+        tuning.enable()
+        for name in ("arxiv", "arxiv-comm"):
+            for numbering in ("none", "community"):
+                ds = synth.make_dataset(name, device=DEV, seed=0, reorder=None if numbering == "none" else numbering)
+                g, C = ds.graph, ds.n_classes
+                torch.manual_seed(0)
+                model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **workloads.ARXIV_GAT).to(DEV)
+                opt = torch.optim.RMSprop(model.parameters(), lr=0.002)
+                step = lambda: T.train_step(model, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, opt, use_labels=True,
+                                            mask_rate=0.5, loss="loge", n_classes=C)
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    step()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / 20 * 1e3
+                print(json.dumps({"graph": name, "numbering": numbering, "plan_order": g.plan_order, "train_step_ms": round(ms, 3),
+                                  "edges_per_s": round(g.number_of_edges() / ms * 1e3)}), flush=True)
     elif mode == "pmc":
         g = build(sys.argv[2], sys.argv[3])
         x, a, out = operands(g)
