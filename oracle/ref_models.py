@@ -196,9 +196,10 @@ def gat_forward(g: CooGraph, feat, sd: dict, *, n_layers, n_heads, n_hidden, n_c
 
 
 def proteins_gatconv_forward(g: CooGraph, feat_src, sd: dict, prefix: str, *, n_heads, out_feats,
-                             feat_edge=None, negative_slope=0.2, keep_eids=None, activation=None):
+                             feat_edge=None, negative_slope=0.2, keep_eids=None, activation=None, leaky=None):
     """ogbn-proteins GATConv.forward — src/ogbn-proteins/models.py:87-168 (full-graph branch,
-    `use_symmetric_norm=False` as constructed at :219); same layer in ogbn-products/models.py:88-167."""
+    `use_symmetric_norm=False` as constructed at :219); same layer in ogbn-products/models.py:88-167.
+    `leaky`: see gatconv_forward (test infrastructure)."""
     n = g.num_nodes
     p = lambda k: sd[f"{prefix}{k}"]
     ft = F.linear(feat_src, p("src_fc.weight")).view(-1, n_heads, out_feats)  # :106
@@ -211,7 +212,7 @@ def proteins_gatconv_forward(g: CooGraph, feat_src, sd: dict, prefix: str, *, n_
         e = _u_add_v(g, a_src, None)
     if feat_edge is not None:  # :130-133
         e = e + F.linear(feat_edge, p("attn_edge_fc.weight")).view(-1, n_heads, 1)
-    e = F.leaky_relu(e, negative_slope)  # :134
+    e = F.leaky_relu(e, negative_slope) if leaky is None else leaky(e, negative_slope)  # :134
     a = _edge_softmax(g, e, keep_eids)  # :136-141 (edge drop) / :143
     rst = _u_mul_e_sum(g, ft, a)  # :146-148
     rst = rst + res  # :159-160
@@ -221,9 +222,10 @@ def proteins_gatconv_forward(g: CooGraph, feat_src, sd: dict, prefix: str, *, n_
 
 
 def proteins_gat_forward(g: CooGraph, node_feat, edge_feat, sd: dict, *, n_layers, n_heads, n_hidden,
-                         training=False, use_node_encoder=True, residual=True):
+                         training=False, use_node_encoder=True, residual=True, activation=F.relu, leaky=None):
     """ogbn-proteins GAT.forward full-graph branch — src/ogbn-proteins/models.py:230-264
-    (`use_node_encoder=False, residual=<flag>` gives ogbn-products/models.py:233-265)."""
+    (`use_node_encoder=False, residual=<flag>` gives ogbn-products/models.py:233-265).  `activation` is the stack's
+    (the reference passes F.relu, gat.py:100); `activation` / `leaky` may be tests/full_size.py:KinkGates hooks."""
     h = node_feat
     if use_node_encoder:  # :237-239
         h = F.relu(F.linear(h, sd["node_encoder.weight"], sd["node_encoder.bias"]))
@@ -233,12 +235,12 @@ def proteins_gat_forward(g: CooGraph, node_feat, edge_feat, sd: dict, *, n_layer
         if edge_feat is not None and f"edge_encoder.{i}.weight" in sd:  # :244-248
             ee = F.relu(F.linear(edge_feat, sd[f"edge_encoder.{i}.weight"], sd[f"edge_encoder.{i}.bias"]))
         h = proteins_gatconv_forward(g, h, sd, f"convs.{i}.", n_heads=n_heads, out_feats=n_hidden,
-                                     feat_edge=ee).flatten(1, -1)  # :251
+                                     feat_edge=ee, leaky=leaky).flatten(1, -1)  # :251
         if residual and h_last is not None:  # :253-254
             h = h + h_last
         h_last = h
         h = _bn(h, sd, f"norms.{i}", training)  # :258
-        h = F.relu(h)
+        h = activation(h)
     return F.linear(h, sd["pred_linear.weight"], sd["pred_linear.bias"])  # :262
 
 

@@ -104,6 +104,7 @@ def tap_kinks():
     import bot_amd.nn as bnn
     from bot_amd import _C
     from bot_amd.nn import fused
+    from bot_amd.nn import edge_gat
     relu_taps, leaky_taps = [], []
     orig_e, orig_f, orig_a = bnn._epilogue, fused.gat_hidden_layer, _C.gat_attn_fwd
 
@@ -133,11 +134,11 @@ def tap_kinks():
             leaky_taps.append(gate.cpu())
         return orig_a(d, el, er, ee, eperm, keep, slope, H, aperm, zsign, **kw)
 
-    bnn._epilogue, fused.gat_hidden_layer, _C.gat_attn_fwd = epi, hid, attn
+    bnn._epilogue, fused.gat_hidden_layer, _C.gat_attn_fwd, edge_gat._epilogue = epi, hid, attn, epi
     try:
         yield relu_taps, leaky_taps
     finally:
-        bnn._epilogue, fused.gat_hidden_layer, _C.gat_attn_fwd = orig_e, orig_f, orig_a
+        bnn._epilogue, fused.gat_hidden_layer, _C.gat_attn_fwd, edge_gat._epilogue = orig_e, orig_f, orig_a, orig_e
 
 
 def hip_step(g, feat, labels, train_idx, mask, sd, cfg, n_classes, loss="loge", fuse=True):
@@ -218,3 +219,36 @@ def gcn_hip_step(g, feat, labels, train_idx, sd, cfg, n_classes, loss="logit"):
         out.backward()
     assert len(relu_gates) == cfg["n_layers"] - 1
     return pred.detach(), {k: p.grad.detach() for k, p in model.named_parameters()}, (relu_gates, None)
+
+
+# ---------------------------------------------------------------------------------------------- edge-feature GAT (configs 4 / 5)
+def edge_gat_oracle_step(src, dst, n, nfeat, efeat, labels, train_idx, sd, *, n_layers, n_heads, n_hidden, node_loss, use_node_encoder,
+                         residual, threads=None, gates=None):
+    """One train step of the ogbn-proteins / ogbn-products stack (full-graph branch) on the oracle's C kernels."""
+    from oracle import c_ops
+    from oracle import ref_models as RM
+    if threads is None:
+        threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    c_ops.set_num_threads(threads)
+    g = c_ops.CGraph(src, dst, n)
+    sdg = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    names = [k for k, v in sdg.items() if v.requires_grad and (use_node_encoder or not k.startswith("node_encoder"))]
+    kg = None if gates is None else KinkGates(*gates)
+    t0 = time.perf_counter()
+    pred = RM.proteins_gat_forward(g, nfeat, efeat, sdg, n_layers=n_layers, n_heads=n_heads, n_hidden=n_hidden, training=True,
+                                   use_node_encoder=use_node_encoder, residual=residual,
+                                   activation=F.relu if kg is None else kg.relu, leaky=None if kg is None else kg.leaky)
+    out = node_loss(pred[train_idx], labels[train_idx]).mean()
+    grads = torch.autograd.grad(out, [sdg[k] for k in names], allow_unused=True)
+    return pred.detach(), {k: g_ for k, g_ in zip(names, grads) if g_ is not None}, time.perf_counter() - t0, (kg.stats if kg else None)
+
+
+def edge_gat_hip_step(model, g, labels, train_idx, node_loss):
+    """The same step on the HIP path (model already on the device, inputs in g.ndata / g.edata)."""
+    model.train()
+    model.zero_grad(set_to_none=True)
+    with tap_kinks() as (relu_gates, leaky_gates):
+        pred = model(g)
+        node_loss(pred[train_idx], labels[train_idx]).mean().backward()
+    return pred.detach(), {k: p.grad.detach() for k, p in model.named_parameters() if p.grad is not None}, (relu_gates, leaky_gates)

@@ -1005,3 +1005,27 @@ def test_merged_weight_kernels_match_tensor_ops():
                     assert a is None or float(a.abs().max()) == 0.0, p[0]
                 else:
                     assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max())), p[0]
+
+
+def test_full_size_config5_products_gat_against_c_oracle():
+    """BASELINE config 5 at its full synthetic size — S-products, 2 449 029 nodes / 126 M edges, GAT 3 layers x 4 heads x 120
+    (src/ogbn-products/models.py, full-graph branch) — one train step (drop rates 0, loge loss of gat.py:107-118) on the HIP path
+    against the oracle's C kernels on the host cores: logits within 1e-4 (relative to their scale beyond 10), every gradient entry
+    within 1e-4 of its gradient's largest entry, the oracle at the HIP run's ReLU / leaky-ReLU gates."""
+    import torch.nn.functional as F
+    from bot_amd import workloads
+    from tests import full_size as FS
+    wl = workloads.build("products", DEV, drop=False)
+    model, g, ds = wl.model, wl.graph, wl.dataset
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    pred, grads, gates = FS.edge_gat_hip_step(model, g, ds.labels, ds.train_idx, workloads._loge)
+    s, d = (t.cpu() for t in g.edges())
+    rp, rg, secs, gstats = FS.edge_gat_oracle_step(s, d, g.number_of_nodes(), ds.feat.cpu(), None, ds.labels.cpu(), ds.train_idx.cpu(), sd,
+                                                   n_layers=3, n_heads=4, n_hidden=120, node_loss=workloads._loge, use_node_encoder=False,
+                                                   residual=False, gates=gates)
+    r = FS.compare(pred, grads, rp, rg, gstats)
+    print("full-size parity S-products GAT", r, "oracle step %.1f s" % secs)
+    assert r["n"] == 2449029 and g.number_of_edges() > 120_000_000
+    assert r["max_abs_logit_diff"] <= PC.FWD_ATOL * max(1.0, r["logit_scale"] / 10), r
+    assert r["max_rel_grad_err"] <= PC.GRAD_RTOL, r
+    assert r["max_abs_preact_at_differing_gate"] <= 1e-4, r
