@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -71,6 +71,7 @@ _SIGS = {
     "bot_random_keep_u8": (ctypes.c_int, [c_int64, c_int64, c_uint64, _P, _P, _P]),
     "bot_bn_workspace_floats": (c_int64, [c_int32]),
     "bot_colstats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
+    "bot_colsum_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
     "bot_bn_stats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "bot_bn_act_fwd_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, _P, c_int64, _P]),
     "bot_bn_act_bwd_reduce_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
@@ -557,6 +558,16 @@ def colstats(x):
     _check(_lib.bot_colstats_f32(x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), m2.data_ptr(), _bn_ws(F, x.device).data_ptr(),
                                  _stream()), "colstats")
     return mean, m2
+
+
+def colsum(x):
+    """Per-column sum of x [n,F] -> [F] (two-stage, finished in double)."""
+    _dev(x)
+    x = _mat(x, "x")
+    n, F = x.shape
+    out = torch.empty(F, dtype=torch.float32, device=x.device)
+    _check(_lib.bot_colsum_f32(x.data_ptr(), x.stride(0), n, F, out.data_ptr(), _bn_ws(F, x.device).data_ptr(), _stream()), "colsum")
+    return out
 
 
 def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):

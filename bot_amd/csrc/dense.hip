@@ -114,7 +114,7 @@ struct BnArgs {
 // part[rb][0][c] = sum_{rows of block rb} (x - pivot_c),  part[rb][1][c] = sum (x - pivot_c)^2,  pivot = x[0,c]
 template <int VEC>
 __global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float* x, int64_t ldx, int64_t n, int32_t F, float* part,
-                                                                   bool wx) {
+                                                                   bool wx, bool pivot) {
     __shared__ float lds[2][kTY][kTX * VEC];
     const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
     const int c = (blockIdx.x * kTX + tx) * VEC;
@@ -124,6 +124,10 @@ __global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float*
     for (int t = 0; t < VEC; ++t) s[t] = q[t] = 0.f;
     if (c < F) {
         load_cols<VEC>(piv, x + c, wx, nv);
+        if (!pivot) {   // plain sums (colsum): a pivot far from the column mean would only inflate the partial sums
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) piv[t] = 0.f;
+        }
 #pragma unroll 4
         for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < n; r += (int64_t)gridDim.y * kTY) {
             float v[VEC];
@@ -191,6 +195,16 @@ __global__ __launch_bounds__(kBlock) void colstats_final_kernel(const float* x, 
         }
     }
     if (num_batches && blockIdx.x == 0 && threadIdx.x == 0) num_batches[0] += 1;
+}
+
+// sum[c] = the unshifted partial sums added in double: the column SUM (a bias gradient).  Going through the pivot-shifted
+// fp32 mean instead loses ~eps * |pivot| * n — 2e-7 on gradients whose true sum is 0 at n = 2.45 M.
+__global__ __launch_bounds__(kBlock) void colsum_final_kernel(const float* part, int32_t F, int nblk, float* sum) {
+    __shared__ double lds[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    double S, Q;
+    pair_reduce(part, nblk, F, c, grp, lds, S, Q);
+    if (grp == 0 && c < F) sum[c] = (float)S;
 }
 
 template <int VEC>
@@ -384,12 +398,28 @@ int bot_colstats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* m
     const int vec = bn_vec(F, {ldx}, {x}, &quad);
     const bool wx = !quad || rows16(x, ldx);
     const dim3 grid = bn_grid(F, vec, n);
-    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, wx);
-    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true);
-    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true);
+    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, wx, true);
+    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true, true);
+    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true, true);
     hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
                        mean, m2, (float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (int64_t*)nullptr);
     return hip_status("colstats launch");
+}
+
+int bot_colsum_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* sum, float* workspace, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 1 && F >= 1 && ldx >= F, BOT_E_RANGE, "colsum: n=%lld F=%d ldx=%lld", (long long)n, F, (long long)ldx);
+    BOT_REQUIRE(x && sum && workspace, BOT_E_NULL, "colsum: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    bool quad;
+    const int vec = bn_vec(F, {ldx}, {x}, &quad);
+    const bool wx = !quad || rows16(x, ldx);
+    const dim3 grid = bn_grid(F, vec, n);
+    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, wx, false);
+    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true, false);
+    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true, false);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, workspace, F, (int)grid.y, sum);
+    return hip_status("colsum launch");
 }
 
 int bot_bn_stats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float eps, float momentum, float* mean, float* invstd,
@@ -405,9 +435,9 @@ int bot_bn_stats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float ep
     const int vec = bn_vec(F, {ldx}, {x}, &quad);
     const bool wx = !quad || rows16(x, ldx);
     const dim3 grid = bn_grid(F, vec, n);
-    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, wx);
-    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true);
-    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true);
+    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, wx, true);
+    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true, true);
+    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true, true);
     hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
                        mean, (float*)nullptr, invstd, eps, momentum, running_mean, running_var, num_batches_tracked);
     return hip_status("bn_stats launch");

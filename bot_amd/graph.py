@@ -15,6 +15,21 @@ import torch
 
 from . import _C
 
+_TAKE_CHUNK = 1 << 24
+
+
+def take_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """`x[idx]` along dim 0 for index tensors of any length.  torch-ROCm 2.10's row gather returns wrong rows (or raises
+    hipErrorInvalidConfiguration) from 2^26 indices on when a row is 16 bytes — measured on S-products / S-proteins edge
+    tensors, tools/exp_torch_large.py — so edge-sized gathers go through here: pieces of 2^24 indices into one output buffer."""
+    idx = idx.long()
+    if idx.numel() <= _TAKE_CHUNK:
+        return x[idx]
+    out = torch.empty((idx.numel(),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    for a in range(0, idx.numel(), _TAKE_CHUNK):
+        torch.index_select(x, 0, idx[a:a + _TAKE_CHUNK], out=out[a:a + _TAKE_CHUNK])
+    return out
+
 
 @dataclass
 class Direction:
@@ -85,7 +100,7 @@ def build_direction(rows: torch.Tensor, cols: torch.Tensor, n_rows: int, chunk: 
     if order == "xcd":
         items = xcd_item_order(items)
     n_long = int(long_rows.numel())
-    return Direction(indptr32.contiguous(), cols[eid].to(torch.int32).contiguous(), eid.to(torch.int32).contiguous(),
+    return Direction(indptr32.contiguous(), take_rows(cols, eid).to(torch.int32).contiguous(), eid.to(torch.int32).contiguous(),
                      items.to(dev), long_rows.to(dev) if n_long else None, long_ptr.to(dev) if n_long else None,
                      int(n_rows), nnz, int(items.shape[0]), n_long, n_slots, int(chunk))
 
@@ -252,7 +267,7 @@ class Graph:
     def csr2csc(self) -> torch.Tensor:
         """int32 [E]: CSC position of the edge that sits at CSR position k."""
         if self._csr2csc is None:
-            self._csr2csc = self._inverse(self.csc.eid)[self.csr.eid.long()].contiguous()
+            self._csr2csc = take_rows(self._inverse(self.csc.eid), self.csr.eid).contiguous()
         return self._csr2csc
 
     @property

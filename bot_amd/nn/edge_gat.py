@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..graph import take_rows
 from . import _bcast, _epilogue, _pair, degree_norm, has_zero_in_degree
 from . import fused as _fused
 
@@ -66,7 +67,7 @@ class GATConv(nn.Module):
         if feat_edge is not None and edge_encoder is not None:
             ee = _C.edge_mlp_fwd(ops.edge_features_csc(graph, feat_edge), edge_encoder.weight, edge_encoder.bias, self.attn_edge_fc.weight)
         elif feat_edge is not None:
-            ee = self.attn_edge_fc(feat_edge).view(-1, H)[csc.eid.long()]          # edge-id order -> position order
+            ee = take_rows(self.attn_edge_fc(feat_edge).view(-1, H), csc.eid)          # edge-id order -> position order
         scale, shift, relu = epilogue if epilogue is not None else (None, None, False)
         _fused.count_infer()
         return _C.gat_infer(csc, ft, attn_src.reshape(-1, H), None if attn_dst is None else attn_dst.reshape(-1, H), ee, None,
@@ -99,7 +100,9 @@ class GATConv(nn.Module):
             bias = None
             if any(b is not None for b in biases):
                 bias = torch.cat([b if b is not None else w.new_zeros(w.shape[0]) for w, b in zip(parts, biases)])
-            pieces = list(torch.split(F.linear(feat_src, torch.cat(parts), bias), [w.shape[0] for w in parts], dim=1))
+            proj = ops.linear(feat_src, torch.cat(parts), bias) if feat_src.dim() == 2 and (feat_src.is_cuda or _fused.FORCE) \
+                else F.linear(feat_src, torch.cat(parts), bias)
+            pieces = list(torch.split(proj, [w.shape[0] for w in parts], dim=1))
             ft = pieces.pop(0).unflatten(1, (H, D))
             if self.dst_fc is not None:
                 res = pieces.pop(0).unflatten(1, (H, D))

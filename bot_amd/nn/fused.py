@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _C
+from ..graph import take_rows
 from ..ops import bn_batch_stats, new_dropout_seed
 
 
@@ -50,7 +51,7 @@ def sym_scales(graph):
         s_out, s_in = degree_norm(graph, "out", -0.5), degree_norm(graph, "in", 0.5)
         deg = (csc.indptr[1:] - csc.indptr[:-1]).long()
         dst = torch.repeat_interleave(torch.arange(csc.n_rows, device=deg.device), deg)
-        c["sym_scales"] = (s_out, (s_out[csc.indices.long()] * s_in[dst]).unsqueeze(1).contiguous())
+        c["sym_scales"] = (s_out, (take_rows(s_out, csc.indices) * s_in[dst]).unsqueeze(1).contiguous())
     return c["sym_scales"]
 
 

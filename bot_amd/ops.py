@@ -19,6 +19,7 @@ from __future__ import annotations
 import torch
 
 from . import _C
+from .graph import take_rows
 
 __all__ = ["copy_u_sum", "u_mul_e_sum", "copy_e_sum", "copy_u", "u_add_v", "edge_softmax", "gat_attention"]
 
@@ -186,7 +187,7 @@ def edge_features_csc(g, efeat):
         cache = g._bot_cache = {}
     key = ("ef_csc", efeat.data_ptr(), efeat._version, tuple(efeat.shape))
     if key not in cache:
-        cache[key] = efeat[g.csc.eid.long()].contiguous()
+        cache[key] = take_rows(efeat, g.csc.eid).contiguous()
     return cache[key]
 
 
@@ -210,7 +211,7 @@ class _GatAttention(torch.autograd.Function):
         if keep is not None and ee is not None and keep_csc != ee_csc:
             if keep_csc:
                 raise ValueError("gat_attention: a CSC-ordered keep mask needs CSC-ordered (or no) edge logits")
-            keep = keep[csc.eid.long()].contiguous()
+            keep = take_rows(keep, csc.eid).contiguous()
         in_csc = ee_csc if ee is not None else keep_csc
         eperm = csc.eid if ((ee is not None or keep is not None) and not in_csc) else None
         zs = _C.zsign_buffer(csc, H, slope)
@@ -269,7 +270,7 @@ def edge_softmax(graph, logits, eids=None, norm_by="dst"):
     keep = torch.zeros(E, dtype=torch.uint8, device=logits.device)
     keep[eids] = 1
     a = gat_attention(graph, None, None, full, keep=keep, negative_slope=1.0, order="eid")
-    return a.view(full.shape)[eids]
+    return take_rows(a.view(full.shape), eids)
 
 
 # ------------------------------------------------------------------------------------------------ fused hidden-layer epilogue
@@ -379,8 +380,7 @@ class _AddBias(torch.autograd.Function):
     def backward(ctx, dy):
         db = None
         if ctx.needs_input_grad[1]:
-            mean, _ = _C.colstats(dy)          # column means by the tree-reduction kernel of the BatchNorm statistics
-            db = mean * dy.shape[0]
+            db = _C.colsum(dy)                 # column sums by the tree-reduction kernel of the BatchNorm statistics
         return dy, db
 
 
@@ -389,10 +389,48 @@ def add_bias(x, b):
     return _AddBias.apply(x, b) if x.dim() == 2 and x.is_cuda == b.is_cuda else x + b
 
 
+SPLITK_MIN_ROWS = 1 << 20      # weight gradients over at least this many rows are reduced in row chunks
+SPLITK_CHUNK_ROWS = 1 << 14
+
+
+def weight_grad(dy, x):
+    """dy^T x ([P,N] x [N,K]) — the weight gradient of a Linear, a reduction over all N rows.  From 2^20 rows on it is computed
+    as N / 2^14 partial products over row chunks (ONE batched GEMM) summed afterwards: at S-products (N = 2.45 M, P = K = 480)
+    the single GEMM's fp32 accumulation is 1.0e-4 of the largest entry away from the fp64 product, the chunked one 1.3e-6 to
+    5e-6, and it is faster (8.7 vs 9.7 ms; tools/exp_splitk_dw.py).  The pre-BatchNorm gradients make this reduction
+    cancellation-heavy (their column sums are zero), which is why the accumulation order shows."""
+    n = x.shape[0]
+    if n < SPLITK_MIN_ROWS or not dy.is_contiguous() or not x.is_contiguous():
+        return dy.t() @ x
+    S = n // SPLITK_CHUNK_ROWS
+    R = n // S
+    dw = torch.bmm(dy[:S * R].view(S, R, -1).transpose(1, 2), x[:S * R].view(S, R, -1)).sum(0)
+    if S * R < n:
+        dw = dw + dy[S * R:].t() @ x[S * R:]
+    return dw
+
+
+class _MatmulT(torch.autograd.Function):
+    """y = x W^T with the weight gradient through `weight_grad`."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.mm(x, w.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = torch.mm(dy, w) if ctx.needs_input_grad[0] else None
+        dw = weight_grad(dy.contiguous(), x) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
 def linear(x, weight, bias=None):
-    """`F.linear` whose bias gradient (a column sum over all N rows) runs on the colstats kernel: the stock reduction takes
-    19 ms for [2 449 029, 47] (S-products classifier, ogbn-products/models.py:262) — longer than the classifier GEMMs."""
-    y = torch.mm(x, weight.t())
+    """`F.linear` for [N, K] inputs whose two all-row reductions are done carefully: the bias gradient (a column sum over N
+    rows) runs on the colstats kernel — the stock reduction takes 19 ms for [2 449 029, 47] (S-products classifier,
+    ogbn-products/models.py:262), longer than the classifier GEMMs — and the weight gradient goes through `weight_grad`."""
+    y = _MatmulT.apply(x, weight) if x.shape[0] >= SPLITK_MIN_ROWS and torch.is_grad_enabled() else torch.mm(x, weight.t())
     return y if bias is None else _AddBias.apply(y, bias)
 
 

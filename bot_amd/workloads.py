@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from . import ops, synth
 from . import nn as bnn
 from . import train as T
-from .graph import Graph, preprocess, to_bidirected
+from .graph import Graph, preprocess, take_rows, to_bidirected
 from .nn import edge_gat
 
 NAMES = ("cora", "arxiv", "reddit", "proteins", "products")
@@ -160,7 +160,7 @@ def build(name: str, device, *, rank=0, world=1, partitioned=False, seed=0, scal
             pg = part.graph
             pg.ndata["feat"] = part.feat
             if ds.efeat is not None:
-                pg.edata["feat"] = ds.efeat[part.edge_ids]
+                pg.edata["feat"] = take_rows(ds.efeat, part.edge_ids)
             node_loss = _bce if name == "proteins" else _loge
 
             def step():

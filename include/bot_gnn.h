@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 3
+#define BOT_ABI_VERSION 4
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -338,6 +338,9 @@ int bot_scatter_add_rows_f32(float* x, int64_t ldx, const int32_t* rows, int64_t
 int64_t bot_bn_workspace_floats(int32_t F);
 int bot_colstats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* mean, float* m2, float* workspace,
                      bot_stream_t stream);
+/* sum[c] = sum_r x[r,c], the same two-stage reduction without the pivot shift, finished in double: the bias gradient of the Linear /
+ * GATConv bias over all N rows (src/no-sampling/models.py:548, src/ogbn-products/models.py:107, :262). */
+int bot_colsum_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* sum, float* workspace, bot_stream_t stream);
 /* colstats + everything nn.BatchNorm1d does with them in training mode, in one call: mean, invstd = rsqrt(m2/n + eps),
  * running_mean / running_var (may both be NULL) moved by `momentum` towards the batch mean / unbiased batch variance,
  * *num_batches_tracked (may be NULL) += 1.  Single-GPU form; the partitioned mode all-reduces between the two halves. */

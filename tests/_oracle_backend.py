@@ -190,6 +190,10 @@ def colstats(x):
     return mean, ((x - mean) ** 2).sum(0)
 
 
+def colsum(x):
+    return x.sum(0)
+
+
 def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
     n = x.shape[0]
     mean = x.mean(0)
@@ -255,7 +259,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

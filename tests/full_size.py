@@ -120,17 +120,22 @@ def tap_kinks():
         return y
 
     def attn(d, el, er, ee, eperm, keep, slope, H, aperm, zsign=None, **kw):
+        # in pieces of 2^24 edges: torch-ROCm's row gather is wrong from 2^26 indices on (bot_amd.graph.take_rows)
         with torch.no_grad():
-            deg = (d.indptr[1:] - d.indptr[:-1]).long()
-            z = torch.zeros((d.nnz, H), dtype=torch.float32, device=d.indptr.device)
-            if er is not None:
-                z = z + er.reshape(-1, H)[torch.repeat_interleave(torch.arange(d.n_rows, device=deg.device), deg)]
-            if el is not None:
-                z = z + el.reshape(-1, H)[d.indices.long()]
-            if ee is not None:
-                z = z + (ee.reshape(-1, H) if eperm is None else ee.reshape(-1, H)[eperm.long()])
-            gate = torch.empty((d.nnz, H), dtype=torch.uint8, device=z.device)
-            gate[d.eid.long()] = (z > 0).to(torch.uint8)
+            dev = d.indptr.device
+            gate = torch.empty((d.nnz, H), dtype=torch.uint8, device=dev)
+            indptr = d.indptr.long()
+            for a in range(0, d.nnz, 1 << 24):
+                b = min(d.nnz, a + (1 << 24))
+                pos = torch.arange(a, b, device=dev)
+                z = torch.zeros((b - a, H), dtype=torch.float32, device=dev)
+                if er is not None:
+                    z = z + er.reshape(-1, H)[torch.searchsorted(indptr, pos, right=True) - 1]
+                if el is not None:
+                    z = z + el.reshape(-1, H)[d.indices[a:b].long()]
+                if ee is not None:
+                    z = z + (ee.reshape(-1, H)[a:b] if eperm is None else ee.reshape(-1, H)[eperm[a:b].long()])
+                gate[d.eid[a:b].long()] = (z > 0).to(torch.uint8)
             leaky_taps.append(gate.cpu())
         return orig_a(d, el, er, ee, eperm, keep, slope, H, aperm, zsign, **kw)
 
@@ -159,20 +164,27 @@ def hip_step(g, feat, labels, train_idx, mask, sd, cfg, n_classes, loss="loge", 
     return pred.detach(), {k: p.grad.detach() for k, p in model.named_parameters()}, (relu_gates, leaky_gates)
 
 
-def compare(pred_hip, grads_hip, pred_ref, grads_ref, gate_stats=None, tol=1e-4):
+def compare(pred_hip, grads_hip, pred_ref, grads_ref, gate_stats=None, tol=1e-4, zero_grads=None):
     """max |logit diff| over all nodes; the worst parameter-gradient error relative to that gradient's largest entry; the
     number of gradient entries beyond `tol` of it; and (with gates given to the oracle) how many ReLU / leaky-ReLU gates the two
-    runs would have set differently and how large the pre-activation was there."""
+    runs would have set differently and how large the pre-activation was there.
+    `zero_grads` {param: companion param}: gradients that are identically zero in exact arithmetic (a bias in front of a
+    training-mode BatchNorm: the batch mean is subtracted again) — both runs hold rounding noise there, so those are measured
+    against the companion weight gradient's largest entry instead of their own."""
     d = float((pred_hip.detach().cpu().double() - pred_ref.double()).abs().max())
-    worst, which, over, total = 0.0, None, 0, 0
+    worst, which, over, total, table = 0.0, None, 0, 0, {}
     for k, gr in grads_ref.items():
         gh = grads_hip[k].detach().cpu().double()
-        scale = max(float(gr.double().abs().max()), 1e-30)
+        scale = max(float(grads_ref[(zero_grads or {}).get(k, k)].double().abs().max()), 1e-30)
         e = (gh - gr.double()).abs() / scale
+        table[k] = (scale, float(gh.abs().max()), float(e.max()), int((e > tol).sum()), e.numel())
         over += int((e > tol).sum())
         total += e.numel()
         if float(e.max()) > worst:
             worst, which = float(e.max()), k
+    if os.environ.get("BOT_PARITY_TABLE"):
+        for k, t in table.items():
+            print("  %-28s |ref|max %.3e |hip|max %.3e  max err/|ref|max %.3e  over %d of %d" % ((k,) + t))
     r = {"max_abs_logit_diff": d, "max_rel_grad_err": worst, "worst_grad": which, "grad_entries_over_1e-4": over,
          "grad_entries": total, "n": int(pred_ref.shape[0]), "logit_scale": float(pred_ref.abs().max())}
     if gate_stats is not None:
@@ -223,8 +235,9 @@ def gcn_hip_step(g, feat, labels, train_idx, sd, cfg, n_classes, loss="logit"):
 
 # ---------------------------------------------------------------------------------------------- edge-feature GAT (configs 4 / 5)
 def edge_gat_oracle_step(src, dst, n, nfeat, efeat, labels, train_idx, sd, *, n_layers, n_heads, n_hidden, node_loss, use_node_encoder,
-                         residual, threads=None, gates=None):
-    """One train step of the ogbn-proteins / ogbn-products stack (full-graph branch) on the oracle's C kernels."""
+                         residual, threads=None, gates=None, f64_weight_grads=False):
+    """One train step of the ogbn-proteins / ogbn-products stack (full-graph branch) on the oracle's C kernels.
+    `f64_weight_grads`: the Linear weight gradients accumulated in fp64 (oracle.ref_models.linear_f64grad)."""
     from oracle import c_ops
     from oracle import ref_models as RM
     if threads is None:
@@ -238,7 +251,8 @@ def edge_gat_oracle_step(src, dst, n, nfeat, efeat, labels, train_idx, sd, *, n_
     t0 = time.perf_counter()
     pred = RM.proteins_gat_forward(g, nfeat, efeat, sdg, n_layers=n_layers, n_heads=n_heads, n_hidden=n_hidden, training=True,
                                    use_node_encoder=use_node_encoder, residual=residual,
-                                   activation=F.relu if kg is None else kg.relu, leaky=None if kg is None else kg.leaky)
+                                   activation=F.relu if kg is None else kg.relu, leaky=None if kg is None else kg.leaky,
+                                   linear=RM.linear_f64grad if f64_weight_grads else F.linear)
     out = node_loss(pred[train_idx], labels[train_idx]).mean()
     grads = torch.autograd.grad(out, [sdg[k] for k in names], allow_unused=True)
     return pred.detach(), {k: g_ for k, g_ in zip(names, grads) if g_ is not None}, time.perf_counter() - t0, (kg.stats if kg else None)
