@@ -16,18 +16,21 @@ import torch
 
 from . import ref_ops as R
 
-_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "liboracle.so")
-_lib = None
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build")
+_LIB = os.path.join(_DIR, "liboracle.so")
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB):
-            raise RuntimeError(f"{_LIB} missing: run `make -C oracle/csrc`")
-        _lib = ctypes.CDLL(_LIB)
+def lib(dtype=torch.float32):
+    """liboracle.so (float32) or liboracle_f64.so (the same loops in double, for ranking two fp32 runs against an exact one)."""
+    if dtype not in _libs:
+        path = {torch.float32: _LIB, torch.float64: os.path.join(_DIR, "liboracle_f64.so")}[dtype]
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle/csrc`")
+        _lib = _libs[dtype] = ctypes.CDLL(path)
         P, I = c_void_p, c_int64
         _lib.oracle_num_threads.restype = ctypes.c_int
+        _lib.oracle_set_num_threads.argtypes = [ctypes.c_int]
         for name, args in {
             "oracle_spmm": [P, P, P, I, P, P, I, I, P],
             "oracle_sddmm_dot": [P, P, P, I, P, P, I, I, P],
@@ -38,7 +41,7 @@ def lib():
         }.items():
             getattr(_lib, name).argtypes = args
             getattr(_lib, name).restype = None
-    return _lib
+    return _libs[dtype]
 
 
 def num_threads():
@@ -47,8 +50,9 @@ def num_threads():
 
 def set_num_threads(n: int):
     """Thread count of the OpenMP kernels (torch's own pool is set with torch.set_num_threads)."""
-    lib().oracle_set_num_threads.argtypes = [ctypes.c_int]
-    lib().oracle_set_num_threads(int(n))
+    for dt in (torch.float32, torch.float64):
+        if dt is torch.float32 or os.path.exists(os.path.join(_DIR, "liboracle_f64.so")):
+            lib(dt).oracle_set_num_threads(int(n))
 
 
 class CGraph:
@@ -71,8 +75,8 @@ def _p(t):
 def _spmm(direction, n, x3, w2):
     ip, idx, eid = direction
     H, D = x3.shape[1], x3.shape[2]
-    out = torch.empty((n, H, D), dtype=torch.float32)
-    lib().oracle_spmm(_p(ip), _p(idx), _p(eid), n, _p(x3), _p(w2), H, D, _p(out))
+    out = torch.empty((n, H, D), dtype=x3.dtype)
+    lib(x3.dtype).oracle_spmm(_p(ip), _p(idx), _p(eid), n, _p(x3), _p(w2), H, D, _p(out))
     return out
 
 
@@ -95,7 +99,7 @@ class _SpMM(torch.autograd.Function):
         if a2 is not None:
             ip, idx, eid = g.csc
             da = torch.empty_like(a2)
-            lib().oracle_sddmm_dot(_p(ip), _p(idx), _p(eid), g.num_nodes, _p(x3), _p(d3), x3.shape[1], x3.shape[2], _p(da))
+            lib(x3.dtype).oracle_sddmm_dot(_p(ip), _p(idx), _p(eid), g.num_nodes, _p(x3), _p(d3), x3.shape[1], x3.shape[2], _p(da))
             da = da.view(ctx.as_)
         return None, dx, da
 
@@ -114,8 +118,8 @@ class _UAddV(torch.autograd.Function):
         ctx.g, ctx.xs, ctx.has_y = g, x.shape, y is not None
         x2 = x.reshape(x.shape[0], -1).contiguous()
         y2 = None if y is None else y.reshape(y.shape[0], -1).contiguous()
-        out = torch.empty((g.num_edges, x2.shape[1]), dtype=torch.float32)
-        lib().oracle_u_add_v(_p(g.src), _p(g.dst), g.num_edges, _p(x2), _p(y2), x2.shape[1], _p(out))
+        out = torch.empty((g.num_edges, x2.shape[1]), dtype=x2.dtype)
+        lib(x2.dtype).oracle_u_add_v(_p(g.src), _p(g.dst), g.num_edges, _p(x2), _p(y2), x2.shape[1], _p(out))
         return out.view((g.num_edges,) + tuple(x.shape[1:]))
 
     @staticmethod
@@ -129,8 +133,8 @@ class _UAddV(torch.autograd.Function):
                 outs.append(None)
                 continue
             ip, _, eid = direction
-            o = torch.empty((g.num_nodes, W), dtype=torch.float32)
-            lib().oracle_segment_sum(_p(ip), _p(eid), g.num_nodes, _p(de2), W, _p(o))
+            o = torch.empty((g.num_nodes, W), dtype=de2.dtype)
+            lib(de2.dtype).oracle_segment_sum(_p(ip), _p(eid), g.num_nodes, _p(de2), W, _p(o))
             outs.append(o.view(ctx.xs))
         return None, outs[0], outs[1]
 
@@ -149,7 +153,7 @@ class _EdgeSoftmax(torch.autograd.Function):
         ip, _, eid = g.csc
         e2 = e.reshape(e.shape[0], -1).contiguous()
         a = torch.empty_like(e2)
-        lib().oracle_edge_softmax_fwd(_p(ip), _p(eid), g.num_nodes, _p(e2), _p(keep), e2.shape[1], _p(a))
+        lib(e2.dtype).oracle_edge_softmax_fwd(_p(ip), _p(eid), g.num_nodes, _p(e2), _p(keep), e2.shape[1], _p(a))
         ctx.g, ctx.shape = g, e.shape
         ctx.save_for_backward(a)
         return a.view(e.shape)
@@ -161,7 +165,7 @@ class _EdgeSoftmax(torch.autograd.Function):
         ip, _, eid = g.csc
         da2 = da.reshape(a.shape).contiguous()
         de = torch.empty_like(a)
-        lib().oracle_edge_softmax_bwd(_p(ip), _p(eid), g.num_nodes, _p(a), _p(da2), a.shape[1], _p(de))
+        lib(a.dtype).oracle_edge_softmax_bwd(_p(ip), _p(eid), g.num_nodes, _p(a), _p(da2), a.shape[1], _p(de))
         return None, de.view(ctx.shape), None
 
 

@@ -20,6 +20,18 @@
 #include <omp.h>
 #endif
 
+/* REAL = float: the restatement proper (liboracle.so).  -DORACLE_F64 builds the same loops in double (liboracle_f64.so): the
+ * "exact" side when two fp32 implementations have to be ranked against each other (tests/full_size.py). */
+#ifdef ORACLE_F64
+#define REAL double
+#define FMAX fmax
+#define EXP exp
+#else
+#define REAL float
+#define FMAX fmaxf
+#define EXP expf
+#endif
+
 void oracle_set_num_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);
@@ -37,17 +49,17 @@ int oracle_num_threads(void) {
 }
 
 /* out[r,h,:] = sum_{k in row r} w[eid[k],h] * x[indices[k],h,:]     (w == NULL: copy_u_sum) */
-void oracle_spmm(const int64_t* indptr, const int64_t* indices, const int64_t* eid, int64_t n_rows, const float* x,
-                 const float* w, int64_t H, int64_t D, float* out) {
+void oracle_spmm(const int64_t* indptr, const int64_t* indices, const int64_t* eid, int64_t n_rows, const REAL* x,
+                 const REAL* w, int64_t H, int64_t D, REAL* out) {
     const int64_t F = H * D;
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t r = 0; r < n_rows; ++r) {
-        float* o = out + r * F;
-        memset(o, 0, sizeof(float) * F);
+        REAL* o = out + r * F;
+        memset(o, 0, sizeof(REAL) * F);
         for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k) {
-            const float* xs = x + indices[k] * F;
+            const REAL* xs = x + indices[k] * F;
             if (w) {
-                const float* we = w + eid[k] * H;
+                const REAL* we = w + eid[k] * H;
                 for (int64_t h = 0; h < H; ++h)
                     for (int64_t d = 0; d < D; ++d) o[h * D + d] += xs[h * D + d] * we[h];
             } else {
@@ -58,16 +70,16 @@ void oracle_spmm(const int64_t* indptr, const int64_t* indices, const int64_t* e
 }
 
 /* out[eid[k],h] = < x[indices[k],h,:], y[r,h,:] > */
-void oracle_sddmm_dot(const int64_t* indptr, const int64_t* indices, const int64_t* eid, int64_t n_rows, const float* x,
-                      const float* y, int64_t H, int64_t D, float* out) {
+void oracle_sddmm_dot(const int64_t* indptr, const int64_t* indices, const int64_t* eid, int64_t n_rows, const REAL* x,
+                      const REAL* y, int64_t H, int64_t D, REAL* out) {
     const int64_t F = H * D;
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t r = 0; r < n_rows; ++r) {
-        const float* yr = y + r * F;
+        const REAL* yr = y + r * F;
         for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k) {
-            const float* xs = x + indices[k] * F;
+            const REAL* xs = x + indices[k] * F;
             for (int64_t h = 0; h < H; ++h) {
-                float s = 0.f;
+                REAL s = (REAL)0;
                 for (int64_t d = 0; d < D; ++d) s += xs[h * D + d] * yr[h * D + d];
                 out[eid[k] * H + h] = s;
             }
@@ -76,37 +88,37 @@ void oracle_sddmm_dot(const int64_t* indptr, const int64_t* indices, const int64
 }
 
 /* out[e,:] = x[src[e],:] (+ y[dst[e],:]) */
-void oracle_u_add_v(const int64_t* src, const int64_t* dst, int64_t n_edges, const float* x, const float* y, int64_t W,
-                    float* out) {
+void oracle_u_add_v(const int64_t* src, const int64_t* dst, int64_t n_edges, const REAL* x, const REAL* y, int64_t W,
+                    REAL* out) {
 #pragma omp parallel for schedule(static)
     for (int64_t e = 0; e < n_edges; ++e)
-        for (int64_t j = 0; j < W; ++j) out[e * W + j] = x[src[e] * W + j] + (y ? y[dst[e] * W + j] : 0.f);
+        for (int64_t j = 0; j < W; ++j) out[e * W + j] = x[src[e] * W + j] + (y ? y[dst[e] * W + j] : (REAL)0);
 }
 
 /* a[eid[k],h] = softmax over the positions k of row r of e[eid[k],h]; keep == 0 edges are excluded, a = 0 */
-void oracle_edge_softmax_fwd(const int64_t* indptr, const int64_t* eid, int64_t n_rows, const float* e,
-                             const uint8_t* keep, int64_t H, float* a) {
+void oracle_edge_softmax_fwd(const int64_t* indptr, const int64_t* eid, int64_t n_rows, const REAL* e,
+                             const uint8_t* keep, int64_t H, REAL* a) {
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t r = 0; r < n_rows; ++r) {
         for (int64_t h = 0; h < H; ++h) {
-            float m = -INFINITY, s = 0.f;
+            REAL m = -INFINITY, s = (REAL)0;
             for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k)
-                if (!keep || keep[eid[k]]) m = fmaxf(m, e[eid[k] * H + h]);
+                if (!keep || keep[eid[k]]) m = FMAX(m, e[eid[k] * H + h]);
             for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k)
-                if (!keep || keep[eid[k]]) s += expf(e[eid[k] * H + h] - m);
+                if (!keep || keep[eid[k]]) s += EXP(e[eid[k] * H + h] - m);
             for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k)
-                a[eid[k] * H + h] = (!keep || keep[eid[k]]) ? expf(e[eid[k] * H + h] - m) / s : 0.f;
+                a[eid[k] * H + h] = (!keep || keep[eid[k]]) ? EXP(e[eid[k] * H + h] - m) / s : (REAL)0;
         }
     }
 }
 
 /* de = a*da - a * sum_row(a*da) */
-void oracle_edge_softmax_bwd(const int64_t* indptr, const int64_t* eid, int64_t n_rows, const float* a, const float* da,
-                             int64_t H, float* de) {
+void oracle_edge_softmax_bwd(const int64_t* indptr, const int64_t* eid, int64_t n_rows, const REAL* a, const REAL* da,
+                             int64_t H, REAL* de) {
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t r = 0; r < n_rows; ++r) {
         for (int64_t h = 0; h < H; ++h) {
-            float t = 0.f;
+            REAL t = (REAL)0;
             for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k) t += a[eid[k] * H + h] * da[eid[k] * H + h];
             for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k) {
                 const int64_t o = eid[k] * H + h;
@@ -117,12 +129,12 @@ void oracle_edge_softmax_bwd(const int64_t* indptr, const int64_t* eid, int64_t 
 }
 
 /* out[r,:] = sum_{k in row r} vals[eid[k],:] */
-void oracle_segment_sum(const int64_t* indptr, const int64_t* eid, int64_t n_rows, const float* vals, int64_t W,
-                        float* out) {
+void oracle_segment_sum(const int64_t* indptr, const int64_t* eid, int64_t n_rows, const REAL* vals, int64_t W,
+                        REAL* out) {
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t r = 0; r < n_rows; ++r) {
-        float* o = out + r * W;
-        memset(o, 0, sizeof(float) * W);
+        REAL* o = out + r * W;
+        memset(o, 0, sizeof(REAL) * W);
         for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k)
             for (int64_t j = 0; j < W; ++j) o[j] += vals[eid[k] * W + j];
     }

@@ -164,6 +164,17 @@ def hip_step(g, feat, labels, train_idx, mask, sd, cfg, n_classes, loss="loge", 
     return pred.detach(), {k: p.grad.detach() for k, p in model.named_parameters()}, (relu_gates, leaky_gates)
 
 
+def rank_against_exact(grads_hip, grads_ref, grads_exact, zero_grads=None):
+    """Per parameter: (error of the HIP gradient, error of the fp32 oracle's gradient), both against the fp64 run and relative
+    to the exact gradient's largest entry (the companion's for `zero_grads`, see compare)."""
+    out = {}
+    for k, gx in grads_exact.items():
+        scale = max(float(grads_exact[(zero_grads or {}).get(k, k)].abs().max()), 1e-300)
+        out[k] = (float((grads_hip[k].detach().cpu().double() - gx).abs().max()) / scale,
+                  float((grads_ref[k].double() - gx).abs().max()) / scale)
+    return out
+
+
 def compare(pred_hip, grads_hip, pred_ref, grads_ref, gate_stats=None, tol=1e-4, zero_grads=None):
     """max |logit diff| over all nodes; the worst parameter-gradient error relative to that gradient's largest entry; the
     number of gradient entries beyond `tol` of it; and (with gates given to the oracle) how many ReLU / leaky-ReLU gates the two
@@ -235,9 +246,11 @@ def gcn_hip_step(g, feat, labels, train_idx, sd, cfg, n_classes, loss="logit"):
 
 # ---------------------------------------------------------------------------------------------- edge-feature GAT (configs 4 / 5)
 def edge_gat_oracle_step(src, dst, n, nfeat, efeat, labels, train_idx, sd, *, n_layers, n_heads, n_hidden, node_loss, use_node_encoder,
-                         residual, threads=None, gates=None, f64_weight_grads=False):
+                         residual, threads=None, gates=None, f64_weight_grads=False, dtype=torch.float32):
     """One train step of the ogbn-proteins / ogbn-products stack (full-graph branch) on the oracle's C kernels.
-    `f64_weight_grads`: the Linear weight gradients accumulated in fp64 (oracle.ref_models.linear_f64grad)."""
+    `f64_weight_grads`: the Linear weight gradients accumulated in fp64 (oracle.ref_models.linear_f64grad).
+    `dtype=torch.float64`: the whole step in double (liboracle_f64.so + torch fp64) — the exact side when two fp32 runs are
+    ranked against each other."""
     from oracle import c_ops
     from oracle import ref_models as RM
     if threads is None:
@@ -245,7 +258,11 @@ def edge_gat_oracle_step(src, dst, n, nfeat, efeat, labels, train_idx, sd, *, n_
     torch.set_num_threads(threads)
     c_ops.set_num_threads(threads)
     g = c_ops.CGraph(src, dst, n)
-    sdg = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    sdg = {k: (v.to(dtype).requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    if dtype != torch.float32:
+        sdg = {k: (v.to(dtype) if v.is_floating_point() and not v.requires_grad else v) for k, v in sdg.items()}
+        nfeat = None if nfeat is None else nfeat.to(dtype)
+        efeat = None if efeat is None else efeat.to(dtype)
     names = [k for k, v in sdg.items() if v.requires_grad and (use_node_encoder or not k.startswith("node_encoder"))]
     kg = None if gates is None else KinkGates(*gates)
     t0 = time.perf_counter()
