@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -69,6 +69,11 @@ _SIGS = {
     "bot_edge_mlp_bwd_f32": (ctypes.c_int, [_P, c_int32, _P, _P, c_int32, _P, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
     "bot_random_keep_workspace_bytes": (c_int64, []),
     "bot_random_keep_u8": (ctypes.c_int, [c_int64, c_int64, c_uint64, _P, _P, _P]),
+    "bot_halves_workspace_floats": (c_int64, []),
+    "bot_halves_scale_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
+    "bot_halves_split_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int32, _P, c_int64, c_int32, _P]),
+    "bot_gemm_halves_f32": (ctypes.c_int, [c_int32, c_int32, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int64,
+                                           c_int32, c_int64, c_int64, c_int64, _P, c_int64, c_int32, _P]),
     "bot_bn_workspace_floats": (c_int64, [c_int32]),
     "bot_colstats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
     "bot_colsum_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
@@ -558,6 +563,61 @@ def colstats(x):
     _check(_lib.bot_colstats_f32(x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), m2.data_ptr(), _bn_ws(F, x.device).data_ptr(),
                                  _stream()), "colstats")
     return mean, m2
+
+
+def halves_scale(x):
+    """scale [2] = (s, 1/s), s = 2^(14 - ceil(log2 max|x|)) of x [n,F] — stays on the device."""
+    _dev(x)
+    x = _mat(x, "x")
+    scale = torch.empty(2, dtype=torch.float32, device=x.device)
+    ws = torch.empty(int(_lib.bot_halves_workspace_floats()), dtype=torch.float32, device=x.device)
+    _check(_lib.bot_halves_scale_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], scale.data_ptr(), ws.data_ptr(), _stream()),
+           "halves_scale")
+    return scale
+
+
+def halves_split(x, scale, order, piece, out=None):
+    """fp16 halves of x [n,F] scaled by scale[0]: [h1|h1|h2] (order 0) or [h1|h2|h1] (order 1), pieces `piece` columns wide."""
+    _dev(x, scale)
+    x = _mat(x, "x")
+    n, F = x.shape
+    if out is None:
+        out = torch.empty((n, 3 * piece), dtype=torch.float16, device=x.device)
+    _check(_lib.bot_halves_split_f16(x.data_ptr(), x.stride(0), n, F, _ptr(scale), order, out.data_ptr(), out.stride(0), piece, _stream()),
+           "halves_split")
+    return out
+
+
+_GEMM_WS = {}
+GEMM_TUNE = os.environ.get("BOT_GEMM_TUNE", "1") != "0"
+
+
+def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1, strides=(0, 0, 0), m=None, n=None, k=None):
+    """C[m,n] = alpha[j] * op(a) op(b): a, b fp16 matrices (row-major views, unit column stride), C fp32; `alpha` a device
+    vector of n floats (a 1-element tensor is expanded).  m / n / k default to the operands' shapes; batch > 1 with element strides (a, b, c) for strided batches."""
+    _dev(a, b, alpha)
+    if a.dtype != torch.float16 or b.dtype != torch.float16 or a.stride(-1) != 1 or b.stride(-1) != 1:
+        raise BotKernelError("gemm_halves: operands must be fp16 with unit column stride")
+    if m is None:
+        m, k = (a.shape[-1], a.shape[-2]) if trans_a else (a.shape[-2], a.shape[-1])
+    if n is None:
+        n = b.shape[-2] if trans_b else b.shape[-1]
+    if out is None:
+        out = torch.empty((m, n) if batch == 1 else (batch, m, n), dtype=torch.float32, device=a.device)
+    if alpha.numel() == 1:
+        alpha = alpha.reshape(1).expand(n).contiguous()
+    if alpha.numel() != n or alpha.dtype != torch.float32:
+        raise BotKernelError("gemm_halves: alpha must hold n floats")
+    ws = _GEMM_WS.get(a.device)
+    if ws is None:
+        ws = _GEMM_WS[a.device] = torch.empty(64 << 20, dtype=torch.uint8, device=a.device)
+    sa, sb, sc = strides
+    if batch > 1 and sc == 0:
+        sc = out.stride(0)
+    _check(_lib.bot_gemm_halves_f32(int(trans_a), int(trans_b), m, n, k, alpha.data_ptr(), a.data_ptr(), a.stride(-2), b.data_ptr(),
+                                    b.stride(-2), out.data_ptr(), out.stride(-2), batch, sa, sb, sc, ws.data_ptr(), ws.numel(),
+                                    int(GEMM_TUNE), _stream()), "gemm_halves")
+    return out
 
 
 def colsum(x):

@@ -1,0 +1,142 @@
+// bot_gemm_halves_f32: C[m,n] = alpha[n] * op(A)[m,k] op(B)[k,n] for row-major fp16 operands with fp32 accumulation and output,
+// alpha a DEVICE vector over the n output columns (the product of two halves_scale reciprocals, never seen by the host;
+// hipBLASLt's device-SCALAR pointer mode is not honoured by the library build torch ships, the device-vector mode is) — hipBLASLt does the
+// MFMA work (a plain library GEMM; the halves format around it is halves.hip).  Optional strided batches (the row chunks of a
+// weight gradient).  The first call for a shape times hipBLASLt's candidate kernels on the caller's buffers and keeps the
+// fastest (beta is 0, so repeated runs are idempotent); under stream capture the top heuristic is used instead.
+#include <hipblaslt/hipblaslt.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+
+namespace bot {
+namespace {
+
+using Key = std::tuple<int, int, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int64_t, int64_t, int64_t, int>;
+
+struct Plan {
+    hipblasLtMatmulDesc_t desc = nullptr;
+    hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
+    hipblasLtMatmulAlgo_t algo;
+    size_t ws = 0;
+    bool tuned = false;
+    std::vector<hipblasLtMatmulHeuristicResult_t> cand;
+};
+
+std::mutex g_mu;
+std::map<Key, Plan> g_plans;
+hipblasLtHandle_t g_handle = nullptr;
+const float kZero = 0.f;   // beta (host side of HIPBLASLT_POINTER_MODE_ALPHA_DEVICE_VECTOR_BETA_HOST)
+
+#define LT_CHECK(expr, what)                                                   \
+    do {                                                                       \
+        hipblasStatus_t st_ = (expr);                                          \
+        if (st_ != HIPBLAS_STATUS_SUCCESS) {                                   \
+            set_error("gemm_halves: %s failed (hipblasStatus %d)", what, (int)st_); \
+            return 1000 + (int)st_;                                            \
+        }                                                                      \
+    } while (0)
+
+int make_layout(hipblasLtMatrixLayout_t* l, hipDataType t, int64_t rows, int64_t cols, int64_t ld, int32_t batch, int64_t stride) {
+    LT_CHECK(hipblasLtMatrixLayoutCreate(l, t, (uint64_t)rows, (uint64_t)cols, ld), "MatrixLayoutCreate");
+    if (batch > 1) {
+        LT_CHECK(hipblasLtMatrixLayoutSetAttribute(*l, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &batch, sizeof(batch)), "layout batch");
+        LT_CHECK(hipblasLtMatrixLayoutSetAttribute(*l, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &stride, sizeof(stride)), "layout stride");
+    }
+    return 0;
+}
+
+}  // namespace
+}  // namespace bot
+
+extern "C" {
+
+int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, const float* alpha, const uint16_t* A,
+                        int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t batch, int64_t stride_a,
+                        int64_t stride_b, int64_t stride_c, void* workspace, int64_t workspace_bytes, int32_t tune,
+                        bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(m >= 1 && n >= 1 && k >= 1 && batch >= 1, BOT_E_RANGE, "gemm_halves: m=%lld n=%lld k=%lld batch=%d", (long long)m,
+                (long long)n, (long long)k, batch);
+    BOT_REQUIRE(lda >= (trans_a ? m : k) && ldb >= (trans_b ? k : n) && ldc >= n, BOT_E_RANGE, "gemm_halves: lda=%lld ldb=%lld ldc=%lld",
+                (long long)lda, (long long)ldb, (long long)ldc);
+    BOT_REQUIRE(alpha && A && B && C && (workspace || workspace_bytes == 0), BOT_E_NULL, "gemm_halves: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_handle) {
+        LT_CHECK(hipblasLtCreate(&g_handle), "hipblasLtCreate");
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const Key key{trans_a, trans_b, m, n, k, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, dev};
+    Plan& p = g_plans[key];
+    if (!p.desc) {
+        // row-major C = op(A) op(B)  <=>  column-major C^T = op(B)^T op(A)^T: B is hipBLASLt's first operand, A its second
+        LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F), "MatmulDescCreate");
+        const hipblasOperation_t op1 = trans_b ? HIPBLAS_OP_T : HIPBLAS_OP_N, op2 = trans_a ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+        LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op1, sizeof(op1)), "desc transA");
+        LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op2, sizeof(op2)), "desc transB");
+        const int32_t pm = HIPBLASLT_POINTER_MODE_ALPHA_DEVICE_VECTOR_BETA_HOST;
+        LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_POINTER_MODE, &pm, sizeof(pm)), "desc pointer mode");
+        int rc;
+        if ((rc = make_layout(&p.la, HIP_R_16F, trans_b ? k : n, trans_b ? n : k, ldb, batch, stride_b))) return rc;   // first = B
+        if ((rc = make_layout(&p.lb, HIP_R_16F, trans_a ? m : k, trans_a ? k : m, lda, batch, stride_a))) return rc;   // second = A
+        if ((rc = make_layout(&p.lc, HIP_R_32F, n, m, ldc, batch, stride_c))) return rc;
+        hipblasLtMatmulPreference_t pref;
+        LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref), "PreferenceCreate");
+        const uint64_t wsb = (uint64_t)workspace_bytes;
+        LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof(wsb)), "pref workspace");
+        p.cand.resize(16);
+        int found = 0;
+        LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.la, p.lb, p.lc, p.lc, pref, (int)p.cand.size(), p.cand.data(), &found),
+                 "AlgoGetHeuristic");
+        hipblasLtMatmulPreferenceDestroy(pref);
+        p.cand.resize(found);
+        if (found == 0) {
+            set_error("gemm_halves: hipBLASLt has no kernel for m=%lld n=%lld k=%lld", (long long)m, (long long)n, (long long)k);
+            hipblasLtMatmulDescDestroy(p.desc);
+            p.desc = nullptr;
+            return 2;
+        }
+        p.algo = p.cand[0].algo;
+        p.ws = p.cand[0].workspaceSize;
+    }
+    auto run = [&](const hipblasLtMatmulAlgo_t& algo) {
+        return hipblasLtMatmul(g_handle, p.desc, alpha, B, p.la, A, p.lb, &kZero, C, p.lc, C, p.lc, &algo, workspace, (size_t)workspace_bytes, st);
+    };
+    if (!p.tuned && tune && p.cand.size() > 1) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cs);
+        if (cs == hipStreamCaptureStatusNone) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            float best = 1e30f;
+            for (const auto& c : p.cand) {
+                if (c.state != HIPBLAS_STATUS_SUCCESS || c.workspaceSize > (size_t)workspace_bytes) continue;
+                if (run(c.algo) != HIPBLAS_STATUS_SUCCESS) continue;          // warm-up (and: does it launch at all)
+                (void)hipEventRecord(e0, st);
+                bool ok = true;
+                for (int i = 0; i < 3 && ok; ++i) ok = run(c.algo) == HIPBLAS_STATUS_SUCCESS;
+                (void)hipEventRecord(e1, st);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ok && ms < best) best = ms, p.algo = c.algo, p.ws = c.workspaceSize;
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            p.tuned = true;
+            p.cand.clear();
+        }
+    }
+    set_kernel("hipblaslt_f16_f32 m=%lld n=%lld k=%lld batch=%d", (long long)m, (long long)n, (long long)k, batch);
+    LT_CHECK(run(p.algo), "hipblasLtMatmul");
+    return hip_status("gemm_halves launch");
+}
+
+}  // extern "C"

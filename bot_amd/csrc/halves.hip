@@ -1,0 +1,128 @@
+// fp32 matrices as pairs of fp16 halves, the operand format of bot_gemm_halves_f32 (gemm.cpp).
+//
+//   x = (h1 + h2) / s,   h1 = fp16(s x),   h2 = fp16(s x - h1)      (round to nearest; s a power of two)
+//
+// h1 + h2 reproduces s x to within 2^-23 |s x| (two 11-bit significands, the second one signed), the size of fp32's own
+// rounding, so a product sum_k a_k b_k evaluated as  sum a1 b1 + a1 b2 + a2 b1  with fp32 accumulation differs from an fp32
+// GEMM by the dropped a2 b2 term (2^-22 relative per product) — measured against fp64 it is as close as hipBLASLt's fp32
+// GEMM (tools/exp_split_gemm*.py).  The fp16 MFMA rate of gfx950 is 16x the fp32 one, so three fp16 products are ~3x faster.
+//
+//   halves_scale : s = 2^(14 - ceil(log2 max|x|))  puts the largest entry in (2^13, 2^14] (fp16 max 2^16; entries below
+//                  2^-38 of the largest flush to zero) — computed on the device, never read by the host
+//   halves_split : out[r] = [h1 | h1 | h2] (order 0, left operands) or [h1 | h2 | h1] (order 1, right operands), each piece
+//                  zero-padded to `piece` columns, so that ONE GEMM over the concatenated axis forms the three terms
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace bot {
+
+constexpr int kMaxBlocks = 1024;
+
+__global__ __launch_bounds__(kBlock) void absmax_partial_kernel(const float* x, int64_t ldx, int64_t n, int32_t F, float* part) {
+    __shared__ float lds[kBlock / kWave];
+    float m = 0.f;
+    const int64_t total = n * (int64_t)F;
+    if (ldx == F) {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) m = fmaxf(m, fabsf(x[i]));
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+            const int64_t r = i / F;
+            m = fmaxf(m, fabsf(x[r * ldx + (i - r * F)]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / kWave; ++w) m = fmaxf(m, lds[w]);
+        part[blockIdx.x] = m;
+    }
+}
+
+// fmaxf drops NaNs, an infinite entry gives s = 1: non-finite inputs then reach the GEMM as fp16 inf/NaN and poison the
+// product exactly as they would in fp32.
+__global__ __launch_bounds__(kWave) void halves_scale_kernel(const float* part, int nblk, float* scale) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += kWave) m = fmaxf(m, part[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (threadIdx.x == 0) {
+        float s = 1.f;
+        if (m > 0.f && m < INFINITY) {
+            int e;
+            const float f = frexpf(m, &e);          // m = f * 2^e, f in [0.5, 1)
+            if (f == 0.5f) e -= 1;                  // exact power of two: ceil(log2 m) = e - 1
+            s = ldexpf(1.f, 14 - e);
+        }
+        scale[0] = s;
+        scale[1] = 1.f / s;
+    }
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(128) void halves_split_kernel(const float* x, int64_t ldx, int32_t F, const float* scale, __half* out,
+                                                           int64_t ldo, int32_t piece, bool wide) {
+    const int64_t r = blockIdx.x;
+    const int c = (blockIdx.y * 128 + threadIdx.x) * 2;
+    if (c >= piece) return;
+    const float s = scale ? scale[0] : 1.f;
+    float v0 = 0.f, v1 = 0.f;
+    const float* xr = x + r * ldx;
+    if (c + 1 < F) {
+        if (wide) {
+            const float2 v = *reinterpret_cast<const float2*>(xr + c);
+            v0 = v.x * s, v1 = v.y * s;
+        } else {
+            v0 = xr[c] * s, v1 = xr[c + 1] * s;
+        }
+    } else if (c < F) {
+        v0 = xr[c] * s;
+    }
+    const __half a0 = __float2half_rn(v0), a1 = __float2half_rn(v1);
+    const __half b0 = __float2half_rn(v0 - __half2float(a0)), b1 = __float2half_rn(v1 - __half2float(a1));
+    __half* o = out + r * ldo + c;
+    const __half2 hi = __halves2half2(a0, a1), lo = __halves2half2(b0, b1);
+    *reinterpret_cast<__half2*>(o) = hi;
+    *reinterpret_cast<__half2*>(o + piece) = ORDER == 0 ? hi : lo;
+    *reinterpret_cast<__half2*>(o + 2 * (int64_t)piece) = ORDER == 0 ? lo : hi;
+}
+
+}  // namespace bot
+
+extern "C" {
+
+int64_t bot_halves_workspace_floats(void) { return bot::kMaxBlocks; }
+
+int bot_halves_scale_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* scale, float* workspace, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F, BOT_E_RANGE, "halves_scale: n=%lld F=%d ldx=%lld", (long long)n, F, (long long)ldx);
+    BOT_REQUIRE(scale && workspace && (x || n == 0), BOT_E_NULL, "halves_scale: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = n * (int64_t)F;
+    const int blocks = (int)max((int64_t)1, min((int64_t)kMaxBlocks, (total + kBlock * 8 - 1) / (kBlock * 8)));
+    hipLaunchKernelGGL(absmax_partial_kernel, dim3(blocks), dim3(kBlock), 0, st, x, ldx, n, F, workspace);
+    hipLaunchKernelGGL(halves_scale_kernel, dim3(1), dim3(kWave), 0, st, workspace, blocks, scale);
+    return hip_status("halves_scale launch");
+}
+
+int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
+                         int64_t ldo, int32_t piece, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && piece >= F && ldo >= 3 * (int64_t)piece, BOT_E_RANGE,
+                "halves_split: n=%lld F=%d ldx=%lld piece=%d ldo=%lld", (long long)n, F, (long long)ldx, piece, (long long)ldo);
+    BOT_REQUIRE(order == 0 || order == 1, BOT_E_RANGE, "halves_split: order=%d", order);
+    BOT_REQUIRE(piece % 2 == 0 && ldo % 2 == 0 && aligned(x, 4) && aligned(out, 4), BOT_E_ALIGN,
+                "halves_split: piece and ldo must be even, x and out 4-byte aligned");
+    const bool wide = ldx % 2 == 0 && aligned(x, 8);
+    BOT_REQUIRE((x && out) || n == 0, BOT_E_NULL, "halves_split: NULL pointer");
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)n, (unsigned)((piece / 2 + 127) / 128));
+    if (order == 0) hipLaunchKernelGGL(halves_split_kernel<0>, grid, dim3(128), 0, st, x, ldx, F, scale, (__half*)out, ldo, piece, wide);
+    else hipLaunchKernelGGL(halves_split_kernel<1>, grid, dim3(128), 0, st, x, ldx, F, scale, (__half*)out, ldo, piece, wide);
+    return hip_status("halves_split launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+"""The layer's dense projections as fp32 GEMMs on the fp16 matrix cores (include/bot_gnn.h: halves_scale / halves_split /
+gemm_halves; kernels in csrc/halves.hip, hipBLASLt call in csrc/gemm.cpp).
+
+An fp32 matrix is held as two fp16 halves per entry, x = (h1 + h2) / s (s a power of two found on the device), laid out as
+[h1 | h1 | h2] for left operands and [h1 | h2 | h1] for right operands, so that ONE fp16 GEMM over the three-fold reduction
+axis forms a1 b1 + a1 b2 + a2 b1 with fp32 accumulation.  Against an fp64 product the result is as close as hipBLASLt's fp32
+GEMM (1e-6 of the largest entry at the config-2 shapes) and ~3x faster: the fp32 MFMA rate, not HBM, bounds these GEMMs.
+
+`BOT_GEMM=f32` switches every projection back to the stock fp32 GEMM.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import _C
+
+MODE = os.environ.get("BOT_GEMM", "halves")
+MIN_ROWS = 8192            # below this many rows the fp32 GEMM is launch-bound anyway
+PIECE_ALIGN = 64
+CHUNK_ROWS = 8192          # row chunk of the weight-gradient reduction (one batch entry each)
+
+
+def enabled(x) -> bool:
+    return MODE == "halves" and x.is_cuda and x.dim() == 2 and x.shape[0] >= MIN_ROWS and x.dtype == torch.float32
+
+
+class Halves:
+    """fp16 halves of an fp32 matrix [n, F]: `buf` [n, 3 * piece] fp16, `scale` [2] = (s, 1/s) on the device."""
+    __slots__ = ("buf", "scale", "n", "F", "piece", "order")
+
+    def __init__(self, buf, scale, n, F, piece, order):
+        self.buf, self.scale, self.n, self.F, self.piece, self.order = buf, scale, n, F, piece, order
+
+
+def split(x, order: int) -> Halves:
+    """order 0: left operand [h1 | h1 | h2]; order 1: right operand [h1 | h2 | h1] (both reduce over their columns)."""
+    n, F = x.shape
+    piece = (F + PIECE_ALIGN - 1) // PIECE_ALIGN * PIECE_ALIGN
+    scale = _C.halves_scale(x)
+    return Halves(_C.halves_split(x, scale, order, piece), scale, n, F, piece, order)
+
+
+def _alpha(a: Halves, b: Halves):
+    return a.scale[1:] * b.scale[1:]
+
+
+def mm_nt(a: Halves, b: Halves, out=None):
+    """a [n, F] (order 0) times b [p, F]^T (order 1) -> fp32 [n, p]."""
+    assert a.order == 0 and b.order == 1 and a.F == b.F and a.piece == b.piece
+    return _C.gemm_halves(a.buf, b.buf, _alpha(a, b), trans_b=True, out=out)
+
+
+def tn(x: Halves, d: Halves):
+    """x^T d for two LEFT-operand layouts x [N, K], d [N, P] (order 0 both): the weight gradient, a reduction over the N rows.
+    Row chunks of CHUNK_ROWS are batch entries (x1^T [d1 | d2] and x2^T d1 per chunk), the partial products are added
+    afterwards — faster than one long-K GEMM and a pairwise-style summation (bot_amd.ops.weight_grad)."""
+    assert x.order == 0 and d.order == 0 and x.n == d.n
+    N, K, P, KP, PP = x.n, x.F, d.F, x.piece, d.piece
+    alpha = _alpha(x, d)
+    S = max(1, N // CHUNK_ROWS)
+    R = N // S
+    ldx, ldd = x.buf.stride(0), d.buf.stride(0)
+    x1, x2 = x.buf[:, :K], x.buf[:, 2 * KP:2 * KP + K]
+    d12, d1 = d.buf[:, PP:3 * PP], d.buf[:, :PP]
+
+    def part(xa, db, n, rows, batch, r0):
+        return _C.gemm_halves(xa[r0:], db[r0:], alpha, trans_a=True, m=K, n=n, k=rows, batch=batch,
+                              strides=(rows * ldx, rows * ldd, 0))
+
+    a = part(x1, d12, 2 * PP, R, S, 0)
+    b = part(x2, d1, PP, R, S, 0)
+    if S > 1:
+        a, b = a.sum(0), b.sum(0)
+    out = a[:, :P] + a[:, PP:PP + P] + b[:, :P]
+    if S * R < N:
+        ra = part(x1, d12, 2 * PP, N - S * R, 1, S * R)
+        rb = part(x2, d1, PP, N - S * R, 1, S * R)
+        out = out + ra[:, :P] + ra[:, PP:PP + P] + rb[:, :P]
+    return out

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 4
+#define BOT_ABI_VERSION 5
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -401,6 +401,31 @@ int bot_edge_mlp_bwd_f32(const float* ef, int32_t I, const float* W1, const floa
  * ------------------------------------------------------------------------------------------- */
 int64_t bot_random_keep_workspace_bytes(void);
 int bot_random_keep_u8(int64_t n, int64_t n_keep, uint64_t seed, uint8_t* keep, void* workspace, bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fp32 GEMMs on the fp16 matrix cores.  The dense projections of the layer (`self.fc`, `self.res_fc`, the folded attention
+ * columns: src/no-sampling/models.py:490-492, :519-522, :553-557; their backward) are fp32 GEMMs of [N, 750] x [750, 1536]
+ * size, MFMA-bound at gfx950's fp32 rate.  Each fp32 operand is written as two fp16 halves, x = (h1 + h2) / s with
+ * h1 = fp16(s x), h2 = fp16(s x - h1), s a power of two chosen ON THE DEVICE from max|x| (halves_scale: scale[0] = s,
+ * scale[1] = 1/s), and a product is evaluated as a1 b1 + a1 b2 + a2 b1 with fp32 accumulation: ONE fp16 GEMM over the
+ * concatenated reduction axis.  h1 + h2 carries 22-23 of the 24 significand bits; against fp64 the result is as close as
+ * hipBLASLt's fp32 GEMM (tools/exp_split_gemm*.py), at ~3x its speed.
+ *
+ *   halves_split  out[r, :] = [h1 | h1 | h2] (order 0: left operands) or [h1 | h2 | h1] (order 1: right operands), every piece
+ *                 `piece` >= F columns wide (zero padded; use a multiple of 64), out fp16 with row pitch ldo >= 3 * piece
+ *   gemm_halves   C[m,n] = alpha[j] * op(A)[m,k] op(B)[k,n], row-major, A / B fp16, C fp32, `alpha` a DEVICE vector of n
+ *                 floats (one per output column; normally n copies of the product of the two operands' 1/s); trans_x != 0: the operand is stored transposed.  batch > 1: strided
+ *                 batches (element strides).  tune != 0: the first call per shape times hipBLASLt's candidates on these
+ *                 buffers (C is overwritten; beta is 0).  `workspace`: device scratch for hipBLASLt (32 MiB is plenty).
+ * ------------------------------------------------------------------------------------------- */
+int64_t bot_halves_workspace_floats(void);
+int bot_halves_scale_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* scale, float* workspace, bot_stream_t stream);
+int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
+                         int64_t ldo, int32_t piece, bot_stream_t stream);
+int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, const float* alpha, const uint16_t* A,
+                        int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t batch, int64_t stride_a,
+                        int64_t stride_b, int64_t stride_c, void* workspace, int64_t workspace_bytes, int32_t tune,
+                        bot_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 4
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 5
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
@@ -1128,3 +1128,36 @@ def test_full_size_config4_proteins_gat_against_c_oracle():
     assert r["logit_err_vs_fp64"] <= PC.FWD_ATOL * max(1.0, r["logit_scale"] / 10), r
     for k, (eh, eo) in rank.items():
         assert eh <= max(PC.GRAD_RTOL, 2 * eo), (k, eh, eo)
+
+
+def test_gemm_halves_against_fp64():
+    """bot_amd.gemm (halves_scale / halves_split / gemm_halves through the C ABI): the fp16-halves GEMMs against an fp64 product,
+    next to the stock fp32 GEMM's own error — forward (x w^T), input gradient and the chunked weight gradient, at operand
+    magnitudes from 1e-9 to 1e3 and ragged sizes."""
+    from bot_amd import gemm
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    for n, K, P, sx, sd in ((20000, 750, 1536, 4.0, 1e-7), (9000, 100, 47, 1e3, 1e-9), (8192 * 2 + 5, 168, 250, 1.0, 1.0)):
+        x = torch.randn(n, K, device=DEV, generator=gen) * sx
+        x[:, ::7] = 0
+        w = torch.randn(P, K, device=DEV, generator=gen) * 0.05
+        d = torch.randn(n, P, device=DEV, generator=gen) * sd
+        xs = gemm.split(x, 0)
+        assert xs.scale.shape == (2,) and float(xs.scale[0] * xs.scale[1]) == 1.0
+        top = float(x.abs().max() * xs.scale[0])
+        assert 2 ** 13 < top <= 2 ** 14
+        # the halves reproduce the operand to fp32's own rounding
+        h1, h2 = xs.buf[:, :K].double(), xs.buf[:, 2 * xs.piece:2 * xs.piece + K].double()
+        assert torch.equal(xs.buf[:, :K], xs.buf[:, xs.piece:xs.piece + K])
+        assert ((h1 + h2) * float(xs.scale[1]) - x.double()).abs().max() <= 2.0 ** -22 * x.abs().max()
+        assert not xs.buf[:, K:xs.piece].any()
+        for name, got, ref, stock in (
+                ("fwd", gemm.mm_nt(xs, gemm.split(w, 1)), x.double() @ w.double().t(), x @ w.t()),
+                ("dx", gemm.mm_nt(gemm.split(d, 0), gemm.split(w.t().contiguous(), 1)), d.double() @ w.double(), d @ w),
+                ("dw", gemm.tn(xs, gemm.split(d, 0)), x.double().t() @ d.double(), x.t() @ d)):
+            scale = ref.abs().max()
+            e, e32 = float((got.double() - ref).abs().max() / scale), float((stock.double() - ref).abs().max() / scale)
+            print(f"gemm_halves {name} n={n} K={K} P={P}: err {e:.2e} (stock fp32 {e32:.2e})")
+            assert got.shape == ref.shape and e <= max(4e-6, 3 * e32), (name, e, e32)
+    # zeros and a single huge entry
+    z = gemm.split(torch.zeros(9000, 64, device=DEV), 0)
+    assert float(z.scale[0]) == 1.0 and not z.buf.any()
