@@ -73,7 +73,7 @@ _SIGS = {
     "bot_halves_scale_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
     "bot_halves_split_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int32, _P, c_int64, c_int32, _P]),
     "bot_gemm_halves_f32": (ctypes.c_int, [c_int32, c_int32, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int64,
-                                           c_int32, c_int64, c_int64, c_int64, _P, c_int64, c_int32, _P]),
+                                           c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, _P]),
     "bot_bn_workspace_floats": (c_int64, [c_int32]),
     "bot_colstats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
     "bot_colsum_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
@@ -592,9 +592,11 @@ _GEMM_WS = {}
 GEMM_TUNE = os.environ.get("BOT_GEMM_TUNE", "1") != "0"
 
 
-def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1, strides=(0, 0, 0), m=None, n=None, k=None):
+def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1, strides=(0, 0, 0), m=None, n=None, k=None, beta=0.0,
+                ldc=None):
     """C[m,n] = alpha[j] * op(a) op(b): a, b fp16 matrices (row-major views, unit column stride), C fp32; `alpha` a device
-    vector of n floats (a 1-element tensor is expanded).  m / n / k default to the operands' shapes; batch > 1 with element strides (a, b, c) for strided batches."""
+    vector of n floats (a 1-element tensor is expanded).  beta != 0 accumulates onto `out`; `ldc` overrides out's row pitch
+    (batched products written side by side into the columns of one matrix: strides[2] = the column offset per batch).  m / n / k default to the operands' shapes; batch > 1 with element strides (a, b, c) for strided batches."""
     _dev(a, b, alpha)
     if a.dtype != torch.float16 or b.dtype != torch.float16 or a.stride(-1) != 1 or b.stride(-1) != 1:
         raise BotKernelError("gemm_halves: operands must be fp16 with unit column stride")
@@ -615,7 +617,8 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     if batch > 1 and sc == 0:
         sc = out.stride(0)
     _check(_lib.bot_gemm_halves_f32(int(trans_a), int(trans_b), m, n, k, alpha.data_ptr(), a.data_ptr(), a.stride(-2), b.data_ptr(),
-                                    b.stride(-2), out.data_ptr(), out.stride(-2), batch, sa, sb, sc, ws.data_ptr(), ws.numel(),
+                                    b.stride(-2), out.data_ptr(), out.stride(-2) if ldc is None else ldc, batch, sa, sb, sc, float(beta),
+                                    ws.data_ptr(), ws.numel(),
                                     int(GEMM_TUNE), _stream()), "gemm_halves")
     return out
 

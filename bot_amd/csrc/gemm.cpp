@@ -1,9 +1,9 @@
-// bot_gemm_halves_f32: C[m,n] = alpha[n] * op(A)[m,k] op(B)[k,n] for row-major fp16 operands with fp32 accumulation and output,
+// bot_gemm_halves_f32: C[m,n] = alpha[n] * op(A)[m,k] op(B)[k,n] + beta * C for row-major fp16 operands with fp32 accumulation and output,
 // alpha a DEVICE vector over the n output columns (the product of two halves_scale reciprocals, never seen by the host;
 // hipBLASLt's device-SCALAR pointer mode is not honoured by the library build torch ships, the device-vector mode is) — hipBLASLt does the
 // MFMA work (a plain library GEMM; the halves format around it is halves.hip).  Optional strided batches (the row chunks of a
 // weight gradient).  The first call for a shape times hipBLASLt's candidate kernels on the caller's buffers and keeps the
-// fastest (beta is 0, so repeated runs are idempotent); under stream capture the top heuristic is used instead.
+// fastest (only for beta == 0, where repeated runs are idempotent); under stream capture the top heuristic is used instead.
 #include <hipblaslt/hipblaslt.h>
 
 #include <map>
@@ -16,7 +16,7 @@
 namespace bot {
 namespace {
 
-using Key = std::tuple<int, int, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int64_t, int64_t, int64_t, int>;
+using Key = std::tuple<int, int, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int64_t, int64_t, int64_t, int, bool>;
 
 struct Plan {
     hipblasLtMatmulDesc_t desc = nullptr;
@@ -30,7 +30,6 @@ struct Plan {
 std::mutex g_mu;
 std::map<Key, Plan> g_plans;
 hipblasLtHandle_t g_handle = nullptr;
-const float kZero = 0.f;   // beta (host side of HIPBLASLT_POINTER_MODE_ALPHA_DEVICE_VECTOR_BETA_HOST)
 
 #define LT_CHECK(expr, what)                                                   \
     do {                                                                       \
@@ -57,7 +56,7 @@ extern "C" {
 
 int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, const float* alpha, const uint16_t* A,
                         int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t batch, int64_t stride_a,
-                        int64_t stride_b, int64_t stride_c, void* workspace, int64_t workspace_bytes, int32_t tune,
+                        int64_t stride_b, int64_t stride_c, float beta, void* workspace, int64_t workspace_bytes, int32_t tune,
                         bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(m >= 1 && n >= 1 && k >= 1 && batch >= 1, BOT_E_RANGE, "gemm_halves: m=%lld n=%lld k=%lld batch=%d", (long long)m,
@@ -72,7 +71,7 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
     }
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const Key key{trans_a, trans_b, m, n, k, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, dev};
+    const Key key{trans_a, trans_b, m, n, k, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, dev, beta != 0.f};
     Plan& p = g_plans[key];
     if (!p.desc) {
         // row-major C = op(A) op(B)  <=>  column-major C^T = op(B)^T op(A)^T: B is hipBLASLt's first operand, A its second
@@ -106,9 +105,9 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
         p.ws = p.cand[0].workspaceSize;
     }
     auto run = [&](const hipblasLtMatmulAlgo_t& algo) {
-        return hipblasLtMatmul(g_handle, p.desc, alpha, B, p.la, A, p.lb, &kZero, C, p.lc, C, p.lc, &algo, workspace, (size_t)workspace_bytes, st);
+        return hipblasLtMatmul(g_handle, p.desc, alpha, B, p.la, A, p.lb, &beta, C, p.lc, C, p.lc, &algo, workspace, (size_t)workspace_bytes, st);
     };
-    if (!p.tuned && tune && p.cand.size() > 1) {
+    if (!p.tuned && tune && beta == 0.f && p.cand.size() > 1) {   // timing runs overwrite C: only when nothing is accumulated
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cs);
         if (cs == hipStreamCaptureStatusNone) {

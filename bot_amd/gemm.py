@@ -79,3 +79,46 @@ def tn(x: Halves, d: Halves):
         rb = part(x2, d1, PP, N - S * R, 1, S * R)
         out = out + ra[:, :P] + ra[:, PP:PP + P] + rb[:, :P]
     return out
+
+
+
+class _Matmul(torch.autograd.Function):
+    """y = x w (kp: w is [K, P]) or y = x w^T (w is [P, K], nn.Linear's layout), forward and both gradients on the halves."""
+
+    @staticmethod
+    def forward(ctx, x, w, kp):
+        xh = split(x, 0)
+        ctx.kp, ctx.meta = kp, (xh.n, xh.F, xh.piece)
+        ctx.save_for_backward(xh.buf, xh.scale, w)
+        return mm_nt(xh, split(w.t().contiguous() if kp else w, 1))
+
+    @staticmethod
+    def backward(ctx, dy):
+        buf, scale, w = ctx.saved_tensors
+        kp = ctx.kp
+        dh = split(dy.contiguous(), 0)
+        dx = mm_nt(dh, split(w if kp else w.t().contiguous(), 1)) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = tn(Halves(buf, scale, *ctx.meta, 0), dh)               # [K, P]
+            dw = dw if kp else dw.t().contiguous()
+        return dx, dw, None
+
+
+def worth(x, K: int, P: int) -> bool:
+    """Shapes for which the halves pay: enough rows, and a weight big enough that the GEMM (not the split passes) dominates."""
+    return enabled(x) and min(K, P) >= 32 and K * P >= 128 * 128
+
+
+def matmul(x, w):
+    """x [N, K] @ w [K, P] (GraphConv's weight layout, src/no-sampling/models.py:371)."""
+    if worth(x, w.shape[0], w.shape[1]):
+        return _Matmul.apply(x, w, True)
+    return torch.matmul(x, w)
+
+
+def linear(x, weight):
+    """x [N, K] @ weight[P, K]^T (nn.Linear's layout); None when the shapes do not pay (the caller keeps its own path)."""
+    if worth(x, weight.shape[1], weight.shape[0]):
+        return _Matmul.apply(x, weight, False)
+    return None

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import gemm, ops
 from ..errors import DGLError
 
 __all__ = ["ElementWiseLinear", "GraphConv", "GATConv", "GCN", "GAT"]
@@ -145,12 +145,12 @@ class GraphConv(nn.Module):
         # narrowing GEMM when there is one (so the narrower tensor is what crosses xGMI)
         if self._in_feats > self._out_feats:
             if w is not None:
-                h = torch.matmul(h, w)
+                h = gemm.matmul(h, w)
             rst = ops.copy_u_sum(graph, graph.extend(h))
         else:
             rst = ops.copy_u_sum(graph, graph.extend(h))
             if w is not None:
-                rst = torch.matmul(rst, w)
+                rst = gemm.matmul(rst, w)
         if self._norm == "both":
             rst = rst * _bcast(degree_norm(graph, "in", -0.5), rst)
         elif self._norm == "right":

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _C
+from .. import _C, gemm
 from ..graph import take_rows
 from ..ops import bn_batch_stats, new_dropout_seed
 
@@ -151,7 +151,13 @@ class _GATHidden(torch.autograd.Function):
         csc = graph.csc
         ctx.sym = sym                                                   # symmetric normalisation folded into the edge weights
         ctx.kp = kp                                                     # Wcat is [K, P] (see WEIGHT_KP) instead of [P, K]
-        out = torch.mm(h, Wcat) if kp else torch.mm(h, Wcat.t())        # [N, P] = [ft | res | el | er | pad]
+        xh = None
+        if gemm.enabled(h):                                             # fp32 GEMM on the fp16 matrix cores (bot_amd.gemm)
+            xh = gemm.split(h, 0)
+            out = gemm.mm_nt(xh, gemm.split(Wcat.t().contiguous() if kp else Wcat, 1))
+        else:
+            out = torch.mm(h, Wcat) if kp else torch.mm(h, Wcat.t())    # [N, P] = [ft | res | el | er | pad]
+        ctx.halves = None if xh is None else (xh.n, xh.F, xh.piece)
         c = 2 * HD if has_res else HD
         ext = None
         if graph.halo is not None:                                      # partitioned: owned + halo source rows
@@ -181,7 +187,10 @@ class _GATHidden(torch.autograd.Function):
         else:
             x = _C.spmm(csc, ft, a_d, None, addend=res).view(N, HD)     # aggregation + residual (models.py:547-560)
         ctx.graph = graph
-        keep = (h, Wcat, ext if ext is not None else out, el, er, a, a_d)
+        # the weight gradient needs the layer input: its fp16 halves when the GEMMs run on them (h itself is not kept then)
+        keep = (h if xh is None else xh.buf, Wcat, ext if ext is not None else out, el, er, a, a_d)
+        if xh is not None:
+            ctx.xscale = xh.scale
         if bn is None:                                                  # output layer: no epilogue
             ctx.save_for_backward(*keep)
             ctx.cfg = (H, D, has_res, has_er, slope, None)
@@ -207,8 +216,8 @@ class _GATHidden(torch.autograd.Function):
             drop_p, seed, bn_training, sync, group, total = epi
         kp = ctx.kp
         N, HD, P = h.shape[0], H * D, Wcat.shape[1 if kp else 0]
-        dout = torch.empty((N, P), dtype=h.dtype, device=h.device)
-        dx = dout[:, HD:2 * HD] if has_res else torch.empty((N, HD), dtype=h.dtype, device=h.device)
+        dout = torch.empty((N, P), dtype=dy.dtype, device=h.device)
+        dx = dout[:, HD:2 * HD] if has_res else torch.empty((N, HD), dtype=dy.dtype, device=h.device)
         if epi is None:
             dx.copy_(dy)
         else:
@@ -250,12 +259,20 @@ class _GATHidden(torch.autograd.Function):
         used = c + (2 * H if has_er else H)
         if used < P:
             dout[:, used:].zero_()
-        dW = None
-        if ctx.needs_input_grad[1]:
-            dW = torch.mm(h.t(), dout) if kp else torch.mm(dout.t(), h)
-        dh = None
-        if ctx.needs_input_grad[0]:
-            dh = torch.mm(dout, Wcat.t()) if kp else torch.mm(dout, Wcat)
+        dW = dh = None
+        if ctx.halves is not None:
+            xh = gemm.Halves(h, ctx.xscale, *ctx.halves, 0)
+            dh_ = gemm.split(dout, 0)
+            if ctx.needs_input_grad[1]:
+                dW = gemm.tn(xh, dh_)                                    # [K, P]
+                dW = dW if kp else dW.t().contiguous()
+            if ctx.needs_input_grad[0]:
+                dh = gemm.mm_nt(dh_, gemm.split(Wcat if kp else Wcat.t().contiguous(), 1))
+        else:
+            if ctx.needs_input_grad[1]:
+                dW = torch.mm(h.t(), dout) if kp else torch.mm(dout.t(), h)
+            if ctx.needs_input_grad[0]:
+                dh = torch.mm(dout, Wcat.t()) if kp else torch.mm(dout, Wcat)
         return (dh, dW, d_bn_w if ctx.needs_input_grad[2] else None, d_bn_b if ctx.needs_input_grad[3] else None,
                 None, None, None, None, None, None, None, None, None, None, None, None)
 
@@ -596,6 +613,8 @@ def gat_infer_layer(conv, epi, graph, h, relu, first=False):
         if ctx.store.get("key") != key:                                 # the static columns' share of the projection
             ctx.store["key"], ctx.store["base"] = key, torch.mm(h[:, :F0], Wk[:F0])
         out = torch.addmm(ctx.store["base"], h[:, F0:], Wk[F0:])
+    elif gemm.enabled(h) and h.shape[1] >= 256:                         # fp32 GEMM on the fp16 matrix cores (bot_amd.gemm)
+        out = gemm.mm_nt(gemm.split(h, 0), _cached(conv, "infer_halves", (id(W),), lambda: gemm.split(W.t().contiguous() if WEIGHT_KP else W, 1)))
     else:
         out = torch.mm(h, W) if WEIGHT_KP else torch.mm(h, W.t())       # [N, P] = [ft | res | el | er | pad]
     c = 2 * HD if has_res else HD

@@ -430,7 +430,10 @@ def linear(x, weight, bias=None):
     """`F.linear` for [N, K] inputs whose two all-row reductions are done carefully: the bias gradient (a column sum over N
     rows) runs on the colstats kernel — the stock reduction takes 19 ms for [2 449 029, 47] (S-products classifier,
     ogbn-products/models.py:262), longer than the classifier GEMMs — and the weight gradient goes through `weight_grad`."""
-    y = _MatmulT.apply(x, weight) if x.shape[0] >= SPLITK_MIN_ROWS and torch.is_grad_enabled() else torch.mm(x, weight.t())
+    from . import gemm
+    y = gemm.linear(x, weight)                                          # on the fp16 matrix cores where the shapes pay
+    if y is None:
+        y = _MatmulT.apply(x, weight) if x.shape[0] >= SPLITK_MIN_ROWS and torch.is_grad_enabled() else torch.mm(x, weight.t())
     return y if bias is None else _AddBias.apply(y, bias)
 
 

@@ -413,10 +413,10 @@ int bot_random_keep_u8(int64_t n, int64_t n_keep, uint64_t seed, uint8_t* keep, 
  *
  *   halves_split  out[r, :] = [h1 | h1 | h2] (order 0: left operands) or [h1 | h2 | h1] (order 1: right operands), every piece
  *                 `piece` >= F columns wide (zero padded; use a multiple of 64), out fp16 with row pitch ldo >= 3 * piece
- *   gemm_halves   C[m,n] = alpha[j] * op(A)[m,k] op(B)[k,n], row-major, A / B fp16, C fp32, `alpha` a DEVICE vector of n
+ *   gemm_halves   C[m,n] = alpha[j] * op(A)[m,k] op(B)[k,n] + beta * C[m,n], row-major, A / B fp16, C fp32, `alpha` a DEVICE vector of n
  *                 floats (one per output column; normally n copies of the product of the two operands' 1/s); trans_x != 0: the operand is stored transposed.  batch > 1: strided
  *                 batches (element strides).  tune != 0: the first call per shape times hipBLASLt's candidates on these
- *                 buffers (C is overwritten; beta is 0).  `workspace`: device scratch for hipBLASLt (32 MiB is plenty).
+ *                 buffers (beta == 0 only: C is overwritten).  `workspace`: device scratch for hipBLASLt (32 MiB is plenty).
  * ------------------------------------------------------------------------------------------- */
 int64_t bot_halves_workspace_floats(void);
 int bot_halves_scale_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* scale, float* workspace, bot_stream_t stream);
@@ -424,7 +424,7 @@ int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, cons
                          int64_t ldo, int32_t piece, bot_stream_t stream);
 int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, const float* alpha, const uint16_t* A,
                         int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t batch, int64_t stride_a,
-                        int64_t stride_b, int64_t stride_c, void* workspace, int64_t workspace_bytes, int32_t tune,
+                        int64_t stride_b, int64_t stride_c, float beta, void* workspace, int64_t workspace_bytes, int32_t tune,
                         bot_stream_t stream);
 
 #ifdef __cplusplus
