@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--gemm-tuning", default="file", choices=["file", "off", "tune"],
                     help="file: hipBLASLt/rocBLAS kernel selections from bot_amd/tuning (TunableOp, read-only); "
                          "tune: also time shapes missing from the file and write them to gpurun_out/ (maintenance)")
+    ap.add_argument("--gemm", default=None, choices=["halves", "f32"],
+                    help="dense projections: fp32 operands as two fp16 halves each on the fp16 matrix cores (default, "
+                         "bot_amd/gemm.py) or the stock fp32 GEMM; default: $BOT_GEMM or halves")
     ap.add_argument("--norm-adj", default="rw", choices=["rw", "symm"],
                     help="arxiv only. rw: BASELINE config 2 (run.py:1011-1013); symm: the --norm-adj=symm variant of the same "
                          "command (run.py:1023-1025), reported in config")
@@ -124,7 +127,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from bot_amd import _C, tuning, workloads
+    from bot_amd import _C, gemm, tuning, workloads
+    if args.gemm is not None:
+        gemm.MODE = args.gemm
     tuned = tuning.enable(tune_missing=args.gemm_tuning == "tune") if args.gemm_tuning != "off" else False
     if args.gemm_tuning == "tune":
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -214,7 +219,12 @@ def main():
             "value": wl.n_edges / (ms * 1e-3), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl.describe, "gemm_kernel_selection": "TunableOp file" if tuned else "library default",
+            "config": {"workload": wl.describe,
+                       "gemm": ("fp32 operands as two fp16 halves each (h1 + h2 = 22-23 of the 24 significand bits, power-of-two scale found "
+                                "on the device), a1 b1 + a1 b2 + a2 b1 as one fp16 MFMA GEMM with fp32 accumulation; error against fp64 equal "
+                                "to the stock fp32 GEMM's (tests/test_gpu_parity.py::test_gemm_halves_against_fp64); --gemm f32 = stock fp32")
+                       if gemm.MODE == "halves" else "stock fp32 GEMM (hipBLASLt / rocBLAS)",
+                       "gemm_kernel_selection": "TunableOp file" if tuned else "library default",
                        "scale": args.scale, "launch": "one hipGraph replay per step" if wl.captured else "eager",
                        "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world} ({args.partitioner} ranges)"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
