@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -78,6 +78,9 @@ _SIGS = {
     "bot_colstats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
     "bot_colsum_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
     "bot_bn_stats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "bot_bn_stats_halves_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "bot_bn_act_fwd_halves_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, _P, c_int64,
+                                                 _P, _P, c_int64, c_int32, _P]),
     "bot_bn_act_fwd_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, _P, c_int64, _P]),
     "bot_bn_act_bwd_reduce_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
                                                  c_uint64, _P, _P, _P, _P, _P]),
@@ -647,12 +650,35 @@ def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_
     return mean, invstd
 
 
-def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed):
-    """y = dropout_p(relu?((x - mean) * invstd * weight + bias)); Philox mask from `seed`."""
+def bn_stats_halves(x, eps, momentum, running_mean, running_var, num_batches_tracked, weight, bias, p):
+    """bn_stats plus hscale [2] = (s, 1/s) bounding the epilogue's output (include/bot_gnn.h bot_bn_stats_halves_f32)."""
+    _dev(x, running_mean, running_var, weight, bias)
+    x = _mat(x, "x")
+    n, F = x.shape
+    mean = torch.empty(F, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(F, dtype=torch.float32, device=x.device)
+    hscale = torch.empty(2, dtype=torch.float32, device=x.device)
+    _check(_lib.bot_bn_stats_halves_f32(x.data_ptr(), x.stride(0), n, F, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
+                                        _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(weight), _ptr(bias),
+                                        float(p), hscale.data_ptr(), _bn_ws(F, x.device).data_ptr(), _stream()), "bn_stats_halves")
+    return mean, invstd, hscale
+
+
+def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=None):
+    """y = dropout_p(relu?((x - mean) * invstd * weight + bias)); Philox mask from `seed`.
+    halves = (hscale [2], piece): also returns y's fp16 halves [n, 3 * piece] scaled by hscale[0] -> (y, buf)."""
     _dev(x, mean, invstd)
     x = _mat(x, "x")
     n, F = x.shape
     y = torch.empty((n, F), dtype=torch.float32, device=x.device)
+    if halves is not None:
+        hscale, piece = halves
+        buf = torch.empty((n, 3 * piece), dtype=torch.float16, device=x.device)
+        _check(_timed("bn_act_fwd", (F,), lambda: _lib.bot_bn_act_fwd_halves_f32(
+            x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p),
+            int(seed), _seed_off(p), y.data_ptr(), y.stride(0), hscale.data_ptr(), buf.data_ptr(), buf.stride(0), piece, _stream())),
+            "bn_act_fwd_halves")
+        return y, buf
     _check(_timed("bn_act_fwd", (F,), lambda: _lib.bot_bn_act_fwd_f32(
         x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p),
         int(seed), _seed_off(p), y.data_ptr(), y.stride(0), _stream())), "bn_act_fwd")

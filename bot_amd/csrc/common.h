@@ -9,7 +9,9 @@
 namespace bot {
 
 void set_error(const char* fmt, ...);
-void set_kernel(const char* fmt, ...);  // name of the main device kernel a launch function dispatched (bot_last_kernel)
+void set_kernel(const char* fmt, ...);
+// scale[0] = 2^(14 - ceil(log2 max_i part[i])), scale[1] = 1 / scale[0]  (halves.hip; part: n non-negative floats on the device)
+void launch_halves_scale(const float* part, int n, float* scale, hipStream_t st);  // name of the main device kernel a launch function dispatched (bot_last_kernel)
 
 inline int hip_status(const char* what) {
     hipError_t e = hipGetLastError();

@@ -15,6 +15,8 @@
 // The split at the column statistics is deliberate: in the vertex-partitioned mode the (mean, M2, count) triples
 // and the (sum_g, sum_gx) pairs are what gets all-reduced between the two kernels.
 // HBM roofline: algorithmic bytes = 4*n*F * {1 (stats), 2 (fwd), 2 (bwd reduce), 3 (bwd apply)}.
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace bot {
@@ -97,6 +99,10 @@ struct BnArgs {
     uint64_t seed;
     const uint64_t* seed_offset;  // optional device word mixed into the seed at run time (hipGraph replays: see eff_seed)
     // fwd
+    __half* hout;          // optional: the output also as fp16 halves [h1 | h1 | h2] (halves.hip), scaled by hscale[0]
+    int64_t ldh;
+    int32_t piece;
+    const float* hscale;
     float* y;
     int64_t ldy;
     // bwd
@@ -114,14 +120,14 @@ struct BnArgs {
 // part[rb][0][c] = sum_{rows of block rb} (x - pivot_c),  part[rb][1][c] = sum (x - pivot_c)^2,  pivot = x[0,c]
 template <int VEC>
 __global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float* x, int64_t ldx, int64_t n, int32_t F, float* part,
-                                                                   bool wx, bool pivot) {
+                                                                   bool wx, bool pivot, float* minmax = nullptr) {
     __shared__ float lds[2][kTY][kTX * VEC];
     const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
     const int c = (blockIdx.x * kTX + tx) * VEC;
     const int nv = min(VEC, F - c);
-    float s[VEC], q[VEC], piv[VEC];
+    float s[VEC], q[VEC], piv[VEC], mn[VEC], mx[VEC];
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) s[t] = q[t] = 0.f;
+    for (int t = 0; t < VEC; ++t) s[t] = q[t] = 0.f, mn[t] = INFINITY, mx[t] = -INFINITY;
     if (c < F) {
         load_cols<VEC>(piv, x + c, wx, nv);
         if (!pivot) {   // plain sums (colsum): a pivot far from the column mean would only inflate the partial sums
@@ -137,6 +143,7 @@ __global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float*
                 const float d = v[t] - piv[t];
                 s[t] += d;
                 q[t] = fmaf(d, d, q[t]);
+                mn[t] = fminf(mn[t], v[t]), mx[t] = fmaxf(mx[t], v[t]);
             }
         }
     }
@@ -154,6 +161,34 @@ __global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float*
             part[((int64_t)blockIdx.y * 2 + 1) * F + c + t] = b;
         }
     }
+    if (minmax) {   // per-column extremes of the rows of this block (the caller bounds the BatchNorm output with them)
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) lds[0][ty][tx * VEC + t] = mn[t], lds[1][ty][tx * VEC + t] = mx[t];
+        __syncthreads();
+        if (ty == 0 && c < F) {
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                if (t >= nv) break;
+                float a = lds[0][0][tx * VEC + t], b = lds[1][0][tx * VEC + t];
+#pragma unroll
+                for (int j = 1; j < kTY; ++j) a = fminf(a, lds[0][j][tx * VEC + t]), b = fmaxf(b, lds[1][j][tx * VEC + t]);
+                minmax[((int64_t)blockIdx.y * 2 + 0) * F + c + t] = a;
+                minmax[((int64_t)blockIdx.y * 2 + 1) * F + c + t] = b;
+            }
+        }
+    }
+}
+
+// bound[c] >= max_r |dropout(relu?(BatchNorm(x)))[r, c]| from the column extremes:  (|w| max(|max - mean|, |min - mean|) invstd + |b|) / (1 - p)
+__global__ __launch_bounds__(kBlock) void bn_bound_kernel(int32_t F, const float* minmax, int nblk, const float* mean, const float* invstd,
+                                                         const float* w, const float* b, float p, float* bound) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= F) return;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int k = 0; k < nblk; ++k) mn = fminf(mn, minmax[((int64_t)k * 2 + 0) * F + c]), mx = fmaxf(mx, minmax[((int64_t)k * 2 + 1) * F + c]);
+    const float dev = fmaxf(fabsf(mx - mean[c]), fabsf(mn - mean[c])) * invstd[c];
+    bound[c] = (fabsf(w ? w[c] : 1.f) * dev + fabsf(b ? b[c] : 0.f)) / (1.f - p);
 }
 
 // Second stage of the column reductions: 64 columns x 4 row-groups per workgroup; group g adds the partials
@@ -211,8 +246,20 @@ template <int VEC>
 __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
     const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
     const int c = (blockIdx.x * kTX + tx) * VEC;
+    if constexpr (VEC == 4) {
+        if (a.hout && c >= a.F) {   // zero padding of the three pieces
+            if (c < a.piece)
+                for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < a.n; r += (int64_t)gridDim.y * kTY) {
+                    __half* o = a.hout + r * a.ldh + c;
+                    const uint2 z = make_uint2(0u, 0u);
+                    *reinterpret_cast<uint2*>(o) = z, *reinterpret_cast<uint2*>(o + a.piece) = z, *reinterpret_cast<uint2*>(o + 2 * (int64_t)a.piece) = z;
+                }
+            return;
+        }
+    }
     if (c >= a.F) return;
     const int nv = min(VEC, a.F - c);
+    const float hs = a.hout ? a.hscale[0] : 1.f;
     float mu[VEC], sc[VEC], sh[VEC], wv[VEC];
     load_param<VEC>(mu, a.mean, c, a.F, 0.f);
     load_param<VEC>(sc, a.invstd, c, a.F, 0.f);
@@ -246,6 +293,20 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
                 v[u][t] = o;
             }
             store_cols<VEC>(a.y + r * a.ldy + c, v[u], a.wy, nv);
+            if constexpr (VEC == 4) {
+                if (a.hout) {
+                    __half h1[4], h2[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float z = t < nv ? v[u][t] * hs : 0.f;
+                        h1[t] = __float2half_rn(z);
+                        h2[t] = __float2half_rn(z - __half2float(h1[t]));
+                    }
+                    __half* o = a.hout + r * a.ldh + c;
+                    const uint2 hi = *reinterpret_cast<const uint2*>(h1), lo = *reinterpret_cast<const uint2*>(h2);
+                    *reinterpret_cast<uint2*>(o) = hi, *reinterpret_cast<uint2*>(o + a.piece) = hi, *reinterpret_cast<uint2*>(o + 2 * (int64_t)a.piece) = lo;
+                }
+            }
         }
     }
 }
@@ -386,7 +447,7 @@ static dim3 bn_grid(int32_t F, int vec, int64_t n) {
 
 extern "C" {
 
-int64_t bot_bn_workspace_floats(int32_t F) { return (int64_t)bot::kRowBlocks * 2 * F; }
+int64_t bot_bn_workspace_floats(int32_t F) { return (int64_t)bot::kRowBlocks * 4 * F + F; }   // sums, extremes, bounds (bn_stats_halves)
 
 int bot_colstats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* mean, float* m2, float* workspace,
                      bot_stream_t stream) {
@@ -443,9 +504,36 @@ int bot_bn_stats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float ep
     return hip_status("bn_stats launch");
 }
 
-int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
-                       const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
-                       const uint64_t* seed_offset, float* y, int64_t ldy, bot_stream_t stream) {
+int bot_bn_stats_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float eps, float momentum, float* mean, float* invstd,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* weight,
+                            const float* bias, float p, float* hscale, float* workspace, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 1 && F >= 1 && ldx >= F, BOT_E_RANGE, "bn_stats_halves: n=%lld F=%d ldx=%lld", (long long)n, F, (long long)ldx);
+    BOT_REQUIRE(x && mean && invstd && workspace && hscale, BOT_E_NULL, "bn_stats_halves: NULL pointer");
+    BOT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), BOT_E_NULL, "bn_stats_halves: running_mean and running_var go together");
+    BOT_REQUIRE(eps >= 0.f && momentum >= 0.f && momentum <= 1.f && p >= 0.f && p < 1.f, BOT_E_RANGE, "bn_stats_halves: eps=%f momentum=%f p=%f",
+                (double)eps, (double)momentum, (double)p);
+    hipStream_t st = (hipStream_t)stream;
+    bool quad;
+    const int vec = bn_vec(F, {ldx}, {x}, &quad);
+    const bool wx = !quad || rows16(x, ldx);
+    const dim3 grid = bn_grid(F, vec, n);
+    float* minmax = workspace + (int64_t)kRowBlocks * 2 * F;     // [row block][min, max][F]
+    float* bound = workspace + (int64_t)kRowBlocks * 4 * F;      // [F]
+    if (vec == 4) hipLaunchKernelGGL((colstats_partial_kernel<4>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, wx, true, minmax);
+    else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true, true, minmax);
+    else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true, true, minmax);
+    hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
+                       mean, (float*)nullptr, invstd, eps, momentum, running_mean, running_var, num_batches_tracked);
+    hipLaunchKernelGGL(bn_bound_kernel, dim3((F + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F, minmax, (int)grid.y, mean, invstd, weight, bias, p, bound);
+    launch_halves_scale(bound, F, hscale, st);
+    return hip_status("bn_stats_halves launch");
+}
+
+static int bn_act_fwd_impl(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
+                           const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
+                           const uint64_t* seed_offset, float* y, int64_t ldy, const float* hscale, uint16_t* hout, int64_t ldh,
+                           int32_t piece, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && ldy >= F, BOT_E_RANGE, "bn_act_fwd: n=%lld F=%d", (long long)n, F);
     BOT_REQUIRE(p >= 0.f && p < 1.f, BOT_E_RANGE, "bn_act_fwd: dropout p=%f must be in [0,1)", (double)p);
@@ -454,8 +542,16 @@ int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const 
     BnArgs a{};
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
     a.seed = seed, a.seed_offset = seed_offset, a.y = y, a.ldy = ldy;
+    a.hout = reinterpret_cast<__half*>(hout), a.ldh = ldh, a.piece = piece, a.hscale = hscale;
     bool quad;
     const int vec = bn_vec(F, {ldx, ldy}, {x, y}, &quad);
+    if (hout) {
+        BOT_REQUIRE(hscale, BOT_E_NULL, "bn_act_fwd_halves: NULL scale");
+        BOT_REQUIRE(vec == 4 && piece >= F && piece % 4 == 0 && piece <= (int64_t)((F + kTX * 4 - 1) / (kTX * 4)) * kTX * 4 && ldh >= 3 * (int64_t)piece &&
+                        ldh % 4 == 0 && aligned(hout, 8),
+                    BOT_E_ALIGN, "bn_act_fwd_halves: needs the 4-column form (even F, 8-byte aligned rows) and piece = F rounded up to x64 "
+                                 "(F=%d piece=%d ldh=%lld)", F, piece, (long long)ldh);
+    }
     a.wx = !quad || rows16(x, ldx), a.wy = !quad || rows16(y, ldy);
     const dim3 grid = bn_grid(F, vec, n);
     hipStream_t st = (hipStream_t)stream;
@@ -463,6 +559,20 @@ int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const 
     else if (vec == 2) hipLaunchKernelGGL((bn_act_fwd_kernel<2>), grid, dim3(kTX * kTY), 0, st, a);
     else hipLaunchKernelGGL((bn_act_fwd_kernel<1>), grid, dim3(kTX * kTY), 0, st, a);
     return hip_status("bn_act_fwd launch");
+}
+
+int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
+                       const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
+                       const uint64_t* seed_offset, float* y, int64_t ldy, bot_stream_t stream) {
+    return bn_act_fwd_impl(x, ldx, n, F, mean, invstd, weight, bias, relu, p, seed, seed_offset, y, ldy, nullptr, nullptr, 0, 0, stream);
+}
+
+int bot_bn_act_fwd_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
+                              const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
+                              const uint64_t* seed_offset, float* y, int64_t ldy, const float* hscale, uint16_t* hout, int64_t ldh,
+                              int32_t piece, bot_stream_t stream) {
+    BOT_REQUIRE(hout, BOT_E_NULL, "bn_act_fwd_halves: NULL output");
+    return bn_act_fwd_impl(x, ldx, n, F, mean, invstd, weight, bias, relu, p, seed, seed_offset, y, ldy, hscale, hout, ldh, piece, stream);
 }
 
 int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,

@@ -89,6 +89,10 @@ __global__ __launch_bounds__(128) void halves_split_kernel(const float* x, int64
     *reinterpret_cast<__half2*>(o + 2 * (int64_t)piece) = ORDER == 0 ? lo : hi;
 }
 
+void launch_halves_scale(const float* part, int n, float* scale, hipStream_t st) {
+    hipLaunchKernelGGL(halves_scale_kernel, dim3(1), dim3(kWave), 0, st, part, n, scale);
+}
+
 }  // namespace bot
 
 extern "C" {
@@ -103,7 +107,7 @@ int bot_halves_scale_f32(const float* x, int64_t ldx, int64_t n, int32_t F, floa
     const int64_t total = n * (int64_t)F;
     const int blocks = (int)max((int64_t)1, min((int64_t)kMaxBlocks, (total + kBlock * 8 - 1) / (kBlock * 8)));
     hipLaunchKernelGGL(absmax_partial_kernel, dim3(blocks), dim3(kBlock), 0, st, x, ldx, n, F, workspace);
-    hipLaunchKernelGGL(halves_scale_kernel, dim3(1), dim3(kWave), 0, st, workspace, blocks, scale);
+    launch_halves_scale(workspace, blocks, scale, st);
     return hip_status("halves_scale launch");
 }
 

@@ -42,6 +42,30 @@ def split(x, order: int) -> Halves:
     return Halves(_C.halves_split(x, scale, order, piece), scale, n, F, piece, order)
 
 
+_STASH = {}
+
+
+def stash(y, h: Halves):
+    """The halves of `y` were produced together with it (fused BatchNorm epilogue): the next projection takes them from here
+    instead of splitting y again.  One entry at a time per tensor identity; consumed by `take`."""
+    _STASH.clear()
+    _STASH[(y.data_ptr(), y._version, tuple(y.shape))] = h
+
+
+def take(x, order: int):
+    h = _STASH.pop((x.data_ptr(), x._version, tuple(x.shape)), None)
+    if h is not None and h.order == order:
+        return h
+    return split(x, order)
+
+
+def epilogue_piece(F: int, x) -> int | None:
+    """Piece width for halves written by the BatchNorm epilogue of a [n, F] tensor, None when the fused form does not apply."""
+    if MODE != "halves" or not x.is_cuda or x.shape[0] < MIN_ROWS or F % 2 or x.stride(0) % 2:
+        return None
+    return (F + PIECE_ALIGN - 1) // PIECE_ALIGN * PIECE_ALIGN
+
+
 def _alpha(a: Halves, b: Halves):
     return a.scale[1:] * b.scale[1:]
 

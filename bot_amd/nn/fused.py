@@ -144,6 +144,23 @@ def _extend_backward(graph, dext, n_own):
     return own
 
 
+def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p):
+    """BatchNorm statistics + the fused BatchNorm / ReLU / dropout pass.  When the next projection runs on fp16 halves
+    (bot_amd.gemm) the pass writes them too and the scale comes from the statistics pass: y is not read again before its GEMM."""
+    HD = x.shape[1]
+    piece = gemm.epilogue_piece(HD, x) if bn_training else None
+    seed = new_dropout_seed(drop_p)
+    if piece is not None:
+        mean, invstd, total, sync, group, hscale = bn_batch_stats(x, bn, bn_training, halves_p=drop_p)
+        if hscale is not None:
+            y, buf = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed, halves=(hscale, piece))
+            gemm.stash(y, gemm.Halves(buf, hscale, x.shape[0], HD, piece, 0))
+            return y, mean, invstd, total, sync, group, seed
+    else:
+        mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
+    return _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed), mean, invstd, total, sync, group, seed
+
+
 class _GATHidden(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, Wcat, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp, sym):
@@ -153,7 +170,7 @@ class _GATHidden(torch.autograd.Function):
         ctx.kp = kp                                                     # Wcat is [K, P] (see WEIGHT_KP) instead of [P, K]
         xh = None
         if gemm.enabled(h):                                             # fp32 GEMM on the fp16 matrix cores (bot_amd.gemm)
-            xh = gemm.split(h, 0)
+            xh = gemm.take(h, 0)                                        # written by the previous layer's epilogue, or split here
             out = gemm.mm_nt(xh, gemm.split(Wcat.t().contiguous() if kp else Wcat, 1))
         else:
             out = torch.mm(h, Wcat) if kp else torch.mm(h, Wcat.t())    # [N, P] = [ft | res | el | er | pad]
@@ -195,9 +212,7 @@ class _GATHidden(torch.autograd.Function):
             ctx.save_for_backward(*keep)
             ctx.cfg = (H, D, has_res, has_er, slope, None)
             return x
-        mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
-        seed = new_dropout_seed(drop_p)
-        y = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
+        y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p)
         ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
         ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
         return y
@@ -369,9 +384,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             ctx.save_for_backward(*keep)
             ctx.cfg = (H, D, has_res, has_er, slope, None)
             return x
-        mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
-        seed = new_dropout_seed(drop_p)
-        y = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
+        y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p)
         ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
         ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
         return y

@@ -282,22 +282,30 @@ def _dist_group(bn):
     return False, None
 
 
-def bn_batch_stats(x, bn, bn_training):
+def bn_batch_stats(x, bn, bn_training, halves_p=None):
     """Column statistics for the fused epilogue: (mean, invstd, total_count, sync, group); updates bn's running statistics
     exactly like nn.BatchNorm1d (momentum, unbiased running variance).  In partitioned mode the (count, mean, M2) triples of
-    the ranks are merged with Chan et al.'s pairwise formula through two small all-reduces."""
+    the ranks are merged with Chan et al.'s pairwise formula through two small all-reduces.
+    `halves_p` (the epilogue's dropout rate) asks for a sixth value: the fp16-halves scale of the epilogue's output, derived
+    from the column extremes in the same pass (bot_bn_stats_halves_f32) — None where that call does not apply (partitioned
+    statistics, eval mode)."""
     import torch.distributed as dist
     n = x.shape[0]
     sync, group = _dist_group(bn)
     total = float(n)
+    extra = () if halves_p is None else (None,)
     if not bn_training:
-        return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps), total, sync, group
+        return (bn.running_mean, torch.rsqrt(bn.running_var + bn.eps), total, sync, group) + extra
     if not sync and (bn.momentum is not None or not bn.track_running_stats):
         # one GPU: statistics, invstd and the running-statistics update in ONE call (nine elementwise launches per layer before)
         track = bn.track_running_stats
+        args = (x, bn.eps, bn.momentum if track else 0.0, bn.running_mean if track else None, bn.running_var if track else None,
+                bn.num_batches_tracked if track else None)
         with torch.no_grad():
-            mean, invstd = _C.bn_stats(x, bn.eps, bn.momentum if track else 0.0, bn.running_mean if track else None,
-                                       bn.running_var if track else None, bn.num_batches_tracked if track else None)
+            if halves_p is not None:
+                mean, invstd, hscale = _C.bn_stats_halves(*args, bn.weight, bn.bias, halves_p)
+                return mean, invstd, total, sync, group, hscale
+            mean, invstd = _C.bn_stats(*args)
         return mean, invstd, total, sync, group
     mean, m2 = _C.colstats(x)
     if sync:
@@ -324,7 +332,7 @@ def bn_batch_stats(x, bn, bn_training):
             mom = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
             bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
             bn.running_var.mul_(1 - mom).add_(m2 / max(total - 1.0, 1.0), alpha=mom)
-    return mean, invstd, total, sync, group
+    return (mean, invstd, total, sync, group) + extra
 
 
 def random_edge_keep(graph, drop):

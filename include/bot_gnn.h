@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 5
+#define BOT_ABI_VERSION 6
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -350,6 +350,18 @@ int bot_bn_stats_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float ep
 int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
                        const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
                        const uint64_t* seed_offset, float* y, int64_t ldy, bot_stream_t stream);
+/* The same two calls when the epilogue's output is the next layer's GEMM operand (fp16 halves, see bot_gemm_halves_f32 below):
+ * bn_stats_halves also tracks the column extremes and derives hscale = (s, 1/s) from the bound
+ * max_c (|weight_c| max(|max_c - mean_c|, |min_c - mean_c|) invstd_c + |bias_c|) / (1 - p) >= max |y| — no pass over y;
+ * bn_act_fwd_halves writes y AND its halves [h1 | h1 | h2] (pieces of `piece` = F rounded up to x64 columns, zero padded), so the
+ * separate halves_scale / halves_split passes over y disappear.  Needs the 4-column form (even F, 8-byte aligned rows). */
+int bot_bn_stats_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float eps, float momentum, float* mean, float* invstd,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* weight,
+                            const float* bias, float p, float* hscale, float* workspace, bot_stream_t stream);
+int bot_bn_act_fwd_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
+                              const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
+                              const uint64_t* seed_offset, float* y, int64_t ldy, const float* hscale, uint16_t* hout, int64_t ldh,
+                              int32_t piece, bot_stream_t stream);
 int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
                               const float* mean, const float* invstd, const float* weight, const float* bias,
                               int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, float* sum_g, float* sum_gx,

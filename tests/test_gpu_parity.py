@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 5
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 6
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
@@ -1156,3 +1156,27 @@ def test_gemm_halves_against_fp64():
     # zeros and a single huge entry
     z = gemm.split(torch.zeros(9000, 64, device=DEV), 0)
     assert float(z.scale[0]) == 1.0 and not z.buf.any()
+
+
+def test_bn_epilogue_writes_halves():
+    """bot_bn_stats_halves_f32 + bot_bn_act_fwd_halves_f32: the same y as the plain epilogue (bit for bit), the scale bounds max|y|
+    (derived from the column extremes, no pass over y), and the halves buffer equals halves_split of y at that scale, padding
+    zeroed; strided input rows (pitch 752) and a ragged last quad (F = 750)."""
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    for n, F, ld, p in ((20001, 750, 752, 0.75), (9000, 256, 256, 0.0), (8200, 120, 120, 0.5)):
+        x = torch.randn(n, ld, device=DEV, generator=gen)[:, :F] * 3 + 0.5
+        w = torch.randn(F, device=DEV, generator=gen)
+        b = torch.randn(F, device=DEV, generator=gen)
+        rm, rv, nbt = torch.zeros(F, device=DEV), torch.ones(F, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+        mean, invstd, hscale = _C.bn_stats_halves(x, 1e-5, 0.1, rm, rv, nbt, w, b, p)
+        mean2, invstd2 = _C.bn_stats(x, 1e-5, 0.0)
+        assert torch.equal(mean, mean2) and torch.equal(invstd, invstd2) and int(nbt) == 1
+        piece = (F + 63) // 64 * 64
+        y, buf = _C.bn_act_fwd(x, mean, invstd, w, b, True, p, 1234, halves=(hscale, piece))
+        y2 = _C.bn_act_fwd(x, mean, invstd, w, b, True, p, 1234)
+        assert torch.equal(y, y2)
+        s = float(hscale[0])
+        assert float(hscale[0] * hscale[1]) == 1.0 and float(y.abs().max()) * s <= 2.0 ** 14 * (1 + 1e-6)
+        assert float(y.abs().max()) * s > 2.0 ** 5                     # the bound is not absurdly loose
+        ref = _C.halves_split(y, hscale, 0, piece)
+        assert torch.equal(buf, ref)
