@@ -43,6 +43,7 @@ def split(x, order: int) -> Halves:
 
 
 _STASH = {}
+STATS = {"stashed": 0, "taken": 0, "split": 0}   # how often an epilogue's halves were reused (tests, tools)
 
 
 def stash(y, h: Halves):
@@ -50,12 +51,15 @@ def stash(y, h: Halves):
     instead of splitting y again.  One entry at a time per tensor identity; consumed by `take`."""
     _STASH.clear()
     _STASH[(y.data_ptr(), y._version, tuple(y.shape))] = h
+    STATS["stashed"] += 1
 
 
 def take(x, order: int):
     h = _STASH.pop((x.data_ptr(), x._version, tuple(x.shape)), None)
     if h is not None and h.order == order:
+        STATS["taken"] += 1
         return h
+    STATS["split"] += 1
     return split(x, order)
 
 
@@ -111,7 +115,7 @@ class _Matmul(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, kp):
-        xh = split(x, 0)
+        xh = take(x, 0)
         ctx.kp, ctx.meta = kp, (xh.n, xh.F, xh.piece)
         ctx.save_for_backward(xh.buf, xh.scale, w)
         return mm_nt(xh, split(w.t().contiguous() if kp else w, 1))

@@ -53,11 +53,12 @@ def degree_norm(graph, which: str, power: float) -> torch.Tensor:
     return c[key]
 
 
-def _epilogue(h, norm, activation, dropout, training):
+def _epilogue(h, norm, activation, dropout, training, halves=False):
     """`dropout(activation(norm(h)))` — models.py:636-639 / :726-731.  BatchNorm1d + ReLU (+ dropout) run as the
-    fused HIP epilogue (2 reads + 1 write instead of ~10 round trips); other activations take the stock ops."""
+    fused HIP epilogue (2 reads + 1 write instead of ~10 round trips); other activations take the stock ops.
+    `halves`: the result feeds a projection that runs on fp16 halves (bot_amd.gemm): write them in the same pass."""
     if isinstance(norm, nn.BatchNorm1d) and activation in (F.relu, torch.relu) and h.dim() == 2:
-        return ops.bn_relu_dropout(h, norm, relu=True, p=dropout.p, training=training)
+        return ops.bn_relu_dropout(h, norm, relu=True, p=dropout.p, training=training, halves=halves)
     return dropout(activation(norm(h)))
 
 

@@ -198,7 +198,7 @@ class _EdgeGAT(nn.Module):
             if residual and h_last is not None:
                 h = h + h_last[: h.shape[0], :]
             h_last = h
-            h = _epilogue(h, self.norms[i], self.activation, self.dropout, self.training)  # BatchNorm + ReLU + dropout, fused
+            h = _epilogue(h, self.norms[i], self.activation, self.dropout, self.training, halves=True)  # BatchNorm + ReLU + dropout (+ the next GEMM's operand), fused
         return g.to_original(ops.linear(h, self.pred_linear.weight, self.pred_linear.bias))
 
 

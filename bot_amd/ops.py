@@ -349,10 +349,20 @@ def new_dropout_seed(p):
 
 class _BNActDrop(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, bn, relu, p, bn_training):
-        mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
+    def forward(ctx, x, weight, bias, bn, relu, p, bn_training, halves=False):
+        from . import gemm
         seed = new_dropout_seed(p)
-        y = _C.bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed)
+        piece = gemm.epilogue_piece(x.shape[1], x) if halves and bn_training else None
+        hscale = None
+        if piece is not None:
+            mean, invstd, total, sync, group, hscale = bn_batch_stats(x, bn, bn_training, halves_p=p)
+        else:
+            mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
+        if hscale is not None:       # the next projection's fp16 halves written by this pass (bot_amd.gemm.take picks them up)
+            y, buf = _C.bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=(hscale, piece))
+            gemm.stash(y, gemm.Halves(buf, hscale, x.shape[0], x.shape[1], piece, 0))
+        else:
+            y = _C.bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed)
         ctx.save_for_backward(x, mean, invstd, weight, bias)
         ctx.cfg = (relu, p, seed, bn_training, sync, group, total)
         return y
@@ -376,7 +386,7 @@ class _BNActDrop(torch.autograd.Function):
                 dx = _C.bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sg, sgx, total)
             else:
                 dx = _C.bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, None, None, total)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class _AddBias(torch.autograd.Function):
@@ -445,7 +455,7 @@ def linear(x, weight, bias=None):
     return y if bias is None else _AddBias.apply(y, bias)
 
 
-def bn_relu_dropout(x, bn, *, relu=True, p=0.0, training=False):
+def bn_relu_dropout(x, bn, *, relu=True, p=0.0, training=False, halves=False):
     """`dropout(relu(bn(x)))` over the node axis in 2 reads + 1 write (models.py:636-639, :726-731).
 
     `bn` is the layer's nn.BatchNorm1d (its parameters, running statistics and train/eval state are used and
@@ -453,4 +463,4 @@ def bn_relu_dropout(x, bn, *, relu=True, p=0.0, training=False):
     w = bn.weight if bn.affine else None
     b = bn.bias if bn.affine else None
     bn_training = bn.training or not bn.track_running_stats
-    return _BNActDrop.apply(x, w, b, bn, bool(relu), float(p) if training else 0.0, bn_training)
+    return _BNActDrop.apply(x, w, b, bn, bool(relu), float(p) if training else 0.0, bn_training, bool(halves))

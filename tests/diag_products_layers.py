@@ -19,8 +19,8 @@ for i, conv in enumerate(model.convs):
 from bot_amd.nn import edge_gat
 orig = edge_gat._epilogue
 cnt = [0]
-def epi(h, norm, activation, dropout, training):
-    y = orig(h, norm, activation, dropout, training)
+def epi(h, norm, activation, dropout, training, **kw):
+    y = orig(h, norm, activation, dropout, training, **kw)
     hip[("act", cnt[0])] = y.detach().cpu(); cnt[0] += 1
     return y
 edge_gat._epilogue = epi

@@ -108,8 +108,8 @@ def tap_kinks():
     relu_taps, leaky_taps = [], []
     orig_e, orig_f, orig_a = bnn._epilogue, fused.gat_hidden_layer, _C.gat_attn_fwd
 
-    def epi(h, norm, activation, dropout, training):
-        y = orig_e(h, norm, activation, dropout, training)
+    def epi(h, norm, activation, dropout, training, **kw):
+        y = orig_e(h, norm, activation, dropout, training, **kw)
         relu_taps.append((y.detach() > 0).to(torch.uint8).cpu())
         return y
 
