@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kWave) void halves_scale_kernel(const float* part, 
             int e;
             const float f = frexpf(m, &e);          // m = f * 2^e, f in [0.5, 1)
             if (f == 0.5f) e -= 1;                  // exact power of two: ceil(log2 m) = e - 1
-            s = ldexpf(1.f, 14 - e);
+            s = ldexpf(1.f, min(60, 14 - e));   // clamped for tiny tensors: 1/s and the product of two of them stay normal fp32 numbers
         }
         scale[0] = s;
         scale[1] = 1.f / s;

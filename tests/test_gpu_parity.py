@@ -1153,9 +1153,17 @@ def test_gemm_halves_against_fp64():
             e, e32 = float((got.double() - ref).abs().max() / scale), float((stock.double() - ref).abs().max() / scale)
             print(f"gemm_halves {name} n={n} K={K} P={P}: err {e:.2e} (stock fp32 {e32:.2e})")
             assert got.shape == ref.shape and e <= max(4e-6, 3 * e32), (name, e, e32)
-    # zeros and a single huge entry
+    # zeros, magnitudes beyond the clamp of the scale's exponent, non-finite entries
     z = gemm.split(torch.zeros(9000, 64, device=DEV), 0)
     assert float(z.scale[0]) == 1.0 and not z.buf.any()
+    for mag, want in ((1e-30, 2.0 ** 60), (1e30, 2.0 ** -86)):
+        t = gemm.split(torch.full((9000, 64), mag, device=DEV), 0)
+        assert float(t.scale[0]) == want and float(t.scale[0] * t.scale[1]) == 1.0 and bool(torch.isfinite(t.buf.float()).all())
+    bad = torch.ones(9000, 64, device=DEV)
+    bad[5, 5] = float("inf")
+    assert float(gemm.split(bad, 0).scale[0]) == 1.0
+    w = torch.randn(64, 64, device=DEV)
+    assert not bool(torch.isfinite(gemm.mm_nt(gemm.split(bad, 0), gemm.split(w, 1))[5]).any())   # poisons its row like fp32 would
 
 
 def test_bn_epilogue_writes_halves():
