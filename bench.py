@@ -159,6 +159,29 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
 
+    # ---- the same K steps once more with the stock fp32 GEMMs (outside the timed region above; reported beside `value` so that
+    # both numbers come from one process, one graph, one set of weights)
+    stock = None
+    if gemm.MODE == "halves" and args.gemm is None and not wl.captured:
+        gemm.MODE = "f32"
+        for _ in range(max(2, args.warmup)):
+            wl.step()
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step()
+        torch.cuda.synchronize()
+        barrier()
+        dt1 = time.perf_counter() - t1
+        gemm.MODE = "halves"
+        if partitioned:
+            t = torch.tensor([dt1], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt1 = float(t.item())
+        stock = {"ms_per_step": dt1 / args.steps * 1e3, "value": wl.n_edges / (dt1 / args.steps), "unit": "edges/s",
+                 "what": "the same steps with every projection on the stock fp32 GEMM (--gemm f32)"}
+
     # ---- roofline of the dominant kernel: the SpMM of the hidden layers' shape (forward CSC sweep; for the dense graphs the
     # L2-blocked form), HIP events recorded around each launch on the launch stream inside the timed region.
     H, D, weighted = wl.dominant_shape
@@ -227,7 +250,7 @@ def main():
                        "gemm_kernel_selection": "TunableOp file" if tuned else "library default",
                        "scale": args.scale, "launch": "one hipGraph replay per step" if wl.captured else "eager",
                        "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world} ({args.partitioner} ranges)"},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "stock_fp32_gemm": stock,
         }
     if partitioned:
         torch.distributed.destroy_process_group()
