@@ -183,10 +183,19 @@ __global__ __launch_bounds__(kTX* kTY) void colstats_partial_kernel(const float*
 // bound[c] >= max_r |dropout(relu?(BatchNorm(x)))[r, c]| from the column extremes:  (|w| max(|max - mean|, |min - mean|) invstd + |b|) / (1 - p)
 __global__ __launch_bounds__(kBlock) void bn_bound_kernel(int32_t F, const float* minmax, int nblk, const float* mean, const float* invstd,
                                                          const float* w, const float* b, float p, float* bound) {
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= F) return;
+    // 64 columns x 4 row-block groups per workgroup: group g folds the partials g, g+4, ... (independent loads, unrolled)
+    __shared__ float lds[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float mn = INFINITY, mx = -INFINITY;
-    for (int k = 0; k < nblk; ++k) mn = fminf(mn, minmax[((int64_t)k * 2 + 0) * F + c]), mx = fmaxf(mx, minmax[((int64_t)k * 2 + 1) * F + c]);
+    if (c < F) {
+#pragma unroll 8
+        for (int k = grp; k < nblk; k += 4) mn = fminf(mn, minmax[((int64_t)k * 2 + 0) * F + c]), mx = fmaxf(mx, minmax[((int64_t)k * 2 + 1) * F + c]);
+    }
+    lds[0][grp][threadIdx.x & 63] = mn, lds[1][grp][threadIdx.x & 63] = mx;
+    __syncthreads();
+    if (grp != 0 || c >= F) return;
+#pragma unroll
+    for (int g = 1; g < 4; ++g) mn = fminf(mn, lds[0][g][threadIdx.x]), mx = fmaxf(mx, lds[1][g][threadIdx.x]);
     const float dev = fmaxf(fabsf(mx - mean[c]), fabsf(mn - mean[c])) * invstd[c];
     bound[c] = (fabsf(w ? w[c] : 1.f) * dev + fabsf(b ? b[c] : 0.f)) / (1.f - p);
 }
@@ -525,7 +534,7 @@ int bot_bn_stats_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, f
     else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true, true, minmax);
     hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
                        mean, (float*)nullptr, invstd, eps, momentum, running_mean, running_var, num_batches_tracked);
-    hipLaunchKernelGGL(bn_bound_kernel, dim3((F + kBlock - 1) / kBlock), dim3(kBlock), 0, st, F, minmax, (int)grid.y, mean, invstd, weight, bias, p, bound);
+    hipLaunchKernelGGL(bn_bound_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, F, minmax, (int)grid.y, mean, invstd, weight, bias, p, bound);
     launch_halves_scale(bound, F, hscale, st);
     return hip_status("bn_stats_halves launch");
 }
