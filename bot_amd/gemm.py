@@ -17,13 +17,14 @@ import torch
 from . import _C
 
 MODE = os.environ.get("BOT_GEMM", "halves")
+FORCE = False              # tests set this to run the halves path over the emulated (CPU) backend at any row count
 MIN_ROWS = 8192            # below this many rows the fp32 GEMM is launch-bound anyway
 PIECE_ALIGN = 64
 CHUNK_ROWS = 8192          # row chunk of the weight-gradient reduction (one batch entry each)
 
 
 def enabled(x) -> bool:
-    return MODE == "halves" and x.is_cuda and x.dim() == 2 and x.shape[0] >= MIN_ROWS and x.dtype == torch.float32
+    return MODE == "halves" and x.dim() == 2 and x.dtype == torch.float32 and (FORCE or (x.is_cuda and x.shape[0] >= MIN_ROWS))
 
 
 class Halves:
@@ -65,7 +66,7 @@ def take(x, order: int):
 
 def epilogue_piece(F: int, x) -> int | None:
     """Piece width for halves written by the BatchNorm epilogue of a [n, F] tensor, None when the fused form does not apply."""
-    if MODE != "halves" or not x.is_cuda or x.shape[0] < MIN_ROWS or F % 2 or x.stride(0) % 2:
+    if MODE != "halves" or not (FORCE or (x.is_cuda and x.shape[0] >= MIN_ROWS)) or F % 2 or x.stride(0) % 2:
         return None
     return (F + PIECE_ALIGN - 1) // PIECE_ALIGN * PIECE_ALIGN
 

@@ -214,9 +214,78 @@ def _bn_gate(x, mean, invstd, weight, bias, relu, p):
     return xh, o
 
 
-def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed):
+def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=None):
     _, o = _bn_gate(x, mean, invstd, weight, bias, relu, p)
-    return torch.relu(o) if relu else o
+    y = torch.relu(o) if relu else o
+    if halves is not None:                      # bot_bn_act_fwd_halves_f32: the output also as fp16 halves
+        hscale, piece = halves
+        return y, halves_split(y, hscale, 0, piece)
+    return y
+
+
+# ---- fp16 halves (include/bot_gnn.h: bot_halves_scale_f32 / bot_halves_split_f16 / bot_gemm_halves_f32), restated with torch CPU ops
+def _pow2_scale(m):
+    import math
+    s = 1.0
+    if m > 0.0 and math.isfinite(m):
+        f, e = math.frexp(m)
+        if f == 0.5:
+            e -= 1
+        s = 2.0 ** min(60, 14 - e)
+    return torch.tensor([s, 1.0 / s], dtype=torch.float32)
+
+
+def halves_scale(x):
+    return _pow2_scale(float(x.abs().max()) if x.numel() else 0.0)
+
+
+def halves_split(x, scale, order, piece, out=None):
+    n, F = x.shape
+    z = x.float() * (float(scale[0]) if scale is not None else 1.0)
+    h1 = z.half()
+    h2 = (z - h1.float()).half()
+    buf = torch.zeros((n, 3 * piece), dtype=torch.float16) if out is None else out
+    if out is not None:
+        buf[:, :3 * piece] = 0
+    buf[:, :F] = h1
+    buf[:, piece:piece + F] = h1 if order == 0 else h2
+    buf[:, 2 * piece:2 * piece + F] = h2 if order == 0 else h1
+    return buf
+
+
+def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1, strides=(0, 0, 0), m=None, n=None, k=None, beta=0.0,
+                ldc=None):
+    if m is None:
+        m, k = (a.shape[-1], a.shape[-2]) if trans_a else (a.shape[-2], a.shape[-1])
+    if n is None:
+        n = b.shape[-2] if trans_b else b.shape[-1]
+    if out is None:
+        out = torch.empty((m, n) if batch == 1 else (batch, m, n), dtype=torch.float32)
+    alpha = alpha.reshape(-1)
+    alpha = alpha.expand(n) if alpha.numel() == 1 else alpha
+    sa, sb, sc = strides
+    if batch > 1 and sc == 0:
+        sc = out.stride(0)
+    lda, ldb = a.stride(-2), b.stride(-2)
+    ldc = out.stride(-2) if ldc is None else ldc
+
+    def view(t, rows, cols, ld, off):
+        return torch.as_strided(t, (rows, cols), (ld, 1), t.storage_offset() + off)
+
+    for i in range(batch):
+        A = view(a, k, m, lda, i * sa).t() if trans_a else view(a, m, k, lda, i * sa)
+        B = view(b, n, k, ldb, i * sb).t() if trans_b else view(b, k, n, ldb, i * sb)
+        C = view(out, m, n, ldc, i * sc)
+        res = (A.float() @ B.float()) * alpha           # fp16 x fp16 products are exact in fp32; fp32 accumulation
+        C.copy_(res if beta == 0.0 else res + beta * C)
+    return out
+
+
+def bn_stats_halves(x, eps, momentum, running_mean, running_var, num_batches_tracked, weight, bias, p):
+    mean, invstd = bn_stats(x, eps, momentum, running_mean, running_var, num_batches_tracked)
+    dev = torch.maximum((x.max(0).values - mean).abs(), (x.min(0).values - mean).abs()) * invstd
+    bound = ((weight.abs() if weight is not None else 1.0) * dev + (bias.abs() if bias is not None else 0.0)) / (1.0 - p)
+    return mean, invstd, _pow2_scale(float(bound.max()))
 
 
 def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed):
@@ -259,7 +328,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -316,3 +316,45 @@ def test_stacks_unchanged_by_reordering(golden, cpu_backend, monkeypatch, method
                 assert torch.allclose(a, b, rtol=1e-4, atol=2e-5)
             for a, b in zip(g0, g1):
                 assert torch.allclose(a, b, atol=1e-4 * max(1.0, float(a.abs().max())))
+
+
+def test_halves_gemm_host_logic(cpu_backend, monkeypatch):
+    """bot_amd.gemm over the emulated backend: operand layouts, the strided-batch weight gradient with a ragged row remainder,
+    the autograd wrapper in both weight layouts — against fp64 products."""
+    from bot_amd import gemm
+    monkeypatch.setattr(gemm, "FORCE", True)
+    monkeypatch.setattr(gemm, "CHUNK_ROWS", 64)
+    gen = torch.Generator().manual_seed(0)
+    n, K, P = 64 * 5 + 13, 160, 136
+    x = torch.randn(n, K, generator=gen) * 3
+    d = torch.randn(n, P, generator=gen) * 1e-6
+    w = torch.randn(P, K, generator=gen) * 0.1
+    xs, ds = gemm.split(x, 0), gemm.split(d, 0)
+    assert xs.buf.shape == (n, 3 * 192) and xs.piece == 192 and ds.piece == 192
+    for got, ref in ((gemm.mm_nt(xs, gemm.split(w, 1)), x.double() @ w.double().t()),
+                     (gemm.mm_nt(ds, gemm.split(w.t().contiguous(), 1)), d.double() @ w.double()),
+                     (gemm.tn(xs, ds), x.double().t() @ d.double())):
+        assert got.shape == ref.shape and float((got.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+    for kp in (True, False):
+        wl = (w.t().contiguous() if kp else w.clone()).requires_grad_()
+        xl = x.clone().requires_grad_()
+        y = gemm.matmul(xl, wl) if kp else gemm.linear(xl, wl)
+        y.backward(d)
+        x2, w2 = x.clone().requires_grad_(), w.clone().requires_grad_()
+        torch.nn.functional.linear(x2, w2).backward(d)
+        assert torch.allclose(y, torch.nn.functional.linear(x2, w2).detach(), atol=1e-5, rtol=1e-5)
+        assert torch.allclose(xl.grad, x2.grad, atol=1e-11, rtol=1e-4)
+        assert torch.allclose(wl.grad if not kp else wl.grad.t(), w2.grad, atol=1e-9, rtol=1e-4)
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_stacks_golden_on_halves(golden, cpu_backend, monkeypatch, fuse):
+    """The golden stack cases once more with every projection on the fp16-halves path (emulated): the fused layer's merged GEMM
+    and its gradients, the BatchNorm epilogue handing its halves to the next layer (stash / take), GraphConv's weight product."""
+    from bot_amd import gemm
+    from bot_amd.nn import fused
+    monkeypatch.setattr(fused, "FORCE", True)
+    monkeypatch.setattr(gemm, "FORCE", True)
+    gemm.STATS.update(stashed=0, taken=0, split=0)
+    PC.check_stacks_golden(golden, "cpu", fuse=fuse)
+    assert not fuse or (gemm.STATS["split"] > 0 and gemm.STATS["taken"] > 0)   # the modular path's golden shapes are below gemm.worth()
