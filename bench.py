@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak of one MI355X (/opt/skills/guides/MI355X_MICROARCH.md; not the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md "Chip-level parameters"
 
 
@@ -143,7 +144,8 @@ def main():
     for _ in range(args.warmup):
         wl.step()
     # ---- timed region: exactly K steps between barrier + synchronize
-    _C.PROFILE = prof = []
+    _C.PROFILE, _C.PROFILE_SKIP = [], ("gemm_halves",)    # the sparse sweeps are timed live; the GEMMs in three extra steps below
+    prof = _C.PROFILE
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -152,7 +154,15 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    _C.PROFILE = None
+    _C.PROFILE, _C.PROFILE_SKIP = None, ()
+    gprof, gsteps = [], 3
+    if gemm.MODE == "halves" and not wl.captured:      # the dense projections' launches, HIP events on the launch stream, 3 more steps
+        _C.PROFILE = gprof
+        for _ in range(gsteps):
+            wl.step()
+        torch.cuda.synchronize()
+        _C.PROFILE = None
+        gprof = [r for r in gprof if r[0] == "gemm_halves"]
     if partitioned:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -231,6 +241,17 @@ def main():
                        "algorithmic_GBs": round(b / avg_ms / 1e6, 1), "frac": round(b / avg_ms / 1e6 / HBM_PEAK_GBS, 4)})
     if roof is not None:
         roof["all_sparse_sweeps"] = others
+        # the dense projections on the fp16 matrix cores, same live events: fp16 MFMA flops actually issued (three products per
+        # fp32 product, zero padding included) against gfx950's dense fp16 peak
+        gs = gprof
+        if gs:
+            g_ms = sum(r[2].elapsed_time(r[3]) for r in gs)
+            g_fl = sum(2.0 * r[1][0] * r[1][1] * r[1][2] * r[1][3] for r in gs)
+            roof["dense_projections"] = {"bound": "mfma", "what": "bot_gemm_halves_f32 (hipBLASLt fp16 -> fp32) launches of three more steps after the timed region (HIP events)",
+                                         "launches_per_step": len(gs) / gsteps, "ms_per_step": round(g_ms / gsteps, 3),
+                                         "achieved": round(g_fl / g_ms / 1e9, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": round(g_fl / g_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, 4),
+                                         "fp32_equivalent_TFLOPs": round(g_fl / 3 / g_ms / 1e9, 1)}
 
     cpu = parity = None
     if rank == 0 and world == 1 and args.cpu_baseline != "off" and args.workload == "arxiv" and args.norm_adj == "rw":

@@ -105,8 +105,11 @@ class BotKernelError(RuntimeError):
 PROFILE = None
 
 
+PROFILE_SKIP = ()   # kernel families not to time while PROFILE is a list
+
+
 def _timed(name, key, launch):
-    if PROFILE is None:
+    if PROFILE is None or name in PROFILE_SKIP:
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -619,10 +622,10 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     sa, sb, sc = strides
     if batch > 1 and sc == 0:
         sc = out.stride(0)
-    _check(_lib.bot_gemm_halves_f32(int(trans_a), int(trans_b), m, n, k, alpha.data_ptr(), a.data_ptr(), a.stride(-2), b.data_ptr(),
-                                    b.stride(-2), out.data_ptr(), out.stride(-2) if ldc is None else ldc, batch, sa, sb, sc, float(beta),
-                                    ws.data_ptr(), ws.numel(),
-                                    int(GEMM_TUNE), _stream()), "gemm_halves")
+    _check(_timed("gemm_halves", (m, n, k, batch), lambda: _lib.bot_gemm_halves_f32(
+        int(trans_a), int(trans_b), m, n, k, alpha.data_ptr(), a.data_ptr(), a.stride(-2), b.data_ptr(), b.stride(-2), out.data_ptr(),
+        out.stride(-2) if ldc is None else ldc, batch, sa, sb, sc, float(beta), ws.data_ptr(), ws.numel(), int(GEMM_TUNE), _stream())),
+        "gemm_halves")
     return out
 
 
