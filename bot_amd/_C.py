@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -73,7 +73,8 @@ _SIGS = {
     "bot_halves_scale_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
     "bot_halves_split_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int32, _P, c_int64, c_int32, _P]),
     "bot_gemm_halves_f32": (ctypes.c_int, [c_int32, c_int32, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int64,
-                                           c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, _P]),
+                                           c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, c_int32, _P]),
+    "bot_gemm_halves_last_algo": (ctypes.c_int, [_P, _P]),
     "bot_bn_workspace_floats": (c_int64, [c_int32]),
     "bot_colstats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
     "bot_colsum_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
@@ -595,7 +596,29 @@ def halves_split(x, scale, order, piece, out=None):
 
 
 _GEMM_WS = {}
-GEMM_TUNE = os.environ.get("BOT_GEMM_TUNE", "1") != "0"
+GEMM_TUNE = int(os.environ.get("BOT_GEMM_TUNE", "1"))   # 0: heuristic's first choice; 1: fastest of 16 candidates; 2: of all solutions
+GEMM_ALGOS = None      # {shape key: hipBLASLt solution index} recorded by tools/tune_halves_gemm.py (bot_amd/tuning/halves_gemm.json)
+GEMM_SEEN = None       # tools set this to a dict to collect {shape key: (solution index, ms in the search)} of the launches
+
+
+def _gemm_algos():
+    global GEMM_ALGOS
+    if GEMM_ALGOS is None:
+        GEMM_ALGOS = {}
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "halves_gemm.json")
+        if os.environ.get("BOT_GEMM_ALGOS", "1") != "0" and os.path.exists(path):
+            import json
+            with open(path) as f:
+                rec = json.load(f)
+            # indices are only meaningful for the library build they were recorded on
+            if rec.get("hipblaslt") == _hipblaslt_tag():
+                GEMM_ALGOS = {k: int(v["index"]) for k, v in rec.get("shapes", {}).items()}
+    return GEMM_ALGOS
+
+
+def _hipblaslt_tag():
+    """Identifies the hipBLASLt build whose solution indices the tuning file holds: torch's version string (it ships the library)."""
+    return f"torch {torch.__version__} hip {torch.version.hip}"
 
 
 def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1, strides=(0, 0, 0), m=None, n=None, k=None, beta=0.0,
@@ -622,10 +645,16 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     sa, sb, sc = strides
     if batch > 1 and sc == 0:
         sc = out.stride(0)
+    ldc = out.stride(-2) if ldc is None else ldc
+    key = f"{int(trans_a)}{int(trans_b)} m{m} n{n} k{k} lda{a.stride(-2)} ldb{b.stride(-2)} ldc{ldc} b{batch} s{sa},{sb},{sc}"
+    index = _gemm_algos().get(key, -1) if beta == 0.0 else -1
     _check(_timed("gemm_halves", (m, n, k, batch), lambda: _lib.bot_gemm_halves_f32(
         int(trans_a), int(trans_b), m, n, k, alpha.data_ptr(), a.data_ptr(), a.stride(-2), b.data_ptr(), b.stride(-2), out.data_ptr(),
-        out.stride(-2) if ldc is None else ldc, batch, sa, sb, sc, float(beta), ws.data_ptr(), ws.numel(), int(GEMM_TUNE), _stream())),
-        "gemm_halves")
+        ldc, batch, sa, sb, sc, float(beta), ws.data_ptr(), ws.numel(), int(GEMM_TUNE), index, _stream())), "gemm_halves")
+    if GEMM_SEEN is not None and key not in GEMM_SEEN:
+        idx, ms = ctypes.c_int32(-1), ctypes.c_float(0.0)
+        _lib.bot_gemm_halves_last_algo(ctypes.byref(idx), ctypes.byref(ms))
+        GEMM_SEEN[key] = (idx.value, ms.value)
     return out
 
 

@@ -2,10 +2,14 @@
 // alpha a DEVICE vector over the n output columns (the product of two halves_scale reciprocals, never seen by the host;
 // hipBLASLt's device-SCALAR pointer mode is not honoured by the library build torch ships, the device-vector mode is) — hipBLASLt does the
 // MFMA work (a plain library GEMM; the halves format around it is halves.hip).  Optional strided batches (the row chunks of a
-// weight gradient).  The first call for a shape times hipBLASLt's candidate kernels on the caller's buffers and keeps the
-// fastest (only for beta == 0, where repeated runs are idempotent); under stream capture the top heuristic is used instead.
+// weight gradient).  Kernel choice per shape, first call: a recorded solution index when the caller has one (algo_index >= 0);
+// else (tune == 1) the fastest of hipBLASLt's 16 heuristic candidates timed on the caller's buffers, or (tune == 2, the tuning
+// tool) of ALL the library's solutions for these types; only for beta == 0, where repeated runs are idempotent, and never under
+// stream capture (top heuristic then).
 #include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -24,9 +28,14 @@ struct Plan {
     hipblasLtMatmulAlgo_t algo;
     size_t ws = 0;
     bool tuned = false;
+    int index = -1;        // solution index of `algo` when known
+    float ms = 0.f;        // its time in the search that picked it
+    int searched = 0;      // candidates timed by the exhaustive search
     std::vector<hipblasLtMatmulHeuristicResult_t> cand;
 };
 
+int g_last_index = -1;     // solution index / time of the kernel the last call selected (bot_gemm_halves_last_algo)
+float g_last_ms = 0.f;
 std::mutex g_mu;
 std::map<Key, Plan> g_plans;
 hipblasLtHandle_t g_handle = nullptr;
@@ -57,7 +66,7 @@ extern "C" {
 int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, const float* alpha, const uint16_t* A,
                         int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t batch, int64_t stride_a,
                         int64_t stride_b, int64_t stride_c, float beta, void* workspace, int64_t workspace_bytes, int32_t tune,
-                        bot_stream_t stream) {
+                        int32_t algo_index, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(m >= 1 && n >= 1 && k >= 1 && batch >= 1, BOT_E_RANGE, "gemm_halves: m=%lld n=%lld k=%lld batch=%d", (long long)m,
                 (long long)n, (long long)k, batch);
@@ -107,6 +116,62 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
     auto run = [&](const hipblasLtMatmulAlgo_t& algo) {
         return hipblasLtMatmul(g_handle, p.desc, alpha, B, p.la, A, p.lb, &beta, C, p.lc, C, p.lc, &algo, workspace, (size_t)workspace_bytes, st);
     };
+    if (!p.tuned && algo_index >= 0) {   // a recorded selection (bot_amd/tuning/halves_gemm.json, made by tune == 2 on this library build)
+        std::vector<int> idx{algo_index};
+        std::vector<hipblasLtMatmulHeuristicResult_t> res;
+        size_t ws = 0;
+        if (hipblaslt_ext::getAlgosFromIndex(g_handle, idx, res) == HIPBLAS_STATUS_SUCCESS && !res.empty() &&
+            hipblaslt_ext::matmulIsAlgoSupported(g_handle, p.desc, alpha, p.la, p.lb, &beta, p.lc, p.lc, res[0].algo, ws) == HIPBLAS_STATUS_SUCCESS &&
+            ws <= (size_t)workspace_bytes) {
+            p.algo = res[0].algo, p.ws = ws, p.tuned = true, p.index = algo_index;
+            p.cand.clear();
+        }
+    }
+    if (!p.tuned && tune == 2 && beta == 0.f) {   // exhaustive: every solution of the library for these types that supports the problem
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cs);
+        if (cs == hipStreamCaptureStatusNone) {
+            const hipblasOperation_t op1 = trans_b ? HIPBLAS_OP_T : HIPBLAS_OP_N, op2 = trans_a ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+            std::vector<hipblasLtMatmulHeuristicResult_t> all;
+            (void)hipblaslt_ext::getAllAlgos(g_handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, op1, op2, HIP_R_16F, HIP_R_16F, HIP_R_32F, HIP_R_32F,
+                                             HIPBLAS_COMPUTE_32F, all);
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            auto time_of = [&](hipblasLtMatmulAlgo_t& algo, int reps) {
+                (void)hipEventRecord(e0, st);
+                for (int i = 0; i < reps; ++i)
+                    if (run(algo) != HIPBLAS_STATUS_SUCCESS) return 1e30f;
+                (void)hipEventRecord(e1, st);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                return ms / reps;
+            };
+            std::vector<std::pair<float, size_t>> first;   // (one-run time, position in `all`)
+            std::vector<size_t> wss(all.size(), 0);
+            for (size_t i = 0; i < all.size(); ++i) {
+                size_t ws = 0;
+                if (hipblaslt_ext::matmulIsAlgoSupported(g_handle, p.desc, alpha, p.la, p.lb, &beta, p.lc, p.lc, all[i].algo, ws) != HIPBLAS_STATUS_SUCCESS ||
+                    ws > (size_t)workspace_bytes)
+                    continue;
+                wss[i] = ws;
+                if (run(all[i].algo) != HIPBLAS_STATUS_SUCCESS) continue;    // warm-up
+                first.emplace_back(time_of(all[i].algo, 1), i);
+            }
+            std::sort(first.begin(), first.end());
+            float best = 1e30f;
+            for (size_t j = 0; j < first.size() && j < 12; ++j) {            // the dozen fastest once more, five runs each
+                const size_t i = first[j].second;
+                const float ms = time_of(all[i].algo, 5);
+                if (ms < best) best = ms, p.algo = all[i].algo, p.ws = wss[i], p.index = hipblaslt_ext::getIndexFromAlgo(all[i].algo);
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            if (best < 1e29f) p.tuned = true, p.ms = best, p.cand.clear();
+            p.searched = (int)first.size();
+        }
+    }
     if (!p.tuned && tune && beta == 0.f && p.cand.size() > 1) {   // timing runs overwrite C: only when nothing is accumulated
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cs);
@@ -125,7 +190,7 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
                 (void)hipEventSynchronize(e1);
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, e0, e1);
-                if (ok && ms < best) best = ms, p.algo = c.algo, p.ws = c.workspaceSize;
+                if (ok && ms < best) best = ms, p.algo = c.algo, p.ws = c.workspaceSize, p.ms = ms / 3.f;
             }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
@@ -134,8 +199,17 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
         }
     }
     set_kernel("hipblaslt_f16_f32 m=%lld n=%lld k=%lld batch=%d", (long long)m, (long long)n, (long long)k, batch);
+    if (p.index < 0) p.index = hipblaslt_ext::getIndexFromAlgo(p.algo);
+    g_last_index = p.index, g_last_ms = p.ms;
     LT_CHECK(run(p.algo), "hipblasLtMatmul");
     return hip_status("gemm_halves launch");
+}
+
+int bot_gemm_halves_last_algo(int32_t* index, float* ms) {
+    std::lock_guard<std::mutex> lock(bot::g_mu);
+    if (index) *index = bot::g_last_index;
+    if (ms) *ms = bot::g_last_ms;
+    return 0;
 }
 
 }  // extern "C"

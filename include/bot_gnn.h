@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 6
+#define BOT_ABI_VERSION 7
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -427,7 +427,7 @@ int bot_random_keep_u8(int64_t n, int64_t n_keep, uint64_t seed, uint8_t* keep, 
  *                 `piece` >= F columns wide (zero padded; use a multiple of 64), out fp16 with row pitch ldo >= 3 * piece
  *   gemm_halves   C[m,n] = alpha[j] * op(A)[m,k] op(B)[k,n] + beta * C[m,n], row-major, A / B fp16, C fp32, `alpha` a DEVICE vector of n
  *                 floats (one per output column; normally n copies of the product of the two operands' 1/s); trans_x != 0: the operand is stored transposed.  batch > 1: strided
- *                 batches (element strides).  tune != 0: the first call per shape times hipBLASLt's candidates on these
+ *                 batches (element strides).  tune = 1 / 2: the first call per shape times hipBLASLt's 16 heuristic candidates / all its solutions on these
  *                 buffers (beta == 0 only: C is overwritten).  `workspace`: device scratch for hipBLASLt (32 MiB is plenty).
  * ------------------------------------------------------------------------------------------- */
 int64_t bot_halves_workspace_floats(void);
@@ -437,7 +437,10 @@ int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, cons
 int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, const float* alpha, const uint16_t* A,
                         int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t batch, int64_t stride_a,
                         int64_t stride_b, int64_t stride_c, float beta, void* workspace, int64_t workspace_bytes, int32_t tune,
-                        bot_stream_t stream);
+                        int32_t algo_index, bot_stream_t stream);
+/* solution index (hipblaslt_ext::getIndexFromAlgo) and search time in ms of the kernel the last gemm_halves call used; what
+ * tools/tune_halves_gemm.py records into bot_amd/tuning/halves_gemm.json and passes back as `algo_index` (-1: none) */
+int bot_gemm_halves_last_algo(int32_t* index, float* ms);
 
 #ifdef __cplusplus
 }
