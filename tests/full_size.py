@@ -245,6 +245,12 @@ def gcn_hip_step(g, feat, labels, train_idx, sd, cfg, n_classes, loss="logit"):
 
 
 # ---------------------------------------------------------------------------------------------- edge-feature GAT (configs 4 / 5)
+def _oracle_threads(default=32):
+    """Host threads for the oracle's C kernels and torch CPU ops; BOT_ORACLE_THREADS overrides.  32 is the fastest on the
+    256-thread hosts of the GPU boxes (S-products oracle step: 104-130 s at 32 threads, 147 s at 64, 216 s at 128)."""
+    return min(os.cpu_count() or 1, int(os.environ.get("BOT_ORACLE_THREADS", default)))
+
+
 def edge_gat_oracle_step(src, dst, n, nfeat, efeat, labels, train_idx, sd, *, n_layers, n_heads, n_hidden, node_loss, use_node_encoder,
                          residual, threads=None, gates=None, f64_weight_grads=False, dtype=torch.float32):
     """One train step of the ogbn-proteins / ogbn-products stack (full-graph branch) on the oracle's C kernels.
@@ -254,7 +260,7 @@ def edge_gat_oracle_step(src, dst, n, nfeat, efeat, labels, train_idx, sd, *, n_
     from oracle import c_ops
     from oracle import ref_models as RM
     if threads is None:
-        threads = min(os.cpu_count() or 1, 32)
+        threads = _oracle_threads(32)
     torch.set_num_threads(threads)
     c_ops.set_num_threads(threads)
     g = c_ops.CGraph(src, dst, n)
