@@ -626,7 +626,7 @@ def gat_infer_layer(conv, epi, graph, h, relu, first=False):
         if ctx.store.get("key") != key:                                 # the static columns' share of the projection
             ctx.store["key"], ctx.store["base"] = key, torch.mm(h[:, :F0], Wk[:F0])
         out = torch.addmm(ctx.store["base"], h[:, F0:], Wk[F0:])
-    elif gemm.enabled(h) and h.shape[1] >= 256:                         # fp32 GEMM on the fp16 matrix cores (bot_amd.gemm)
+    elif gemm.enabled(h):                                               # fp32 GEMM on the fp16 matrix cores (bot_amd.gemm)
         out = gemm.mm_nt(gemm.split(h, 0), _cached(conv, "infer_halves", (id(W),), lambda: gemm.split(W.t().contiguous() if WEIGHT_KP else W, 1)))
     else:
         out = torch.mm(h, W) if WEIGHT_KP else torch.mm(h, W.t())       # [N, P] = [ft | res | el | er | pad]
