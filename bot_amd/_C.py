@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -75,6 +75,8 @@ _SIGS = {
     "bot_gemm_halves_f32": (ctypes.c_int, [c_int32, c_int32, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int64,
                                            c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, c_int32, _P]),
     "bot_gemm_halves_last_algo": (ctypes.c_int, [_P, _P]),
+    "bot_skinny_gemm_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                           c_int64, c_int64, c_int64, _P]),
     "bot_bn_workspace_floats": (c_int64, [c_int32]),
     "bot_colstats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P]),
     "bot_colsum_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
@@ -655,6 +657,25 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
         idx, ms = ctypes.c_int32(-1), ctypes.c_float(0.0)
         _lib.bot_gemm_halves_last_algo(ctypes.byref(idx), ctypes.byref(ms))
         GEMM_SEEN[key] = (idx.value, ms.value)
+    return out
+
+
+def skinny_gemm(a, b, *, b_is_kn, out, accumulate=False, batch=1, strides=(0, 0, 0), m=None, n=None, k=None, ldc=None):
+    """out[m,n] (+)= a[m,k] @ (b if b_is_kn else b^T), k <= 256 (include/bot_gnn.h bot_skinny_gemm_f32): fp32 in and out, bf16x6 MFMA
+    products inside.  a, b, out: fp32 row-major views with unit column stride; batch > 1: element strides (a, b, out)."""
+    _dev(a, b, out)
+    for t, name in ((a, "a"), (b, "b"), (out, "out")):
+        _f32(t, name)
+        if t.stride(-1) != 1:
+            raise BotKernelError(f"skinny_gemm: {name} must have unit column stride")
+    if m is None:
+        m, k = a.shape[-2], a.shape[-1]
+    if n is None:
+        n = b.shape[-1] if b_is_kn else b.shape[-2]
+    sa, sb, sc = strides
+    _check(_timed("skinny_gemm", (m, n, k, batch), lambda: _lib.bot_skinny_gemm_f32(
+        a.data_ptr(), a.stride(-2), b.data_ptr(), b.stride(-2), int(b_is_kn), out.data_ptr(), out.stride(-2) if ldc is None else ldc, m, n, k,
+        int(accumulate), batch, sa, sb, sc, _stream())), "skinny_gemm")
     return out
 
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 7
+#define BOT_ABI_VERSION 8
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -441,6 +441,19 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
 /* solution index (hipblaslt_ext::getIndexFromAlgo) and search time in ms of the kernel the last gemm_halves call used; what
  * tools/tune_halves_gemm.py records into bot_amd/tuning/halves_gemm.json and passes back as `algo_index` (-1: none) */
 int bot_gemm_halves_last_algo(int32_t* index, float* ms);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small-K projections: C[m,n] = (accumulate ? C : 0) + A[m,k] op(B), k <= 256, m huge — the per-head products of the
+ * aggregate-before-project layer (W_h . sum_u a x_u: src/no-sampling/models.py:490-492 applied after :547, the reordering
+ * GraphConv does at :377-385) and its residual / score columns (:519-522, :553-557).  fp32 operands are split in registers into
+ * three bf16 terms each (exactly; bf16 has fp32's exponent range, so no scale), six bf16 MFMA products per tile
+ * (a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1, dropped terms <= 2^-24 relative), fp32 accumulation: fp32-GEMM accuracy without
+ * any pass over the operands.  b_is_kn: B is stored [k, n] (1) or [n, k] (0, nn.Linear's weight layout), row-major with
+ * pitch ldb.  batch > 1: strided batches (element strides), e.g. the H heads writing side by side into the columns of one matrix.
+ * ------------------------------------------------------------------------------------------- */
+int bot_skinny_gemm_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int32_t b_is_kn, float* C, int64_t ldc, int64_t m,
+                        int32_t n, int32_t k, int32_t accumulate, int32_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                        bot_stream_t stream);
 
 #ifdef __cplusplus
 }

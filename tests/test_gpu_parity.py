@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 7
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 8
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
@@ -1188,3 +1188,41 @@ def test_bn_epilogue_writes_halves():
         assert float(y.abs().max()) * s > 2.0 ** 5                     # the bound is not absurdly loose
         ref = _C.halves_split(y, hscale, 0, piece)
         assert torch.equal(buf, ref)
+
+
+def test_skinny_gemm_against_fp64():
+    """bot_skinny_gemm_f32 (bf16x6 MFMA products of fp32 operands split in registers) against fp64, next to the stock fp32 GEMM's
+    error: both B layouts, accumulate, strided batches writing side by side, ragged m / n / k, tiny and huge magnitudes."""
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    for m, k, n, mag in ((20000, 168, 250, 1.0), (4099, 250, 168, 1e-8), (1000, 256, 768, 1e4), (130, 7, 5, 1.0), (33, 40, 129, 1.0)):
+        a = torch.randn(m, k, device=DEV, generator=gen) * mag
+        w = torch.randn(n, k, device=DEV, generator=gen) * 0.1           # [n, k]: nn.Linear's layout
+        ref = a.double() @ w.double().t()
+        e32 = float(((a @ w.t()).double() - ref).abs().max() / ref.abs().max())
+        for b_is_kn in (False, True):
+            out = torch.full((m, n), float("nan"), device=DEV)
+            _C.skinny_gemm(a, w.t().contiguous() if b_is_kn else w, b_is_kn=b_is_kn, out=out)
+            e = float((out.double() - ref).abs().max() / ref.abs().max())
+            print(f"skinny_gemm m={m} k={k} n={n} b_is_kn={b_is_kn}: err {e:.2e} (stock fp32 {e32:.2e})")
+            assert e <= max(2e-6, 3 * e32)
+        base = torch.randn(m, n, device=DEV, generator=gen) * mag
+        out = base.clone()
+        _C.skinny_gemm(a, w, b_is_kn=False, out=out, accumulate=True)
+        assert float((out.double() - (base.double() + ref)).abs().max() / (ref.abs().max() + base.abs().max())) <= 3e-6
+    # three heads: z [H, N, Fin] x W [H, D, Fin]^T written side by side into the columns of one [N, 768] matrix, on top of what is there
+    H, N, Fin, D, P = 3, 5000, 168, 250, 768
+    z = torch.randn(H, N, Fin, device=DEV, generator=gen)
+    W = torch.randn(H, D, Fin, device=DEV, generator=gen) * 0.1
+    out = torch.randn(N, P, device=DEV, generator=gen)
+    want = out.double().clone()
+    for i in range(H):
+        want[:, i * D:(i + 1) * D] += z[i].double() @ W[i].double().t()
+    _C.skinny_gemm(z, W, b_is_kn=False, out=out, accumulate=True, batch=H, strides=(N * Fin, D * Fin, D), m=N, n=D, k=Fin)
+    assert float((out.double() - want).abs().max()) <= 2e-5 and torch.equal(out[:, H * D:].double(), want[:, H * D:])
+    # row-strided A (a column slice of a wider matrix) whose rows are only 8-byte aligned, B stored [k, n]
+    dx = torch.randn(N, P, device=DEV, generator=gen)
+    dz = torch.empty(H, N, Fin, device=DEV)
+    _C.skinny_gemm(dx, W, b_is_kn=True, out=dz, batch=H, strides=(D, D * Fin, N * Fin), m=N, n=Fin, k=D)
+    for i in range(H):
+        ref = dx[:, i * D:(i + 1) * D].double() @ W[i].double()
+        assert float((dz[i].double() - ref).abs().max() / ref.abs().max()) <= 2e-6
