@@ -8,7 +8,7 @@
 //     a1 b1 + a1 b2 + a2 b1 + a1 b3 + a2 b2 + a3 b1            (dropped: 2^-24 relative and below)
 // with v_mfma_f32_32x32x16_bf16 and fp32 accumulation: fp32-GEMM accuracy at 16/6 of the fp32 MFMA rate, no extra pass.
 //
-// One workgroup = 4 waves = 128 rows x NT*32 columns; the column block of B lives in LDS as three bf16 images [col][k]
+// One workgroup = 8 waves = 256 rows x NT*32 columns; the column block of B lives in LDS as three bf16 images [col][k]
 // (the MFMA B fragment of a lane is 8 consecutive k of one column: one ds_read_b128); workgroups are persistent over row tiles
 // so that the B images are built once; each wave streams its 32 rows of A from global memory (8 consecutive k per lane and
 // k-step, the next step's loads issued before this step's MFMAs).
@@ -20,7 +20,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kSkMaxK = 256;
-constexpr int kSkRows = 128;   // rows per workgroup tile (32 per wave)
+constexpr int kSkWaves = 12;    // waves per workgroup: two per SIMD, so that one wave's global-load / store latency hides behind the other's MFMAs
+constexpr int kSkRows = 32 * kSkWaves;   // rows per workgroup tile (32 per wave)
+constexpr int kSkThreads = 64 * kSkWaves;
 
 struct SkinnyArgs {
     const float* A;
@@ -33,7 +35,8 @@ struct SkinnyArgs {
     int32_t n, k, kp;      // kp = k rounded up to x16
     int32_t b_is_kn;       // B stored [k, n] (1) or [n, k] (0)
     int32_t accumulate;
-    int32_t a_wide;        // rows of A are 8-byte aligned: float2 loads
+    int32_t a_wide;        // rows of A are 16-byte (2) / 8-byte (1) aligned: float4 / float2 loads
+    int32_t ny, gx, batch; // column blocks, row-tile sequences, batch entries (grid decode)
 };
 
 __device__ __forceinline__ unsigned short bf16_rn(float x) {
@@ -50,105 +53,187 @@ __device__ __forceinline__ void split3(float x, unsigned short& p1, unsigned sho
     p3 = bf16_rn(r1 - bf16_f32(p2));
 }
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two floats -> packed bf16 pair (element 0 in the low half), round to nearest even: v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned int pack_bf16(float x0, float x1) {
+    const f32x2 v = {x0, x1};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+}
+// the three bf16 terms of two floats, packed pairwise
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned int& p1, unsigned int& p2, unsigned int& p3) {
+    p1 = pack_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pack_bf16(r0, r1);
+    p3 = pack_bf16(r0 - __uint_as_float(p2 << 16), r1 - __uint_as_float(p2 & 0xffff0000u));
+}
+
 union Frag {
     bf16x8 v;
     unsigned short s[8];
+    unsigned int u[4];
     uint4 q;
 };
 
-template <int NT>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
+template <int NT, int KP>
+__global__ __launch_bounds__(kSkThreads) void skinny_gemm_kernel(SkinnyArgs a) {
     extern __shared__ unsigned short lds[];             // [3][NT*32][ks]
     constexpr int NB = NT * 32;
-    const int ks = a.kp + 8;                            // row pitch of the LDS images in halfs
-    const int col0 = blockIdx.y * NB;
-    const int64_t z = blockIdx.z;
+    constexpr int ks = KP + 8;                          // row pitch of the LDS images in halfs (compile time: every LDS offset is an immediate)
+    // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs, so id % 8 is the XCD and id / 8 the slot on it.  The ny
+    // column blocks of one (row-tile sequence, batch entry) take ADJACENT slots of ONE XCD: they stream the same rows of A at the
+    // same time, and all but the first find them in that XCD's L2.
+    const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int seq = (slot / a.ny) * 8 + xcd;            // which (row-tile sequence, batch entry)
+    if (seq >= a.gx * a.batch) return;
+    const int col0 = (slot % a.ny) * NB;
+    const int64_t z = seq % a.batch;
+    const int gxi = seq / a.batch;
     const float* A = a.A + z * a.sa;
     const float* B = a.B + z * a.sb;
     float* C = a.C + z * a.sc;
-    // ---- the column block of B as three bf16 images [col][k]
-    if (a.b_is_kn) {
-        for (int idx = threadIdx.x; idx < NB * a.kp; idx += 256) {
-            const int c = idx % NB, k = idx / NB;       // consecutive threads: consecutive columns of one k row
-            const float v = (col0 + c < a.n && k < a.k) ? B[(int64_t)k * a.ldb + col0 + c] : 0.f;
-            unsigned short p1, p2, p3;
-            split3(v, p1, p2, p3);
-            lds[(0 * NB + c) * ks + k] = p1, lds[(1 * NB + c) * ks + k] = p2, lds[(2 * NB + c) * ks + k] = p3;
-        }
-    } else {
-        for (int idx = threadIdx.x; idx < NB * a.kp; idx += 256) {
-            const int c = idx / a.kp, k = idx % a.kp;   // consecutive threads: consecutive k of one stored row
-            const float v = (col0 + c < a.n && k < a.k) ? B[(int64_t)(col0 + c) * a.ldb + k] : 0.f;
-            unsigned short p1, p2, p3;
-            split3(v, p1, p2, p3);
-            lds[(0 * NB + c) * ks + k] = p1, lds[(1 * NB + c) * ks + k] = p2, lds[(2 * NB + c) * ks + k] = p3;
+    // ---- the column block of B as three bf16 images [col][k]: k pairs per thread (one v_cvt_pk per term), four pairs' loads in
+    // flight before any of them is used (B sits in the L2; a dependent load per element would cost a latency each)
+    {
+        constexpr int kh = KP / 2;                      // k pairs per column
+        const int total = NB * kh;
+        unsigned int* lds32 = reinterpret_cast<unsigned int*>(lds);
+        constexpr int ks2 = ks / 2;
+        constexpr int U = 4;
+        for (int base = threadIdx.x; base < total; base += kSkThreads * U) {
+            float v0[U], v1[U];
+            int cc[U], kk2[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * kSkThreads;
+                int c, k2;
+                if (a.b_is_kn) c = idx % NB, k2 = idx / NB;      // consecutive threads: consecutive columns of one k row
+                else c = idx / kh, k2 = idx % kh;                 // consecutive threads: consecutive k of one stored row
+                cc[u] = c, kk2[u] = k2;
+                v0[u] = v1[u] = 0.f;
+                if (idx < total && col0 + c < a.n) {
+                    const int k = 2 * k2;
+                    if (a.b_is_kn) {
+                        if (k < a.k) v0[u] = B[(int64_t)k * a.ldb + col0 + c];
+                        if (k + 1 < a.k) v1[u] = B[(int64_t)(k + 1) * a.ldb + col0 + c];
+                    } else {
+                        const float* bp = B + (int64_t)(col0 + c) * a.ldb + k;
+                        if (k < a.k) v0[u] = bp[0];
+                        if (k + 1 < a.k) v1[u] = bp[1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (base + u * kSkThreads >= total) break;
+                unsigned int p1, p2, p3;
+                split3_pair(v0[u], v1[u], p1, p2, p3);
+                lds32[(0 * NB + cc[u]) * ks2 + kk2[u]] = p1, lds32[(1 * NB + cc[u]) * ks2 + kk2[u]] = p2, lds32[(2 * NB + cc[u]) * ks2 + kk2[u]] = p3;
+            }
         }
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int nsteps = a.kp / 16;
+    constexpr int nsteps = KP / 16;
     const int64_t ntiles = (a.m + kSkRows - 1) / kSkRows;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // 8 consecutive k (k0 = 16 step + 8 h) of this lane's row of a tile; rows beyond m and k beyond K read as zero
+    auto load8 = [&](float (&v)[8], int64_t tile, int step) {
         const int64_t row = tile * kSkRows + wave * 32 + r;
         const bool rok = row < a.m;
         const float* ar = A + (rok ? row : 0) * a.lda;
+        const int k0 = step * 16 + 8 * h;
+        if (rok && k0 + 8 <= a.k && a.a_wide == 2) {
+            const float4 t0 = *reinterpret_cast<const float4*>(ar + k0), t1 = *reinterpret_cast<const float4*>(ar + k0 + 4);
+            v[0] = t0.x, v[1] = t0.y, v[2] = t0.z, v[3] = t0.w, v[4] = t1.x, v[5] = t1.y, v[6] = t1.z, v[7] = t1.w;
+        } else if (rok && k0 + 8 <= a.k && a.a_wide == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2 t2 = *reinterpret_cast<const float2*>(ar + k0 + 2 * j);
+                v[2 * j] = t2.x, v[2 * j + 1] = t2.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (rok && k0 + j < a.k) ? ar[k0 + j] : 0.f;
+        }
+    };
+    // A is fetched TWO k-steps at a time: the two lane halves of a row then consume one whole 128-byte line (k = 32 s' .. 32 s' + 31)
+    // in one go — fetched one step at a time the second half of every line was a second L1 miss one iteration later.
+    float cur[2][8], nxt[2][8];
+    constexpr int npairs = (nsteps + 1) / 2;
+    auto load16 = [&](float (&v)[2][8], int64_t tile, int pair) {
+        load8(v[0], tile, 2 * pair);
+        if (2 * pair + 1 < nsteps) load8(v[1], tile, 2 * pair + 1);
+    };
+    if (gxi < ntiles) load16(cur, gxi, 0);
+    for (int64_t tile = gxi; tile < ntiles; tile += a.gx) {
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
-        float cur[8], nxt[8];
-        auto load8 = [&](float (&v)[8], int step) {
-            const int k0 = step * 16 + 8 * h;
-            if (rok && k0 + 8 <= a.k && a.a_wide) {
+        Frag a1, a2, a3;
+#pragma unroll 1
+        for (int pair = 0; pair < npairs; ++pair) {
+            {                        // the next pair of k-steps of this tile, or — at the end — the first pair of the next tile (in flight over the stores)
+                if (pair + 1 < npairs) load16(nxt, tile, pair + 1);
+                else if (tile + a.gx < ntiles) load16(nxt, tile + a.gx, 0);
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float2 t2 = *reinterpret_cast<const float2*>(ar + k0 + 2 * j);
-                    v[2 * j] = t2.x, v[2 * j + 1] = t2.y;
+            for (int half = 0; half < 2; ++half) {
+                const int step = 2 * pair + half;
+                if (step >= nsteps) break;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split3_pair(cur[half][2 * j], cur[half][2 * j + 1], a1.u[j], a2.u[j], a3.u[j]);
+                const unsigned short* bl = lds + r * ks + 8 * h + step * 16;      // + (p * NB + t * 32) * ks: immediates
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    Frag b1, b2, b3;
+                    b1.q = *reinterpret_cast<const uint4*>(bl + (0 * NB + t * 32) * ks);
+                    b2.q = *reinterpret_cast<const uint4*>(bl + (1 * NB + t * 32) * ks);
+                    b3.q = *reinterpret_cast<const uint4*>(bl + (2 * NB + t * 32) * ks);
+                    // smallest terms first: they are added into the accumulator before the leading product
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.v, b1.v, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b3.v, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, b2.v, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, b1.v, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b2.v, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b1.v, acc[t], 0, 0, 0);
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (rok && k0 + j < a.k) ? ar[k0 + j] : 0.f;
-            }
-        };
-        load8(cur, 0);
-        for (int step = 0; step < nsteps; ++step) {
-            if (step + 1 < nsteps) load8(nxt, step + 1);
-            Frag a1, a2, a3;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) split3(cur[j], a1.s[j], a2.s[j], a3.s[j]);
-            const int kk = step * 16 + 8 * h;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                Frag b1, b2, b3;
-                const int c = t * 32 + r;
-                b1.q = *reinterpret_cast<const uint4*>(&lds[(0 * NB + c) * ks + kk]);
-                b2.q = *reinterpret_cast<const uint4*>(&lds[(1 * NB + c) * ks + kk]);
-                b3.q = *reinterpret_cast<const uint4*>(&lds[(2 * NB + c) * ks + kk]);
-                // smallest terms first: they are added into the accumulator before the leading product
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.v, b1.v, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b3.v, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, b2.v, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, b1.v, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b2.v, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b1.v, acc[t], 0, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
+            for (int j = 0; j < 8; ++j) cur[0][j] = nxt[0][j], cur[1][j] = nxt[1][j];
         }
         // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-        const int64_t rbase = tile * kSkRows + wave * 32;
+        const int64_t rwave = tile * kSkRows + wave * 32;
+        const int64_t rbase = rwave + 4 * h;
+        if (rwave + 32 <= a.m) {            // the whole 32-row group exists: no per-row guards
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int c = col0 + t * 32 + r;
-            if (c >= a.n) continue;
+            for (int t = 0; t < NT; ++t) {
+                const int c = col0 + t * 32 + r;
+                if (c >= a.n) continue;
+                float* p = C + rbase * a.ldc + c;
+                if (a.accumulate) {         // all sixteen loads in flight, then the stores
+                    float old[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int64_t rr = rbase + (j & 3) + 8 * (j >> 2) + 4 * h;
-                if (rr < a.m) {
-                    float* p = C + rr * a.ldc + c;
-                    *p = a.accumulate ? *p + acc[t][j] : acc[t][j];
+                    for (int j = 0; j < 16; ++j) old[j] = p[(int64_t)((j & 3) + 8 * (j >> 2)) * a.ldc];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[t][j] += old[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) p[(int64_t)((j & 3) + 8 * (j >> 2)) * a.ldc] = acc[t][j];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = col0 + t * 32 + r;
+                if (c >= a.n) continue;
+                float* p = C + rbase * a.ldc + c;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int dr = (j & 3) + 8 * (j >> 2);
+                    if (rbase + dr < a.m) p[(int64_t)dr * a.ldc] = a.accumulate ? p[(int64_t)dr * a.ldc] + acc[t][j] : acc[t][j];
                 }
             }
         }
@@ -170,27 +255,35 @@ int bot_skinny_gemm_f32(const float* A, int64_t lda, const float* B, int64_t ldb
     if (m == 0) return 0;
     BOT_REQUIRE(A && B && C, BOT_E_NULL, "skinny_gemm: NULL pointer");
     BOT_REQUIRE(aligned(A, 4) && aligned(B, 4) && aligned(C, 4), BOT_E_ALIGN, "skinny_gemm: pointers must be 4-byte aligned");
-    SkinnyArgs a{A, lda, stride_a, B, ldb, stride_b, C, ldc, stride_c, m, n, k, (k + 15) / 16 * 16, b_is_kn, accumulate, 0};
-    a.a_wide = aligned(A, 8) && lda % 2 == 0 && stride_a % 2 == 0;
+    SkinnyArgs a{A, lda, stride_a, B, ldb, stride_b, C, ldc, stride_c, m, n, k, (k + 15) / 16 * 16, b_is_kn, accumulate, 0, 0, 0, 0};
+    a.a_wide = aligned(A, 16) && lda % 4 == 0 && stride_a % 4 == 0 ? 2 : (aligned(A, 8) && lda % 2 == 0 && stride_a % 2 == 0 ? 1 : 0);
+    // the reduction axis is padded to one of four compiled lengths (every LDS offset of the inner loop is then an immediate);
     // column blocks of 128 (4 MFMA tiles) while the three LDS images fit, else 96
-    const int nt = (size_t)3 * 128 * (a.kp + 8) * 2 <= 160 * 1024 - 1024 ? 4 : 3;
+    const int kp = k <= 64 ? 64 : (k <= 128 ? 128 : (k <= 176 ? 176 : 256));
+    a.kp = kp;
+    const int nt = kp <= 176 ? 4 : 3;
     const int nb = nt * 32;
     const int ny = (n + nb - 1) / nb;
     const int64_t ntiles = (m + kSkRows - 1) / kSkRows;
     // persistent over row tiles: about two workgroups' worth of work queued per CU in total
     int64_t gx = (int64_t)512 / ((int64_t)ny * batch);
     gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
-    const size_t lds = (size_t)3 * nb * (a.kp + 8) * 2;
+    const size_t lds = (size_t)3 * nb * (kp + 8) * 2;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)gx, (unsigned)ny, (unsigned)batch);
-    if (nt == 4) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gemm_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((skinny_gemm_kernel<4>), grid, dim3(256), lds, st, a);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gemm_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((skinny_gemm_kernel<3>), grid, dim3(256), lds, st, a);
-    }
-    set_kernel("bot::skinny_gemm_kernel<%d> k=%d n=%d batch=%d", nt, k, n, batch);
+    a.ny = ny, a.gx = (int)gx, a.batch = batch;
+    const dim3 grid((unsigned)(8 * ((gx * batch + 7) / 8) * ny));
+#define BOT_SK_LAUNCH(NT_, KP_)                                                                                                       \
+    do {                                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gemm_kernel<NT_, KP_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds);                                                                                          \
+        hipLaunchKernelGGL((skinny_gemm_kernel<NT_, KP_>), grid, dim3(kSkThreads), lds, st, a);                                         \
+    } while (0)
+    if (kp == 64) BOT_SK_LAUNCH(4, 64);
+    else if (kp == 128) BOT_SK_LAUNCH(4, 128);
+    else if (kp == 176) BOT_SK_LAUNCH(4, 176);
+    else BOT_SK_LAUNCH(3, 256);
+#undef BOT_SK_LAUNCH
+    set_kernel("bot::skinny_gemm_kernel<%d,%d> k=%d n=%d batch=%d", nt, kp, k, n, batch);
     return hip_status("skinny_gemm launch");
 }
 

@@ -16,6 +16,8 @@ the same golden vectors.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -25,6 +27,7 @@ from ..graph import take_rows
 from ..ops import bn_batch_stats, new_dropout_seed
 
 
+SKINNY = os.environ.get("BOT_SKINNY", "1") != "0"   # the small-K products of the aggregate-first layer on bot_skinny_gemm_f32
 FORCE = False  # tests set this to run the fused node over the emulated (CPU) backend
 CALLS = 0      # number of fused-layer invocations (tests assert the path was actually taken)
 AGG_CALLS = 0  # ... of which aggregate-before-project
@@ -337,7 +340,13 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         csc = graph.csc
         ctx.sym = sym
         ctx.kp = kp                                                     # Wr is [Fin, P2] (see WEIGHT_KP) instead of [P2, Fin]
-        out2 = torch.mm(h, Wr) if kp else torch.mm(h, Wr.t())           # [N, P2] = [res | el | er | pad]
+        # small-K products (K = Fin <= 256) on bot_skinny_gemm_f32: fp32 operands split in registers into bf16 terms, MFMA products
+        skinny = SKINNY and h.is_cuda and Fin <= 256 and N >= 4096
+        if skinny:
+            out2 = _C.skinny_gemm(h, Wr, b_is_kn=kp, out=torch.empty((N, Wr.shape[1 if kp else 0]), dtype=h.dtype, device=h.device))
+        else:
+            out2 = torch.mm(h, Wr) if kp else torch.mm(h, Wr.t())       # [N, P2] = [res | el | er | pad]
+        ctx.skinny = skinny
         c = HD if has_res else 0
         ext = None
         if graph.halo is not None:
@@ -369,10 +378,17 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         Wh = W.view(H, D, Fin)
         # per-head projection (plain 2-D GEMMs: each has its own tuned kernel selection, see bot_amd/tuning), accumulated in
         # place onto the residual columns of the [N, P2] buffer (beta = 1): no [N, H, D] add pass, x is a row-strided view
-        if has_res:
+        if has_res and skinny:      # the H heads as one strided batch, written side by side onto the residual columns
+            _C.skinny_gemm(z, Wh, b_is_kn=False, out=out2, accumulate=True, batch=H, strides=(N * Fin, D * Fin, D), m=N, n=D, k=Fin)
+            x = out2[:, :HD]
+        elif has_res:
             for i in range(H):
                 out2[:, i * D:(i + 1) * D].addmm_(z[i], Wh[i].t())
             x = out2[:, :HD]
+        elif skinny:
+            agg = _C.skinny_gemm(z, Wh, b_is_kn=False, out=torch.empty((H, N, D), dtype=h.dtype, device=h.device), batch=H,
+                                 strides=(N * Fin, D * Fin, N * D), m=N, n=D, k=Fin)
+            x = agg.permute(1, 0, 2).reshape(N, HD)
         else:
             agg = torch.empty((H, N, D), dtype=h.dtype, device=h.device)
             for i in range(H):
@@ -419,9 +435,12 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         Wh = W.view(H, D, Fin)
         dz = torch.empty((H, N, Fin), dtype=h.dtype, device=h.device)    # gradient of the aggregated slab
         dW3 = torch.empty((H, D, Fin), dtype=h.dtype, device=h.device) if ctx.needs_input_grad[1] else None
+        if ctx.skinny and D <= 256:     # d z_i = d x_i W_i for the H heads in one launch (A = column slices of d x)
+            _C.skinny_gemm(dx, Wh, b_is_kn=True, out=dz, batch=H, strides=(D, D * Fin, N * Fin), m=N, n=Fin, k=D)
         for i in range(H):
             dxi = dx[:, i * D:(i + 1) * D]                               # [N, D] column slice (row-strided)
-            torch.mm(dxi, Wh[i], out=dz[i])
+            if not (ctx.skinny and D <= 256):
+                torch.mm(dxi, Wh[i], out=dz[i])
             if dW3 is not None:
                 torch.mm(dxi.t(), z[i], out=dW3[i])
         dW = dW3.view(HD, Fin) if dW3 is not None else None
