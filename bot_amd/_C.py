@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -75,6 +75,8 @@ _SIGS = {
     "bot_gemm_halves_f32": (ctypes.c_int, [c_int32, c_int32, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int64,
                                            c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, c_int32, _P]),
     "bot_gemm_halves_last_algo": (ctypes.c_int, [_P, _P]),
+    "bot_tn_gemm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32, c_int32]),
+    "bot_tn_gemm_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int32, c_int64, c_int64, c_int64, _P, _P]),
     "bot_skinny_gemm_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
                                            c_int64, c_int64, c_int64, _P]),
     "bot_bn_workspace_floats": (c_int64, [c_int32]),
@@ -676,6 +678,27 @@ def skinny_gemm(a, b, *, b_is_kn, out, accumulate=False, batch=1, strides=(0, 0,
     _check(_timed("skinny_gemm", (m, n, k, batch), lambda: _lib.bot_skinny_gemm_f32(
         a.data_ptr(), a.stride(-2), b.data_ptr(), b.stride(-2), int(b_is_kn), out.data_ptr(), out.stride(-2) if ldc is None else ldc, m, n, k,
         int(accumulate), batch, sa, sb, sc, _stream())), "skinny_gemm")
+    return out
+
+
+def tn_gemm(x, y, *, out=None, batch=1, strides=(0, 0, 0), n=None, kx=None, ky=None):
+    """out[kx, ky] = x[n, kx]^T y[n, ky] (include/bot_gnn.h bot_tn_gemm_f32: exact fp32 MFMA, reduction over the n rows).
+    x, y: fp32 row-major views with unit column stride; batch > 1: element strides (x, y, out), out [batch, kx, ky]."""
+    _dev(x, y)
+    _f32(x, "x"), _f32(y, "y")
+    if x.stride(-1) != 1 or y.stride(-1) != 1:
+        raise BotKernelError("tn_gemm: operands must have unit column stride")
+    if n is None:
+        n, kx, ky = x.shape[-2], x.shape[-1], y.shape[-1]
+    if out is None:
+        out = torch.empty((kx, ky) if batch == 1 else (batch, kx, ky), dtype=torch.float32, device=x.device)
+    sx, sy, so = strides
+    if batch > 1 and so == 0:
+        so = out.stride(0)
+    ws = torch.empty(int(_lib.bot_tn_gemm_workspace_floats(n, kx, ky, batch)), dtype=torch.float32, device=x.device)
+    _check(_timed("tn_gemm", (n, kx, ky, batch), lambda: _lib.bot_tn_gemm_f32(
+        x.data_ptr(), x.stride(-2), y.data_ptr(), y.stride(-2), n, kx, ky, out.data_ptr(), out.stride(-2), batch, sx, sy, so, ws.data_ptr(),
+        _stream())), "tn_gemm")
     return out
 
 

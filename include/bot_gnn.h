@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 8
+#define BOT_ABI_VERSION 9
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -454,6 +454,17 @@ int bot_gemm_halves_last_algo(int32_t* index, float* ms);
 int bot_skinny_gemm_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int32_t b_is_kn, float* C, int64_t ldc, int64_t m,
                         int32_t n, int32_t k, int32_t accumulate, int32_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c,
                         bot_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight gradients of the small-K projections: out[kx, ky] = sum_r X[r, kx] Y[r, ky] over the n node rows, kx / ky a few hundred
+ * (d W_r = h^T d out2, d W_i = d x_i^T z_i of the aggregate-before-project layer; the backward of the nn.Linear calls at
+ * src/no-sampling/models.py:490-492, 553-557).  Exact fp32 MFMA (v_mfma_f32_32x32x2_f32: with the reduction index on the rows both
+ * operands are read as coalesced row segments, no transposition), one wave per block of output tiles and row chunk, per-chunk
+ * partials in `workspace` (bot_tn_gemm_workspace_floats) added in chunk order: deterministic.  batch > 1: element strides.
+ * ------------------------------------------------------------------------------------------- */
+int64_t bot_tn_gemm_workspace_floats(int64_t n, int32_t kx, int32_t ky, int32_t batch);
+int bot_tn_gemm_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int64_t n, int32_t kx, int32_t ky, float* out, int64_t ldo,
+                    int32_t batch, int64_t stride_x, int64_t stride_y, int64_t stride_out, float* workspace, bot_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 8
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 9
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
@@ -1226,3 +1226,25 @@ def test_skinny_gemm_against_fp64():
     for i in range(H):
         ref = dx[:, i * D:(i + 1) * D].double() @ W[i].double()
         assert float((dz[i].double() - ref).abs().max() / ref.abs().max()) <= 2e-6
+
+
+def test_tn_gemm_against_fp64():
+    """bot_tn_gemm_f32 (exact fp32 MFMA, reduction over the node rows, per-chunk partials added in order) against fp64: the two
+    weight-gradient shapes of the aggregate-first layer incl. the strided per-head batch, ragged sizes, determinism."""
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    for n, kx, ky in ((50001, 168, 768), (20000, 250, 168), (300, 5, 7), (4097, 33, 65)):
+        x = torch.randn(n, kx, device=DEV, generator=gen)
+        y = torch.randn(n, ky, device=DEV, generator=gen) * 1e-3
+        ref = x.double().t() @ y.double()
+        got = _C.tn_gemm(x, y)
+        e, e32 = float((got.double() - ref).abs().max() / ref.abs().max()), float(((x.t() @ y).double() - ref).abs().max() / ref.abs().max())
+        print(f"tn_gemm n={n} kx={kx} ky={ky}: err {e:.2e} (stock fp32 {e32:.2e})")
+        assert got.shape == (kx, ky) and e <= max(2e-6, 3 * e32)
+        assert torch.equal(got, _C.tn_gemm(x, y))
+    H, N, Fin, D, P = 3, 30000, 168, 250, 768
+    dx = torch.randn(N, P, device=DEV, generator=gen)
+    z = torch.randn(H, N, Fin, device=DEV, generator=gen)
+    got = _C.tn_gemm(dx, z, batch=H, strides=(D, N * Fin, 0), n=N, kx=D, ky=Fin)
+    for i in range(H):
+        ref = dx[:, i * D:(i + 1) * D].double().t() @ z[i].double()
+        assert float((got[i].double() - ref).abs().max() / ref.abs().max()) <= 2e-6
