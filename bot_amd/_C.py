@@ -76,7 +76,8 @@ _SIGS = {
                                            c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, c_int32, _P]),
     "bot_gemm_halves_last_algo": (ctypes.c_int, [_P, _P]),
     "bot_tn_gemm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32, c_int32]),
-    "bot_tn_gemm_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int32, c_int64, c_int64, c_int64, _P, _P]),
+    "bot_tn_gemm_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int32, c_int32, c_int64, c_int64,
+                                       c_int64, _P, _P]),
     "bot_skinny_gemm_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
                                            c_int64, c_int64, c_int64, _P]),
     "bot_bn_workspace_floats": (c_int64, [c_int32]),
@@ -681,8 +682,9 @@ def skinny_gemm(a, b, *, b_is_kn, out, accumulate=False, batch=1, strides=(0, 0,
     return out
 
 
-def tn_gemm(x, y, *, out=None, batch=1, strides=(0, 0, 0), n=None, kx=None, ky=None):
-    """out[kx, ky] = x[n, kx]^T y[n, ky] (include/bot_gnn.h bot_tn_gemm_f32: exact fp32 MFMA, reduction over the n rows).
+def tn_gemm(x, y, *, out=None, batch=1, strides=(0, 0, 0), n=None, kx=None, ky=None, transpose_out=False):
+    """out[kx, ky] = x[n, kx]^T y[n, ky] (include/bot_gnn.h bot_tn_gemm_f32: exact fp32 MFMA, reduction over the n rows);
+    transpose_out: out[ky, kx] (workgroup blocks are 256 columns of x by 192 of y: pass the wider operand as x).
     x, y: fp32 row-major views with unit column stride; batch > 1: element strides (x, y, out), out [batch, kx, ky]."""
     _dev(x, y)
     _f32(x, "x"), _f32(y, "y")
@@ -691,13 +693,15 @@ def tn_gemm(x, y, *, out=None, batch=1, strides=(0, 0, 0), n=None, kx=None, ky=N
     if n is None:
         n, kx, ky = x.shape[-2], x.shape[-1], y.shape[-1]
     if out is None:
-        out = torch.empty((kx, ky) if batch == 1 else (batch, kx, ky), dtype=torch.float32, device=x.device)
+        shp = (ky, kx) if transpose_out else (kx, ky)
+        out = torch.empty(shp if batch == 1 else (batch,) + shp, dtype=torch.float32, device=x.device)
     sx, sy, so = strides
     if batch > 1 and so == 0:
         so = out.stride(0)
     ws = torch.empty(int(_lib.bot_tn_gemm_workspace_floats(n, kx, ky, batch)), dtype=torch.float32, device=x.device)
     _check(_timed("tn_gemm", (n, kx, ky, batch), lambda: _lib.bot_tn_gemm_f32(
-        x.data_ptr(), x.stride(-2), y.data_ptr(), y.stride(-2), n, kx, ky, out.data_ptr(), out.stride(-2), batch, sx, sy, so, ws.data_ptr(),
+        x.data_ptr(), x.stride(-2), y.data_ptr(), y.stride(-2), n, kx, ky, out.data_ptr(), out.stride(-2), int(transpose_out), batch, sx, sy, so,
+        ws.data_ptr(),
         _stream())), "tn_gemm")
     return out
 

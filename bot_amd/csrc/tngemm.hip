@@ -5,9 +5,8 @@
 // The fp32 MFMA v_mfma_f32_32x32x2_f32 takes this product without any transposition: its A operand is A[i = lane & 31][k = lane >> 5]
 // and its B operand B[k = lane >> 5][j = lane & 31]; with k = the row index, lane (i, k) reads X[r0 + k][kx0 + i] and
 // Y[r0 + k][ky0 + i] — for each k the 32 lanes read 32 CONSECUTIVE columns of one row: coalesced 128-byte segments straight from
-// global memory, no LDS, no conversion, exact fp32 products.  One wave owns a TI x TJ block of 32x32 output tiles for one chunk of
-// rows (8 rows = 4 MFMA k-steps per iteration, the next iteration's loads in flight); the per-chunk partial results go to a
-// workspace and a second kernel adds them in chunk order (deterministic, no atomics).
+// memory, no transposition, no conversion, exact fp32 products.  The per-chunk partial results go to a workspace and a second kernel
+// adds them in chunk order (deterministic, no atomics).
 #include "common.h"
 
 namespace bot {
@@ -21,81 +20,105 @@ struct TnArgs {
     int64_t ldy, sy;
     float* part;           // [batch][chunks][kxp][kyp]
     int64_t n;
-    int32_t kx, ky, kxp, kyp;   // kxp / kyp: kx / ky rounded up to the tile block (32 TI / 32 TJ)
-    int32_t chunks, rows_per_chunk, nbi, nbj, batch;
+    int32_t kx, ky, kxp, kyp;   // kxp / kyp: kx / ky rounded up to the workgroup block (kTnBX / kTnBY)
+    int32_t chunks, rows_per_chunk, ngx, ngy, batch;
 };
 
-template <int TI, int TJ>
-__global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
+constexpr int kTnTI = 2, kTnTJ = 3;            // 32x32 tiles per wave: TI along X's columns, TJ along Y's
+constexpr int kTnWI = 4, kTnWJ = 2;            // waves per workgroup along the two axes
+constexpr int kTnBX = 32 * kTnTI * kTnWI;      // 256 columns of X per workgroup
+constexpr int kTnBY = 32 * kTnTJ * kTnWJ;      // 192 columns of Y per workgroup
+constexpr int kTnStage = 16;                   // rows per LDS stage (8 MFMA k-steps)
+constexpr int kTnThreads = 64 * kTnWI * kTnWJ;
+
+// One workgroup = 8 waves = a 256 x 192 block of the output for one chunk of rows.  The rows of X (256 columns) and Y (192
+// columns) are staged through LDS 16 at a time (double buffered: the next stage's global loads are issued before this stage's
+// MFMAs), so each operand element is read from memory once per workgroup, as whole coalesced row segments.
+__global__ __launch_bounds__(kTnThreads) void tn_gemm_kernel(TnArgs a) {
+    __shared__ float xs[2][kTnStage][kTnBX + 4];
+    __shared__ float ys[2][kTnStage][kTnBY + 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 31, lk = lane >> 5;
-    // wave -> (batch, row chunk, tile block): the four waves of a workgroup take consecutive tile blocks of ONE row chunk
-    int64_t w = (int64_t)blockIdx.x * 4 + wave;
-    const int nblk = a.nbi * a.nbj;
-    const int blk = (int)(w % nblk);
-    w /= nblk;
+    const int wi = wave / kTnWJ, wj = wave % kTnWJ;
+    int64_t w = blockIdx.x;                         // -> (batch, row chunk, X column group, Y column group)
+    const int gy = (int)(w % a.ngy);
+    w /= a.ngy;
+    const int gxc = (int)(w % a.ngx);
+    w /= a.ngx;
     const int chunk = (int)(w % a.chunks);
     const int64_t z = w / a.chunks;
-    if (z >= a.batch) return;
-    const int bi = blk / a.nbj, bj = blk % a.nbj;
-    const float* X = a.X + z * a.sx + (int64_t)bi * 32 * TI + li;
-    const float* Y = a.Y + z * a.sy + (int64_t)bj * 32 * TJ + li;
-    bool xok[TI], yok[TJ];
-#pragma unroll
-    for (int t = 0; t < TI; ++t) xok[t] = bi * 32 * TI + t * 32 + li < a.kx;
-#pragma unroll
-    for (int t = 0; t < TJ; ++t) yok[t] = bj * 32 * TJ + t * 32 + li < a.ky;
-    f32x16 acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const float* X = a.X + z * a.sx + (int64_t)gxc * kTnBX;
+    const float* Y = a.Y + z * a.sy + (int64_t)gy * kTnBY;
+    const int xcols = a.kx - gxc * kTnBX, ycols = a.ky - gy * kTnBY;      // valid columns of this block (may exceed the block width)
     const int64_t r_begin = (int64_t)chunk * a.rows_per_chunk;
     const int64_t r_end = r_begin + a.rows_per_chunk < a.n ? r_begin + a.rows_per_chunk : a.n;
-    constexpr int U = 4;                         // MFMA k-steps (2 rows each) per iteration
-    float xa[U][TI], ya[U][TJ], xn[U][TI], yn[U][TJ];
-    auto load = [&](float (&xv)[U][TI], float (&yv)[U][TJ], int64_t r0) {
+    constexpr int NX = kTnStage * kTnBX / kTnThreads, NY = kTnStage * kTnBY / kTnThreads;    // 8 and 6 elements per thread and stage
+    float xr[NX], yr[NY];
+    auto gload = [&](int64_t r0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t r = r0 + 2 * u + lk;
-            const bool rok = r < r_end;
-            const float* xr = X + r * a.ldx;
-            const float* yr = Y + r * a.ldy;
+        for (int q = 0; q < NX; ++q) {
+            const int idx = threadIdx.x + q * kTnThreads, row = idx / kTnBX, col = idx % kTnBX;
+            xr[q] = (r0 + row < r_end && col < xcols) ? X[(r0 + row) * a.ldx + col] : 0.f;
+        }
 #pragma unroll
-            for (int t = 0; t < TI; ++t) xv[u][t] = (rok && xok[t]) ? xr[t * 32] : 0.f;
-#pragma unroll
-            for (int t = 0; t < TJ; ++t) yv[u][t] = (rok && yok[t]) ? yr[t * 32] : 0.f;
+        for (int q = 0; q < NY; ++q) {
+            const int idx = threadIdx.x + q * kTnThreads, row = idx / kTnBY, col = idx % kTnBY;
+            yr[q] = (r0 + row < r_end && col < ycols) ? Y[(r0 + row) * a.ldy + col] : 0.f;
         }
     };
-    if (r_begin < r_end) load(xa, ya, r_begin);
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * U) {
-        if (r0 + 2 * U < r_end) load(xn, yn, r0 + 2 * U);
+    auto lstore = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][i], ya[u][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int t = 0; t < TI; ++t) xa[u][t] = xn[u][t];
-#pragma unroll
-            for (int t = 0; t < TJ; ++t) ya[u][t] = yn[u][t];
+        for (int q = 0; q < NX; ++q) {
+            const int idx = threadIdx.x + q * kTnThreads;
+            xs[buf][idx / kTnBX][idx % kTnBX] = xr[q];
         }
+#pragma unroll
+        for (int q = 0; q < NY; ++q) {
+            const int idx = threadIdx.x + q * kTnThreads;
+            ys[buf][idx / kTnBY][idx % kTnBY] = yr[q];
+        }
+    };
+    f32x16 acc[kTnTI][kTnTJ];
+#pragma unroll
+    for (int i = 0; i < kTnTI; ++i)
+#pragma unroll
+        for (int j = 0; j < kTnTJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (r_begin < r_end) {
+        gload(r_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += kTnStage, buf ^= 1) {
+        const bool more = r0 + kTnStage < r_end;
+        if (more) gload(r0 + kTnStage);
+#pragma unroll
+        for (int ks = 0; ks < kTnStage / 2; ++ks) {
+            float xa[kTnTI], ya[kTnTJ];
+#pragma unroll
+            for (int t = 0; t < kTnTI; ++t) xa[t] = xs[buf][2 * ks + lk][(wi * kTnTI + t) * 32 + li];
+#pragma unroll
+            for (int t = 0; t < kTnTJ; ++t) ya[t] = ys[buf][2 * ks + lk][(wj * kTnTJ + t) * 32 + li];
+#pragma unroll
+            for (int i = 0; i < kTnTI; ++i)
+#pragma unroll
+                for (int j = 0; j < kTnTJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i], ya[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
     }
     // C/D map: column (j) = lane & 31, row (i) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     float* P = a.part + ((z * a.chunks + chunk) * a.kxp) * (int64_t)a.kyp;
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+    for (int i = 0; i < kTnTI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int col = bj * 32 * TJ + j * 32 + li;
+        for (int j = 0; j < kTnTJ; ++j) {
+            const int col = gy * kTnBY + (wj * kTnTJ + j) * 32 + li;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = bi * 32 * TI + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                const int row = gxc * kTnBX + (wi * kTnTI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                 P[(int64_t)row * a.kyp + col] = acc[i][j][e];
             }
         }
@@ -103,7 +126,7 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
 
 // out[z][kx][ky] = sum over chunks of part[z][chunk][kx][ky], in chunk order
 __global__ __launch_bounds__(kBlock) void tn_reduce_kernel(const float* part, int chunks, int kxp, int kyp, int kx, int ky, float* out, int64_t ldo,
-                                                          int64_t so) {
+                                                          int64_t so, bool transposed) {
     const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int z = blockIdx.y;
     if (idx >= (int64_t)kx * ky) return;
@@ -111,47 +134,47 @@ __global__ __launch_bounds__(kBlock) void tn_reduce_kernel(const float* part, in
     const float* p = part + ((int64_t)z * chunks * kxp + r) * kyp + c;
     float s = 0.f;
     for (int k = 0; k < chunks; ++k) s += p[(int64_t)k * kxp * kyp];
-    out[z * so + (int64_t)r * ldo + c] = s;
+    out[z * so + (transposed ? (int64_t)c * ldo + r : (int64_t)r * ldo + c)] = s;
 }
-
-constexpr int kTnTI = 2, kTnTJ = 3;
 
 }  // namespace bot
 
 extern "C" {
 
-int64_t bot_tn_gemm_workspace_floats(int64_t n, int32_t kx, int32_t ky, int32_t batch) {
+static void tn_shape(int64_t n, int32_t kx, int32_t ky, int32_t batch, int64_t* kxp, int64_t* kyp, int64_t* chunks) {
     using namespace bot;
-    const int64_t kxp = (kx + 32 * kTnTI - 1) / (32 * kTnTI) * (32 * kTnTI), kyp = (ky + 32 * kTnTJ - 1) / (32 * kTnTJ) * (32 * kTnTJ);
-    const int64_t nblk = (kxp / (32 * kTnTI)) * (kyp / (32 * kTnTJ));
-    int64_t chunks = (4096 + nblk * batch - 1) / (nblk * batch);          // ~4 waves per SIMD in total
-    const int64_t max_chunks = (n + 255) / 256;                           // at least 256 rows per chunk
-    chunks = chunks < 1 ? 1 : (chunks > max_chunks ? (max_chunks < 1 ? 1 : max_chunks) : chunks);
-    return (int64_t)batch * chunks * kxp * kyp + 2;                       // the last two slots are not used by the kernels
+    *kxp = (kx + kTnBX - 1) / kTnBX * kTnBX, *kyp = (ky + kTnBY - 1) / kTnBY * kTnBY;
+    const int64_t groups = (*kxp / kTnBX) * (*kyp / kTnBY) * batch;
+    int64_t c = (768 + groups - 1) / groups;                            // ~3 workgroups per CU in total
+    const int64_t max_chunks = (n + 255) / 256;                         // at least 256 rows per chunk
+    *chunks = c < 1 ? 1 : (c > max_chunks ? (max_chunks < 1 ? 1 : max_chunks) : c);
+}
+
+int64_t bot_tn_gemm_workspace_floats(int64_t n, int32_t kx, int32_t ky, int32_t batch) {
+    int64_t kxp, kyp, chunks;
+    tn_shape(n, kx, ky, batch, &kxp, &kyp, &chunks);
+    return (int64_t)batch * chunks * kxp * kyp;
 }
 
 int bot_tn_gemm_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int64_t n, int32_t kx, int32_t ky, float* out, int64_t ldo,
-                    int32_t batch, int64_t stride_x, int64_t stride_y, int64_t stride_out, float* workspace, bot_stream_t stream) {
+                    int32_t transpose_out, int32_t batch, int64_t stride_x, int64_t stride_y, int64_t stride_out, float* workspace,
+                    bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n >= 1 && kx >= 1 && ky >= 1 && batch >= 1, BOT_E_RANGE, "tn_gemm: n=%lld kx=%d ky=%d batch=%d", (long long)n, kx, ky, batch);
-    BOT_REQUIRE(ldx >= kx && ldy >= ky && ldo >= ky, BOT_E_RANGE, "tn_gemm: ldx=%lld ldy=%lld ldo=%lld", (long long)ldx, (long long)ldy, (long long)ldo);
+    BOT_REQUIRE(ldx >= kx && ldy >= ky && ldo >= (transpose_out ? kx : ky), BOT_E_RANGE, "tn_gemm: ldx=%lld ldy=%lld ldo=%lld", (long long)ldx,
+                (long long)ldy, (long long)ldo);
     BOT_REQUIRE(X && Y && out && workspace, BOT_E_NULL, "tn_gemm: NULL pointer");
+    int64_t kxp, kyp, chunks;
+    tn_shape(n, kx, ky, batch, &kxp, &kyp, &chunks);
     TnArgs a{};
     a.X = X, a.ldx = ldx, a.sx = stride_x, a.Y = Y, a.ldy = ldy, a.sy = stride_y, a.part = workspace, a.n = n, a.kx = kx, a.ky = ky;
-    a.kxp = (kx + 32 * kTnTI - 1) / (32 * kTnTI) * (32 * kTnTI), a.kyp = (ky + 32 * kTnTJ - 1) / (32 * kTnTJ) * (32 * kTnTJ);
-    a.nbi = a.kxp / (32 * kTnTI), a.nbj = a.kyp / (32 * kTnTJ);
-    const int64_t nblk = (int64_t)a.nbi * a.nbj;
-    int64_t chunks = (4096 + nblk * batch - 1) / (nblk * batch);
-    const int64_t max_chunks = (n + 255) / 256;
-    chunks = chunks < 1 ? 1 : (chunks > max_chunks ? (max_chunks < 1 ? 1 : max_chunks) : chunks);
-    a.chunks = (int)chunks, a.batch = batch;
-    a.rows_per_chunk = (int)(((n + chunks - 1) / chunks + 7) / 8 * 8);
+    a.kxp = (int)kxp, a.kyp = (int)kyp, a.ngx = (int)(kxp / kTnBX), a.ngy = (int)(kyp / kTnBY), a.chunks = (int)chunks, a.batch = batch;
+    a.rows_per_chunk = (int)(((n + chunks - 1) / chunks + kTnStage - 1) / kTnStage * kTnStage);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t waves = nblk * chunks;                                  // per batch entry
-    hipLaunchKernelGGL((tn_gemm_kernel<kTnTI, kTnTJ>), dim3((unsigned)((waves * batch + 3) / 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((int64_t)a.ngx * a.ngy * chunks * batch)), dim3(kTnThreads), 0, st, a);
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(((int64_t)kx * ky + kBlock - 1) / kBlock), (unsigned)batch), dim3(kBlock), 0, st, workspace,
-                       (int)chunks, a.kxp, a.kyp, kx, ky, out, ldo, stride_out);
-    set_kernel("bot::tn_gemm_kernel<%d,%d> kx=%d ky=%d chunks=%d batch=%d", kTnTI, kTnTJ, kx, ky, (int)chunks, batch);
+                       (int)chunks, a.kxp, a.kyp, kx, ky, out, ldo, stride_out, transpose_out != 0);
+    set_kernel("bot::tn_gemm_kernel kx=%d ky=%d chunks=%d batch=%d", kx, ky, (int)chunks, batch);
     return hip_status("tn_gemm launch");
 }
 

@@ -437,11 +437,13 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         dW3 = torch.empty((H, D, Fin), dtype=h.dtype, device=h.device) if ctx.needs_input_grad[1] else None
         if ctx.skinny and D <= 256:     # d z_i = d x_i W_i for the H heads in one launch (A = column slices of d x)
             _C.skinny_gemm(dx, Wh, b_is_kn=True, out=dz, batch=H, strides=(D, D * Fin, N * Fin), m=N, n=Fin, k=D)
+        if ctx.skinny and dW3 is not None:   # d W_i = d x_i^T z_i, reductions over the N rows: fp32 MFMA, chunked, one launch for the H heads
+            _C.tn_gemm(dx, z, out=dW3, batch=H, strides=(D, N * Fin, 0), n=N, kx=D, ky=Fin)
         for i in range(H):
             dxi = dx[:, i * D:(i + 1) * D]                               # [N, D] column slice (row-strided)
             if not (ctx.skinny and D <= 256):
                 torch.mm(dxi, Wh[i], out=dz[i])
-            if dW3 is not None:
+            if dW3 is not None and not ctx.skinny:
                 torch.mm(dxi.t(), z[i], out=dW3[i])
         dW = dW3.view(HD, Fin) if dW3 is not None else None
         halo = g.halo is not None

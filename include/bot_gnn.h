@@ -459,12 +459,14 @@ int bot_skinny_gemm_f32(const float* A, int64_t lda, const float* B, int64_t ldb
  * Weight gradients of the small-K projections: out[kx, ky] = sum_r X[r, kx] Y[r, ky] over the n node rows, kx / ky a few hundred
  * (d W_r = h^T d out2, d W_i = d x_i^T z_i of the aggregate-before-project layer; the backward of the nn.Linear calls at
  * src/no-sampling/models.py:490-492, 553-557).  Exact fp32 MFMA (v_mfma_f32_32x32x2_f32: with the reduction index on the rows both
- * operands are read as coalesced row segments, no transposition), one wave per block of output tiles and row chunk, per-chunk
+ * operands are read as coalesced row segments, no transposition), one workgroup per 256 x 192 output block and row chunk with the rows
+ * staged through LDS, transpose_out: out[ky, kx] instead (put the wider operand first: blocks are 256 of X by 192 of Y), per-chunk
  * partials in `workspace` (bot_tn_gemm_workspace_floats) added in chunk order: deterministic.  batch > 1: element strides.
  * ------------------------------------------------------------------------------------------- */
 int64_t bot_tn_gemm_workspace_floats(int64_t n, int32_t kx, int32_t ky, int32_t batch);
 int bot_tn_gemm_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int64_t n, int32_t kx, int32_t ky, float* out, int64_t ldo,
-                    int32_t batch, int64_t stride_x, int64_t stride_y, int64_t stride_out, float* workspace, bot_stream_t stream);
+                    int32_t transpose_out, int32_t batch, int64_t stride_x, int64_t stride_y, int64_t stride_out, float* workspace,
+                    bot_stream_t stream);
 
 #ifdef __cplusplus
 }

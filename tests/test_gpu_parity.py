@@ -1241,6 +1241,7 @@ def test_tn_gemm_against_fp64():
         print(f"tn_gemm n={n} kx={kx} ky={ky}: err {e:.2e} (stock fp32 {e32:.2e})")
         assert got.shape == (kx, ky) and e <= max(2e-6, 3 * e32)
         assert torch.equal(got, _C.tn_gemm(x, y))
+        assert torch.equal(_C.tn_gemm(y, x, transpose_out=True), _C.tn_gemm(y, x).t())
     H, N, Fin, D, P = 3, 30000, 168, 250, 768
     dx = torch.randn(N, P, device=DEV, generator=gen)
     z = torch.randn(H, N, Fin, device=DEV, generator=gen)
