@@ -11,6 +11,7 @@ GEMM (1e-6 of the largest entry at the config-2 shapes) and ~3x faster: the fp32
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -51,13 +52,13 @@ def stash(y, h: Halves):
     """The halves of `y` were produced together with it (fused BatchNorm epilogue): the next projection takes them from here
     instead of splitting y again.  One entry at a time per tensor identity; consumed by `take`."""
     _STASH.clear()
-    _STASH[(y.data_ptr(), y._version, tuple(y.shape))] = h
+    _STASH[(y.data_ptr(), y._version, tuple(y.shape))] = (weakref.ref(y), h)   # y itself must still be alive when the halves are taken
     STATS["stashed"] += 1
 
 
 def take(x, order: int):
-    h = _STASH.pop((x.data_ptr(), x._version, tuple(x.shape)), None)
-    if h is not None and h.order == order:
+    ref, h = _STASH.pop((x.data_ptr(), x._version, tuple(x.shape)), (None, None))
+    if h is not None and ref() is not None and h.order == order:    # a dead y: the address was recycled for another tensor
         STATS["taken"] += 1
         return h
     STATS["split"] += 1
