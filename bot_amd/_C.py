@@ -134,6 +134,12 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _ld(t):
+    """Row pitch of a row-major matrix view; torch leaves the stride of a size-1 dimension arbitrary, so a one-row matrix reports
+    its width."""
+    return max(int(t.stride(-2)), int(t.shape[-1])) if t.shape[-2] == 1 else int(t.stride(-2))
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -650,11 +656,12 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     sa, sb, sc = strides
     if batch > 1 and sc == 0:
         sc = out.stride(0)
-    ldc = out.stride(-2) if ldc is None else ldc
-    key = f"{int(trans_a)}{int(trans_b)} m{m} n{n} k{k} lda{a.stride(-2)} ldb{b.stride(-2)} ldc{ldc} b{batch} s{sa},{sb},{sc}"
+    ldc = _ld(out) if ldc is None else ldc
+    lda, ldb = _ld(a), _ld(b)
+    key = f"{int(trans_a)}{int(trans_b)} m{m} n{n} k{k} lda{lda} ldb{ldb} ldc{ldc} b{batch} s{sa},{sb},{sc}"
     index = _gemm_algos().get(key, -1) if beta == 0.0 else -1
     _check(_timed("gemm_halves", (m, n, k, batch), lambda: _lib.bot_gemm_halves_f32(
-        int(trans_a), int(trans_b), m, n, k, alpha.data_ptr(), a.data_ptr(), a.stride(-2), b.data_ptr(), b.stride(-2), out.data_ptr(),
+        int(trans_a), int(trans_b), m, n, k, alpha.data_ptr(), a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(),
         ldc, batch, sa, sb, sc, float(beta), ws.data_ptr(), ws.numel(), int(GEMM_TUNE), index, _stream())), "gemm_halves")
     if GEMM_SEEN is not None and key not in GEMM_SEEN:
         idx, ms = ctypes.c_int32(-1), ctypes.c_float(0.0)
@@ -677,7 +684,7 @@ def skinny_gemm(a, b, *, b_is_kn, out, accumulate=False, batch=1, strides=(0, 0,
         n = b.shape[-1] if b_is_kn else b.shape[-2]
     sa, sb, sc = strides
     _check(_timed("skinny_gemm", (m, n, k, batch), lambda: _lib.bot_skinny_gemm_f32(
-        a.data_ptr(), a.stride(-2), b.data_ptr(), b.stride(-2), int(b_is_kn), out.data_ptr(), out.stride(-2) if ldc is None else ldc, m, n, k,
+        a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), int(b_is_kn), out.data_ptr(), _ld(out) if ldc is None else ldc, m, n, k,
         int(accumulate), batch, sa, sb, sc, _stream())), "skinny_gemm")
     return out
 
@@ -700,7 +707,7 @@ def tn_gemm(x, y, *, out=None, batch=1, strides=(0, 0, 0), n=None, kx=None, ky=N
         so = out.stride(0)
     ws = torch.empty(int(_lib.bot_tn_gemm_workspace_floats(n, kx, ky, batch)), dtype=torch.float32, device=x.device)
     _check(_timed("tn_gemm", (n, kx, ky, batch), lambda: _lib.bot_tn_gemm_f32(
-        x.data_ptr(), x.stride(-2), y.data_ptr(), y.stride(-2), n, kx, ky, out.data_ptr(), out.stride(-2), int(transpose_out), batch, sx, sy, so,
+        x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), n, kx, ky, out.data_ptr(), _ld(out), int(transpose_out), batch, sx, sy, so,
         ws.data_ptr(),
         _stream())), "tn_gemm")
     return out

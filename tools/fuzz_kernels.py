@@ -134,4 +134,37 @@ for t in range(trials):
             ys = torch.randn(Hi, n, Di, generator=gen, dtype=torch.float64).to(DEV)
             refd = (xs[srcp].unsqueeze(1) * ys[:, dstp].permute(1, 0, 2)).sum(-1)
             assert close(_C.sddmm_dot_bcast(csc, xs.float(), ys.float()), refd, 1e-4), ("sddmm_dot_bcast", t, n, E, Hi, Di)
+    # --- dense products of round 2: random shapes, strides, magnitudes (fp64 reference; errors relative to the largest entry)
+    m, k, nn = ri(1, 3000), ri(1, 256), ri(1, 300)
+    mag = 10.0 ** ri(-9, 4)
+    lda = k + ri(0, 5)
+    A = (torch.randn(m, lda, generator=gen) * mag).to(DEV)[:, :k]
+    Bw = (torch.randn(nn, k, generator=gen) * 0.3).to(DEV)
+    refg = A.double() @ Bw.double().t()
+    ldc = nn + ri(0, 7)
+    Cbuf = torch.randn(m, ldc, generator=gen).to(DEV) * mag
+    base = Cbuf[:, :nn].double().clone()
+    acc = ri(0, 1) == 1
+    b_kn = ri(0, 1) == 1
+    _C.skinny_gemm(A, Bw.t().contiguous() if b_kn else Bw, b_is_kn=b_kn, out=Cbuf[:, :nn], accumulate=acc)
+    want = refg + base if acc else refg
+    assert close(Cbuf[:, :nn], want, 3e-6 * max(1.0, amax(want)) / max(1.0, amax(want))) or \
+        float((Cbuf[:, :nn].double() - want).abs().max()) <= 3e-6 * amax(want), ("skinny_gemm", t, m, k, nn, mag, acc, b_kn)
+    ky = ri(1, 300)
+    Yt = (torch.randn(m, ky, generator=gen)).to(DEV)
+    reft = A.double().t() @ Yt.double()
+    gott = _C.tn_gemm(A, Yt)
+    assert float((gott.double() - reft).abs().max()) <= 3e-6 * max(amax(reft), 1e-300), ("tn_gemm", t, m, k, ky, mag)
+    if t % 8 == 0:
+        from bot_amd import gemm
+        mm = ri(8192, 12000)
+        X = (torch.randn(mm, k, generator=gen) * mag).to(DEV)
+        xs = gemm.split(X, 0)
+        refh = X.double() @ Bw.double().t()
+        goth = gemm.mm_nt(xs, gemm.split(Bw, 1))
+        assert float((goth.double() - refh).abs().max()) <= 4e-6 * amax(refh), ("gemm_halves fwd", t, mm, k, nn, mag)
+        Dm = (torch.randn(mm, nn, generator=gen) * mag).to(DEV)
+        refw = X.double().t() @ Dm.double()
+        gotw = gemm.tn(xs, gemm.split(Dm, 0))
+        assert float((gotw.double() - refw).abs().max()) <= 4e-6 * amax(refw), ("gemm_halves tn", t, mm, k, nn, mag)
 print(f"fuzz ok: {trials} trials (seed {seed}), {blocked_hits} of them on the L2-blocked path")
