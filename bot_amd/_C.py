@@ -676,7 +676,7 @@ def skinny_gemm(a, b, *, b_is_kn, out, accumulate=False, batch=1, strides=(0, 0,
     _dev(a, b, out)
     for t, name in ((a, "a"), (b, "b"), (out, "out")):
         _f32(t, name)
-        if t.stride(-1) != 1:
+        if t.stride(-1) != 1 and t.shape[-1] != 1:
             raise BotKernelError(f"skinny_gemm: {name} must have unit column stride")
     if m is None:
         m, k = a.shape[-2], a.shape[-1]
@@ -695,7 +695,7 @@ def tn_gemm(x, y, *, out=None, batch=1, strides=(0, 0, 0), n=None, kx=None, ky=N
     x, y: fp32 row-major views with unit column stride; batch > 1: element strides (x, y, out), out [batch, kx, ky]."""
     _dev(x, y)
     _f32(x, "x"), _f32(y, "y")
-    if x.stride(-1) != 1 or y.stride(-1) != 1:
+    if (x.stride(-1) != 1 and x.shape[-1] != 1) or (y.stride(-1) != 1 and y.shape[-1] != 1):
         raise BotKernelError("tn_gemm: operands must have unit column stride")
     if n is None:
         n, kx, ky = x.shape[-2], x.shape[-1], y.shape[-1]
