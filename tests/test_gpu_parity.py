@@ -1249,3 +1249,28 @@ def test_tn_gemm_against_fp64():
     for i in range(H):
         ref = dx[:, i * D:(i + 1) * D].double().t() @ z[i].double()
         assert float((got[i].double() - ref).abs().max() / ref.abs().max()) <= 2e-6
+
+
+def test_bench_line_contract():
+    """`python bench.py` (small scale, few steps) prints ONE JSON object as the last stdout line with the driver's keys, the roofline
+    and cpu_baseline objects, and — new in round 2 — the stock-fp32-GEMM timing of the same steps beside `value`."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--scale", "0.2",
+                          "--cpu-steps", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["unit"] == "edges/s" and line["dtype"] == "f32"
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and line["higher_is_better"] is True
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "kernel" in r
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["value"] > 0
+    assert "workload" in line["config"] and "gemm" in line["config"]
+    s = line["stock_fp32_gemm"]
+    assert s is not None and s["ms_per_step"] > 0 and s["unit"] == "edges/s"
