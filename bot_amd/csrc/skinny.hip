@@ -270,12 +270,18 @@ int bot_skinny_gemm_f32(const float* A, int64_t lda, const float* B, int64_t ldb
     gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
     const size_t lds = (size_t)3 * nb * (kp + 8) * 2;
     hipStream_t st = (hipStream_t)stream;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     a.ny = ny, a.gx = (int)gx, a.batch = batch;
     const dim3 grid((unsigned)(8 * ((gx * batch + 7) / 8) * ny));
 #define BOT_SK_LAUNCH(NT_, KP_)                                                                                                       \
     do {                                                                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gemm_kernel<NT_, KP_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)lds);                                                                                          \
+        static bool attr_set[64] = {};  /* the LDS size of an instantiation is fixed: raise its limit once per device */                \
+        if (!attr_set[dev & 63]) {                                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gemm_kernel<NT_, KP_>),                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                          \
+            attr_set[dev & 63] = true;                                                                                                        \
+        }                                                                                                                             \
         hipLaunchKernelGGL((skinny_gemm_kernel<NT_, KP_>), grid, dim3(kSkThreads), lds, st, a);                                         \
     } while (0)
     if (kp == 64) BOT_SK_LAUNCH(4, 64);
