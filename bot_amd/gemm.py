@@ -72,14 +72,17 @@ def epilogue_piece(F: int, x) -> int | None:
     return (F + PIECE_ALIGN - 1) // PIECE_ALIGN * PIECE_ALIGN
 
 
-def _alpha(a: Halves, b: Halves):
-    return a.scale[1:] * b.scale[1:]
+def _alpha(a: Halves, b: Halves, n=None):
+    """1 / (s_a s_b) on the device, one value per output column when `n` is given (hipBLASLt's device-vector alpha): ONE launch."""
+    if n is None:
+        return a.scale[1:] * b.scale[1:]
+    return torch.mul(a.scale[1:].expand(n), b.scale[1:].expand(n))
 
 
 def mm_nt(a: Halves, b: Halves, out=None):
     """a [n, F] (order 0) times b [p, F]^T (order 1) -> fp32 [n, p]."""
     assert a.order == 0 and b.order == 1 and a.F == b.F and a.piece == b.piece
-    return _C.gemm_halves(a.buf, b.buf, _alpha(a, b), trans_b=True, out=out)
+    return _C.gemm_halves(a.buf, b.buf, _alpha(a, b, b.n), trans_b=True, out=out)
 
 
 def tn(x: Halves, d: Halves):
@@ -88,7 +91,7 @@ def tn(x: Halves, d: Halves):
     afterwards — faster than one long-K GEMM and a pairwise-style summation (bot_amd.ops.weight_grad)."""
     assert x.order == 0 and d.order == 0 and x.n == d.n
     N, K, P, KP, PP = x.n, x.F, d.F, x.piece, d.piece
-    alpha = _alpha(x, d)
+    alpha = _alpha(x, d, 2 * PP)                # one value per output column; the narrower products take a prefix
     S = max(1, N // CHUNK_ROWS)
     R = N // S
     ldx, ldd = x.buf.stride(0), d.buf.stride(0)
@@ -96,7 +99,7 @@ def tn(x: Halves, d: Halves):
     d12, d1 = d.buf[:, PP:3 * PP], d.buf[:, :PP]
 
     def part(xa, db, n, rows, batch, r0):
-        return _C.gemm_halves(xa[r0:], db[r0:], alpha, trans_a=True, m=K, n=n, k=rows, batch=batch,
+        return _C.gemm_halves(xa[r0:], db[r0:], alpha[:n], trans_a=True, m=K, n=n, k=rows, batch=batch,
                               strides=(rows * ldx, rows * ldd, 0))
 
     a = part(x1, d12, 2 * PP, R, S, 0)
