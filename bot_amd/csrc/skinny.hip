@@ -76,7 +76,7 @@ union Frag {
     uint4 q;
 };
 
-template <int NT, int KP>
+template <int NT, int KP, int AW>
 __global__ __launch_bounds__(kSkThreads) void skinny_gemm_kernel(SkinnyArgs a) {
     extern __shared__ unsigned short lds[];             // [3][NT*32][ks]
     constexpr int NB = NT * 32;
@@ -138,24 +138,32 @@ __global__ __launch_bounds__(kSkThreads) void skinny_gemm_kernel(SkinnyArgs a) {
     const int r = lane & 31, h = lane >> 5;
     constexpr int nsteps = KP / 16;
     const int64_t ntiles = (a.m + kSkRows - 1) / kSkRows;
-    // 8 consecutive k (k0 = 16 step + 8 h) of this lane's row of a tile; rows beyond m and k beyond K read as zero
+    // 8 consecutive k (k0 = 16 step + 8 h) of this lane's row of a tile, branch-free on the main path: rows beyond m are clamped to
+    // the last row (their accumulator rows are never stored) and k beyond K is multiplied by the zero padding of the B images, so
+    // only the ONE partial k-step of a row (K not a multiple of 8 per lane half) takes guarded element loads — it must not read
+    // past the end of the matrix, and whatever it reads has to be finite.
     auto load8 = [&](float (&v)[8], int64_t tile, int step) {
-        const int64_t row = tile * kSkRows + wave * 32 + r;
-        const bool rok = row < a.m;
-        const float* ar = A + (rok ? row : 0) * a.lda;
+        int64_t row = tile * kSkRows + wave * 32 + r;
+        row = row < a.m ? row : a.m - 1;
+        const float* ar = A + row * a.lda;
         const int k0 = step * 16 + 8 * h;
-        if (rok && k0 + 8 <= a.k && a.a_wide == 2) {
-            const float4 t0 = *reinterpret_cast<const float4*>(ar + k0), t1 = *reinterpret_cast<const float4*>(ar + k0 + 4);
-            v[0] = t0.x, v[1] = t0.y, v[2] = t0.z, v[3] = t0.w, v[4] = t1.x, v[5] = t1.y, v[6] = t1.z, v[7] = t1.w;
-        } else if (rok && k0 + 8 <= a.k && a.a_wide == 1) {
+        if (k0 + 8 <= a.k) {
+            if constexpr (AW == 2) {
+                const float4 t0 = *reinterpret_cast<const float4*>(ar + k0), t1 = *reinterpret_cast<const float4*>(ar + k0 + 4);
+                v[0] = t0.x, v[1] = t0.y, v[2] = t0.z, v[3] = t0.w, v[4] = t1.x, v[5] = t1.y, v[6] = t1.z, v[7] = t1.w;
+            } else if constexpr (AW == 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float2 t2 = *reinterpret_cast<const float2*>(ar + k0 + 2 * j);
-                v[2 * j] = t2.x, v[2 * j + 1] = t2.y;
+                for (int j = 0; j < 4; ++j) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(ar + k0 + 2 * j);
+                    v[2 * j] = t2.x, v[2 * j + 1] = t2.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ar[k0 + j];
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (rok && k0 + j < a.k) ? ar[k0 + j] : 0.f;
+            for (int j = 0; j < 8; ++j) v[j] = k0 + j < a.k ? ar[k0 + j] : 0.f;
         }
     };
     // A is fetched TWO k-steps at a time: the two lane halves of a row then consume one whole 128-byte line (k = 32 s' .. 32 s' + 31)
@@ -205,35 +213,38 @@ __global__ __launch_bounds__(kSkThreads) void skinny_gemm_kernel(SkinnyArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) cur[0][j] = nxt[0][j], cur[1][j] = nxt[1][j];
         }
-        // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-        const int64_t rwave = tile * kSkRows + wave * 32;
-        const int64_t rbase = rwave + 4 * h;
+        // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  The address of an element is
+        // split into a wave-uniform part (tile, wave, register row: scalar registers) and a 32-bit per-lane offset (lane half, column).
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+        const int64_t rwave = tile * kSkRows + wave_s * 32;
+        float* Cw = C + rwave * a.ldc + col0;
         if (rwave + 32 <= a.m) {            // the whole 32-row group exists: no per-row guards
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int c = col0 + t * 32 + r;
-                if (c >= a.n) continue;
-                float* p = C + rbase * a.ldc + c;
+                if (col0 + t * 32 + r >= a.n) continue;
+                const int voff = 4 * h * (int)a.ldc + t * 32 + r;
                 if (a.accumulate) {         // all sixteen loads in flight, then the stores
                     float old[16];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) old[j] = p[(int64_t)((j & 3) + 8 * (j >> 2)) * a.ldc];
+                    for (int j = 0; j < 16; ++j) old[j] = (Cw + (int64_t)((j & 3) + 8 * (j >> 2)) * a.ldc)[voff];
 #pragma unroll
                     for (int j = 0; j < 16; ++j) acc[t][j] += old[j];
                 }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) p[(int64_t)((j & 3) + 8 * (j >> 2)) * a.ldc] = acc[t][j];
+                for (int j = 0; j < 16; ++j) (Cw + (int64_t)((j & 3) + 8 * (j >> 2)) * a.ldc)[voff] = acc[t][j];
             }
         } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int c = col0 + t * 32 + r;
-                if (c >= a.n) continue;
-                float* p = C + rbase * a.ldc + c;
+                if (col0 + t * 32 + r >= a.n) continue;
+                const int voff = 4 * h * (int)a.ldc + t * 32 + r;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int dr = (j & 3) + 8 * (j >> 2);
-                    if (rbase + dr < a.m) p[(int64_t)dr * a.ldc] = a.accumulate ? p[(int64_t)dr * a.ldc] + acc[t][j] : acc[t][j];
+                    if (rwave + 4 * h + dr < a.m) {
+                        float* p = Cw + (int64_t)dr * a.ldc + voff;
+                        *p = a.accumulate ? *p + acc[t][j] : acc[t][j];
+                    }
                 }
             }
         }
@@ -265,8 +276,10 @@ int bot_skinny_gemm_f32(const float* A, int64_t lda, const float* B, int64_t ldb
     const int nb = nt * 32;
     const int ny = (n + nb - 1) / nb;
     const int64_t ntiles = (m + kSkRows - 1) / kSkRows;
-    // persistent over row tiles: about two workgroups' worth of work queued per CU in total
-    int64_t gx = (int64_t)512 / ((int64_t)ny * batch);
+    // persistent over row tiles: ONE workgroup per CU (the LDS images allow no second one) and no more workgroups than CUs —
+    // a few left over for a second round would run alone for a whole round
+    // (32 CUs per XCD: floor(32 / ny) row-tile sequences per XCD, each with its ny column blocks)
+    int64_t gx = (int64_t)(32 / ny > 0 ? 32 / ny : 1) * 8 / batch;
     gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
     const size_t lds = (size_t)3 * nb * (kp + 8) * 2;
     hipStream_t st = (hipStream_t)stream;
@@ -274,20 +287,27 @@ int bot_skinny_gemm_f32(const float* A, int64_t lda, const float* B, int64_t ldb
     (void)hipGetDevice(&dev);
     a.ny = ny, a.gx = (int)gx, a.batch = batch;
     const dim3 grid((unsigned)(8 * ((gx * batch + 7) / 8) * ny));
-#define BOT_SK_LAUNCH(NT_, KP_)                                                                                                       \
+#define BOT_SK_LAUNCH1(NT_, KP_, AW_)                                                                                                 \
     do {                                                                                                                              \
         static bool attr_set[64] = {};  /* the LDS size of an instantiation is fixed: raise its limit once per device */                \
-        if (!attr_set[dev & 63]) {                                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gemm_kernel<NT_, KP_>),                                    \
+        if (!attr_set[dev & 63]) {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gemm_kernel<NT_, KP_, AW_>),                               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                          \
-            attr_set[dev & 63] = true;                                                                                                        \
+            attr_set[dev & 63] = true;                                                                                                \
         }                                                                                                                             \
-        hipLaunchKernelGGL((skinny_gemm_kernel<NT_, KP_>), grid, dim3(kSkThreads), lds, st, a);                                         \
+        hipLaunchKernelGGL((skinny_gemm_kernel<NT_, KP_, AW_>), grid, dim3(kSkThreads), lds, st, a);                                    \
+    } while (0)
+#define BOT_SK_LAUNCH(NT_, KP_)                        \
+    do {                                               \
+        if (a.a_wide == 2) BOT_SK_LAUNCH1(NT_, KP_, 2); \
+        else if (a.a_wide == 1) BOT_SK_LAUNCH1(NT_, KP_, 1); \
+        else BOT_SK_LAUNCH1(NT_, KP_, 0);               \
     } while (0)
     if (kp == 64) BOT_SK_LAUNCH(4, 64);
     else if (kp == 128) BOT_SK_LAUNCH(4, 128);
     else if (kp == 176) BOT_SK_LAUNCH(4, 176);
     else BOT_SK_LAUNCH(3, 256);
+#undef BOT_SK_LAUNCH1
 #undef BOT_SK_LAUNCH
     set_kernel("bot::skinny_gemm_kernel<%d,%d> k=%d n=%d batch=%d", nt, kp, k, n, batch);
     return hip_status("skinny_gemm launch");
