@@ -26,3 +26,7 @@ def dz32():
     for i in range(H): torch.mm(dx[:, i * D:(i + 1) * D], W[i], out=dz[i])
 print("per-head dz:                 fp32 %.3f ms   skinny %.3f ms" % (
     timed(dz32), timed(lambda: _C.skinny_gemm(dx, W, b_is_kn=True, out=dz, batch=H, strides=(D, D * Fin, N * Fin), m=N, n=Fin, k=D))))
+# what a fused [z_i | h] product could save: the per-head product without the read-modify-write, h @ Wr for the score columns only
+print("per-head fwd, plain stores:   skinny %.3f ms" % timed(lambda: _C.skinny_gemm(z, W, b_is_kn=False, out=out2, accumulate=False, batch=H, strides=(N * Fin, D * Fin, D), m=N, n=D, k=Fin)))
+Ws = Wr[:, 750:].contiguous(); outs = torch.empty(N, 18, device=dev)
+print("h @ Wr[:, 750:] (18 columns): skinny %.3f ms   fp32 %.3f ms" % (timed(lambda: _C.skinny_gemm(h, Ws, b_is_kn=True, out=outs)), timed(lambda: torch.mm(h, Ws, out=outs))))
