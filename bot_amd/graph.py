@@ -373,12 +373,13 @@ def reorder_permutation(g: Graph, method: str = "community"):
     return by_deg[torch.argsort(labels[by_deg], stable=True)], labels
 
 
-def reorder_graph(g: Graph, method: str = "community") -> Graph:
+def reorder_graph(g: Graph, method: str = "community", plan_order: str | None = None) -> Graph:
     """The same graph under a locality-friendly vertex numbering.  Edge e keeps its id and its endpoints
     (relabelled), so per-destination sums run over the same edges in the same order and every integer property (degrees,
     edge ids, CSC/CSR contents) maps back through `node_perm` exactly; node tensors handed to / returned by the stacks stay
     in ORIGINAL order (`to_internal` / `to_original`).  With method="community" and a real community structure (no label
-    holding over a quarter of the vertices) the row plans use the XCD-aware item order."""
+    holding over a quarter of the vertices) the row plans use the XCD-aware item order; `plan_order` ("degree" | "xcd")
+    overrides that choice (the item order never changes a result, only where a row is swept)."""
     assert not g.is_block, "reorder applies to whole graphs"
     perm, labels = reorder_permutation(g, method)
     n = g.number_of_nodes()
@@ -388,12 +389,16 @@ def reorder_graph(g: Graph, method: str = "community") -> Graph:
     h = Graph(inv[s], inv[d], n, chunk=g._chunk)
     h.node_perm, h.node_inv = perm, inv
     h.ndata, h.edata = _Frame(g.ndata), _Frame(g.edata)                 # frames stay in original node / edge order
-    if labels is not None and int(torch.bincount(labels).max()) * 4 <= n:
+    if plan_order is not None:
+        if plan_order not in ("degree", "xcd"):
+            raise ValueError(f"unknown plan order {plan_order!r}")
+        h.plan_order = plan_order
+    elif labels is not None and int(torch.bincount(labels).max()) * 4 <= n:
         h.plan_order = "xcd"
     return h
 
 
-def preprocess(g: Graph, reorder: str | None = None) -> Graph:
+def preprocess(g: Graph, reorder: str | None = None, plan_order: str | None = None) -> Graph:
     """The graph half of `preprocess(graph)` — run.py:133-148.  `reorder` ("degree" | "community", default None): renumber
     the vertices for locality afterwards (see `reorder_graph`); results of the stacks are unchanged and stay in original order."""
     feat = g.ndata.get("feat")
@@ -402,6 +407,6 @@ def preprocess(g: Graph, reorder: str | None = None) -> Graph:
         g.ndata["feat"] = feat
     g = g.remove_self_loop().add_self_loop()
     if reorder:
-        g = reorder_graph(g, reorder)
+        g = reorder_graph(g, reorder, plan_order)
     g.create_formats_()
     return g

@@ -492,3 +492,204 @@ def check_keep_mask_orders(golden, device):
         a2 = ops.gat_attention(g, el, er, keep=ke, order="csc", **kw)
         assert torch.equal(a1, a2)
         assert torch.equal((a1.reshape(E, H)[:, 0] == 0), kc == 0)
+
+
+# ---------------------------------------------------------------------------------------------- f4: ingest + locality (run.py:133-148)
+F4_COMM_NODES = 20000   # the CPU suite (emulated backend) shrinks this
+
+
+def f4_cases(golden):
+    """(name, raw src, raw dst, n): the golden g300 input and a 20k-node graph with planted communities (bot_amd.synth)."""
+    from bot_amd import synth
+    rs, rd, n = golden.graph("g300_raw")
+    yield "g300", rs, rd, n
+    n2 = F4_COMM_NODES
+    cs, cd = synth.community_edges(n2, n2 * 15 // 2, 3, n_blocks=16, p_in=0.9)
+    yield "comm20k", cs, cd, n2
+
+
+def _rows_of(direction):
+    deg = (direction.indptr[1:] - direction.indptr[:-1]).long()
+    return torch.repeat_interleave(torch.arange(direction.n_rows, device=deg.device), deg)
+
+
+def check_f4_integer_invariants(golden, device):
+    """`preprocess(reorder=...)` ON THE DEVICE is the reference's `preprocess` (run.py:133-148: oracle `preprocess_edges`, edge
+    ids bit-exact) under a pure renumbering: node_perm is a permutation with the stated inverse, edge e keeps its id and its
+    endpoints, degrees map back bit-exact, every destination's in-edge list holds the same edge ids in the same order, node
+    tensors round-trip, and the XCD-aware item order (forced) is a permutation of the row plan with the long-row chunks in
+    front.  Integer work: everything compared with torch.equal."""
+    from bot_amd.graph import build_direction, xcd_item_order
+    for name, rs, rd, n in f4_cases(golden):
+        s, d = R.preprocess_edges(rs, rd, n)
+        ip, idx, eid = R.build_csc(s, d, n)
+        in_deg, out_deg = torch.bincount(d, minlength=n), torch.bincount(s, minlength=n)
+        for method, order in (("degree", None), ("community", None), ("community", "xcd"), ("degree", "xcd")):
+            h = bot_amd.preprocess(bot_amd.Graph(rs, rd, n).to(device), reorder=method, plan_order=order)
+            assert str(h.device).startswith(str(device)) and h.node_perm.device == h.device
+            if order is not None:
+                assert h.plan_order == order
+            elif name == "comm20k" and method == "community":
+                assert h.plan_order == "xcd"                                  # planted blocks are found: XCD-aware plans by default
+            perm, inv = h.node_perm.cpu(), h.node_inv.cpu()
+            ar = torch.arange(n)
+            assert torch.equal(torch.sort(perm).values, ar) and torch.equal(perm[inv], ar) and torch.equal(inv[perm], ar)
+            hs, hd = (t.cpu() for t in h.edges())
+            assert torch.equal(perm[hs], s) and torch.equal(perm[hd], d)      # edge e: the oracle's endpoints, the oracle's id
+            assert torch.equal(h.to_original(h.in_degrees()).cpu(), in_deg) and h.in_degrees().dtype == torch.int64
+            assert torch.equal(h.to_original(h.out_degrees()).cpu(), out_deg)
+            x = torch.arange(n * 3).view(n, 3).to(device)
+            assert torch.equal(h.to_original(h.to_internal(x)), x) and torch.equal(h.to_internal(x).cpu()[inv], x.cpu())
+            # in-edge lists: regrouped by ORIGINAL destination they are the oracle's CSC (same edge ids in the same order)
+            c = h.csc
+            o = torch.argsort(perm[_rows_of(c).cpu()], stable=True)
+            assert torch.equal(c.eid.cpu().long()[o], eid) and torch.equal(perm[c.indices.cpu().long()[o]], idx)
+            assert torch.equal(torch.bincount(perm[_rows_of(c).cpu()], minlength=n).cumsum(0), ip[1:])
+            r = h.csr
+            o = torch.argsort(perm[_rows_of(r).cpu()], stable=True)
+            rip, ridx, reid = R.build_csr(s, d, n)
+            assert torch.equal(r.eid.cpu().long()[o], reid) and torch.equal(perm[r.indices.cpu().long()[o]], ridx)
+            assert torch.equal(c.eid.cpu()[h.csr2csc.cpu().long()], r.eid.cpu())
+            if method == "degree":
+                deg = h.in_degrees()
+                assert bool((deg[:-1] >= deg[1:]).all())
+            # the plan: every (row, begin, end, slot) item exactly once, whatever the order
+            plain = build_direction(h.edges()[1], h.edges()[0], n, None, "degree")
+            key = lambda t: sorted(map(tuple, t.cpu().tolist()))
+            assert c.items.shape == plain.items.shape and key(c.items) == key(plain.items)
+            if h.plan_order == "xcd":
+                n_long = int((plain.items[:, 3] >= 0).sum())
+                assert torch.equal(c.items[:n_long].cpu(), plain.items[:n_long].cpu())
+                assert torch.equal(c.items.cpu(), xcd_item_order(plain.items).cpu())
+                whole = c.items[n_long:, 0].cpu()
+                assert name != "comm20k" or not torch.equal(whole, plain.items[n_long:, 0].cpu())   # the order did change
+
+
+def check_f4_layers_in_original_order(golden, device):
+    """The sparse sweeps on a renumbered graph with (forced) XCD-aware plans, operands and results in ORIGINAL node order,
+    against oracle/ref_ops.py: one GAT layer's attention + aggregation forward and backward (config-2 hidden and output
+    shapes), the 3-layer stacks of tests/golden/stacks.npz on g300 (the reference's own modules), and on the planted graph a
+    config-2-style 3-layer GAT (fused nodes, aggregate-first layer 0) against oracle/ref_models.py."""
+    from bot_amd.nn import fused
+    for name, rs, rd, n in f4_cases(golden):
+        s, d = R.preprocess_edges(rs, rd, n)
+        gen = torch.Generator().manual_seed(41)
+        layer_refs = []                                                       # the oracle's side, once per graph
+        for H, D in ((3, 250), (1, 40)):
+            x = torch.randn(n, H, D, generator=gen)
+            el, er = torch.randn(n, H, 1, generator=gen), torch.randn(n, H, 1, generator=gen)
+            gout = torch.randn(n, H, D, generator=gen)
+            xo, lo, ro = leaf(x), leaf(el), leaf(er)
+            ref = R.u_mul_e_sum(s, d, n, xo, R.edge_softmax(d, n, F.leaky_relu(R.u_add_v(s, d, lo, ro), 0.2)))
+            (ref * gout).sum().backward()
+            layer_refs.append((x, el, er, gout, ref.detach().numpy(), xo.grad.numpy(), lo.grad.numpy(), ro.grad.numpy()))
+        if name != "g300":
+            fin, C = 9, 5
+            cfg = dict(n_layers=3, n_heads=3, n_hidden=16, norm="batch", non_interactive_attn=False, use_symmetric_norm=False,
+                       linear=True, residual=False)
+            torch.manual_seed(11)
+            model0 = bnn.GAT(dim_node=fin, dim_edge=0, dim_output=C, activation=F.relu, **cfg).train()
+            sd0 = {k: v.clone() for k, v in model0.state_dict().items()}
+            feat0, gout0 = torch.randn(n, fin, generator=gen), torch.randn(n, C, generator=gen)
+            p = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd0.items()}
+            sref = RM.gat_forward(RM.CooGraph(s, d, n), feat0, p, n_classes=C, training=True, **cfg)
+            names = [k for k, v in p.items() if v.requires_grad]
+            sref_grads = torch.autograd.grad((sref * gout0).sum(), [p[k] for k in names])
+        for method, order in (("community", "xcd"), ("degree", "xcd"), ("community", None)):
+            h = bot_amd.preprocess(bot_amd.Graph(rs, rd, n).to(device), reorder=method, plan_order=order)
+            for x, el, er, gout, ref, dxr, dlr, drr in layer_refs:
+                xt, lt, rt = leaf(x, device), leaf(el, device), leaf(er, device)
+                a = ops.gat_attention(h, h.to_internal(lt), h.to_internal(rt), negative_slope=0.2, order="csc")
+                out = h.to_original(ops.u_mul_e_sum(h, h.to_internal(xt), a, order="csc"))
+                (out * gout.to(device)).sum().backward()
+                fwd_close(out, ref)
+                grad_close(xt.grad, dxr)
+                grad_close(lt.grad, dlr)
+                grad_close(rt.grad, drr)
+            if name == "g300":
+                n_run = 0
+                for c in golden.cases("stacks"):
+                    gname, kind, training, cfg = (str(v) for v in c["meta"])
+                    if gname != "g300":
+                        continue
+                    cfg = ast.literal_eval(cfg)
+                    model = load_params(build_stack(kind, cfg), c, device).train(bool(int(training)))
+                    feat = leaf(c.t("feat"), device)
+                    logits = model(h, feat)                                   # node tensors in ORIGINAL order in and out
+                    fwd_close(logits, c["logits"])
+                    (logits * c.t("gout").to(device)).sum().backward()
+                    grad_close(feat.grad, c["dfeat"], 3e-4)
+                    for k, p in model.named_parameters():
+                        grad_close(p.grad, c[f"g.{k}"], 3e-4)
+                    if not bool(int(training)):
+                        with torch.no_grad():
+                            fwd_close(model(h, feat.detach()), c["logits"])  # the inference-only sweep on the renumbered graph
+                    n_run += 1
+                assert n_run == 10
+            else:
+                model = bnn.GAT(dim_node=fin, dim_edge=0, dim_output=C, activation=F.relu, **cfg).train()
+                model.load_state_dict(sd0)
+                model = model.to(device)
+                c0, a0 = fused.CALLS, fused.AGG_CALLS
+                logits = model(h, leaf(feat0, device))
+                if str(device) != "cpu" or fused.FORCE:
+                    assert fused.CALLS == c0 + 3 and fused.AGG_CALLS == a0 + 1
+                (logits * gout0.to(device)).sum().backward()
+                fwd_close(logits, sref.detach().numpy())
+                got = dict(model.named_parameters())
+                for k, rg in zip(names, sref_grads):
+                    grad_close(got[k].grad, rg.numpy(), 3e-4)
+
+
+def check_f4_community_partition_blocks(golden, device, worlds=(2, 3)):
+    """`partition_dataset(partitioner="community")` on the device: the blocks of all ranks computed side by side in one process
+    (halo rows supplied by indexing) reproduce the full-graph GAT aggregation of oracle/ref_ops.py forward and backward, the
+    ranges follow the community order (node_ids = the original ids, a permutation overall), degrees of the owned rows are
+    bit-exact, and the partition cuts fewer edges / needs fewer halo rows than contiguous ranges of the given (random) ids."""
+    from bot_amd import dist as bdist
+    from bot_amd import synth
+    name, rs, rd, n = list(f4_cases(golden))[1]
+    s, d = R.preprocess_edges(rs, rd, n)
+    g = bot_amd.preprocess(bot_amd.Graph(rs, rd, n).to(device))
+    gen = torch.Generator().manual_seed(43)
+    H, D = 3, 20
+    x = torch.randn(n, H, D, generator=gen)
+    el, er = torch.randn(n, H, 1, generator=gen), torch.randn(n, H, 1, generator=gen)
+    gout = torch.randn(n, H, D, generator=gen)
+    xo, lo, ro = leaf(x), leaf(el), leaf(er)
+    ref = R.u_mul_e_sum(s, d, n, xo, R.edge_softmax(d, n, F.leaky_relu(R.u_add_v(s, d, lo, ro), 0.2)))
+    (ref * gout).sum().backward()
+    in_deg = torch.bincount(d, minlength=n)
+    labels = torch.randint(0, 5, (n, 1), generator=gen)
+    idx = torch.randperm(n, generator=gen)
+    ds = synth.Dataset(g, x.flatten(1).to(device), labels.to(device), idx[:n // 2].to(device), idx[n // 2:3 * n // 4].to(device),
+                       idx[3 * n // 4:].to(device), 5, rs.numel())
+    xd, ld, rdv, gd = (t.to(device) for t in (x, el, er, gout))
+    for world in worlds:
+        parts = [bdist.partition_dataset(ds, r, world, device, partitioner="community") for r in range(world)]
+        perm = torch.cat([p.node_ids for p in parts])                          # new id -> original id
+        assert torch.equal(torch.sort(perm.cpu()).values, torch.arange(n))
+        full = torch.zeros(n, H, D, device=device)
+        dx, dl, dr = torch.zeros_like(xd), torch.zeros_like(ld), torch.zeros_like(rdv)
+        halo_rows = cut = 0
+        for p in parts:
+            own = p.node_ids
+            glob = torch.cat([own, perm[p.halo_global]])
+            assert torch.equal(p.feat, ds.feat[own]) and torch.equal(p.labels, ds.labels[own])
+            assert torch.equal(torch.sort(own[p.train_idx]).values.cpu(), torch.sort(ds.train_idx[torch.isin(ds.train_idx, own)]).values.cpu())
+            xe, le, re = leaf(xd[glob], device), leaf(ld[glob], device), leaf(rdv[own], device)
+            out = ops.u_mul_e_sum(p.graph, xe, ops.gat_attention(p.graph, le, re, negative_slope=0.2, order="csc"), order="csc")
+            (out * gd[own]).sum().backward()
+            full[own] = out.detach()
+            dx.index_add_(0, glob, xe.grad)
+            dl.index_add_(0, glob, le.grad)
+            dr[own] += re.grad
+            assert torch.equal(p.graph.in_degrees().cpu(), in_deg[own.cpu()])
+            halo_rows += p.halo_global.numel()
+            cut += int((p.graph.edges()[0] >= p.n_owned).sum())
+        fwd_close(full, ref.detach().numpy())
+        grad_close(dx, xo.grad.numpy())
+        grad_close(dl, lo.grad.numpy())
+        grad_close(dr, ro.grad.numpy())
+        base = bdist.halo_statistics(s, d, n, world)
+        assert halo_rows < 0.6 * sum(base["halo_rows_per_rank"]) and cut < 0.5 * base["cut_edges"], (halo_rows, cut, base)

@@ -172,6 +172,23 @@ def test_block_graphs_reproduce_full_graph(golden):
     assert torch.allclose(dx, xf.grad, atol=1e-4) and torch.allclose(dl, lf.grad, atol=1e-4) and torch.allclose(dr, rf.grad, atol=1e-4)
 
 
+def test_f4_reorder_integer_invariants_on_device(golden):
+    """SURVEY §8 f4 on the real device path: `preprocess(reorder="degree" | "community")` with the integer work done by device-side
+    ops, forced and default XCD-aware plans — all integer invariants bit-exact against the oracle's preprocess (run.py:133-148)."""
+    PC.check_f4_integer_invariants(golden, DEV)
+
+
+def test_f4_kernels_on_reordered_graphs_against_oracle(golden):
+    """The real kernels over XCD-ordered plans of renumbered graphs, in ORIGINAL id order, against oracle/ref_ops.py, the stacks
+    golden (g300) and oracle/ref_models.py (20k-node planted-community graph, fused layer nodes)."""
+    PC.check_f4_layers_in_original_order(golden, DEV)
+
+
+def test_f4_community_partition_blocks_on_device(golden):
+    """`partition_dataset(partitioner="community")` blocks of 2 and 3 ranks side by side on the real kernels vs the oracle."""
+    PC.check_f4_community_partition_blocks(golden, DEV)
+
+
 def test_proteins_golden(golden):
     PC.check_proteins_golden(golden, DEV)
 

@@ -358,3 +358,18 @@ def test_stacks_golden_on_halves(golden, cpu_backend, monkeypatch, fuse):
     gemm.STATS.update(stashed=0, taken=0, split=0)
     PC.check_stacks_golden(golden, "cpu", fuse=fuse)
     assert not fuse or (gemm.STATS["split"] > 0 and gemm.STATS["taken"] > 0)   # the modular path's golden shapes are below gemm.worth()
+
+
+def test_f4_integer_invariants_emulated(golden, cpu_backend):
+    PC.check_f4_integer_invariants(golden, "cpu")
+
+
+def test_f4_layers_in_original_order_emulated(golden, cpu_backend, monkeypatch):
+    from bot_amd.nn import fused
+    monkeypatch.setattr(fused, "FORCE", True)
+    monkeypatch.setattr(PC, "F4_COMM_NODES", 4000)
+    PC.check_f4_layers_in_original_order(golden, "cpu")
+
+
+def test_f4_community_partition_blocks_emulated(golden, cpu_backend):
+    PC.check_f4_community_partition_blocks(golden, "cpu", worlds=(2,))
