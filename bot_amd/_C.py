@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -75,6 +75,7 @@ _SIGS = {
     "bot_gemm_halves_f32": (ctypes.c_int, [c_int32, c_int32, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int64,
                                            c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, c_int32, _P]),
     "bot_gemm_halves_last_algo": (ctypes.c_int, [_P, _P]),
+    "bot_gemm_halves_library_version": (ctypes.c_int, [_P, _P]),
     "bot_tn_gemm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32, c_int32]),
     "bot_tn_gemm_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int32, c_int32, c_int64, c_int64,
                                        c_int64, _P, _P]),
@@ -607,7 +608,11 @@ def halves_split(x, scale, order, piece, out=None):
 
 
 _GEMM_WS = {}
-GEMM_TUNE = int(os.environ.get("BOT_GEMM_TUNE", "1"))   # 0: heuristic's first choice; 1: fastest of 16 candidates; 2: of all solutions
+# Kernel choice for shapes without a recorded selection.  0 (default): hipBLASLt's first heuristic choice — no timing runs, no
+# synchronisation, the same kernel in every run and on every rank.  Opt-in (maintenance / exploration, NOT bitwise reproducible across
+# runs, synchronises on the first call per shape): 1 = fastest of 16 heuristic candidates timed on the caller's buffers, 2 = of all
+# solutions (tools/tune_halves_gemm.py, which records the winners in bot_amd/tuning/halves_gemm.json).
+GEMM_TUNE = int(os.environ.get("BOT_GEMM_TUNE", "0"))
 GEMM_ALGOS = None      # {shape key: hipBLASLt solution index} recorded by tools/tune_halves_gemm.py (bot_amd/tuning/halves_gemm.json)
 GEMM_SEEN = None       # tools set this to a dict to collect {shape key: (solution index, ms in the search)} of the launches
 
@@ -630,6 +635,18 @@ def _gemm_algos():
 def _hipblaslt_tag():
     """Identifies the hipBLASLt build whose solution indices the tuning file holds: torch's version string (it ships the library)."""
     return f"torch {torch.__version__} hip {torch.version.hip}"
+
+
+def hipblaslt_versions():
+    """(compiled-against, running-on) hipBLASLt versions as major * 100000 + minor * 100 + patch; running-on is 0 before the first
+    gemm_halves call.  The library is built with /opt/rocm's headers and binds whichever libhipblaslt.so the process loaded first
+    — torch's bundled copy when torch is imported (same soname).  A different MAJOR means another struct layout: refuse."""
+    c, r = c_int32(0), c_int32(0)
+    _lib.bot_gemm_halves_library_version(ctypes.byref(c), ctypes.byref(r))
+    return c.value, r.value
+
+
+_LT_CHECKED = False
 
 
 def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1, strides=(0, 0, 0), m=None, n=None, k=None, beta=0.0,
@@ -663,6 +680,13 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     _check(_timed("gemm_halves", (m, n, k, batch), lambda: _lib.bot_gemm_halves_f32(
         int(trans_a), int(trans_b), m, n, k, alpha.data_ptr(), a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(),
         ldc, batch, sa, sb, sc, float(beta), ws.data_ptr(), ws.numel(), int(GEMM_TUNE), index, _stream())), "gemm_halves")
+    global _LT_CHECKED
+    if not _LT_CHECKED:
+        _LT_CHECKED = True
+        c, r = hipblaslt_versions()
+        if r and c // 100000 != r // 100000:
+            raise BotKernelError(f"libbot_gnn.so was built against hipBLASLt {c} but the process runs on hipBLASLt {r}: rebuild against "
+                                 "the headers of the library that is loaded")
     if GEMM_SEEN is not None and key not in GEMM_SEEN:
         idx, ms = ctypes.c_int32(-1), ctypes.c_float(0.0)
         _lib.bot_gemm_halves_last_algo(ctypes.byref(idx), ctypes.byref(ms))
@@ -723,6 +747,14 @@ def colsum(x):
     return out
 
 
+def _written(*ts):
+    """The library wrote these tensors through raw pointers: move their autograd version counters, as an in-place torch op
+    would, so that anything keyed on `_version` (the inference-path caches of bot_amd.nn.fused, saved-tensor checks) sees it."""
+    for t in ts:
+        if t is not None:
+            torch._C._increment_version(t)
+
+
 def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
     """Training-mode statistics step of nn.BatchNorm1d over the rows of x [n,F] in one call: returns (mean, invstd) and updates
     the running statistics / step counter in place (include/bot_gnn.h bot_bn_stats_f32)."""
@@ -734,6 +766,7 @@ def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_
     _check(_lib.bot_bn_stats_f32(x.data_ptr(), x.stride(0), n, F, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
                                  _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _bn_ws(F, x.device).data_ptr(),
                                  _stream()), "bn_stats")
+    _written(running_mean, running_var, num_batches_tracked)
     return mean, invstd
 
 
@@ -748,6 +781,7 @@ def bn_stats_halves(x, eps, momentum, running_mean, running_var, num_batches_tra
     _check(_lib.bot_bn_stats_halves_f32(x.data_ptr(), x.stride(0), n, F, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
                                         _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(weight), _ptr(bias),
                                         float(p), hscale.data_ptr(), _bn_ws(F, x.device).data_ptr(), _stream()), "bn_stats_halves")
+    _written(running_mean, running_var, num_batches_tracked)
     return mean, invstd, hscale
 
 

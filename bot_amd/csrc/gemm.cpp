@@ -3,11 +3,13 @@
 // hipBLASLt's device-SCALAR pointer mode is not honoured by the library build torch ships, the device-vector mode is) — hipBLASLt does the
 // MFMA work (a plain library GEMM; the halves format around it is halves.hip).  Optional strided batches (the row chunks of a
 // weight gradient).  Kernel choice per shape, first call: a recorded solution index when the caller has one (algo_index >= 0);
-// else (tune == 1) the fastest of hipBLASLt's 16 heuristic candidates timed on the caller's buffers, or (tune == 2, the tuning
-// tool) of ALL the library's solutions for these types; only for beta == 0, where repeated runs are idempotent, and never under
-// stream capture (top heuristic then).
+// else hipBLASLt's first heuristic choice (tune == 0, the default of the Python binding: no timing, no synchronisation,
+// reproducible).  Opt-in: (tune == 1) the fastest of the 16 heuristic candidates timed on the caller's buffers, or (tune == 2, the
+// tuning tool) of ALL the library's solutions for these types; only for beta == 0, where repeated runs are idempotent, and never
+// under stream capture (top heuristic then).
 #include <hipblaslt/hipblaslt.h>
 #include <hipblaslt/hipblaslt-ext.hpp>
+#include <hipblaslt/hipblaslt-version.h>
 
 #include <algorithm>
 #include <map>
@@ -38,7 +40,20 @@ int g_last_index = -1;     // solution index / time of the kernel the last call 
 float g_last_ms = 0.f;
 std::mutex g_mu;
 std::map<Key, Plan> g_plans;
-hipblasLtHandle_t g_handle = nullptr;
+std::map<int, hipblasLtHandle_t> g_handles;   // one library handle per device
+int g_runtime_version = 0;                    // hipblasLtGetVersion of the library actually loaded
+
+void destroy(Plan& p) {
+    if (p.la) hipblasLtMatrixLayoutDestroy(p.la);
+    if (p.lb) hipblasLtMatrixLayoutDestroy(p.lb);
+    if (p.lc) hipblasLtMatrixLayoutDestroy(p.lc);
+    if (p.desc) hipblasLtMatmulDescDestroy(p.desc);
+    p = Plan();
+}
+
+// Shapes vary without bound when the row count does (partitions, scaled graphs): keep the plan table small.  Evicted shapes are
+// simply planned again.
+constexpr size_t MAX_PLANS = 512;
 
 #define LT_CHECK(expr, what)                                                   \
     do {                                                                       \
@@ -75,44 +90,62 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
     BOT_REQUIRE(alpha && A && B && C && (workspace || workspace_bytes == 0), BOT_E_NULL, "gemm_halves: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lock(g_mu);
-    if (!g_handle) {
-        LT_CHECK(hipblasLtCreate(&g_handle), "hipblasLtCreate");
-    }
     int dev = 0;
     (void)hipGetDevice(&dev);
+    hipblasLtHandle_t& g_handle = g_handles[dev];
+    if (!g_handle) {
+        LT_CHECK(hipblasLtCreate(&g_handle), "hipblasLtCreate");
+        int v = 0;
+        if (hipblasLtGetVersion(g_handle, &v) == HIPBLAS_STATUS_SUCCESS) g_runtime_version = v;
+    }
     const Key key{trans_a, trans_b, m, n, k, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, dev, beta != 0.f};
-    Plan& p = g_plans[key];
-    if (!p.desc) {
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+        // Built in a local and moved into the table only when complete: an error on the way leaves no half-initialised entry
+        // behind (descriptor without layouts / algorithm) for later calls with the same key to run.
+        Plan q;
+        struct Guard {
+            Plan& q;
+            hipblasLtMatmulPreference_t pref = nullptr;
+            bool done = false;
+            ~Guard() {
+                if (pref) hipblasLtMatmulPreferenceDestroy(pref);
+                if (!done) destroy(q);
+            }
+        } guard{q};
         // row-major C = op(A) op(B)  <=>  column-major C^T = op(B)^T op(A)^T: B is hipBLASLt's first operand, A its second
-        LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F), "MatmulDescCreate");
+        LT_CHECK(hipblasLtMatmulDescCreate(&q.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F), "MatmulDescCreate");
         const hipblasOperation_t op1 = trans_b ? HIPBLAS_OP_T : HIPBLAS_OP_N, op2 = trans_a ? HIPBLAS_OP_T : HIPBLAS_OP_N;
-        LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op1, sizeof(op1)), "desc transA");
-        LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op2, sizeof(op2)), "desc transB");
+        LT_CHECK(hipblasLtMatmulDescSetAttribute(q.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op1, sizeof(op1)), "desc transA");
+        LT_CHECK(hipblasLtMatmulDescSetAttribute(q.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op2, sizeof(op2)), "desc transB");
         const int32_t pm = HIPBLASLT_POINTER_MODE_ALPHA_DEVICE_VECTOR_BETA_HOST;
-        LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_POINTER_MODE, &pm, sizeof(pm)), "desc pointer mode");
+        LT_CHECK(hipblasLtMatmulDescSetAttribute(q.desc, HIPBLASLT_MATMUL_DESC_POINTER_MODE, &pm, sizeof(pm)), "desc pointer mode");
         int rc;
-        if ((rc = make_layout(&p.la, HIP_R_16F, trans_b ? k : n, trans_b ? n : k, ldb, batch, stride_b))) return rc;   // first = B
-        if ((rc = make_layout(&p.lb, HIP_R_16F, trans_a ? m : k, trans_a ? k : m, lda, batch, stride_a))) return rc;   // second = A
-        if ((rc = make_layout(&p.lc, HIP_R_32F, n, m, ldc, batch, stride_c))) return rc;
-        hipblasLtMatmulPreference_t pref;
-        LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref), "PreferenceCreate");
+        if ((rc = make_layout(&q.la, HIP_R_16F, trans_b ? k : n, trans_b ? n : k, ldb, batch, stride_b))) return rc;   // first = B
+        if ((rc = make_layout(&q.lb, HIP_R_16F, trans_a ? m : k, trans_a ? k : m, lda, batch, stride_a))) return rc;   // second = A
+        if ((rc = make_layout(&q.lc, HIP_R_32F, n, m, ldc, batch, stride_c))) return rc;
+        LT_CHECK(hipblasLtMatmulPreferenceCreate(&guard.pref), "PreferenceCreate");
         const uint64_t wsb = (uint64_t)workspace_bytes;
-        LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof(wsb)), "pref workspace");
-        p.cand.resize(16);
+        LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(guard.pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof(wsb)), "pref workspace");
+        q.cand.resize(16);
         int found = 0;
-        LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.la, p.lb, p.lc, p.lc, pref, (int)p.cand.size(), p.cand.data(), &found),
+        LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(g_handle, q.desc, q.la, q.lb, q.lc, q.lc, guard.pref, (int)q.cand.size(), q.cand.data(), &found),
                  "AlgoGetHeuristic");
-        hipblasLtMatmulPreferenceDestroy(pref);
-        p.cand.resize(found);
+        q.cand.resize(found);
         if (found == 0) {
             set_error("gemm_halves: hipBLASLt has no kernel for m=%lld n=%lld k=%lld", (long long)m, (long long)n, (long long)k);
-            hipblasLtMatmulDescDestroy(p.desc);
-            p.desc = nullptr;
             return 2;
         }
-        p.algo = p.cand[0].algo;
-        p.ws = p.cand[0].workspaceSize;
+        q.algo = q.cand[0].algo;
+        q.ws = q.cand[0].workspaceSize;
+        if (g_plans.size() >= MAX_PLANS) {
+            for (auto& kv : g_plans) destroy(kv.second);
+            g_plans.clear();
+        }
+        guard.done = true;
+        it = g_plans.emplace(key, std::move(q)).first;
     }
+    Plan& p = it->second;
     auto run = [&](const hipblasLtMatmulAlgo_t& algo) {
         return hipblasLtMatmul(g_handle, p.desc, alpha, B, p.la, A, p.lb, &beta, C, p.lc, C, p.lc, &algo, workspace, (size_t)workspace_bytes, st);
     };
@@ -203,6 +236,13 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
     g_last_index = p.index, g_last_ms = p.ms;
     LT_CHECK(run(p.algo), "hipblasLtMatmul");
     return hip_status("gemm_halves launch");
+}
+
+int bot_gemm_halves_library_version(int32_t* compiled, int32_t* runtime) {
+    std::lock_guard<std::mutex> lock(bot::g_mu);
+    if (compiled) *compiled = HIPBLASLT_VERSION_MAJOR * 100000 + HIPBLASLT_VERSION_MINOR * 100 + HIPBLASLT_VERSION_PATCH;
+    if (runtime) *runtime = bot::g_runtime_version;
+    return 0;
 }
 
 int bot_gemm_halves_last_algo(int32_t* index, float* ms) {

@@ -357,8 +357,8 @@ def forward_backward(model, part: Partition, *, use_labels=True, mask_rate=0.5, 
             pred = model(part.graph, feat)
     wn = torch.zeros(pred.shape[0], device=pred.device, dtype=pred.dtype)   # weighted mean over all owned rows: see bot_amd.train
     wn[tr] = w
-    y = T.per_node_loss(pred, part.labels, loss)
-    local = _global_mean(y, wn, group)
+    y = T.per_node_loss(pred, part.labels.clamp(0, pred.shape[1] - 1), loss)   # placeholder labels outside the set: bot_amd.train
+    local = _global_mean(torch.where(wn > 0, y, torch.zeros_like(y)), wn, group)
     local.backward()
     all_reduce_grads(model, group)
     total = local.detach().clone()

@@ -533,8 +533,18 @@ def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
 # a whole layer is ONE GEMM + ONE sweep over the in-edges (bot_gat_infer_f32): no attention weights, no sign bytes and no
 # pre-BatchNorm [N, H*D] tensor reach HBM.
 
+_GENERATION = [0]
+
+
+def bump_generation():
+    """Parameters / running statistics were changed by something that moves no tensor version counter — a hipGraph replay of a
+    train step (bot_amd.train.CapturedTrainStep: optimizer and BatchNorm updates happen inside the graph).  Every cached
+    inference-path value derived from them is stale from here on."""
+    _GENERATION[0] += 1
+
+
 def _versions(*ts):
-    return tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+    return (_GENERATION[0],) + tuple((t.data_ptr(), t._version) for t in ts if t is not None)
 
 
 def _cached(owner, slot, key, make):
@@ -546,11 +556,14 @@ def _cached(owner, slot, key, make):
     return hit[1]
 
 
+def _infer_key(conv):
+    return _versions(conv.fc.weight, conv.res_fc.weight if conv.res_fc is not None else None, conv.attn_l, conv.attn_r) + (WEIGHT_KP,)
+
+
 def infer_weight(conv):
     """Merged projection weight of the layer in the layout the GEMM wants, cached across forward calls (evaluate() calls the
     model 1 + n_label_iters times between two optimizer steps)."""
-    key = _versions(conv.fc.weight, conv.res_fc.weight if conv.res_fc is not None else None, conv.attn_l, conv.attn_r) + (WEIGHT_KP,)
-    return _cached(conv, "wcat", key, lambda: merged_weight(conv).detach())
+    return _cached(conv, "wcat", _infer_key(conv), lambda: merged_weight(conv).detach())
 
 
 def eval_affine(mod):
@@ -648,7 +661,9 @@ def gat_infer_layer(conv, epi, graph, h, relu, first=False):
             ctx.store["key"], ctx.store["base"] = key, torch.mm(h[:, :F0], Wk[:F0])
         out = torch.addmm(ctx.store["base"], h[:, F0:], Wk[F0:])
     elif gemm.enabled(h):                                               # fp32 GEMM on the fp16 matrix cores (bot_amd.gemm)
-        out = gemm.mm_nt(gemm.split(h, 0), _cached(conv, "infer_halves", (id(W),), lambda: gemm.split(W.t().contiguous() if WEIGHT_KP else W, 1)))
+        # the weight's halves live and die with the merged weight they were split from: same key (the parameters' versions)
+        out = gemm.mm_nt(gemm.split(h, 0), _cached(conv, "infer_halves", _infer_key(conv),
+                                                   lambda: gemm.split(W.t().contiguous() if WEIGHT_KP else W, 1)))
     else:
         out = torch.mm(h, W) if WEIGHT_KP else torch.mm(h, W.t())       # [N, P] = [ft | res | el | er | pad]
     c = 2 * HD if has_res else HD

@@ -80,10 +80,13 @@ def forward_backward(model, graph, feat, labels, train_idx, val_idx, test_idx, *
             pred = model(graph, feat)
     # weighted mean over ALL nodes (weight 0 outside the prediction set) instead of `pred[train_pred_idx]`: the backward of an
     # index gather is an index_put with accumulation, which sorts its indices on the device every step
+    # Nodes outside the prediction set contribute nothing, as in `pred[train_pred_idx]` (run.py:281): their labels may be
+    # placeholders (-1, NaN cast to int) — clamped into the class range before the cross entropy so that it neither traps nor
+    # indexes out of range — and their per-node terms are dropped with where(), not multiplied by 0 (0 * inf = NaN)
     wn = torch.zeros(pred.shape[0], device=pred.device, dtype=pred.dtype)
     wn[train_idx] = w
-    y = per_node_loss(pred, labels, loss)
-    out = (y * wn).sum() / w.sum()
+    y = per_node_loss(pred, labels.clamp(0, pred.shape[1] - 1), loss)
+    out = torch.where(wn > 0, y, torch.zeros_like(y)).sum() / w.sum()
     out.backward()
     return out, pred, w
 
@@ -156,7 +159,9 @@ class CapturedTrainStep:
             self.loss, self.pred = body()
 
     def __call__(self):
+        from .nn import fused
         self.graph.replay()
+        fused.bump_generation()     # parameters and BatchNorm statistics moved inside the graph: no version counter saw it
         return self.loss, self.pred
 
 

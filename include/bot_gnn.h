@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 9
+#define BOT_ABI_VERSION 10
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -427,8 +427,16 @@ int bot_random_keep_u8(int64_t n, int64_t n_keep, uint64_t seed, uint8_t* keep, 
  *                 `piece` >= F columns wide (zero padded; use a multiple of 64), out fp16 with row pitch ldo >= 3 * piece
  *   gemm_halves   C[m,n] = alpha[j] * op(A)[m,k] op(B)[k,n] + beta * C[m,n], row-major, A / B fp16, C fp32, `alpha` a DEVICE vector of n
  *                 floats (one per output column; normally n copies of the product of the two operands' 1/s); trans_x != 0: the operand is stored transposed.  batch > 1: strided
- *                 batches (element strides).  tune = 1 / 2: the first call per shape times hipBLASLt's 16 heuristic candidates / all its solutions on these
- *                 buffers (beta == 0 only: C is overwritten).  `workspace`: device scratch for hipBLASLt (32 MiB is plenty).
+ *                 batches (element strides).  Kernel choice: `algo_index` >= 0 = a solution index recorded for this shape on this library
+ *                 build (bot_amd/tuning/halves_gemm.json); else with tune = 0 (what bot_amd passes by default) hipBLASLt's first heuristic
+ *                 choice — no timing, no synchronisation, the same kernel every run.  EXCEPTION to the conventions at the top of this
+ *                 header, opt-in only: tune = 1 / 2 makes the FIRST call per shape time the 16 heuristic candidates / all solutions on the
+ *                 caller's buffers (beta == 0 only: C is overwritten; never under stream capture) — that call creates events,
+ *                 synchronises, and the winner may differ from run to run (different accumulation order).  `workspace`: device
+ *                 scratch for hipBLASLt (32 MiB is plenty).
+ *   bot_gemm_halves_library_version: the hipBLASLt the library was COMPILED against (headers) and the one it is RUNNING on (the
+ *                 first libhipblaslt.so.N the process loaded — with PyTorch in the process, the copy torch ships), both as
+ *                 major * 100000 + minor * 100 + patch; runtime is 0 before the first gemm_halves call on the current device.
  * ------------------------------------------------------------------------------------------- */
 int64_t bot_halves_workspace_floats(void);
 int bot_halves_scale_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* scale, float* workspace, bot_stream_t stream);
@@ -441,6 +449,7 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
 /* solution index (hipblaslt_ext::getIndexFromAlgo) and search time in ms of the kernel the last gemm_halves call used; what
  * tools/tune_halves_gemm.py records into bot_amd/tuning/halves_gemm.json and passes back as `algo_index` (-1: none) */
 int bot_gemm_halves_last_algo(int32_t* index, float* ms);
+int bot_gemm_halves_library_version(int32_t* compiled, int32_t* runtime);
 
 /* ---------------------------------------------------------------------------------------------
  * Small-K projections: C[m,n] = (accumulate ? C : 0) + A[m,k] op(B), k <= 256, m huge — the per-head products of the

@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 9
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 10
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
@@ -920,6 +920,29 @@ def test_captured_train_step_bit_identical_and_fresh_masks():
     assert torch.equal(lc, le) and torch.equal(pc, pe)
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+    # (a') ADVICE r2: evaluate() between replays.  The inference path caches the merged weights and the eval-mode BatchNorm
+    # (scale, shift) per parameter version; a replay moves parameters and running statistics INSIDE the graph, where no
+    # version counter sees it — the captured model must still evaluate like the eager one after every further step.
+    ekw = dict(use_labels=True, n_label_iters=0, loss="loge", n_classes=C)
+    prev = None
+    for _ in range(2):
+        ev_c = T.evaluate(m2, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, **ekw)
+        ev_e = T.evaluate(m1, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, **ekw)
+        assert torch.equal(ev_c[6], ev_e[6]) and ev_c[:3] == ev_e[:3]
+        assert prev is None or not torch.equal(prev, ev_c[6])                    # the step in between did change the model
+        prev = ev_c[6].clone()
+        T.train_step(m1, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o1, mask=mask, **kw)
+        cap()
+    # forward-only passes in training mode move only the running statistics (raw-pointer writes of bot_bn_stats_*): seen too
+    ev0 = T.evaluate(m1, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, **ekw)[6].clone()
+    m1.train()
+    with torch.no_grad():
+        m1(g, T.add_labels(ds.feat, ds.labels, ds.train_idx, C))
+    ev1 = T.evaluate(m1, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, **ekw)[6]
+    m1.fuse_layers = False
+    ev1_generic = T.evaluate(m1, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, **ekw)[6]
+    m1.fuse_layers = True
+    assert not torch.equal(ev0, ev1) and torch.allclose(ev1, ev1_generic, atol=1e-4)
     # (b) dropout on: fresh masks per replay, finite decreasing-ish loss
     m3, o3 = make(True)
     cap3 = T.captured_train_step(m3, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o3, warmup=3, mask_rate=0.5, **kw)

@@ -373,3 +373,33 @@ def test_f4_layers_in_original_order_emulated(golden, cpu_backend, monkeypatch):
 
 def test_f4_community_partition_blocks_emulated(golden, cpu_backend):
     PC.check_f4_community_partition_blocks(golden, "cpu", worlds=(2,))
+
+
+def test_placeholder_labels_outside_the_training_set(golden, cpu_backend, monkeypatch):
+    """the loss runs over all nodes with 0/1 weights (fixed shapes); labels of nodes OUTSIDE train_idx may be
+    placeholders (-1) as in datasets with unlabeled nodes — the step must give the loss and gradients of run.py:281's
+    `pred[train_pred_idx]`, and an infinite per-node term outside the set must not leak into the mean."""
+    import torch.nn.functional as F
+    from bot_amd import train as T
+    from bot_amd.nn import fused
+    monkeypatch.setattr(fused, "FORCE", True)
+    s, d, n = golden.graph("g300")
+    g = bot_amd.Graph(s, d, n)
+    gen = torch.Generator().manual_seed(2)
+    C, fin = 4, 6
+    feat = torch.randn(n, fin, generator=gen)
+    labels = torch.randint(0, C, (n, 1), generator=gen)
+    tr, va, te = torch.arange(0, 150), torch.arange(150, 220), torch.arange(220, n)
+    mask = torch.rand(150, generator=gen) < 0.5
+    bad = labels.clone()
+    bad[150:] = -1
+    out = []
+    for lab in (labels, bad):
+        torch.manual_seed(0)
+        model = bnn.GAT(dim_node=fin + C, dim_edge=0, dim_output=C, n_hidden=5, n_layers=2, n_heads=2, activation=F.relu, norm="batch",
+                        linear=True).train()
+        loss, pred, w = T.forward_backward(model, g, feat, lab, tr, va, te, use_labels=True, n_classes=C, loss="loge", mask=mask)
+        ref = T.compute_loss(pred[tr[~mask]], labels[tr[~mask]], "loge")
+        assert torch.allclose(loss, ref, atol=1e-6)
+        out.append((loss.detach(), [p.grad.clone() for p in model.parameters()]))
+    assert torch.equal(out[0][0], out[1][0]) and all(torch.equal(a, b) for a, b in zip(out[0][1], out[1][1]))
