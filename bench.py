@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; reported in config)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--parity-scale", type=float, default=None,
+                    help="configs 1, 3, 4, 5: size of the bounded sample (a graph of the same generator, same density) on which the "
+                         "CPU baseline is timed and the parity object computed; default tests/full_size.py:PARITY_SCALE "
+                         "(cora 1.0, reddit 0.25, proteins / products 0.125); the full-size comparison is the GPU test-suite's")
     ap.add_argument("--gemm-tuning", default="file", choices=["file", "off", "tune"],
                     help="file: hipBLASLt/rocBLAS kernel selections from bot_amd/tuning (TunableOp, read-only); "
                          "tune: also time shapes missing from the file and write them to gpurun_out/ (maintenance)")
@@ -107,9 +111,31 @@ def cpu_baseline_and_parity(ds, n_classes, steps, dev, fuse=True):
     gp, gg, _, _, gstats = FS.oracle_step(s, d, n, feat, labels, train_idx, mask, sd, cfg, C, gates=gates)
     parity = FS.compare(hp, hg, gp, gg, gstats)
     parity["max_abs_logit_diff"] = max(parity["max_abs_logit_diff"], float((hp.cpu().double() - pred.double()).abs().max()))
+    ok = (parity["max_abs_logit_diff"] <= 1e-4 and parity["max_rel_grad_err"] <= 1e-4 and parity["max_abs_preact_at_differing_gate"] <= 1e-4)
+    parity.update(criterion="abs", criterion_text=FS.CRITERIA["abs"], ok=bool(ok), sample="the bench graph itself (full size)")
     parity["against"] = ("oracle/c_ops.py (C restatement of DGL's CPU kernels): same weights + label mask, dropout 0, training-mode "
                          "BatchNorm; logits vs the plain oracle step, gradients vs the oracle at the HIP run's ReLU / leaky-ReLU gates")
     return cpu, parity
+
+
+def cpu_baseline_and_parity_sample(name, dev, scale):
+    """Configs 1, 3, 4, 5.  One train step (drop rates 0) of the same configuration on a BOUNDED sample — a graph of the same
+    generator and density at `scale` of the bench size — on the HIP path and on the oracle's C kernels (tests/full_size.py:
+    workload_parity): `cpu_baseline` = the oracle step's edges/s on the host cores (ONE step, no warm-up: it is 10-40 s of CPU
+    work), `parity` = every logit and every parameter gradient of that step, with the criterion that was applied.  The same
+    comparison at FULL size is tests/test_gpu_parity.py::test_full_size_config{3,4,5}_* (minutes of CPU time each)."""
+    from tests import full_size as FS
+    r, t = FS.workload_parity(name, dev, scale=scale)
+    r.pop("rank", None)
+    what = f"S-{name} generator at scale {scale}: N={t['nodes']} E={t['edges']}"
+    cpu = {"value": t["edges"] / t["seconds"], "unit": "edges/s", "cores": t["threads"], "kind": "port",
+           "sample": f"ONE train step (fwd+loss+bwd, drop rates 0) of the {what}; {t['seconds']:.2f} s; OpenMP C restatement of DGL's "
+                     f"CPU SpMM/SDDMM/edge_softmax + torch CPU GEMMs",
+           "cpu_model": cpu_model_name(), "host_threads": os.cpu_count()}
+    r["sample"] = what + " (bounded sample; full size: the GPU test-suite's test_full_size_config* tests)"
+    r["against"] = ("oracle/c_ops.py (C restatement of DGL's CPU kernels) + oracle/ref_models.py: same weights, drop rates 0, "
+                    "training-mode BatchNorm, the oracle at the HIP run's ReLU / leaky-ReLU gates")
+    return cpu, r
 
 
 def main():
@@ -207,9 +233,11 @@ def main():
         ach = alg / avg / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "spmm_traffic.json")
-        tj = json.load(open(tf)) if os.path.exists(tf) else {}
-        if world == 1 and args.scale == 1.0 and args.workload == "arxiv" and tj.get("kernel") == kernel:
-            traffic = tj.get("bytes_per_launch")   # PMC passes of the same kernel instance on the same graph (tools/f4_pmc.sh)
+        tj = (json.load(open(tf)) if os.path.exists(tf) else {}).get(args.workload, {})
+        if world == 1 and args.scale == 1.0 and tj.get("kernel") == kernel:
+            # separate rocprofv3 --pmc passes over THIS command (tools/pmc_bench.sh <workload>), per launch of the same kernel
+            # instance on the same graph; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md "HBM"
+            traffic = tj.get("bytes_per_launch")
         roof = {"bound": "hbm", "kernel": f"{kernel} (SpMM forward, H={H} D={D}{', weighted' if weighted else ''}, hidden layers)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg * 1e3, 4),
@@ -217,7 +245,8 @@ def main():
                 # measured L2<->fabric bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/spmm_traffic.json) over the same
                 # launch time: what the memory system actually delivered (Infinity-Cache hits included)
                 "traffic_GBs": round(traffic / avg / 1e9, 1) if traffic else None,
-                "traffic_frac_of_peak": round(traffic / avg / 1e9 / HBM_PEAK_GBS, 4) if traffic else None}
+                "traffic_frac_of_peak": round(traffic / avg / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                "l2_hit_rate": tj.get("l2_hit_rate") if traffic else None, "traffic_source": tj.get("source") if traffic else None}
 
     # the other HIP sweeps of the step, same live events, same byte accounting (SURVEY §8d formulas), for context
     others = []
@@ -256,6 +285,10 @@ def main():
     cpu = parity = None
     if rank == 0 and world == 1 and args.cpu_baseline != "off" and args.workload == "arxiv" and args.norm_adj == "rw":
         cpu, parity = cpu_baseline_and_parity(wl.dataset, wl.dataset.n_classes, args.cpu_steps, dev)
+    elif rank == 0 and world == 1 and args.cpu_baseline != "off" and args.workload != "arxiv":
+        from tests import full_size as FS
+        sample_scale = (args.parity_scale if args.parity_scale is not None else FS.PARITY_SCALE[args.workload]) * args.scale
+        cpu, parity = cpu_baseline_and_parity_sample(args.workload, dev, sample_scale)
 
     if rank == 0:
         out = {

@@ -66,9 +66,12 @@ class KinkGates:
         return torch.where(g, e, e * slope)
 
 
-def oracle_step(src, dst, n, feat, labels, train_idx, mask, sd, cfg, n_classes, loss="loge", threads=None, steps=1, gates=None):
+def oracle_step(src, dst, n, feat, labels, train_idx, mask, sd, cfg, n_classes, loss="loge", threads=None, steps=1, gates=None,
+                dtype=torch.float32):
     """One train step (forward + loss + backward, training-mode BatchNorm, no dropout) on the oracle's C kernels.
     `gates`: (relu gates, leaky gates) as returned by hip_step, see KinkGates (None: the oracle's own).
+    `dtype=torch.float64`: the whole step in double (liboracle_f64.so + torch fp64) — the exact side when two fp32 runs are
+    ranked against each other (`logits_ok`, `rank_against_exact`).
     Returns (pred [N,C], {param name: grad}, [seconds per step], threads, gate stats)."""
     from oracle import c_ops
     from oracle import ref_models as RM
@@ -77,7 +80,9 @@ def oracle_step(src, dst, n, feat, labels, train_idx, mask, sd, cfg, n_classes, 
     torch.set_num_threads(threads)
     c_ops.set_num_threads(threads)
     g = c_ops.CGraph(src, dst, n)
-    sdg = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    sdg = {k: (v.to(dtype).requires_grad_() if v.is_floating_point() and "running" not in k
+               else (v.to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd.items()}
+    feat = feat.to(dtype)
     names = [k for k, v in sdg.items() if v.requires_grad]
     times, pred, grads, kg = [], None, None, None
     for _ in range(steps):
@@ -175,6 +180,26 @@ def rank_against_exact(grads_hip, grads_ref, grads_exact, zero_grads=None):
     return out
 
 
+CRITERIA = {
+    "abs": "every logit within 1e-4 ABSOLUTE of the fp32 oracle's; every gradient entry within 1e-4 of its gradient's largest entry",
+    "fp64-ranked": ("against the SAME step in fp64 (liboracle_f64.so): every logit / gradient entry within 1e-4 (absolute / of the "
+                    "gradient's largest entry) of the exact one, or at most twice as far from it as the reference-order fp32 oracle is — "
+                    "used where two fp32 runs cannot agree to 1e-4 (logits far above O(10), cancelling reductions)"),
+}
+
+
+def logits_ok(pred_hip, pred_ref, pred_exact=None, atol=1e-4):
+    """(ok, criterion name, numbers).  Plain criterion: max |hip - fp32 oracle| <= atol.  With an fp64 run of the same step:
+    max |hip - exact| <= max(atol, 2 max |fp32 oracle - exact|)."""
+    hp = pred_hip.detach().cpu().double()
+    d = float((hp - pred_ref.double()).abs().max())
+    if pred_exact is None:
+        return d <= atol, "abs", {"max_abs_logit_diff": d}
+    eh = float((hp - pred_exact.double()).abs().max())
+    eo = float((pred_ref.double() - pred_exact.double()).abs().max())
+    return eh <= max(atol, 2 * eo), "fp64-ranked", {"max_abs_logit_diff": d, "logit_err_vs_fp64": eh, "oracle_logit_err_vs_fp64": eo}
+
+
 def compare(pred_hip, grads_hip, pred_ref, grads_ref, gate_stats=None, tol=1e-4, zero_grads=None):
     """max |logit diff| over all nodes; the worst parameter-gradient error relative to that gradient's largest entry; the
     number of gradient entries beyond `tol` of it; and (with gates given to the oracle) how many ReLU / leaky-ReLU gates the two
@@ -233,13 +258,21 @@ def gcn_hip_step(g, feat, labels, train_idx, sd, cfg, n_classes, loss="logit"):
     from bot_amd import nn as bnn
     from bot_amd import train as T
     dev = feat.device
-    model = bnn.GCN(in_feats=feat.shape[1], n_classes=n_classes, activation=F.relu, dropout=0.0, input_drop=0.0, **cfg)
+    plain = []                   # without BatchNorm the stack applies `activation` itself (models.py:638-639): record it there
+
+    def act(h):
+        y = F.relu(h)
+        plain.append((y.detach() > 0).to(torch.uint8).cpu())
+        return y
+    model = bnn.GCN(in_feats=feat.shape[1], n_classes=n_classes, activation=F.relu if cfg["norm"] == "batch" else act, dropout=0.0,
+                    input_drop=0.0, **cfg)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).train()
     with tap_kinks() as (relu_gates, leaky_gates):
         pred = model(g, feat)
         out = T.compute_loss(pred[train_idx], labels[train_idx], loss)
         out.backward()
+    relu_gates = relu_gates + plain
     assert len(relu_gates) == cfg["n_layers"] - 1
     return pred.detach(), {k: p.grad.detach() for k, p in model.named_parameters()}, (relu_gates, None)
 
@@ -289,3 +322,61 @@ def edge_gat_hip_step(model, g, labels, train_idx, node_loss):
         pred = model(g)
         node_loss(pred[train_idx], labels[train_idx]).mean().backward()
     return pred.detach(), {k: p.grad.detach() for k, p in model.named_parameters() if p.grad is not None}, (relu_gates, leaky_gates)
+
+
+# ---------------------------------------------------------------------------------------------- one entry point per BASELINE config
+PARITY_SCALE = {"cora": 1.0, "arxiv": 1.0, "reddit": 0.25, "proteins": 0.125, "products": 0.125}   # bench.py's bounded CPU sample
+
+
+def workload_parity(name, dev, scale=1.0, exact="auto"):
+    """One train step (drop rates 0) of BASELINE config `name` (bot_amd.workloads) on the HIP path against the oracle's C
+    kernels on the host cores, graph of the workload's generator at `scale` (1.0 = the size the bench line is quoted on; the
+    density — mean degree — does not depend on it).  The oracle runs at the HIP run's ReLU / leaky-ReLU gates (KinkGates).
+    `exact`: also run the step in fp64 and rank the two fp32 runs against it ("auto": config 4, whose logits reach 125).
+    Returns (parity dict incl. "criterion" / "ok", {"seconds", "threads", "edges", "nodes"} of the fp32 oracle step).
+    Config 2 (arxiv) has its own entry points (oracle_step / hip_step: label mask, fused / modular variants)."""
+    from bot_amd import workloads
+    wl = workloads.build(name, dev, drop=False, scale=scale)
+    model, g, ds = wl.model, wl.graph, wl.dataset
+    s, d = (t.cpu() for t in g.edges())
+    n = g.number_of_nodes()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    if exact == "auto":
+        exact = name == "proteins"
+    xp = xg = None
+    zero = None
+    if name in ("cora", "reddit"):
+        hid, layers = (16, 2) if name == "cora" else (256, 3)
+        cfg = dict(n_layers=layers, n_hidden=hid, norm="none" if name == "cora" else "batch", norm_adj="symm", use_linear=False,
+                   residual=False)
+        pred, grads, gates = gcn_hip_step(g, ds.feat, ds.labels, ds.train_idx, sd, cfg, ds.n_classes)
+        rp, rg, secs, gstats = gcn_oracle_step(s, d, n, ds.feat.cpu(), ds.labels.cpu(), ds.train_idx.cpu(), sd, cfg, gates=gates)
+        threads = _oracle_threads(32)
+    else:
+        prot = name == "proteins"
+        kw = dict(n_layers=6 if prot else 3, n_heads=6 if prot else 4, n_hidden=80 if prot else 120,
+                  node_loss=workloads._bce if prot else workloads._loge, use_node_encoder=prot, residual=prot)
+        pred, grads, gates = edge_gat_hip_step(model, g, ds.labels, ds.train_idx, kw["node_loss"])
+        args = (s, d, n, ds.feat.cpu(), None if ds.efeat is None else ds.efeat.cpu(), ds.labels.cpu(), ds.train_idx.cpu(), sd)
+        # products: Linear weight gradients of the ORACLE accumulated in fp64 (its sgemm over 2.45 M rows is 2.1e-4 off, see
+        # oracle.ref_models.linear_f64grad); dst_fc biases sit in front of a training-mode BatchNorm (exact gradient 0)
+        rp, rg, secs, gstats = edge_gat_oracle_step(*args, gates=gates, f64_weight_grads=not prot, **kw)
+        if exact:
+            xp, xg, _, _ = edge_gat_oracle_step(*args, gates=gates, dtype=torch.float64, **kw)
+        zero = {f"convs.{i}.dst_fc.bias": f"convs.{i}.dst_fc.weight" for i in range(kw["n_layers"])}
+        threads = _oracle_threads(32)
+    r = compare(pred, grads, rp, rg, gstats, zero_grads=zero)
+    ok, crit, nums = logits_ok(pred, rp, xp)
+    r.update(nums)
+    if xg is not None:
+        rank = rank_against_exact(grads, rg, xg, zero)
+        worst = max(rank, key=lambda k: rank[k][0] / max(1e-4, 2 * rank[k][1]))
+        r.update(worst_ranked=worst, hip_err_vs_fp64=rank[worst][0], oracle_err_vs_fp64=rank[worst][1],
+                 max_hip_err_vs_fp64=max(v[0] for v in rank.values()), max_oracle_err_vs_fp64=max(v[1] for v in rank.values()))
+        ok = ok and all(eh <= max(1e-4, 2 * eo) for eh, eo in rank.values())
+        r["rank"] = rank
+    else:
+        ok = ok and r["max_rel_grad_err"] <= 1e-4
+    ok = ok and r.get("max_abs_preact_at_differing_gate", 0.0) <= 1e-4
+    r.update(criterion=crit, criterion_text=CRITERIA[crit], ok=bool(ok), edges=int(s.numel()), scale=scale)
+    return r, {"seconds": secs, "threads": threads, "edges": int(s.numel()), "nodes": n}

@@ -21,10 +21,11 @@ FWD_ATOL = 1e-4
 GRAD_RTOL = 1e-4
 
 
-def fwd_close(a, b, atol=FWD_ATOL):
+def fwd_close(a, b, atol=FWD_ATOL, rtol=0.0):
+    """|a - b| <= atol, ABSOLUTE (BASELINE.json: "logits within 1e-4"); no relative slack unless a caller asks for it and says why."""
     a = a.detach().cpu().double().numpy()
     b = np.asarray(b, dtype=np.float64)
-    np.testing.assert_allclose(a, b, rtol=1e-4, atol=atol)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
 def grad_close(a, b, rtol=GRAD_RTOL):

@@ -766,10 +766,20 @@ def test_full_size_config2_logits_and_grads_against_c_oracle(fuse, symm):
     rp, rg, times, threads, gstats = FS.oracle_step(s, d, ds.graph.number_of_nodes(), ds.feat, ds.labels, ds.train_idx, c["mask"],
                                                     c["sd"], cfg, ds.n_classes, gates=gates)
     r = FS.compare(pred, grads, rp, rg, gstats)
-    print("full-size parity", "fused" if fuse else "modular", "symm" if symm else "", r, "oracle step %.2f s on %d threads" % (times[0], threads))
     assert r["n"] == 169343 and g.number_of_edges() > 2_000_000
-    # 1e-4 absolute on logits of the usual size (|logit| <= 15 here); the symmetric-norm variant's logits reach 57: relative beyond 20
-    assert r["max_abs_logit_diff"] <= PC.FWD_ATOL * max(1.0, r["logit_scale"] / 20), r
+    # Logits: 1e-4 ABSOLUTE against the fp32 oracle (the north star's tolerance) for the BASELINE configuration (|logit| <= 15).
+    # The --norm-adj=symm variant multiplies the aggregation by in_deg^+1/2 (models.py:550-555): logits reach 57 and two fp32 runs
+    # differ by 1.3e-4 there, so it is ranked against the SAME step in fp64, the criterion config 4 uses (FS.CRITERIA).
+    xp = None
+    if symm:
+        xp, xg, t64, _, _ = FS.oracle_step(s, d, ds.graph.number_of_nodes(), ds.feat, ds.labels, ds.train_idx, c["mask"], c["sd"], cfg,
+                                           ds.n_classes, gates=gates, dtype=torch.float64)
+        rank = FS.rank_against_exact(grads, rg, xg)
+        r.update(max_hip_grad_err_vs_fp64=max(v[0] for v in rank.values()), max_oracle_grad_err_vs_fp64=max(v[1] for v in rank.values()))
+    ok, crit, nums = FS.logits_ok(pred, rp, xp, PC.FWD_ATOL)
+    r.update(nums, logit_criterion=crit)
+    print("full-size parity", "fused" if fuse else "modular", "symm" if symm else "", r, "oracle step %.2f s on %d threads" % (times[0], threads))
+    assert ok and crit == ("fp64-ranked" if symm else "abs"), r
     assert r["max_rel_grad_err"] <= PC.GRAD_RTOL, r
     assert r["max_abs_preact_at_differing_gate"] <= 1e-4 and r["relu_gates_differing"] <= 1e-5 * r["relu_gates"] and r["leaky_gates_differing"] <= 1e-5 * r["leaky_gates"], r
 
@@ -999,27 +1009,13 @@ def test_full_size_config3_reddit_gcn_against_c_oracle():
     with BatchNorm — one train step (dropout 0) on the HIP path (L2-blocked SpMM + hub rows, W-first and aggregate-first
     GraphConv) against the oracle's C kernels on the host cores: every logit within 1e-4, every gradient entry within 1e-4 of
     its gradient's largest entry (oracle at the HIP run's ReLU gates, tests/full_size.py:KinkGates)."""
-    import torch.nn.functional as F
-    from bot_amd import nn as bnn, synth
     from tests import full_size as FS
-    ds = synth.make_dataset("reddit", device=DEV, seed=0)
-    g, C = ds.graph, ds.n_classes
-    g.create_formats_()
-    cfg = dict(n_layers=3, n_hidden=256, norm="batch", norm_adj="symm", use_linear=False, residual=False)
-    torch.manual_seed(0)
-    sd = {k: v.detach().clone() for k, v in bnn.GCN(in_feats=ds.feat.shape[1], n_classes=C, activation=F.relu, **cfg).state_dict().items()}
-    pred, grads, gates = FS.gcn_hip_step(g, ds.feat, ds.labels, ds.train_idx, sd, cfg, C)
-    s, d = (t.cpu() for t in g.edges())
-    rp, rg, secs, gstats = FS.gcn_oracle_step(s, d, g.number_of_nodes(), ds.feat.cpu(), ds.labels.cpu(), ds.train_idx.cpu(), sd, cfg,
-                                              gates=gates)
-    r = FS.compare(pred, grads, rp, rg, None)
-    r["relu_gates_differing"] = sum(x["differ"] for x in gstats)
-    r["max_abs_preact_at_differing_gate"] = max(x["max_abs_preact_where_differ"] for x in gstats)
-    print("full-size parity S-reddit GCN", r, "oracle step %.1f s" % secs)
-    assert r["n"] == 232965 and g.number_of_edges() > 100_000_000
-    assert r["max_abs_logit_diff"] <= PC.FWD_ATOL * max(1.0, r["logit_scale"] / 10), r
+    r, cpu = FS.workload_parity("reddit", DEV)
+    print("full-size parity S-reddit GCN", r, "oracle step %.1f s" % cpu["seconds"])
+    assert r["n"] == 232965 and r["edges"] > 100_000_000
+    assert r["criterion"] == "abs" and r["max_abs_logit_diff"] <= PC.FWD_ATOL, r       # 1e-4 absolute (logits up to 13)
     assert r["max_rel_grad_err"] <= PC.GRAD_RTOL, r
-    assert r["max_abs_preact_at_differing_gate"] <= 1e-4, r
+    assert r["max_abs_preact_at_differing_gate"] <= 1e-4 and r["ok"], r
 
 
 def test_merged_weight_kernels_match_tensor_ops():
@@ -1054,23 +1050,13 @@ def test_full_size_config5_products_gat_against_c_oracle():
     fp32 sgemm is 2.1e-4 off the fp64 product of its own operands over 2.45 M rows, the HIP run's GEMM 5e-5), and the dst_fc
     biases — in front of a training-mode BatchNorm, gradient identically zero in exact arithmetic, 1e-10 of noise in both runs —
     are measured against the dst_fc weight gradient's scale."""
-    import torch.nn.functional as F
-    from bot_amd import workloads
     from tests import full_size as FS
-    wl = workloads.build("products", DEV, drop=False)
-    model, g, ds = wl.model, wl.graph, wl.dataset
-    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    pred, grads, gates = FS.edge_gat_hip_step(model, g, ds.labels, ds.train_idx, workloads._loge)
-    s, d = (t.cpu() for t in g.edges())
-    rp, rg, secs, gstats = FS.edge_gat_oracle_step(s, d, g.number_of_nodes(), ds.feat.cpu(), None, ds.labels.cpu(), ds.train_idx.cpu(), sd,
-                                                   n_layers=3, n_heads=4, n_hidden=120, node_loss=workloads._loge, use_node_encoder=False,
-                                                   residual=False, gates=gates, f64_weight_grads=True)
-    r = FS.compare(pred, grads, rp, rg, gstats, zero_grads={f"convs.{i}.dst_fc.bias": f"convs.{i}.dst_fc.weight" for i in range(3)})
-    print("full-size parity S-products GAT", r, "oracle step %.1f s" % secs)
-    assert r["n"] == 2449029 and g.number_of_edges() > 120_000_000
-    assert r["max_abs_logit_diff"] <= PC.FWD_ATOL * max(1.0, r["logit_scale"] / 10), r
+    r, cpu = FS.workload_parity("products", DEV)
+    print("full-size parity S-products GAT", r, "oracle step %.1f s" % cpu["seconds"])
+    assert r["n"] == 2449029 and r["edges"] > 120_000_000
+    assert r["criterion"] == "abs" and r["max_abs_logit_diff"] <= PC.FWD_ATOL, r       # 1e-4 absolute (logits up to 2.6)
     assert r["max_rel_grad_err"] <= PC.GRAD_RTOL, r
-    assert r["max_abs_preact_at_differing_gate"] <= 1e-4, r
+    assert r["max_abs_preact_at_differing_gate"] <= 1e-4 and r["ok"], r
 
 
 def test_take_rows_edge_sized_gather():
@@ -1137,35 +1123,20 @@ def test_full_size_config4_proteins_gat_against_c_oracle():
     gradients that cancel), so two fp32 runs differ by more than 1e-4 on some parameters no matter how they are written.
     The criterion is therefore against the SAME step in fp64 (liboracle_f64.so): every HIP gradient is within 1e-4 of the exact
     one, or at most twice as far from it as the reference-order fp32 CPU run is."""
-    from bot_amd import workloads
     from tests import full_size as FS
-    wl = workloads.build("proteins", DEV, drop=False)
-    model, g, ds = wl.model, wl.graph, wl.dataset
-    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    pred, grads, gates = FS.edge_gat_hip_step(model, g, ds.labels, ds.train_idx, workloads._bce)
-    s, d = (t.cpu() for t in g.edges())
-    kw = dict(n_layers=6, n_heads=6, n_hidden=80, node_loss=workloads._bce, use_node_encoder=True, residual=True, gates=gates)
-    args = (s, d, g.number_of_nodes(), ds.feat.cpu(), ds.efeat.cpu(), ds.labels.cpu(), ds.train_idx.cpu(), sd)
-    rp, rg, secs, gstats = FS.edge_gat_oracle_step(*args, **kw)
-    xp, xg, secs64, _ = FS.edge_gat_oracle_step(*args, dtype=torch.float64, **kw)
-    assert set(rg) == set(grads) == set(xg)
-    zero = {f"convs.{i}.dst_fc.bias": f"convs.{i}.dst_fc.weight" for i in range(6)}
-    r = FS.compare(pred, grads, rp, rg, gstats, zero_grads=zero)
-    rank = FS.rank_against_exact(grads, rg, xg, zero)
-    worst = max(rank, key=lambda k: rank[k][0] / max(1e-4, 2 * rank[k][1]))
-    r.update(logit_err_vs_fp64=float((pred.cpu().double() - xp).abs().max()), oracle_logit_err_vs_fp64=float((rp.double() - xp).abs().max()),
-             worst_ranked=worst, hip_err_vs_fp64=rank[worst][0], oracle_err_vs_fp64=rank[worst][1],
-             max_hip_err_vs_fp64=max(v[0] for v in rank.values()), max_oracle_err_vs_fp64=max(v[1] for v in rank.values()))
-    print("full-size parity S-proteins GAT", r, "oracle step %.1f s (fp32) %.1f s (fp64)" % (secs, secs64))
+    r, cpu = FS.workload_parity("proteins", DEV)
+    rank = r.pop("rank")
+    print("full-size parity S-proteins GAT", r, "fp32 oracle step %.1f s" % cpu["seconds"])
     import os
     if os.environ.get("BOT_PARITY_TABLE"):
         for k, (eh, eo) in rank.items():
             print("  %-28s HIP vs fp64 %.3e   fp32 oracle vs fp64 %.3e" % (k, eh, eo))
-    assert r["n"] == 132534 and g.number_of_edges() > 70_000_000
-    assert r["max_abs_logit_diff"] <= PC.FWD_ATOL * max(1.0, r["logit_scale"] / 10), r
-    assert r["logit_err_vs_fp64"] <= PC.FWD_ATOL * max(1.0, r["logit_scale"] / 10), r
+    assert r["n"] == 132534 and r["edges"] > 70_000_000
+    # logits up to 125: not "within 1e-4 absolute of the fp32 oracle" (3.1e-4) — ranked against the fp64 step instead (FS.CRITERIA)
+    assert r["criterion"] == "fp64-ranked" and r["logit_err_vs_fp64"] <= max(PC.FWD_ATOL, 2 * r["oracle_logit_err_vs_fp64"]), r
     for k, (eh, eo) in rank.items():
         assert eh <= max(PC.GRAD_RTOL, 2 * eo), (k, eh, eo)
+    assert r["ok"], r
 
 
 def test_gemm_halves_against_fp64():

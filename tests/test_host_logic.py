@@ -403,3 +403,23 @@ def test_placeholder_labels_outside_the_training_set(golden, cpu_backend, monkey
         assert torch.allclose(loss, ref, atol=1e-6)
         out.append((loss.detach(), [p.grad.clone() for p in model.parameters()]))
     assert torch.equal(out[0][0], out[1][0]) and all(torch.equal(a, b) for a, b in zip(out[0][1], out[1][1]))
+
+
+@pytest.mark.parametrize("name,scale", [("cora", 0.5), ("reddit", 0.002), ("proteins", 0.004), ("products", 0.001)])
+def test_workload_parity_procedure_emulated(cpu_backend, monkeypatch, name, scale):
+    """tests/full_size.py:workload_parity — the per-config parity procedure of the GPU suite and of bench.py's `parity` object —
+    over the emulated backend on small graphs of each generator: plumbing, criteria and the fp64 ranking of config 4."""
+    from bot_amd.nn import fused
+    from tests import full_size as FS
+    monkeypatch.setattr(fused, "FORCE", True)
+    r, cpu = FS.workload_parity(name, "cpu", scale=scale)
+    r.pop("rank", None)
+    assert r["criterion"] == ("fp64-ranked" if name == "proteins" else "abs"), r
+    if name == "proteins":
+        # 530 nodes of mean degree 280: the gradients that cancel are ~0 in exact arithmetic and the EMULATED backend's index_add
+        # sums are no better than the oracle's — the ranking of the gradients is a statement about the real kernels (GPU suite);
+        # here: the logits rank, and every well-conditioned gradient agrees
+        assert r["logit_err_vs_fp64"] <= max(1e-4, 2 * r["oracle_logit_err_vs_fp64"]) and r["hip_err_vs_fp64"] < 2e-3, r
+    else:
+        assert r["ok"], r
+    assert cpu["edges"] == r["edges"] > 0 and cpu["seconds"] > 0
