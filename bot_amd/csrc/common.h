@@ -152,6 +152,10 @@ struct Philox {
     }
 };
 
+// fp16-halves operand format (halves.hip): the second half of a LEFT operand is stored times 2^11, the third piece of a RIGHT
+// operand is 2^-11 h1, so that the a2 b1 term keeps its bits for rows far below the matrix maximum.
+constexpr float kHalvesShift = 2048.f;
+
 // Vector width usable for a feature slab: every stride and base must keep VEC*4-byte alignment.
 inline int pick_vec(int32_t D, std::initializer_list<int64_t> strides, std::initializer_list<const void*> ptrs) {
     for (int v : {4, 2}) {

@@ -99,7 +99,7 @@ struct BnArgs {
     uint64_t seed;
     const uint64_t* seed_offset;  // optional device word mixed into the seed at run time (hipGraph replays: see eff_seed)
     // fwd
-    __half* hout;          // optional: the output also as fp16 halves [h1 | h1 | h2] (halves.hip), scaled by hscale[0]
+    __half* hout;          // optional: the output also as fp16 halves [h1 | h1 | 2^11 h2] (halves.hip), scaled by hscale[0]
     int64_t ldh;
     int32_t piece;
     const float* hscale;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
                     for (int t = 0; t < 4; ++t) {
                         const float z = t < nv ? v[u][t] * hs : 0.f;
                         h1[t] = __float2half_rn(z);
-                        h2[t] = __float2half_rn(z - __half2float(h1[t]));
+                        h2[t] = __float2half_rn((z - __half2float(h1[t])) * kHalvesShift);   // left operand: [h1 | h1 | 2^11 h2]
                     }
                     __half* o = a.hout + r * a.ldh + c;
                     const uint2 hi = *reinterpret_cast<const uint2*>(h1), lo = *reinterpret_cast<const uint2*>(h2);

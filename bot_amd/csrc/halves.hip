@@ -9,8 +9,16 @@
 //
 //   halves_scale : s = 2^(14 - ceil(log2 max|x|))  puts the largest entry in (2^13, 2^14] (fp16 max 2^16; entries below
 //                  2^-38 of the largest flush to zero) — computed on the device, never read by the host
-//   halves_split : out[r] = [h1 | h1 | h2] (order 0, left operands) or [h1 | h2 | h1] (order 1, right operands), each piece
-//                  zero-padded to `piece` columns, so that ONE GEMM over the concatenated axis forms the three terms
+//   halves_split : out[r] = [h1 | h1 | 2^11 h2] (order 0, left operands) or [h1 | h2 | 2^-11 h1] (order 1, right operands), each
+//                  piece zero-padded to `piece` columns, so that ONE GEMM over the concatenated axis forms the three terms
+//
+// Dynamic range (round 3).  One scale per matrix means an entry 2^-17 of the largest has its SECOND half below fp16's normal
+// range (|h2| <= 2^-11 |h1|), and rows of a left operand that small kept only 11-15 bits (measured: rows 2^-24 of the largest
+// 1e-4 off relative to their own size, tools/exp_halves_range.py).  The left operand therefore stores 2^11 h2 — as large as h1,
+// so it leaves the normal range only where h1 does — and the right operand pairs it with 2^-11 h1 (weights are the right
+// operands: entries within 2^-3..2^14 after scaling stay exact, smaller ones contribute below 2^-39 of the row's largest
+// product).  Rows of the left operand down to 2^-28 of the matrix maximum keep 22 bits; in ABSOLUTE terms every entry is
+// reproduced to 2^-38 of the matrix maximum or better, whatever its size.
 #include <hip/hip_fp16.h>
 
 #include "common.h"
@@ -81,12 +89,18 @@ __global__ __launch_bounds__(128) void halves_split_kernel(const float* x, int64
         v0 = xr[c] * s;
     }
     const __half a0 = __float2half_rn(v0), a1 = __float2half_rn(v1);
-    const __half b0 = __float2half_rn(v0 - __half2float(a0)), b1 = __float2half_rn(v1 - __half2float(a1));
+    const float r0 = v0 - __half2float(a0), r1 = v1 - __half2float(a1);        // exact in fp32
     __half* o = out + r * ldo + c;
-    const __half2 hi = __halves2half2(a0, a1), lo = __halves2half2(b0, b1);
+    const __half2 hi = __halves2half2(a0, a1);
     *reinterpret_cast<__half2*>(o) = hi;
-    *reinterpret_cast<__half2*>(o + piece) = ORDER == 0 ? hi : lo;
-    *reinterpret_cast<__half2*>(o + 2 * (int64_t)piece) = ORDER == 0 ? lo : hi;
+    if (ORDER == 0) {   // [h1 | h1 | 2^11 h2]
+        *reinterpret_cast<__half2*>(o + piece) = hi;
+        *reinterpret_cast<__half2*>(o + 2 * (int64_t)piece) = __halves2half2(__float2half_rn(r0 * kHalvesShift), __float2half_rn(r1 * kHalvesShift));
+    } else {            // [h1 | h2 | 2^-11 h1]
+        *reinterpret_cast<__half2*>(o + piece) = __halves2half2(__float2half_rn(r0), __float2half_rn(r1));
+        *reinterpret_cast<__half2*>(o + 2 * (int64_t)piece) =
+            __halves2half2(__float2half_rn(__half2float(a0) * (1.f / kHalvesShift)), __float2half_rn(__half2float(a1) * (1.f / kHalvesShift)));
+    }
 }
 
 void launch_halves_scale(const float* part, int n, float* scale, hipStream_t st) {

@@ -2,8 +2,9 @@
 gemm_halves; kernels in csrc/halves.hip, hipBLASLt call in csrc/gemm.cpp).
 
 An fp32 matrix is held as two fp16 halves per entry, x = (h1 + h2) / s (s a power of two found on the device), laid out as
-[h1 | h1 | h2] for left operands and [h1 | h2 | h1] for right operands, so that ONE fp16 GEMM over the three-fold reduction
-axis forms a1 b1 + a1 b2 + a2 b1 with fp32 accumulation.  Against an fp64 product the result is as close as hipBLASLt's fp32
+[h1 | h1 | 2^11 h2] for left operands and [h1 | h2 | 2^-11 h1] for right operands, so that ONE fp16 GEMM over the three-fold
+reduction axis forms a1 b1 + a1 b2 + a2 b1 with fp32 accumulation (the 2^11 keeps the second half of a left operand in fp16's
+normal range for rows down to 2^-28 of the matrix maximum, csrc/halves.hip "Dynamic range").  Against an fp64 product the result is as close as hipBLASLt's fp32
 GEMM (1e-6 of the largest entry at the config-2 shapes) and ~3x faster: the fp32 MFMA rate, not HBM, bounds these GEMMs.
 
 `BOT_GEMM=f32` switches every projection back to the stock fp32 GEMM.
@@ -21,6 +22,7 @@ MODE = os.environ.get("BOT_GEMM", "halves")
 FORCE = False              # tests set this to run the halves path over the emulated (CPU) backend at any row count
 MIN_ROWS = 8192            # below this many rows the fp32 GEMM is launch-bound anyway
 PIECE_ALIGN = 64
+SHIFT = 2048.0             # csrc/common.h kHalvesShift: a left operand's third piece is 2^11 h2
 CHUNK_ROWS = 8192          # row chunk of the weight-gradient reduction (one batch entry each)
 
 
@@ -37,7 +39,7 @@ class Halves:
 
 
 def split(x, order: int) -> Halves:
-    """order 0: left operand [h1 | h1 | h2]; order 1: right operand [h1 | h2 | h1] (both reduce over their columns)."""
+    """order 0: left operand [h1 | h1 | 2^11 h2]; order 1: right operand [h1 | h2 | 2^-11 h1] (both reduce over their columns)."""
     n, F = x.shape
     piece = (F + PIECE_ALIGN - 1) // PIECE_ALIGN * PIECE_ALIGN
     scale = _C.halves_scale(x)
@@ -106,11 +108,12 @@ def tn(x: Halves, d: Halves):
     b = part(x2, d1, PP, R, S, 0)
     if S > 1:
         a, b = a.sum(0), b.sum(0)
-    out = a[:, :P] + a[:, PP:PP + P] + b[:, :P]
+    # both operands are LEFT layouts here: x1^T d1 + (x1^T [2^11 d2] + [2^11 x2]^T d1) / 2^11
+    out = a[:, :P] + (a[:, PP:PP + P] + b[:, :P]) * (1.0 / SHIFT)
     if S * R < N:
         ra = part(x1, d12, 2 * PP, N - S * R, 1, S * R)
         rb = part(x2, d1, PP, N - S * R, 1, S * R)
-        out = out + ra[:, :P] + ra[:, PP:PP + P] + rb[:, :P]
+        out = out + ra[:, :P] + (ra[:, PP:PP + P] + rb[:, :P]) * (1.0 / SHIFT)
     return out
 
 

@@ -353,7 +353,7 @@ int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const 
 /* The same two calls when the epilogue's output is the next layer's GEMM operand (fp16 halves, see bot_gemm_halves_f32 below):
  * bn_stats_halves also tracks the column extremes and derives hscale = (s, 1/s) from the bound
  * max_c (|weight_c| max(|max_c - mean_c|, |min_c - mean_c|) invstd_c + |bias_c|) / (1 - p) >= max |y| — no pass over y;
- * bn_act_fwd_halves writes y AND its halves [h1 | h1 | h2] (pieces of `piece` = F rounded up to x64 columns, zero padded), so the
+ * bn_act_fwd_halves writes y AND its halves [h1 | h1 | 2^11 h2] (pieces of `piece` = F rounded up to x64 columns, zero padded), so the
  * separate halves_scale / halves_split passes over y disappear.  Needs the 4-column form (even F, 8-byte aligned rows). */
 int bot_bn_stats_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float eps, float momentum, float* mean, float* invstd,
                             float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* weight,
@@ -423,8 +423,12 @@ int bot_random_keep_u8(int64_t n, int64_t n_keep, uint64_t seed, uint8_t* keep, 
  * concatenated reduction axis.  h1 + h2 carries 22-23 of the 24 significand bits; against fp64 the result is as close as
  * hipBLASLt's fp32 GEMM (tools/exp_split_gemm*.py), at ~3x its speed.
  *
- *   halves_split  out[r, :] = [h1 | h1 | h2] (order 0: left operands) or [h1 | h2 | h1] (order 1: right operands), every piece
- *                 `piece` >= F columns wide (zero padded; use a multiple of 64), out fp16 with row pitch ldo >= 3 * piece
+ *   halves_split  out[r, :] = [h1 | h1 | 2^11 h2] (order 0: left operands) or [h1 | h2 | 2^-11 h1] (order 1: right operands), every
+ *                 piece `piece` >= F columns wide (zero padded; use a multiple of 64), out fp16 with row pitch ldo >= 3 * piece.
+ *                 The 2^11 keeps a left operand's second half in fp16's normal range: ROWS down to 2^-28 of the matrix maximum keep
+ *                 22 significant bits (one scale per matrix alone: 2^-17), and every entry is reproduced to 2^-38 of the matrix
+ *                 maximum in absolute terms.  A product of two LEFT layouts (x^T d, the weight gradient) is formed from separate
+ *                 GEMMs over the pieces with the 2^-11 applied by the caller (bot_amd/gemm.py:tn).
  *   gemm_halves   C[m,n] = alpha[j] * op(A)[m,k] op(B)[k,n] + beta * C[m,n], row-major, A / B fp16, C fp32, `alpha` a DEVICE vector of n
  *                 floats (one per output column; normally n copies of the product of the two operands' 1/s); trans_x != 0: the operand is stored transposed.  batch > 1: strided
  *                 batches (element strides).  Kernel choice: `algo_index` >= 0 = a solution index recorded for this shape on this library

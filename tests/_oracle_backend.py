@@ -243,13 +243,14 @@ def halves_split(x, scale, order, piece, out=None):
     n, F = x.shape
     z = x.float() * (float(scale[0]) if scale is not None else 1.0)
     h1 = z.half()
-    h2 = (z - h1.float()).half()
+    r = z - h1.float()
     buf = torch.zeros((n, 3 * piece), dtype=torch.float16) if out is None else out
     if out is not None:
         buf[:, :3 * piece] = 0
     buf[:, :F] = h1
-    buf[:, piece:piece + F] = h1 if order == 0 else h2
-    buf[:, 2 * piece:2 * piece + F] = h2 if order == 0 else h1
+    # left operands [h1 | h1 | 2^11 h2], right operands [h1 | h2 | 2^-11 h1] (csrc/halves.hip "Dynamic range")
+    buf[:, piece:piece + F] = h1 if order == 0 else r.half()
+    buf[:, 2 * piece:2 * piece + F] = (r * 2048.0).half() if order == 0 else (h1.float() / 2048.0).half()
     return buf
 
 
