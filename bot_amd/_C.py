@@ -750,9 +750,9 @@ def colsum(x):
 def _written(*ts):
     """The library wrote these tensors through raw pointers: move their autograd version counters, as an in-place torch op
     would, so that anything keyed on `_version` (the inference-path caches of bot_amd.nn.fused, saved-tensor checks) sees it."""
-    for t in ts:
-        if t is not None:
-            torch._C._increment_version(t)
+    ts = [t for t in ts if t is not None]
+    if ts:
+        torch._C._increment_version(ts)
 
 
 def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
