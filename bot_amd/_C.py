@@ -38,8 +38,6 @@ _SIGS = {
                                     c_int32, c_int32, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P]),
     "bot_spmm_blocked_f32": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P,
                                             c_int32, c_int32, _P, c_int64, _P, c_int64, _P]),
-    "bot_spmm_dot_blocked_f32": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P, _P,
-                                                c_int64, c_int32, c_int32, _P, c_int64, _P, _P]),
     "bot_spmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                         _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P]),
     "bot_spmm_bcast_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, _P, _P, c_int32,
@@ -298,29 +296,6 @@ def spmm_dot(d, x, w, wperm, y, out=None):
     out_, ldo, hso = _slab(out, "out")
     assert out_ is out
     dot = torch.empty((d.nnz, H), dtype=torch.float32, device=x.device)
-    if _rows_contiguous(x) and _rows_contiguous(y) and _rows_contiguous(out) and not getattr(d, "_no_blocked_dot", False):
-        from . import blocked
-        bp = blocked.plan_for_dot(d, x.shape[0], H, D, wperm)
-        if bp is not None:
-            vec = blocked.layout(H, D)[0]
-            ok = lambda t: t.data_ptr() % (4 * vec) == 0 and t.stride(0) % vec == 0
-            if not (ok(x) and ok(y) and ok(out)):
-                bp = None
-        if bp is not None:  # dense graph: L2-blocked fused backward for the regular rows, row kernel for the hubs
-            _check(_timed("spmm_dot_blocked", (H, D), lambda: _lib.bot_spmm_dot_blocked_f32(
-                bp.tile_rows.data_ptr(), bp.ptr.data_ptr(), bp.b_src.data_ptr(), bp.b_lrow.data_ptr(), bp.b_pos.data_ptr(),
-                bp.n_tiles, bp.nblk, bp.block_rows, bp.T, bp.round_tiles, x.data_ptr(), x.stride(0), w.data_ptr(), y.data_ptr(),
-                y.stride(0), H, D, out.data_ptr(), out.stride(0), dot.data_ptr(), _stream())), "spmm_dot_blocked")
-            if bp.heavy is not None:
-                hv = bp.heavy
-                hv._no_blocked_dot = True
-                partial = torch.empty(int(_lib.bot_spmm_workspace_floats(hv.n_slots, H, D)), dtype=torch.float32, device=x.device)
-                _check(_lib.bot_spmm_dot_f32(
-                    hv.indptr.data_ptr(), hv.indices.data_ptr(), hv.n_rows, hv.nnz, hv.items.data_ptr(), hv.n_items,
-                    _ptr(hv.long_rows), _ptr(hv.long_ptr), hv.n_long, x.data_ptr(), ldx, hsx, w.data_ptr(),
-                    _ptr(_i32(wperm, "wperm")), y.data_ptr(), ldy, hsy, H, D, out.data_ptr(), ldo, hso, dot.data_ptr(),
-                    _ptr(partial), _stream()), "spmm_dot (hub rows)")
-            return out, dot
     partial = None
     if d.n_long:
         partial = torch.empty(int(_lib.bot_spmm_workspace_floats(d.n_slots, H, D)), dtype=torch.float32, device=x.device)

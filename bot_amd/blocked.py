@@ -11,13 +11,10 @@ import torch
 ENABLED = True
 MIN_MEAN_DEGREE = 96       # below this a (row, block) visit holds < 1 edge: nothing to reuse
 L2_BLOCK_BYTES = 2 << 20   # source rows per column block * row bytes (half of the 4 MiB L2 of an XCD; 1 / 2 / 4 / 8 MiB: 7.80 / 6.54 / 6.44 / 7.95 ms on S-reddit)
-DOT_L2_BLOCK_BYTES = 2 << 20   # the same for the fused backward's plan (half-height tiles: fewer edges per (tile, block))
-# The L2-blocked fused backward is correct and tested but NOT faster than the all-heads row kernel, so it is off by default.
-# Measured at S-proteins (H=6, D=80, tools/exp_blocked_dot.py): row kernel 21.9 ms; blocked with 1 / 2 / 4 / 8 / 16 MiB column
-# blocks 34.4 / 28.6 / 25.3 / 23.5 / 22.7 ms.  Two [T, H*D] tiles in LDS leave T = 32 rows, i.e. ~9 edges per wave between two
-# workgroup barriers (130 column blocks): every phase is a couple of dependent gather groups plus a barrier tail, so the sweep is
-# latency-bound long before L2 residency pays; larger blocks trade the residency away and converge to the row kernel's time.
-DOT_ENABLED = False
+# The fused backward (spmm_dot) has NO blocked form.  Round 2 built one (two [T, H*D] tiles in LDS: accumulators and the tile's own
+# rows) and measured it at S-proteins, H=6 D=80: 34.4 / 28.6 / 25.3 / 23.5 / 22.7 ms with 1 / 2 / 4 / 8 / 16 MiB column blocks against
+# 21.9 ms for the all-heads row kernel — T = 32 rows leave ~9 edges per wave between two workgroup barriers, the sweep is latency-bound
+# long before L2 residency pays.  It never won, so round 3 removed it (profiles/r02_blocked_dot_proteins.txt keeps the numbers).
 TILE_ROWS = 128            # destination rows per workgroup (32 / 64 / 128; 256 when rows are gathered by lane groups)
 TILE_LDS_BYTES = 128 * 1024  # LDS per workgroup: one 16-wave workgroup per CU
 WAVES = 16                 # wavefronts per workgroup (bot_amd/csrc/blocked.hip kBWaves)
@@ -70,37 +67,17 @@ def layout(H: int, D: int):
     return vec, epi, (lanes + group - 1) // group * group * vec
 
 
-def dot_tile_rows(H: int, D: int) -> int:
-    """Tile height of the blocked FUSED BACKWARD (spmm_dot_blocked_kernel): two [T, H*D] fp32 tiles (accumulators and the
-    tile's own rows) plus 32 KB of staged weights in the 160 KB of LDS; 0 = the shape does not fit the kernel."""
-    vec = 4 if D % 4 == 0 else (2 if D % 2 == 0 else 1)
-    lanes = (D + vec - 1) // vec
-    hl = 16 if lanes <= 16 else (32 if lanes <= 32 else 64)
-    if lanes > 64 or (H * hl + 63) // 64 > 4 or H > 8 or H < 1:
-        return 0
-    T = TILE_ROWS
-    while T >= 16 and (2 * T * H * D + WAVES * 64 * 8) * 4 > 160 * 1024:
-        T //= 2
-    return T if T >= 16 else 0
-
-
-def build(d, n_src: int, H: int, D: int, dot_wperm=None, dot=False) -> BlockedPlan:
-    """`dot=True`: the plan of the fused backward — compact rows, no lane groups, half-height tiles, and `b_pos` holds the
-    row of the edge in the weight / dot arrays (`dot_wperm[position]`, or the position itself)."""
+def build(d, n_src: int, H: int, D: int) -> BlockedPlan:
     F = H * D
     dev = d.indptr.device
     deg = (d.indptr[1:] - d.indptr[:-1]).long()
     mean = max(1.0, d.nnz / max(1, d.n_rows))
     hub_thr = max(int(HUB_FACTOR * mean), d.chunk)
     vec, epi, Fp = layout(H, D)
-    if dot:
-        epi, T = 1, dot_tile_rows(H, D)
-        assert T > 0
-    else:
-        T = 256 if epi > 1 else TILE_ROWS
-        while T > 32 and Fp * 4 * T > TILE_LDS_BYTES:
-            T //= 2
-    cb = max(64, (DOT_L2_BLOCK_BYTES if dot else L2_BLOCK_BYTES) // (F * 4))
+    T = 256 if epi > 1 else TILE_ROWS
+    while T > 32 and Fp * 4 * T > TILE_LDS_BYTES:
+        T //= 2
+    cb = max(64, L2_BLOCK_BYTES // (F * 4))
     cb = 1 << (cb.bit_length() - 1)
     nblk = (n_src + cb - 1) // cb
     regular = deg <= hub_thr
@@ -146,8 +123,6 @@ def build(d, n_src: int, H: int, D: int, dot_wperm=None, dot=False) -> BlockedPl
     key = (stream * nblk + src // cb) * T + lrow                  # inside a stream: by column block, then row
     key, perm = torch.sort(key, stable=True)                      # ties keep position order = ascending edge id
     b_src, b_lrow, b_pos = src[perm], lrow[perm], pos[perm]
-    if dot and dot_wperm is not None:
-        b_pos = dot_wperm.long()[b_pos]
     counts = torch.bincount(stream, minlength=n_tiles * WAVES)
     if epi > 1 and key.numel():
         # lane groups: every (stream, block, row) run is padded to a multiple of `epi` slots (source -1), so the slots of
@@ -187,16 +162,3 @@ def plan_for(d, n_src: int, H: int, D: int):
     if (H, D) not in cache:
         cache[(H, D)] = build(d, n_src, H, D)
     return cache[(H, D)]
-
-
-def plan_for_dot(d, n_src: int, H: int, D: int, wperm):
-    """BlockedPlan of the fused backward (bot_spmm_dot_blocked_f32) for direction `d`, or None when the row kernel is the right
-    one.  `wperm` (position -> row of the weight / dot arrays, or None) is baked into the plan."""
-    if (not ENABLED or not DOT_ENABLED or d.n_rows == 0 or d.nnz < MIN_MEAN_DEGREE * d.n_rows or not d.indptr.is_cuda or H * D < MIN_ROW_FLOATS
-            or dot_tile_rows(H, D) == 0):
-        return None
-    key = (H, D, "dot", None if wperm is None else wperm.data_ptr())
-    cache = d.blocked
-    if key not in cache:
-        cache[key] = build(d, n_src, H, D, dot_wperm=wperm, dot=True)
-    return cache[key]

@@ -247,195 +247,6 @@ static int launch_blocked(const BlockedArgs& a0, int round_tiles, hipStream_t st
     return hip_status("spmm_blocked launch");
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// L2-blocked form of the FUSED backward of u_mul_e_sum (spmm_dot, spmm.hip) for dense graphs: the same sweep — edge streams
-// per wave sorted by (column block, row, edge id), 16 waves crossing the blocks in lockstep, every workgroup walking the
-// blocks in the same order so the gathered rows are L2-resident — with each gathered row x[v] (the upstream gradient) used
-// twice, as in the row kernel:
-//     out[u,h,:]     = sum_e w[e,h] * x[v_e,h,:]      accumulated in the workgroup's LDS tile          (d ft)
-//     dot_out[e,h]   = < y[u,h,:] , x[v_e,h,:] >      y = the tile's own rows, staged in LDS once      (d a)
-// Both tiles (T rows of H*D floats each) live in LDS, so T is half the forward's; rows sit in registers in the all-heads
-// layout of spmm_dot_rows_kernel (a head = HL lanes, 64 / HL heads per 64-lane chunk) and compactly ([H*D] floats) in LDS.
-// Dots of 4 edges are reduced together by the transposing butterfly; `b_pos` of this plan is the row of `w` / `dot_out`
-// (the CSC position of the edge), precomputed by the host.  No atomics; fixed order; bitwise reproducible.
-// ---------------------------------------------------------------------------------------------------------------------
-struct BlockedDotArgs {
-    const int32_t* tile_rows;
-    const int32_t* ptr;
-    const int32_t* b_src;
-    const uint8_t* b_lrow;
-    const int32_t* b_wp;       // row of w / dot_out of each blocked edge
-    int32_t tile0, n_tiles, nblk;
-    const float* x;
-    int64_t ldx;
-    const float* w;            // [nnz, H]
-    const float* y;
-    int64_t ldy;
-    int32_t H, D, F;
-    int32_t cb_shift;
-    float* out;
-    int64_t ldo;
-    float* dot_out;            // [nnz, H]
-};
-
-template <int VEC, int HL, int NCHUNK, int T>
-__global__ __launch_bounds__(kBThreads) void spmm_dot_blocked_kernel(BlockedDotArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // acc [T][F] | y [T][F] | weights [16][64][8]
-    constexpr int U = 4;
-    constexpr int HPC = 64 / HL;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hl = lane & (HL - 1), seg = lane / HL;
-    const int tile = a.tile0 + blockIdx.x;
-    const int F = a.F;
-    float* acc_lds = lds;
-    float* y_lds = lds + (size_t)T * F;
-    float* wl = lds + (size_t)2 * T * F + wave * (64 * 8);
-    int loff[NCHUNK], hd[NCHUNK];
-    bool act[NCHUNK], live[NCHUNK];
-#pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-        const int head = c * HPC + seg;
-        const int e = hl * VEC;
-        live[c] = head < a.H;
-        act[c] = live[c] && e < a.D;
-        hd[c] = live[c] ? head : 0;
-        loff[c] = act[c] ? head * a.D + e : 0;   // idle lanes re-read element 0: in bounds, never stored
-    }
-    // wave w owns the tile rows w, w+16, ...: zero their accumulators, stage their y rows
-    for (int r = wave; r < T; r += kBWaves) {
-        const int row = a.tile_rows[(int64_t)tile * T + r];
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c)
-            if (act[c]) {
-                float z[VEC], yv[VEC];
-#pragma unroll
-                for (int t = 0; t < VEC; ++t) z[t] = 0.f, yv[t] = 0.f;
-                if (row >= 0) vload<VEC>(yv, a.y + (int64_t)row * a.ldy + loff[c]);
-                vstore<VEC>(acc_lds + r * F + loff[c], z);
-                vstore<VEC>(y_lds + r * F + loff[c], yv);
-            }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    int k0 = __builtin_amdgcn_readfirstlane(a.ptr[(int64_t)tile * kBWaves + wave]);
-    const int end = __builtin_amdgcn_readfirstlane(a.ptr[(int64_t)tile * kBWaves + wave + 1]);
-    int cur = -1;
-    float racc[NCHUNK][VEC];
-#pragma unroll
-    for (int c = 0; c < NCHUNK; ++c)
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) racc[c][t] = 0.f;
-    int idx = 0, lr = 0, wp = 0, i = 0, cnt = 0;
-    auto load_batch = [&]() {
-        cnt = min(64, end - k0);
-        i = 0;
-        if (lane < cnt) {
-            idx = a.b_src[k0 + lane];
-            lr = a.b_lrow[k0 + lane];
-            wp = a.b_wp[k0 + lane];
-            const float* pw = a.w + (int64_t)wp * a.H;
-#pragma unroll
-            for (int h = 0; h < 8; ++h)
-                if (h < a.H) wl[lane * 8 + h] = pw[h];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
-    auto fold = [&]() {  // racc -> the LDS accumulator row `cur`, then clear
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c) {
-            if (act[c]) {
-                float o[VEC];
-                vload<VEC>(o, acc_lds + cur * F + loff[c]);
-#pragma unroll
-                for (int t = 0; t < VEC; ++t) o[t] += racc[c][t];
-                vstore<VEC>(acc_lds + cur * F + loff[c], o);
-            }
-#pragma unroll
-            for (int t = 0; t < VEC; ++t) racc[c][t] = 0.f;
-        }
-    };
-    if (k0 < end) load_batch();
-    int synced = 0;
-    while (cnt > 0) {
-        if (i == cnt) {
-            k0 += 64;
-            if (k0 >= end) break;
-            load_batch();
-        }
-        const int fb = __builtin_amdgcn_readlane(idx, i) >> a.cb_shift;
-        for (; synced < fb; ++synced) __syncthreads();
-        const int g = min(U, cnt - i);
-        float v[U][NCHUNK][VEC], p[NCHUNK][U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = min(i + u, i + g - 1);  // past the group's end: re-read a valid row, weight 0, dot not stored
-            const int sidx = __builtin_amdgcn_readlane(idx, j);
-            const float* px = a.x + (int64_t)sidx * a.ldx;
-#pragma unroll
-            for (int c = 0; c < NCHUNK; ++c) vload<VEC>(v[u][c], px + loff[c]);
-        }
-        // The tile's own row y[r] and the edge's weights are read from LDS per edge (3 + 3 LDS reads against a 1 920-byte
-        // gather): keeping them in registers across a row's edges costs 24 VGPRs and spills at the 128 a 16-wave workgroup gets.
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = min(i + u, i + g - 1);
-            const int r = __builtin_amdgcn_readlane(lr, j);
-            if (u < g && r != cur) {  // wave-uniform
-                if (cur >= 0) fold();
-                cur = r;
-            }
-#pragma unroll
-            for (int c = 0; c < NCHUNK; ++c) {
-                float yv[VEC];
-                vload<VEC>(yv, y_lds + r * F + loff[c]);
-                const float wgt = u < g ? wl[j * 8 + hd[c]] : 0.f;
-                float d = 0.f;
-#pragma unroll
-                for (int t = 0; t < VEC; ++t) {
-                    racc[c][t] = fmaf(wgt, v[u][c][t], racc[c][t]);
-                    d = fmaf(v[u][c][t], yv[t], d);
-                }
-                p[c][u] = (u < g && act[c]) ? d : 0.f;
-            }
-        }
-        const int mywp = __shfl(wp, min(i + (lane & 3), cnt - 1));  // record whose dots this lane holds after the reduction
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c) {
-            const float tot = transpose_reduce4<HL>(p[c], hl);
-            if (hl < U && hl < g && live[c]) a.dot_out[(int64_t)mywp * a.H + hd[c]] = tot;
-        }
-        i += g;
-    }
-    for (; synced < a.nblk; ++synced) __syncthreads();
-    if (cur >= 0) fold();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int r = wave; r < T; r += kBWaves) {
-        const int row = a.tile_rows[(int64_t)tile * T + r];
-        if (row < 0) continue;
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c)
-            if (act[c]) {
-                float o[VEC];
-                vload<VEC>(o, acc_lds + r * F + loff[c]);
-                vstore<VEC>(a.out + (int64_t)row * a.ldo + loff[c], o);
-            }
-    }
-}
-
-template <int VEC, int HL, int NCHUNK, int T>
-static int launch_dot_blocked(const BlockedDotArgs& a0, int round_tiles, hipStream_t st) {
-    const size_t lds = ((size_t)2 * T * a0.F + kBWaves * 64 * 8) * sizeof(float);
-    BlockedDotArgs a = a0;
-    auto k = spmm_dot_blocked_kernel<VEC, HL, NCHUNK, T>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    set_kernel("bot::spmm_dot_blocked_kernel<%d,%d,%d,%d>", VEC, HL, NCHUNK, T);
-    for (int t0 = 0; t0 < a.n_tiles; t0 += round_tiles) {
-        a.tile0 = t0;
-        const int n = a.n_tiles - t0 < round_tiles ? a.n_tiles - t0 : round_tiles;
-        hipLaunchKernelGGL(k, dim3(n), dim3(kBThreads), lds, st, a);
-    }
-    return hip_status("spmm_dot_blocked launch");
-}
-
 }  // namespace bot
 
 extern "C" {
@@ -493,58 +304,6 @@ int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int
 #undef BOT_BLK_V
 #undef BOT_BLK_G
 #undef BOT_BLK
-}
-
-int bot_spmm_dot_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int32_t* b_src, const uint8_t* b_lrow,
-                             const int32_t* b_wp, int32_t n_tiles, int32_t nblk, int32_t block_rows, int32_t T, int32_t round_tiles,
-                             const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, int32_t H, int32_t D,
-                             float* out, int64_t ldo, float* dot_out, bot_stream_t stream) {
-    using namespace bot;
-    BOT_REQUIRE(n_tiles >= 0 && nblk >= 1 && round_tiles >= 1, BOT_E_RANGE, "spmm_dot_blocked: n_tiles=%d nblk=%d round=%d", n_tiles, nblk, round_tiles);
-    BOT_REQUIRE(T == 128 || T == 64 || T == 32 || T == 16, BOT_E_RANGE, "spmm_dot_blocked: tile height %d (16, 32, 64 or 128)", T);
-    int shift = 0;
-    while ((1 << shift) < block_rows) ++shift;
-    BOT_REQUIRE(block_rows >= 1 && (1 << shift) == block_rows, BOT_E_RANGE, "spmm_dot_blocked: block_rows=%d must be a power of two", block_rows);
-    BOT_REQUIRE(H >= 1 && H <= 8 && D >= 1, BOT_E_RANGE, "spmm_dot_blocked: H=%d (1..8) D=%d", H, D);
-    if (n_tiles == 0) return 0;
-    BOT_REQUIRE(tile_rows && ptr && b_src && b_lrow && b_wp && x && w && y && out && dot_out, BOT_E_NULL, "spmm_dot_blocked: NULL pointer");
-    const int F = H * D;
-    BOT_REQUIRE(ldx >= F && ldo >= F && ldy >= F, BOT_E_RANGE, "spmm_dot_blocked: row stride smaller than H*D");
-    const int vec = pick_vec(D, {ldx, ldo, ldy}, {x, out, y});
-    const int L = (D + vec - 1) / vec;
-    BOT_REQUIRE(L <= 64, BOT_E_RANGE, "spmm_dot_blocked: a head of %d x %d-float vectors exceeds one 64-lane chunk", L, vec);
-    const int HLv = L <= 16 ? 16 : (L <= 32 ? 32 : 64);
-    const int nchunk = (H * HLv + 63) / 64;
-    BOT_REQUIRE(nchunk <= 4, BOT_E_RANGE, "spmm_dot_blocked: H=%d heads of %d lanes need %d chunks (max 4)", H, HLv, nchunk);
-    BOT_REQUIRE(((size_t)2 * T * F + kBWaves * 64 * 8) * 4 <= 160 * 1024, BOT_E_RANGE, "spmm_dot_blocked: tiles do not fit LDS (T=%d F=%d)", T, F);
-    BlockedDotArgs a{tile_rows, ptr, b_src, b_lrow, b_wp, 0, n_tiles, nblk, x, ldx, w, y, ldy, H, D, F, shift, out, ldo, dot_out};
-    hipStream_t st = (hipStream_t)stream;
-#define BOT_DB_T(V, HLV, NC)                                                           \
-    do {                                                                               \
-        if (T == 128) return launch_dot_blocked<V, HLV, NC, 128>(a, round_tiles, st);  \
-        if (T == 64) return launch_dot_blocked<V, HLV, NC, 64>(a, round_tiles, st);    \
-        if (T == 32) return launch_dot_blocked<V, HLV, NC, 32>(a, round_tiles, st);    \
-        return launch_dot_blocked<V, HLV, NC, 16>(a, round_tiles, st);                 \
-    } while (0)
-#define BOT_DB_NC(V, HLV)                      \
-    do {                                       \
-        if (nchunk == 1) BOT_DB_T(V, HLV, 1);  \
-        if (nchunk == 2) BOT_DB_T(V, HLV, 2);  \
-        if (nchunk == 3) BOT_DB_T(V, HLV, 3);  \
-        BOT_DB_T(V, HLV, 4);                   \
-    } while (0)
-#define BOT_DB_V(V)                            \
-    do {                                       \
-        if (HLv == 16) BOT_DB_NC(V, 16);       \
-        if (HLv == 32) BOT_DB_NC(V, 32);       \
-        BOT_DB_NC(V, 64);                      \
-    } while (0)
-    if (vec == 4) BOT_DB_V(4);
-    if (vec == 2) BOT_DB_V(2);
-    BOT_DB_V(1);
-#undef BOT_DB_V
-#undef BOT_DB_NC
-#undef BOT_DB_T
 }
 
 }  // extern "C"

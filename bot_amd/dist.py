@@ -319,9 +319,10 @@ def seed_rank_streams(base_seed: int, rank: int):
 
 def _global_mean(y, w, group):
     """sum(y * w) / global sum(w) as this rank's additive share of the global mean (its backward gives the right scale)."""
-    cnt = w.sum().reshape(1)
+    from .ops import sum_all
+    cnt = sum_all(w).reshape(1)
     dist.all_reduce(cnt, group=group)
-    return (y * w).sum() / cnt[0]
+    return sum_all(y * w) / cnt[0]
 
 
 def forward_backward(model, part: Partition, *, use_labels=True, mask_rate=0.5, n_label_iters=0, loss="logit", n_classes=None,

@@ -91,7 +91,9 @@ class ElementWiseLinear(nn.Module):
         if self.weight is not None:
             x = x * self.weight
         if self.bias is not None:
-            x = x + self.bias
+            # on the GPU the bias gradient — a column sum over all N rows — comes from the library's deterministic two-stage kernel:
+            # more accurate than the stock reduction (finished in double) and, unlike it, correct under hipGraph replay (ops._SumAll)
+            x = ops.add_bias(x, self.bias) if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32) else x + self.bias
         return x
 
 

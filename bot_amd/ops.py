@@ -407,6 +407,39 @@ def add_bias(x, b):
     return _AddBias.apply(x, b) if x.dim() == 2 and x.is_cuda == b.is_cuda else x + b
 
 
+class _SumAll(torch.autograd.Function):
+    """Sum of all entries of a float32 CUDA tensor through bot_colsum_f32: the tensor is viewed as [n / 64, 64], the column sums
+    are taken by the two-stage tree kernel (finished in double, fixed order) and the <= 127 leftovers by a single-workgroup reduce.
+
+    Why not `x.sum()`: torch's multi-workgroup reductions (a staging buffer + a semaphore zeroed by a memset in front of the kernel)
+    give WRONG results inside a replayed hipGraph on this stack — measured in round 3 on the final bias gradient of the GAT stack
+    (`dy.sum(0)` over [N, 40]): bit-identical to the eager step for the first replays, then off by ~1e-1 of the gradient on every
+    further replay, identical in every run (tools/dbg_captured_eval.py); the same step with `bot_colsum_f32` matches the eager step bit for
+    bit over any number of replays.  The train step (bot_amd.train / bot_amd.dist) therefore takes its N-sized reductions — the loss
+    numerator, the weight count, bias gradients — through the library's own deterministic kernels."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        flat = x.reshape(-1)
+        n64 = flat.numel() // 64 * 64
+        parts = []
+        if n64:
+            parts.append(_C.colsum(flat[:n64].view(-1, 64)))
+        if n64 < flat.numel():
+            parts.append(flat[n64:])
+        return torch.cat(parts).sum() if parts else flat.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.expand(ctx.shape)
+
+
+def sum_all(x):
+    """x.sum() with a fixed summation order that is also safe under hipGraph replay (see _SumAll); plain x.sum() off the GPU."""
+    return _SumAll.apply(x) if (x.is_cuda and x.dtype == torch.float32 and x.numel() >= 4096) else x.sum()
+
+
 SPLITK_MIN_ROWS = 1 << 20      # weight gradients over at least this many rows are reduced in row chunks
 SPLITK_CHUNK_ROWS = 1 << 14
 

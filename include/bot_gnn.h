@@ -121,17 +121,6 @@ int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int
                          int32_t round_tiles, const float* x, int64_t ldx, const float* w, int32_t H, int32_t D, float* out,
                          int64_t ldo, const float* addend, int64_t lda, bot_stream_t stream);
 
-/* L2-blocked form of bot_spmm_dot_f32 below (the fused backward of u_mul_e_sum) for dense graphs: same blocked structure as
- * bot_spmm_blocked_f32 built on the TRANSPOSED direction (rows = sources u), except that a workgroup keeps TWO [T, H*D] tiles in
- * LDS — the accumulators of out[u,:] and the tile's own rows y[u,:] — so T is half the forward's ((2*T*H*D + 8192) floats <= 160
- * KB), there are no lane groups (epi = 1), and `b_wp[k]` is the row of w / dot_out of blocked edge k (e.g. its CSC position):
- *   out[u,h,:]       = sum_{e: u->v} w[b_wp,h] * x[v,h,:]        dot_out[b_wp,h] = < y[u,h,:] , x[v,h,:] >
- * Rows listed in tile_rows only; hub rows go through bot_spmm_dot_f32 with a plan restricted to them.  H <= 8, a head of at most
- * 64 vector lanes, rows [H*D] contiguous (row strides ldx / ldy / ldo).  Deterministic, no atomics. */
-int bot_spmm_dot_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int32_t* b_src, const uint8_t* b_lrow,
-                             const int32_t* b_wp, int32_t n_tiles, int32_t nblk, int32_t block_rows, int32_t T,
-                             int32_t round_tiles, const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy,
-                             int32_t H, int32_t D, float* out, int64_t ldo, float* dot_out, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused backward of u_mul_e_sum (models.py:547) in ONE sweep over the transposed direction (rows = sources u,

@@ -506,7 +506,8 @@ def test_bcast_kernels_direct(golden):
 
 def test_blocked_spmm_matches_row_kernel():
     """Dense graph (mean degree ~150, a few hubs): the L2-blocked SpMM + hub fallback equals the row-per-group kernel and
-    plain torch, weighted and unweighted, through ops (forward of copy_u_sum / u_mul_e_sum and the GCN backward)."""
+    plain torch, weighted and unweighted, through ops (forward of copy_u_sum / u_mul_e_sum and the GCN backward); the fused
+    backward (row kernel) on the same graph."""
     from bot_amd import blocked
     n = 3000
     gen = torch.Generator().manual_seed(21)
@@ -562,12 +563,11 @@ def test_blocked_spmm_matches_row_kernel():
     (y * gy).sum().backward()
     ref_g = torch.zeros(n, 64, device=DEV).index_add_(0, s.to(DEV), gy[d.to(DEV)])
     assert torch.allclose(xg.grad, ref_g, atol=2e-3, rtol=1e-4)
-    # the fused backward (spmm_dot: d ft and d a from one sweep of the transposed direction) in its L2-blocked form against the
-    # row kernel and plain torch: every head-segment layout (16 / 32 / 64 lanes, 1-4 chunks), slabs of a wider buffer, hub rows
+    # the fused backward (spmm_dot: d ft and d a from one sweep of the transposed direction) on this dense graph — it has no
+    # blocked form (bot_amd/blocked.py: built in round 2, never faster, removed in round 3): every head-segment layout of the row
+    # kernel (16 / 32 / 64 lanes, 1-4 chunks), slabs of a wider buffer, hub rows, against plain torch; bitwise reproducible
     csr, c2c = g.csr, g.csr2csc
-    blocked.DOT_ENABLED = True   # off by default: correct, but measured slower than the row kernel (bot_amd/blocked.py)
     rows_r = torch.repeat_interleave(torch.arange(n, device=DEV), (csr.indptr[1:] - csr.indptr[:-1]).long())
-    seen = set()
     for H, D in ((6, 80), (4, 120), (2, 64), (8, 16), (1, 128), (3, 40), (4, 250), (3, 7), (1, 20)):
         F = H * D
         big = torch.randn(n, 3 * F + 4, generator=gen).to(DEV)
@@ -575,28 +575,17 @@ def test_blocked_spmm_matches_row_kernel():
         ft = big[:, F:2 * F].unflatten(1, (H, D))                 # the rows' own features
         w = torch.rand(csr.nnz, H, generator=gen).to(DEV)         # in CSC position order, reached through csr2csc
         outb = big[:, 2 * F:3 * F].unflatten(1, (H, D))
-        blocked.ENABLED = True
-        bp = blocked.plan_for_dot(csr, n, H, D, c2c)
         o_b, dot_b = _C.spmm_dot(csr, dx, w, c2c, ft, out=outb)
-        seen.add("blocked" if bp is not None else "row")
         o_b, dot_b = o_b.clone(), dot_b.clone()
-        blocked.ENABLED = False
-        o_r, dot_r = _C.spmm_dot(csr, dx, w, c2c, ft)
-        blocked.ENABLED = True
         wr = w[c2c.long()]
         xs = dx[csr.indices.long()]
         ref_o = torch.zeros(n, H, D, device=DEV).index_add_(0, rows_r, xs * wr.unsqueeze(-1))
         ref_dot = torch.empty(csr.nnz, H, device=DEV)
         ref_dot[c2c.long()] = (xs * ft[rows_r]).sum(-1)
-        assert (bp is not None) == (blocked.dot_tile_rows(H, D) > 0 and F >= blocked.MIN_ROW_FLOATS), (H, D)
-        assert torch.allclose(o_b, ref_o, atol=2e-3, rtol=1e-4) and torch.allclose(o_b, o_r, atol=2e-3, rtol=1e-4), (H, D)
-        assert torch.allclose(dot_b, ref_dot, atol=1e-3 * D ** 0.5, rtol=1e-4) and torch.allclose(dot_b, dot_r, atol=1e-3 * D ** 0.5, rtol=1e-4), (H, D)
-        if bp is not None:
-            assert bp.heavy is not None and bp.T in (16, 32, 64, 128) and bp.epi == 1
-            o2, dot2 = _C.spmm_dot(csr, dx, w, c2c, ft)          # bitwise reproducible
-            assert torch.equal(o2, o_b) and torch.equal(dot2, dot_b)
-    assert seen == {"row", "blocked"}, seen
-    blocked.DOT_ENABLED = False
+        assert torch.allclose(o_b, ref_o, atol=2e-3, rtol=1e-4), (H, D)
+        assert torch.allclose(dot_b, ref_dot, atol=1e-3 * D ** 0.5, rtol=1e-4), (H, D)
+        o2, dot2 = _C.spmm_dot(csr, dx, w, c2c, ft)
+        assert torch.equal(o2, o_b) and torch.equal(dot2, dot_b)
 
 
 def test_config1_cora_shape_gcn():
