@@ -290,6 +290,25 @@ def main():
         sample_scale = (args.parity_scale if args.parity_scale is not None else FS.PARITY_SCALE[args.workload]) * args.scale
         cpu, parity = cpu_baseline_and_parity_sample(args.workload, dev, sample_scale)
 
+    part_info = None
+    if partitioned:
+        # what a SCALE line needs to explain itself: per rank the owned rows, the in-edges it sweeps, the halo rows it receives and
+        # the rows it ships per hidden layer and direction, and the bytes those exchanges move per step (fp32; layer 0 of the GAT
+        # ships the narrow inputs, bot_amd/nn/fused.py)
+        p = wl.dataset.part
+        mine = {"rank": rank, "owned_rows": int(p.n_owned), "edges": int(p.n_edges), "halo_rows": int(p.graph.halo.n_halo),
+                "send_rows": int(p.graph.halo.n_send), "peers_recv": int(sum(1 for c in p.graph.halo.recv_splits if c)),
+                "cut_edges": int((p.graph.edges()[0] >= p.n_owned).sum())}
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, mine)
+        if rank == 0:
+            H, D, _ = wl.dominant_shape
+            widths = wl.halo_widths if getattr(wl, "halo_widths", None) else [H * D]
+            per_rank_bytes = [4 * 2 * sum(w * (g["halo_rows"] + g["send_rows"]) for w in widths) for g in gathered]
+            part_info = {"ranks": gathered, "exchange_row_widths_per_layer": widths,
+                         "exchange_bytes_per_rank_per_step": per_rank_bytes,
+                         "note": "forward all-to-all of halo source rows + reverse all-to-all of their gradients per layer (RCCL); "
+                                 "bytes = 4 * 2 directions * sum over layers of width * (rows received + rows sent)"}
     if rank == 0:
         out = {
             "metric": "edges/sec full-batch GAT fwd+bwd on ogbn-arxiv; achieved HBM GB/s vs peak",
@@ -303,7 +322,8 @@ def main():
                        if gemm.MODE == "halves" else "stock fp32 GEMM (hipBLASLt / rocBLAS)",
                        "gemm_kernel_selection": "TunableOp file" if tuned else "library default",
                        "scale": args.scale, "launch": "one hipGraph replay per step" if wl.captured else "eager",
-                       "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world} ({args.partitioner} ranges)"},
+                       "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world} ({args.partitioner} ranges)",
+                       "partition": part_info},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "stock_fp32_gemm": stock,
         }
     if partitioned:

@@ -179,4 +179,16 @@ def build(name: str, device, *, rank=0, world=1, partitioned=False, seed=0, scal
     describe = (f"S-{name}: power-law graph N={n} E={E} (raw {ds.raw_edges}), F={0 if ds.feat is None else ds.feat.shape[1]}, C={C}; {desc}")
     wl = Workload(name, describe, n, E, ds.raw_edges, step, model, ("spmm", shape), shape, n_local, e_local, ds, g)
     wl.captured = captured
+    # row widths (floats) of the halo tables one step exchanges, per layer: the GAT's aggregate-first layer 0 ships [x | el], the
+    # other layers [ft | el] (bot_amd/nn/fused.py:_ext_width); the GCN ships the narrower side of every GraphConv
+    if name == "arxiv":
+        fin = ds.feat.shape[1] + C
+        wl.halo_widths = [fin + 4, 3 * 250 + 4, 40 + 4]
+    elif name in ("cora", "reddit"):
+        dims = [ds.feat.shape[1]] + [hid] * (layers - 1) + [C]
+        wl.halo_widths = [min(dims[i], dims[i + 1]) for i in range(layers)]
+    elif name == "proteins":
+        wl.halo_widths = [6 * 80 + 6] * 6
+    else:
+        wl.halo_widths = [4 * 120 + 4] * 3
     return wl

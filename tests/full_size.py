@@ -377,6 +377,10 @@ def workload_parity(name, dev, scale=1.0, exact="auto"):
         r["rank"] = rank
     else:
         ok = ok and r["max_rel_grad_err"] <= 1e-4
-    ok = ok and r.get("max_abs_preact_at_differing_gate", 0.0) <= 1e-4
+    # gates the two runs set differently may only be rounding noise: |pre-activation| there <= 1e-4, relative to the logit scale where
+    # the fp64-ranked criterion applies (config 4: attention logits and activations of O(100))
+    gate_tol = 1e-4 * (max(1.0, r["logit_scale"] / 10) if crit == "fp64-ranked" else 1.0)
+    r["gate_tolerance"] = gate_tol
+    ok = ok and r.get("max_abs_preact_at_differing_gate", 0.0) <= gate_tol
     r.update(criterion=crit, criterion_text=CRITERIA[crit], ok=bool(ok), edges=int(s.numel()), scale=scale)
     return r, {"seconds": secs, "threads": threads, "edges": int(s.numel()), "nodes": n}
