@@ -20,7 +20,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kSkMaxK = 256;
-constexpr int kSkWaves = 12;    // waves per workgroup: two per SIMD, so that one wave's global-load / store latency hides behind the other's MFMAs
+#ifndef SK_WAVES
+#define SK_WAVES 12
+#endif
+constexpr int kSkWaves = SK_WAVES;    // waves per workgroup: two per SIMD, so that one wave's global-load / store latency hides behind the other's MFMAs
 constexpr int kSkRows = 32 * kSkWaves;   // rows per workgroup tile (32 per wave)
 constexpr int kSkThreads = 64 * kSkWaves;
 
@@ -143,6 +146,11 @@ __global__ __launch_bounds__(kSkThreads) void skinny_gemm_kernel(SkinnyArgs a) {
     // only the ONE partial k-step of a row (K not a multiple of 8 per lane half) takes guarded element loads — it must not read
     // past the end of the matrix, and whatever it reads has to be finite.
     auto load8 = [&](float (&v)[8], int64_t tile, int step) {
+#ifdef SK_ABLATE_LOAD    /* measurement builds only: no A traffic */
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)(lane + j + step) * 0.001f + (float)tile;
+        return;
+#endif
         int64_t row = tile * kSkRows + wave * 32 + r;
         row = row < a.m ? row : a.m - 1;
         const float* ar = A + row * a.lda;
@@ -202,12 +210,16 @@ __global__ __launch_bounds__(kSkThreads) void skinny_gemm_kernel(SkinnyArgs a) {
                     b2.q = *reinterpret_cast<const uint4*>(bl + (1 * NB + t * 32) * ks);
                     b3.q = *reinterpret_cast<const uint4*>(bl + (2 * NB + t * 32) * ks);
                     // smallest terms first: they are added into the accumulator before the leading product
+#ifdef SK_ABLATE_MFMA   /* measurement builds only (tools/exp_skinny_ablate.sh): one product instead of six */
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b1.v, acc[t], 0, 0, 0);
+#else
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3.v, b1.v, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b3.v, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, b2.v, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, b1.v, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b2.v, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b1.v, acc[t], 0, 0, 0);
+#endif
                 }
             }
 #pragma unroll
@@ -218,6 +230,12 @@ __global__ __launch_bounds__(kSkThreads) void skinny_gemm_kernel(SkinnyArgs a) {
         const int wave_s = __builtin_amdgcn_readfirstlane(wave);
         const int64_t rwave = tile * kSkRows + wave_s * 32;
         float* Cw = C + rwave * a.ldc + col0;
+#ifdef SK_ABLATE_STORE   /* measurement builds only: no C traffic unless a (never occurring) value shows up */
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) any |= acc[t][0] == 1234.5f;
+        if (!any) continue;
+#endif
         if (rwave + 32 <= a.m) {            // the whole 32-row group exists: no per-row guards
 #pragma unroll
             for (int t = 0; t < NT; ++t) {

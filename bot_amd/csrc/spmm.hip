@@ -294,6 +294,100 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(SpmmArgs a) {
         }
 }
 
+// The weighted all-heads forward for rows whose head width is NOT a multiple of 4 floats (ogbn-arxiv: 3 x 250): the head-segment
+// layouts above then fall back to 8-byte loads (six per neighbour row and lane), which halves the L2-resident gather rate
+// (0.56 vs 0.38 ms at S-arxiv with every source in the L2, profiles/r02_spmm_lane_width.txt).  When the row is H*D CONTIGUOUS
+// floats on a 16-byte aligned pitch it is read here as flat float4 lanes instead — three 16-byte loads per neighbour row and lane —
+// and the head of every element is resolved per lane: a float4 straddles at most one head boundary (D >= 4), so a lane-chunk holds
+// two weights, `wa` for its first `ns` elements and `wb` for the rest.  The per-edge weights are wave-uniform scalar loads.
+// The tail float4 of a row may reach past F = H*D (750 -> elements 750, 751): the caller guarantees ldx >= roundup4(F), the extra
+// lanes are multiplied into accumulators that are never stored.  Same summation order per element as the head-segment kernels.
+template <int NCHUNK, int HMAX>
+__global__ __launch_bounds__(kBlock) void spmm_flat_kernel(SpmmArgs a) {
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t item = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (item >= a.n_items) return;
+    const int4 it = a.items[item];
+    const int row = __builtin_amdgcn_readfirstlane(it.x), beg = __builtin_amdgcn_readfirstlane(it.y);
+    const int end = __builtin_amdgcn_readfirstlane(it.z), slot = __builtin_amdgcn_readfirstlane(it.w);
+    const int F = a.H * a.D;
+    int off[NCHUNK], ha[NCHUNK], hb[NCHUNK], ns[NCHUNK], nv[NCHUNK];
+    float acc[NCHUNK][4];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int e = (c * 64 + lane) * 4;
+        nv[c] = min(4, max(0, F - e));                  // elements of this lane-chunk inside the row
+        off[c] = nv[c] > 0 ? e : 0;                     // idle lanes re-read the row's first float4: in bounds, never stored
+        const int h0 = min(off[c] / a.D, a.H - 1);
+        ha[c] = h0, hb[c] = min(h0 + 1, a.H - 1);
+        ns[c] = min(4, (h0 + 1) * a.D - off[c]);        // how many of the four elements belong to head h0
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[c][t] = 0.f;
+    }
+    for (int k0 = beg; k0 < end; k0 += 64) {
+        const int k = k0 + lane;
+        int idx = 0, wp = 0;
+        if (k < end) {
+            idx = a.indices[k];
+            wp = a.wperm ? a.wperm[k] : k;
+        }
+        const int cnt = min(64, end - k0);
+        for (int i = 0; i < cnt; i += U) {
+            float v[U][NCHUNK][4], wh[U][HMAX];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = min(i + u, cnt - 1);      // past the end: re-read a valid neighbour with weight 0
+                const int s = __builtin_amdgcn_readlane(idx, j);
+                const int ps = __builtin_amdgcn_readlane(wp, j);
+                const float* px = a.x + (int64_t)s * a.ldx;
+                const float* pw = a.w + (int64_t)ps * a.H;
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c) vload<4>(v[u][c], px + off[c]);
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h) wh[u][h] = (i + u < cnt && h < a.H) ? pw[h] : 0.f;   // uniform address: scalar loads
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < NCHUNK; ++c) {
+                    float wa = wh[u][0], wb = wh[u][0];
+#pragma unroll
+                    for (int h = 1; h < HMAX; ++h) {
+                        wa = ha[c] == h ? wh[u][h] : wa;
+                        wb = hb[c] == h ? wh[u][h] : wb;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[c][t] = fmaf(t < ns[c] ? wa : wb, v[u][c][t], acc[c][t]);
+                }
+        }
+    }
+    // epilogue (not hot): element-wise stores, two or four at a time where the destination allows — the partial slab and a
+    // row-contiguous output have a pitch of F floats, the residual block of a merged GEMM output starts 8-byte aligned only
+    float* ob = slot < 0 ? a.out + (int64_t)row * a.ldo : a.partial + (int64_t)slot * a.ldp;
+    const float* ab = (a.addend && slot < 0) ? a.addend + (int64_t)row * a.lda : nullptr;
+    const bool o16 = ((reinterpret_cast<uintptr_t>(ob) & 15) == 0), o8 = ((reinterpret_cast<uintptr_t>(ob) & 7) == 0);
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        if (nv[c] <= 0) continue;
+        if (ab) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < nv[c]) acc[c][t] += ab[off[c] + t];
+        }
+        if (nv[c] == 4 && o16) vstore<4>(ob + off[c], acc[c]);
+        else if (o8 && (nv[c] & 1) == 0) {
+            float lo[2] = {acc[c][0], acc[c][1]}, hi[2] = {acc[c][2], acc[c][3]};
+            vstore<2>(ob + off[c], lo);
+            if (nv[c] == 4) vstore<2>(ob + off[c] + 2, hi);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < nv[c]) ob[off[c] + t] = acc[c][t];
+        }
+    }
+}
+
 template <int VEC, int LANES, int NCHUNK, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs a) {
     constexpr int TILE = VEC * LANES * NCHUNK;
@@ -747,6 +841,38 @@ static bool dispatch_spmm_rows(const SpmmArgs& a, hipStream_t st) {
     return true;
 }
 
+// BOT_SPMM_FLAT=0 disables the flat 16-byte layout (measurements); read once per process.
+static bool spmm_flat_wanted() {
+    static const bool wanted = [] {
+        const char* e = getenv("BOT_SPMM_FLAT");
+        return !(e && !strcmp(e, "0"));
+    }();
+    return wanted;
+}
+
+// Flat 16-byte lanes (spmm_flat_kernel): weighted, 2..4 heads whose width is not a multiple of 4, rows of H*D contiguous floats
+// on a 16-byte aligned pitch that covers the tail float4, slabs of out / addend / partial with contiguous rows.
+static bool dispatch_spmm_flat(const SpmmArgs& a, hipStream_t st) {
+    const int F = a.H * a.D;
+    if (!spmm_flat_wanted() || a.w == nullptr || a.H < 2 || a.H > 4 || a.D % 4 == 0 || a.D < 4 || F > 1024) return false;
+    if (a.hsx != a.D || a.hso != a.D || (a.addend && a.hsa != a.D) || !aligned(a.x, 16) || a.ldx % 4 != 0 || a.ldx < (F + 3) / 4 * 4) return false;
+    const int nchunk = (F + 255) / 256;
+    const int64_t blocks = (a.n_items * 64 + kBlock - 1) / kBlock;
+    if (blocks == 0) return true;
+    set_kernel("bot::spmm_flat_kernel<%d,%d>", nchunk, a.H <= 3 ? 3 : 4);
+#define BOT_FLAT(NC)                                                                                              \
+    do {                                                                                                          \
+        if (a.H <= 3) hipLaunchKernelGGL((spmm_flat_kernel<NC, 3>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a); \
+        else hipLaunchKernelGGL((spmm_flat_kernel<NC, 4>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);         \
+    } while (0)
+    if (nchunk == 1) BOT_FLAT(1);
+    else if (nchunk == 2) BOT_FLAT(2);
+    else if (nchunk == 3) BOT_FLAT(3);
+    else BOT_FLAT(4);
+#undef BOT_FLAT
+    return true;
+}
+
 template <int VEC>
 static void dispatch_spmm(SpmmArgs& a, hipStream_t st) {
     const int L = (a.D + VEC - 1) / VEC;  // lanes needed for one head slab
@@ -793,7 +919,8 @@ int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, 
     SpmmArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, hsx, w, wperm, H, D, 1, out, ldo, hso, partial,
                (int64_t)H * D, nullptr, 0, 0, nullptr, addend, lda, hsa};
     const int vec = addend ? pick_vec(D, {ldx, hsx, ldo, hso, lda, hsa}, {x, out, partial, addend}) : pick_vec(D, {ldx, hsx, ldo, hso}, {x, out, partial});
-    const bool rows = vec == 4 ? dispatch_spmm_rows<4>(a, st) : (vec == 2 ? dispatch_spmm_rows<2>(a, st) : dispatch_spmm_rows<1>(a, st));
+    const bool rows = dispatch_spmm_flat(a, st) ||
+                      (vec == 4 ? dispatch_spmm_rows<4>(a, st) : (vec == 2 ? dispatch_spmm_rows<2>(a, st) : dispatch_spmm_rows<1>(a, st)));
     if (!rows) {
         if (vec == 4) dispatch_spmm<4>(a, st);
         else if (vec == 2) dispatch_spmm<2>(a, st);

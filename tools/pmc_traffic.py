@@ -11,15 +11,23 @@ import sys
 
 wl, summary, log, tag = sys.argv[1:5]
 line = [l for l in open(log).read().splitlines() if l.startswith("{")][-1]
-kernel = json.loads(line)["roofline"]["kernel"].split(" (")[0]
+bench = json.loads(line)
+kernel = bench["roofline"]["kernel"].split(" (")[0]
+# One roofline "launch" = one call of the launch function, which the L2-blocked SpMM runs as several kernel launches (rounds of
+# one resident wave of workgroups): counters are summed over the kernel launches of a call.  Calls in the profiled run = calls per
+# step (from the bench line: launches_timed / steps) x steps run (timed + warm-up + the 3 extra steps that time the halves GEMMs).
+calls_per_step = bench["roofline"]["launches_timed"] / bench["steps"]
+steps_run = bench["steps"] + bench["warmup"] + (3 if bench["roofline"].get("dense_projections") else 0)
+calls = calls_per_step * steps_run
 norm = lambda k: k.replace(" ", "")
 rows = {r["counter"]: r for r in csv.DictReader(open(summary)) if norm(r["kernel"]) == norm(kernel)}
-f, w = float(rows["FETCH_SIZE"]["avg_per_launch"]), float(rows["WRITE_SIZE"]["avg_per_launch"])
-hit, miss = float(rows["TCC_HIT_sum"]["avg_per_launch"]), float(rows["TCC_MISS_sum"]["avg_per_launch"])
+per_call = lambda c: float(rows[c]["avg_per_launch"]) * int(rows[c]["launches"]) / calls
+f, w = per_call("FETCH_SIZE"), per_call("WRITE_SIZE")
+hit, miss = per_call("TCC_HIT_sum"), per_call("TCC_MISS_sum")
 print(json.dumps({
     "kernel": kernel, "workload": json.loads(line)["config"]["workload"],
     "source": f"profiles/{tag}_pmc_bench_{wl}.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum, separate "
               f"passes over `bench.py --workload {wl}`, tools/pmc_bench.sh)",
-    "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "launches": int(rows["FETCH_SIZE"]["launches"]),
+    "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "kernel_launches_profiled": int(rows["FETCH_SIZE"]["launches"]), "calls_profiled": calls,
     "correction": "gfx950: FETCH_SIZE counts 128-B fabric requests as 64 B (MI355X_MICROARCH.md 'HBM'); doubled",
     "bytes_per_launch": int((2 * f + w) * 1024), "l2_hit_rate": round(hit / max(hit + miss, 1.0), 4), "round": tag}, indent=1))
