@@ -588,6 +588,43 @@ def test_blocked_spmm_matches_row_kernel():
         assert torch.equal(o2, o_b) and torch.equal(dot2, dot_b)
 
 
+def test_spmm_flat_16_byte_lanes():
+    """bot::spmm_flat_kernel — the weighted all-heads forward for head widths that are not a multiple of 4 floats (3 x 250), rows
+    read as flat float4 lanes with the head resolved per element: against torch on a power-law graph with long rows (chunk 8 and
+    default), slabs inside a wider 16-byte aligned buffer (the merged GEMM output), residual addend on an 8-byte aligned offset,
+    row-contiguous and padded outputs; bitwise reproducible; and the dispatcher takes it exactly when the layout allows."""
+    n = 3000
+    rs, rd = _powerlaw(n, 40000, 9)
+    s, d = R.preprocess_edges(rs, rd, n)
+    gen = torch.Generator().manual_seed(5)
+    for chunk in (8, None):
+        g = bot_amd.Graph(s, d, n, chunk=chunk).to(DEV)
+        csc = g.csc
+        rows = torch.repeat_interleave(torch.arange(n, device=DEV), (csc.indptr[1:] - csc.indptr[:-1]).long())
+        for H, D in ((3, 250), (2, 250), (4, 30), (3, 6), (2, 9), (4, 255)):
+            F = H * D
+            P = (2 * F + 3) // 4 * 4 + 8
+            big = torch.randn(n, P, generator=gen).to(DEV)
+            x = big[:, :F].unflatten(1, (H, D))                          # 16-byte aligned rows, pitch P
+            res = big[:, F:2 * F].unflatten(1, (H, D))                   # starts at column F: 8-byte aligned only when F is even
+            w = torch.rand(csc.nnz, H, generator=gen).to(DEV)
+            ref = torch.zeros(n, H, D, device=DEV).index_add_(0, rows, x[csc.indices.long()] * w.unsqueeze(-1))
+            for addend in (None, res):
+                for padded_out in (False, True):
+                    outbuf = torch.empty(n, (F + 3) // 4 * 4 if padded_out else F, device=DEV)
+                    out = outbuf[:, :F].unflatten(1, (H, D))
+                    got = _C.spmm(csc, x, w, None, out=out, addend=addend)
+                    assert _C._lib.bot_last_kernel().decode().startswith("bot::spmm_flat_kernel") == (D % 4 != 0), (H, D, _C._lib.bot_last_kernel())
+                    want = ref if addend is None else ref + res
+                    assert torch.allclose(got, want, atol=2e-4, rtol=1e-5), (H, D, chunk, addend is not None, padded_out)
+                    again = _C.spmm(csc, x, w, None, out=torch.empty_like(outbuf)[:, :F].unflatten(1, (H, D)), addend=addend)
+                    assert torch.equal(again, got)
+            xc = x.contiguous()                                             # pitch F: not 16-byte aligned rows unless F % 4 == 0
+            got = _C.spmm(csc, xc, w, None)
+            assert _C._lib.bot_last_kernel().decode().startswith("bot::spmm_flat_kernel") == (D % 4 != 0 and F % 4 == 0)
+            assert torch.allclose(got, ref, atol=2e-4, rtol=1e-5)
+
+
 def test_config1_cora_shape_gcn():
     """BASELINE config 1 at its exact shape (S-cora: 2 708 nodes / 10 556 raw edges / 1 433 features, 2-layer GCN hidden 16,
     7 classes): forward + backward of the HIP path against the CPU oracle."""

@@ -47,9 +47,12 @@ def timeit(fn, iters=20, warm=3):
 
 def operands(g):
     n, E = g.number_of_nodes(), g.number_of_edges()
-    x = torch.randn(n, H, D, device=DEV)
+    # F4_PITCH (floats): row pitch of x and out; 752 gives 16-byte aligned rows of 750 floats, the layout of the merged GEMM output,
+    # on which the flat 16-byte-lane kernel runs (BOT_SPMM_FLAT=0: the 8-byte head-segment kernel on the same operands)
+    pitch = int(os.environ.get("F4_PITCH", H * D))
+    x = torch.randn(n, pitch, device=DEV)[:, :H * D].unflatten(1, (H, D))
     a = torch.rand(E, H, device=DEV)
-    out = torch.empty(n, H, D, device=DEV)
+    out = torch.empty(n, pitch, device=DEV)[:, :H * D].unflatten(1, (H, D))
     return x, a, out
 
 
