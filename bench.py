@@ -296,12 +296,14 @@ def main():
         # the rows it ships per hidden layer and direction, and the bytes those exchanges move per step (fp32; layer 0 of the GAT
         # ships the narrow inputs, bot_amd/nn/fused.py)
         p = wl.dataset.part
-        mine = {"rank": rank, "owned_rows": int(p.n_owned), "edges": int(p.n_edges), "halo_rows": int(p.graph.halo.n_halo),
-                "send_rows": int(p.graph.halo.n_send), "peers_recv": int(sum(1 for c in p.graph.halo.recv_splits if c)),
-                "cut_edges": int((p.graph.edges()[0] >= p.n_owned).sum())}
-        gathered = [None] * world
-        torch.distributed.all_gather_object(gathered, mine)
+        mine = torch.tensor([rank, int(p.n_owned), int(p.n_edges), int(p.graph.halo.n_halo), int(p.graph.halo.n_send),
+                             int(sum(1 for c in p.graph.halo.recv_splits if c)), int((p.graph.edges()[0] >= p.n_owned).sum())],
+                            dtype=torch.int64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)          # plain tensors: the same collective path as the step itself
         if rank == 0:
+            keys = ("rank", "owned_rows", "edges", "halo_rows", "send_rows", "peers_recv", "cut_edges")
+            gathered = [dict(zip(keys, t.tolist())) for t in allr]
             H, D, _ = wl.dominant_shape
             widths = wl.halo_widths if getattr(wl, "halo_widths", None) else [H * D]
             per_rank_bytes = [4 * 2 * sum(w * (g["halo_rows"] + g["send_rows"]) for w in widths) for g in gathered]

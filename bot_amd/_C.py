@@ -34,6 +34,7 @@ _SIGS = {
     "bot_row_plan_fill_host": (ctypes.c_int, [_P, c_int64, c_int32, _P, _P, _P]),
     "bot_degrees_i64": (ctypes.c_int, [_P, c_int64, _P, _P]),
     "bot_spmm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
+    "bot_spmm_set_layout": (ctypes.c_int, [c_int32]),
     "bot_spmm_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
                                     c_int32, c_int32, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P]),
     "bot_spmm_blocked_f32": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P,
@@ -232,6 +233,9 @@ def _rows_contiguous(t):
     return t.stride(2) == 1 and (t.shape[1] == 1 or t.stride(1) == t.shape[2])
 
 
+SPMM_LAYOUT = None   # None: per direction (flat 16-byte lanes when its plan is in XCD order = the numbering has locality); "flat" / "rows": force
+
+
 def spmm(d, x, w=None, wperm=None, out=None, addend=None):
     """out[r,h,:] = sum_k w[wperm[k],h] * x[indices[k],h,:] (+ addend[r,h,:])   (w None: plain sum).  x: [n_src,H,D]."""
     _dev(x, w, d.indptr)
@@ -271,6 +275,8 @@ def spmm(d, x, w=None, wperm=None, out=None, addend=None):
     partial = None
     if d.n_long:
         partial = torch.empty(int(_lib.bot_spmm_workspace_floats(d.n_slots, H, D)), dtype=torch.float32, device=x.device)
+    flat = SPMM_LAYOUT == "flat" or (SPMM_LAYOUT is None and getattr(d, "plan_order", "degree") == "xcd")
+    _lib.bot_spmm_set_layout(1 if flat else 0)     # thread-local hint; identical results either way (include/bot_gnn.h)
     _check(_timed("spmm", (H, D, w is not None), lambda: _lib.bot_spmm_f32(
         d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
         _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, _ptr(w), _ptr(_i32(wperm, "wperm")), H, D, out.data_ptr(), ldo, hso,

@@ -841,13 +841,18 @@ static bool dispatch_spmm_rows(const SpmmArgs& a, hipStream_t st) {
     return true;
 }
 
-// BOT_SPMM_FLAT=0 disables the flat 16-byte layout (measurements); read once per process.
+// Which all-heads forward layout the calling thread's next bot_spmm_f32 calls take when both fit (bot_spmm_set_layout):
+// 0 = head segments (8-byte loads at D = 250), 1 = flat 16-byte lanes.  Both give bitwise identical results; the flat layout is
+// faster when the gathers are served by the L2 (graphs renumbered for locality: 0.68 -> 0.58 ms on S-arxiv-comm, 0.52 -> 0.37 ms
+// with every source L2-resident) and ~4 % slower when they are fabric-bound (randomly numbered graphs: 1.08 -> 1.13 ms), so the
+// host picks it per graph (bot_amd/_C.py: plans in XCD order = a numbering with locality).  BOT_SPMM_FLAT=0 / 1 overrides.
+static thread_local int g_spmm_layout = 0;
 static bool spmm_flat_wanted() {
-    static const bool wanted = [] {
+    static const int env = [] {
         const char* e = getenv("BOT_SPMM_FLAT");
-        return !(e && !strcmp(e, "0"));
+        return e ? (!strcmp(e, "0") ? 0 : 1) : -1;
     }();
-    return wanted;
+    return env >= 0 ? env == 1 : g_spmm_layout == 1;
 }
 
 // Flat 16-byte lanes (spmm_flat_kernel): weighted, 2..4 heads whose width is not a multiple of 4, rows of H*D contiguous floats
@@ -894,6 +899,12 @@ static void dispatch_spmm(SpmmArgs& a, hipStream_t st) {
 extern "C" {
 
 int64_t bot_spmm_workspace_floats(int64_t n_slots, int32_t H, int32_t D) { return n_slots * (int64_t)H * D; }
+
+int bot_spmm_set_layout(int32_t layout) {
+    BOT_REQUIRE(layout == 0 || layout == 1, BOT_E_RANGE, "spmm_set_layout: %d (0 = head segments, 1 = flat 16-byte lanes)", layout);
+    bot::g_spmm_layout = layout;
+    return 0;
+}
 
 int bot_spmm_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz, const int32_t* items,
                  int64_t n_items, const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, const float* x,

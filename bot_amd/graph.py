@@ -47,6 +47,7 @@ class Direction:
     n_slots: int
     chunk: int
     blocked: dict = None     # row width -> bot_amd.blocked.BlockedPlan (dense graphs; built lazily on the device)
+    plan_order: str = "degree"   # item order of the plan: "degree" (longest first) or "xcd" (xcd_item_order: the numbering has locality)
 
     def __post_init__(self):
         if self.blocked is None:
@@ -55,7 +56,8 @@ class Direction:
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
         return Direction(mv(self.indptr), mv(self.indices), mv(self.eid), mv(self.items), mv(self.long_rows),
-                         mv(self.long_ptr), self.n_rows, self.nnz, self.n_items, self.n_long, self.n_slots, self.chunk)
+                         mv(self.long_ptr), self.n_rows, self.nnz, self.n_items, self.n_long, self.n_slots, self.chunk,
+                         plan_order=self.plan_order)
 
 
 def xcd_item_order(items: torch.Tensor) -> torch.Tensor:
@@ -102,7 +104,7 @@ def build_direction(rows: torch.Tensor, cols: torch.Tensor, n_rows: int, chunk: 
     n_long = int(long_rows.numel())
     return Direction(indptr32.contiguous(), take_rows(cols, eid).to(torch.int32).contiguous(), eid.to(torch.int32).contiguous(),
                      items.to(dev), long_rows.to(dev) if n_long else None, long_ptr.to(dev) if n_long else None,
-                     int(n_rows), nnz, int(items.shape[0]), n_long, n_slots, int(chunk))
+                     int(n_rows), nnz, int(items.shape[0]), n_long, n_slots, int(chunk), plan_order=order)
 
 
 class _Frame(dict):

@@ -597,6 +597,7 @@ def test_spmm_flat_16_byte_lanes():
     rs, rd = _powerlaw(n, 40000, 9)
     s, d = R.preprocess_edges(rs, rd, n)
     gen = torch.Generator().manual_seed(5)
+    _C.SPMM_LAYOUT = "flat"        # the hint the host gives for graphs whose plans are in XCD order (bot_amd/_C.py:spmm)
     for chunk in (8, None):
         g = bot_amd.Graph(s, d, n, chunk=chunk).to(DEV)
         csc = g.csc
@@ -623,6 +624,21 @@ def test_spmm_flat_16_byte_lanes():
             got = _C.spmm(csc, xc, w, None)
             assert _C._lib.bot_last_kernel().decode().startswith("bot::spmm_flat_kernel") == (D % 4 != 0 and F % 4 == 0)
             assert torch.allclose(got, ref, atol=2e-4, rtol=1e-5)
+            # both layouts: bitwise identical results (same per-element summation order)
+            _C.SPMM_LAYOUT = "rows"
+            rows_out = _C.spmm(csc, x, w, None, addend=res, out=torch.empty(n, F, device=DEV).unflatten(1, (H, D)))
+            assert not _C._lib.bot_last_kernel().decode().startswith("bot::spmm_flat_kernel")
+            _C.SPMM_LAYOUT = "flat"
+            assert torch.equal(rows_out, _C.spmm(csc, x, w, None, addend=res, out=torch.empty(n, F, device=DEV).unflatten(1, (H, D))))
+    _C.SPMM_LAYOUT = None
+    # default: the hint follows the plan order of the direction
+    h = bot_amd.reorder_graph(bot_amd.Graph(s, d, n), "degree", plan_order="xcd").to(DEV)
+    big = torch.randn(n, 752, generator=gen).to(DEV)
+    w = torch.rand(h.csc.nnz, 3, generator=gen).to(DEV)
+    _C.spmm(h.csc, big[:, :750].unflatten(1, (3, 250)), w, None)
+    assert _C._lib.bot_last_kernel().decode().startswith("bot::spmm_flat_kernel") and h.csc.plan_order == "xcd"
+    _C.spmm(bot_amd.Graph(s, d, n).to(DEV).csc, big[:, :750].unflatten(1, (3, 250)), w, None)
+    assert _C._lib.bot_last_kernel().decode().startswith("bot::spmm_rows_kernel")
 
 
 def test_config1_cora_shape_gcn():
