@@ -125,7 +125,7 @@ def cpu_baseline_and_parity_sample(name, dev, scale):
     work), `parity` = every logit and every parameter gradient of that step, with the criterion that was applied.  The same
     comparison at FULL size is tests/test_gpu_parity.py::test_full_size_config{3,4,5}_* (minutes of CPU time each)."""
     from tests import full_size as FS
-    r, t = FS.workload_parity(name, dev, scale=scale)
+    r, t = FS.workload_parity(name, dev, scale=scale, timed=True)
     r.pop("rank", None)
     what = f"S-{name} generator at scale {scale}: N={t['nodes']} E={t['edges']}"
     cpu = {"value": t["edges"] / t["seconds"], "unit": "edges/s", "cores": t["threads"], "kind": "port",

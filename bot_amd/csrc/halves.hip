@@ -31,7 +31,25 @@ __global__ __launch_bounds__(kBlock) void absmax_partial_kernel(const float* x, 
     __shared__ float lds[kBlock / kWave];
     float m = 0.f;
     const int64_t total = n * (int64_t)F;
-    if (ldx == F) {
+    if (ldx == F && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        // contiguous and 16-byte aligned: float4 lanes, four independent loads in flight (round 3: the scalar loop ran at 3 TB/s)
+        const int64_t nq = total >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const int64_t stride = (int64_t)gridDim.x * kBlock;
+        int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        for (; i + 3 * stride < nq; i += 4 * stride) {
+            const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                               fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))),
+                               fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+        }
+        for (; i < nq; i += stride) {
+            const float4 a = x4[i];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        }
+        for (int64_t j = (nq << 2) + (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total; j += stride) m = fmaxf(m, fabsf(x[j]));
+    } else if (ldx == F) {
         for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) m = fmaxf(m, fabsf(x[i]));
     } else {
         for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {

@@ -328,11 +328,12 @@ def edge_gat_hip_step(model, g, labels, train_idx, node_loss):
 PARITY_SCALE = {"cora": 1.0, "arxiv": 1.0, "reddit": 0.25, "proteins": 0.125, "products": 0.125}   # bench.py's bounded CPU sample
 
 
-def workload_parity(name, dev, scale=1.0, exact="auto"):
+def workload_parity(name, dev, scale=1.0, exact="auto", timed=False):
     """One train step (drop rates 0) of BASELINE config `name` (bot_amd.workloads) on the HIP path against the oracle's C
     kernels on the host cores, graph of the workload's generator at `scale` (1.0 = the size the bench line is quoted on; the
     density — mean degree — does not depend on it).  The oracle runs at the HIP run's ReLU / leaky-ReLU gates (KinkGates).
     `exact`: also run the step in fp64 and rank the two fp32 runs against it ("auto": config 4, whose logits reach 125).
+    `timed`: the fp32 oracle step's seconds are reported as a CPU baseline — run it alone, not beside the fp64 leg.
     Returns (parity dict incl. "criterion" / "ok", {"seconds", "threads", "edges", "nodes"} of the fp32 oracle step).
     Config 2 (arxiv) has its own entry points (oracle_step / hip_step: label mask, fused / modular variants)."""
     from bot_amd import workloads
@@ -360,9 +361,20 @@ def workload_parity(name, dev, scale=1.0, exact="auto"):
         args = (s, d, n, ds.feat.cpu(), None if ds.efeat is None else ds.efeat.cpu(), ds.labels.cpu(), ds.train_idx.cpu(), sd)
         # products: Linear weight gradients of the ORACLE accumulated in fp64 (its sgemm over 2.45 M rows is 2.1e-4 off, see
         # oracle.ref_models.linear_f64grad); dst_fc biases sit in front of a training-mode BatchNorm (exact gradient 0)
-        rp, rg, secs, gstats = edge_gat_oracle_step(*args, gates=gates, f64_weight_grads=not prot, **kw)
-        if exact:
-            xp, xg, _, _ = edge_gat_oracle_step(*args, gates=gates, dtype=torch.float64, **kw)
+        if exact and not timed:
+            # the fp32 and the fp64 oracle steps side by side on two host threads (each brings its own OpenMP team: 2 x 32 of the
+            # GPU box's 256 hardware threads; ctypes and torch release the GIL inside the kernels) — config 4's two legs are 115 s +
+            # 200 s one after the other, most of the GPU suite's wall time
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(2) as pool:
+                f32 = pool.submit(edge_gat_oracle_step, *args, gates=gates, f64_weight_grads=not prot, **kw)
+                f64 = pool.submit(edge_gat_oracle_step, *args, gates=gates, dtype=torch.float64, **kw)
+                rp, rg, secs, gstats = f32.result()
+                xp, xg, _, _ = f64.result()
+        else:
+            rp, rg, secs, gstats = edge_gat_oracle_step(*args, gates=gates, f64_weight_grads=not prot, **kw)
+            if exact:
+                xp, xg, _, _ = edge_gat_oracle_step(*args, gates=gates, dtype=torch.float64, **kw)
         zero = {f"convs.{i}.dst_fc.bias": f"convs.{i}.dst_fc.weight" for i in range(kw["n_layers"])}
         threads = _oracle_threads(32)
     r = compare(pred, grads, rp, rg, gstats, zero_grads=zero)
