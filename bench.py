@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--parity-scale", type=float, default=None,
                     help="configs 1, 3, 4, 5: size of the bounded sample (a graph of the same generator, same density) on which the "
                          "CPU baseline is timed and the parity object computed; default tests/full_size.py:PARITY_SCALE "
-                         "(cora 1.0, reddit 0.25, proteins / products 0.125); the full-size comparison is the GPU test-suite's")
+                         "(cora and reddit 1.0 = the bench graph itself, proteins / products 0.125); the full-size comparison is the GPU test-suite's")
     ap.add_argument("--gemm-tuning", default="file", choices=["file", "off", "tune"],
                     help="file: hipBLASLt/rocBLAS kernel selections from bot_amd/tuning (TunableOp, read-only); "
                          "tune: also time shapes missing from the file and write them to gpurun_out/ (maintenance)")

@@ -325,7 +325,7 @@ def edge_gat_hip_step(model, g, labels, train_idx, node_loss):
 
 
 # ---------------------------------------------------------------------------------------------- one entry point per BASELINE config
-PARITY_SCALE = {"cora": 1.0, "arxiv": 1.0, "reddit": 0.25, "proteins": 0.125, "products": 0.125}   # bench.py's bounded CPU sample
+PARITY_SCALE = {"cora": 1.0, "arxiv": 1.0, "reddit": 1.0, "proteins": 0.125, "products": 0.125}   # bench.py's bounded CPU sample
 
 
 def workload_parity(name, dev, scale=1.0, exact="auto", timed=False):
