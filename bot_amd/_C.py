@@ -289,9 +289,11 @@ def spmm_dot_max_d(x):
     return 1024 if (x.shape[2] % 4 == 0 and x.stride(0) % 4 == 0) else (512 if x.shape[2] % 2 == 0 and x.stride(0) % 2 == 0 else 256)
 
 
-def spmm_dot(d, x, w, wperm, y, out=None):
+def spmm_dot(d, x, w, wperm, y, out=None, dot=None):
     """Fused backward of u_mul_e_sum on direction `d`:  out[r,h,:] = sum_k w[wperm[k],h] x[indices[k],h,:]  and
-    dot[wperm[k],h] = <y[r,h,:], x[indices[k],h,:]>.  Returns (out [n_rows,H,D], dot [nnz,H])."""
+    dot[wperm[k],h] = <y[r,h,:], x[indices[k],h,:]>.  Returns (out [n_rows,H,D], dot [nnz,H]).
+    `dot`: write into this [E,H] array instead of a fresh one — `d` may be a PART of a larger direction (Graph.halo_split) whose
+    entries are reached through `wperm`; the parts of one direction fill disjoint rows of the same array."""
     _dev(x, w, y, d.indptr)
     x, ldx, hsx = _slab(x, "x")
     y, ldy, hsy = _slab(y, "y")
@@ -301,7 +303,10 @@ def spmm_dot(d, x, w, wperm, y, out=None):
         out = torch.empty((d.n_rows, H, D), dtype=torch.float32, device=x.device)
     out_, ldo, hso = _slab(out, "out")
     assert out_ is out
-    dot = torch.empty((d.nnz, H), dtype=torch.float32, device=x.device)
+    if dot is None:
+        dot = torch.empty((d.nnz, H), dtype=torch.float32, device=x.device)
+    elif dot.dtype != torch.float32 or not dot.is_contiguous() or dot.dim() != 2 or dot.shape[1] != H:
+        raise BotKernelError(f"spmm_dot: dot must be a contiguous float32 [E,{H}] array")
     partial = None
     if d.n_long:
         partial = torch.empty(int(_lib.bot_spmm_workspace_floats(d.n_slots, H, D)), dtype=torch.float32, device=x.device)

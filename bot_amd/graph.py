@@ -107,6 +107,40 @@ def build_direction(rows: torch.Tensor, cols: torch.Tensor, n_rows: int, chunk: 
                      int(n_rows), nnz, int(items.shape[0]), n_long, n_slots, int(chunk), plan_order=order)
 
 
+def sub_direction(d: Direction, positions: torch.Tensor, index_offset: int = 0) -> tuple:
+    """The compressed direction made of the given POSITIONS of `d` (ascending; same rows, same order inside a row) with its own row
+    plan, plus `positions` as int32 — the `wperm` / `operm` through which a kernel on the sub-direction reaches arrays laid out in
+    `d`'s position order (attention weights, per-edge dot products).  `index_offset` is subtracted from the neighbour ids (a table
+    that holds only the halo rows).  Integer work on the device of `d`."""
+    dev = d.indptr.device
+    pos = positions.long()
+    deg = (d.indptr[1:] - d.indptr[:-1]).long()
+    row_of = torch.repeat_interleave(torch.arange(d.n_rows, device=dev), deg)
+    counts = torch.bincount(row_of[pos], minlength=d.n_rows)
+    indptr = torch.zeros(d.n_rows + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(counts, 0)
+    indptr32 = indptr.to(torch.int32).contiguous()
+    items, long_rows, long_ptr, n_slots = _C.row_plan(indptr32.cpu().contiguous(), d.chunk)
+    n_long = int(long_rows.numel())
+    sub = Direction(indptr32, (take_rows(d.indices, pos) - index_offset).to(torch.int32).contiguous(), take_rows(d.eid, pos).contiguous(),
+                    items.to(dev), long_rows.to(dev) if n_long else None, long_ptr.to(dev) if n_long else None, d.n_rows,
+                    int(pos.numel()), int(items.shape[0]), n_long, n_slots, d.chunk, plan_order="degree")
+    return sub, pos.to(torch.int32).contiguous()
+
+
+def row_range_direction(d: Direction, lo: int, hi: int) -> tuple:
+    """Rows [lo, hi) of `d` as a direction of its own (rows renumbered from 0, neighbour ids unchanged) and the int32 positions of its
+    entries in `d` — the rows are contiguous, so this is a slice."""
+    dev = d.indptr.device
+    a, b = int(d.indptr[lo]), int(d.indptr[hi])
+    indptr32 = (d.indptr[lo:hi + 1] - a).to(torch.int32).contiguous()
+    items, long_rows, long_ptr, n_slots = _C.row_plan(indptr32.cpu().contiguous(), d.chunk)
+    n_long = int(long_rows.numel())
+    sub = Direction(indptr32, d.indices[a:b].contiguous(), d.eid[a:b].contiguous(), items.to(dev), long_rows.to(dev) if n_long else None,
+                    long_ptr.to(dev) if n_long else None, hi - lo, b - a, int(items.shape[0]), n_long, n_slots, d.chunk, plan_order="degree")
+    return sub, torch.arange(a, b, dtype=torch.int32, device=dev)
+
+
 class _Frame(dict):
     """Feature dict (`graph.ndata` / `graph.edata`)."""
 
@@ -140,6 +174,7 @@ class Graph:
         self.global_out_degrees = None   # int64 [num_dst_nodes]: out-degrees in the WHOLE graph (partitioned mode)
         self._csc = self._csr = self._csr2csc = self._csc2csr = None
         self._src32 = self._dst32 = None
+        self._halo_split = None
         self.ndata, self.edata = _Frame(), _Frame()
 
     # ---------------------------------------------------------------- dgl-like queries
@@ -271,6 +306,32 @@ class Graph:
         if self._csr2csc is None:
             self._csr2csc = take_rows(self._inverse(self.csc.eid), self.csr.eid).contiguous()
         return self._csr2csc
+
+    @property
+    def halo_split(self):
+        """Partitioned blocks (owned vertices first, halo sources behind): the structures that let a layer work on the edges whose
+        source is OWNED while the halo rows are still in flight, and finish with the halo-source edges afterwards —
+          csc_own / csc_halo   in-edges split by source class (csc_halo's neighbour ids index the halo table alone), with the
+                               positions of their entries in `csc` (the order the attention weights are kept in);
+          csr_own / csr_halo   out-edges of the owned rows / of the halo rows (rows renumbered from 0), with the CSC position of
+                               every entry (csr2csc restricted to them).
+        Per destination the sum then runs over the owned-source edges first and the halo-source edges second (each in edge-id
+        order) — not the single-GPU order, by design; values agree to rounding, not bitwise."""
+        if self._halo_split is None:
+            assert self.is_block, "halo_split applies to partitioned blocks"
+            n_own = self._n_dst
+            csc, csr = self.csc, self.csr
+            own_pos = torch.nonzero(csc.indices < n_own).squeeze(1)
+            halo_pos = torch.nonzero(csc.indices >= n_own).squeeze(1)
+            csc_own, p_own = sub_direction(csc, own_pos)
+            csc_halo, p_halo = sub_direction(csc, halo_pos, index_offset=n_own)
+            csr_own, q_own = row_range_direction(csr, 0, n_own)
+            csr_halo, q_halo = row_range_direction(csr, n_own, self._n)
+            c2c = self.csr2csc
+            self._halo_split = dict(csc_own=csc_own, csc_own_pos=p_own, csc_halo=csc_halo, csc_halo_pos=p_halo,
+                                    csr_own=csr_own, csr_own_c2c=take_rows(c2c, q_own.long()).contiguous(),
+                                    csr_halo=csr_halo, csr_halo_c2c=take_rows(c2c, q_halo.long()).contiguous())
+        return self._halo_split
 
     @property
     def src32(self):

@@ -147,6 +147,45 @@ def _extend_backward(graph, dext, n_own):
     return own
 
 
+# Partitioned mode, overlapped form (round 3).  The merged-GEMM layers (`_GATHidden`) ship `el` of the halo rows in a small exchange,
+# start the big one ([n_halo, H*D] projected rows) ASYNCHRONOUSLY, and meanwhile run everything that does not need it: the attention
+# (scores only) and the aggregation over the in-edges whose source is owned; the halo-source edges follow into the same rows once the
+# transfer has landed (Graph.halo_split).  Backward likewise: the halo rows' gradients are swept first and sent while the owned rows
+# are swept and the attention backward runs.  `torch.distributed` runs the collective on its own stream; `work.wait()` orders the
+# consumer after it — no host synchronisation, capturable.  BOT_HALO_OVERLAP=0: the one-exchange form (`_extend_forward`).
+OVERLAP = os.environ.get("BOT_HALO_OVERLAP", "1") != "0"
+OVERLAP_CALLS = 0   # layer forwards that took the overlapped form (tests assert the path was taken)
+
+
+def _ship_rows(plan, own2d, async_op=False):
+    """The rows of own2d [n_own, W] (row stride allowed) that other ranks need -> (halo [n_halo, W], work handle or None, send buffer:
+    keep it referenced until the work is waited on)."""
+    import torch.distributed as dist
+    W = own2d.shape[1]
+    send = _C.gather_rows(own2d, plan.send_rows) if plan.n_send else own2d.new_empty((0, W))
+    halo = torch.empty((plan.n_halo, W), dtype=own2d.dtype, device=own2d.device)
+    work = dist.all_to_all_single(halo, send, plan.recv_splits, plan.send_splits, group=plan.group, async_op=async_op)
+    return halo, (work if async_op else None), send
+
+
+def _return_rows(plan, dhalo, async_op=False):
+    """Reverse direction: gradients of the halo rows [n_halo, W] go back to their owners -> (back [n_send, W], work or None)."""
+    import torch.distributed as dist
+    back = torch.empty((plan.n_send, dhalo.shape[1]), dtype=dhalo.dtype, device=dhalo.device)
+    work = dist.all_to_all_single(back, dhalo, plan.send_splits, plan.recv_splits, group=plan.group, async_op=async_op)
+    return back, (work if async_op else None)
+
+
+def _fold_back(plan, own2d, back):
+    """own2d[send_rows] += back, peer by peer in rank order (each peer's rows are sorted-unique: one writer per row, deterministic)."""
+    off = 0
+    for cnt in plan.send_splits:
+        if cnt:
+            _C.scatter_add_rows(own2d, plan.send_rows[off:off + cnt], back[off:off + cnt])
+        off += cnt
+    return own2d
+
+
 def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p):
     """BatchNorm statistics + the fused BatchNorm / ReLU / dropout pass.  When the next projection runs on fp16 halves
     (bot_amd.gemm) the pass writes them too and the scale comes from the statistics pass: y is not read again before its GEMM."""
@@ -180,6 +219,38 @@ class _GATHidden(torch.autograd.Function):
         ctx.halves = None if xh is None else (xh.n, xh.F, xh.piece)
         c = 2 * HD if has_res else HD
         ext = None
+        ctx.overlap = graph.halo is not None and OVERLAP and not sym
+        if ctx.overlap:                                                 # partitioned, overlapped: see OVERLAP above
+            global OVERLAP_CALLS
+            OVERLAP_CALLS += 1
+            plan, sp = graph.halo, graph.halo_split
+            el_own = out[:, c:c + H].contiguous()
+            el_halo, _, _ = _ship_rows(plan, el_own)                    # small: the scores of the halo rows, needed first
+            ft_halo, work, send_keep = _ship_rows(plan, out[:, :HD], async_op=True)   # big: in flight from here
+            el = torch.cat([el_own, el_halo])
+            er = out[:, c + H:c + 2 * H].contiguous() if has_er else None
+            ctx.zs = _C.zsign_buffer(csc, H, slope)
+            ctx.adrop = (attn_p, new_dropout_seed(attn_p)) if attn_p > 0 else None
+            a, a_d = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None, ctx.zs, drop=ctx.adrop or (0.0, 0))
+            res = out[:, HD:2 * HD].unflatten(1, (H, D)) if has_res else None
+            x3 = _C.spmm(sp["csc_own"], out[:, :HD].unflatten(1, (H, D)), a_d, sp["csc_own_pos"], addend=res)   # owned-source edges
+            work.wait()
+            del send_keep
+            if sp["csc_halo"].nnz:                                      # halo-source edges into the same rows (in place)
+                _C.spmm(sp["csc_halo"], ft_halo.unflatten(1, (H, D)), a_d, sp["csc_halo_pos"], out=x3, addend=x3)
+            x = x3.view(N, HD)
+            ctx.graph = graph
+            keep = (h if xh is None else xh.buf, Wcat, out, el, er, a, a_d, ft_halo)
+            if xh is not None:
+                ctx.xscale = xh.scale
+            if bn is None:
+                ctx.save_for_backward(*keep)
+                ctx.cfg = (H, D, has_res, has_er, slope, None)
+                return x
+            y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p)
+            ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
+            ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
+            return y
         if graph.halo is not None:                                      # partitioned: owned + halo source rows
             ext = _extend_forward(graph, out, HD, H, c)
             ft = ext[:, :HD].unflatten(1, (H, D))
@@ -227,10 +298,14 @@ class _GATHidden(torch.autograd.Function):
         g = ctx.graph
         dy = dy.contiguous()
         d_bn_w = d_bn_b = None
+        ft_halo = None
+        saved = ctx.saved_tensors
+        if ctx.overlap:
+            ft_halo, saved = saved[7], saved[:7] + saved[8:]
         if epi is None:
-            h, Wcat, table, el, er, a, a_d = ctx.saved_tensors
+            h, Wcat, table, el, er, a, a_d = saved
         else:
-            h, Wcat, table, el, er, a, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
+            h, Wcat, table, el, er, a, a_d, x, mean, invstd, bn_w, bn_b = saved
             drop_p, seed, bn_training, sync, group, total = epi
         kp = ctx.kp
         N, HD, P = h.shape[0], H * D, Wcat.shape[1 if kp else 0]
@@ -248,22 +323,48 @@ class _GATHidden(torch.autograd.Function):
             _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
                                 sgx if bn_training else None, total, out=dx)
         c = 2 * HD if has_res else HD
-        halo = g.halo is not None
+        if ctx.overlap:
+            # halo rows first — their gradients travel back while the owned rows are swept and the attention backward runs
+            plan, sp = g.halo, g.halo_split
+            dx3 = dx.unflatten(1, (H, D))
+            da = torch.empty((g.csr.nnz, H), dtype=dy.dtype, device=h.device)
+            dft_halo = torch.empty((plan.n_halo, HD), dtype=dy.dtype, device=h.device)
+            if sp["csr_halo"].nnz:
+                _C.spmm_dot(sp["csr_halo"], dx3, a_d, sp["csr_halo_c2c"], ft_halo.unflatten(1, (H, D)), out=dft_halo.unflatten(1, (H, D)), dot=da)
+            elif plan.n_halo:
+                dft_halo.zero_()
+            back_ft, work = _return_rows(plan, dft_halo, async_op=True)
+            _C.spmm_dot(sp["csr_own"], dx3, a_d, sp["csr_own_c2c"], table[:, :HD].unflatten(1, (H, D)),
+                        out=dout[:, :HD].unflatten(1, (H, D)), dot=da)
+            dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er, ctx.zs, drop=ctx.adrop)
+            d_el = _C.segment_sum(g.csr, dz, g.csr2csc)                 # [n_own + n_halo, H]
+            back_el, _ = _return_rows(plan, d_el[N:].contiguous())      # small, synchronous
+            work.wait()
+            _fold_back(plan, dout[:, :HD], back_ft)
+            dout[:, c:c + H] = _fold_back(plan, d_el[:N].contiguous(), back_el)
+            halo, skip_sweep = False, True
+        else:
+            halo, skip_sweep = g.halo is not None, False
         ft = table[:, :HD].unflatten(1, (H, D))
-        if halo:                                                        # gradients of the extended table [d ft | d el]
+        if skip_sweep:
+            pass
+        elif halo:                                                      # gradients of the extended table [d ft | d el]
             dext = torch.empty_like(table)
             dft_dst = dext[:, :HD].unflatten(1, (H, D))
         else:
             dft_dst = dout[:, :HD].unflatten(1, (H, D))
-        _, da = _C.spmm_dot(g.csr, dx.unflatten(1, (H, D)), a_d, g.csr2csc, ft, out=dft_dst)
-        if ctx.sym:
-            s_out, w_e = sym_scales(g)
-            da = da * w_e
-        dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er, ctx.zs, drop=ctx.adrop)
-        d_el = _C.segment_sum(g.csr, dz, g.csr2csc)
-        if ctx.sym:
-            d_el = d_el * s_out.unsqueeze(1)
-        if halo:
+        if not skip_sweep:
+            _, da = _C.spmm_dot(g.csr, dx.unflatten(1, (H, D)), a_d, g.csr2csc, ft, out=dft_dst)
+            if ctx.sym:
+                s_out, w_e = sym_scales(g)
+                da = da * w_e
+            dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er, ctx.zs, drop=ctx.adrop)
+            d_el = _C.segment_sum(g.csr, dz, g.csr2csc)
+            if ctx.sym:
+                d_el = d_el * s_out.unsqueeze(1)
+        if skip_sweep:
+            pass
+        elif halo:
             dext[:, HD:HD + H] = d_el
             if dext.shape[1] > HD + H:
                 dext[:, HD + H:].zero_()

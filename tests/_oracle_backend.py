@@ -41,14 +41,15 @@ def spmm_dot_max_d(x):
     return 1024
 
 
-def spmm_dot(d, x, w, wperm, y, out=None):
+def spmm_dot(d, x, w, wperm, y, out=None, dot=None):
     res = spmm(d, x, w, wperm)
     if out is not None:
         out.copy_(res)
     else:
         out = res
     val = (x[d.indices.long()] * y[_rows(d)]).sum(-1)
-    dot = torch.empty_like(val)
+    if dot is None:
+        dot = torch.empty_like(val)
     dot[_perm(wperm, d.nnz)] = val
     return out, dot
 

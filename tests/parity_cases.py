@@ -694,3 +694,55 @@ def check_f4_community_partition_blocks(golden, device, worlds=(2, 3)):
         grad_close(dr, ro.grad.numpy())
         base = bdist.halo_statistics(s, d, n, world)
         assert halo_rows < 0.6 * sum(base["halo_rows_per_rank"]) and cut < 0.5 * base["cut_edges"], (halo_rows, cut, base)
+
+
+# ---------------------------------------------------------------------------------------------- partitioned mode: split sweeps (overlap)
+def check_halo_split_sweeps(golden, device):
+    """`Graph.halo_split` on the blocks of a 2- and 3-way partition: the in-edges split by source class and the out-edges split
+    by row range cover every edge exactly once (integer checks), and the two-pass sweeps the overlapped layer runs — aggregation
+    over the owned-source edges, then the halo-source edges into the same rows; fused backward over the halo rows, then the owned
+    rows, both writing one shared per-edge array — reproduce the one-pass kernels on the same block (values to rounding: the
+    per-destination order differs by design) and, put together over the ranks, the oracle on the whole graph."""
+    from bot_amd import _C
+    from bot_amd import dist as bdist
+    s, d, n = golden.graph("g300")
+    gen = torch.Generator().manual_seed(31)
+    H, D = 3, 10
+    x = torch.randn(n, H, D, generator=gen)
+    a_e = torch.rand(s.numel(), H, generator=gen)                                   # per-edge weights, edge-id order
+    y = torch.randn(n, H, D, generator=gen)
+    ref = R.u_mul_e_sum(s, d, n, x, a_e.unsqueeze(-1)).numpy()
+    for world in (2, 3):
+        full = torch.zeros(n, H, D)
+        for rank in range(world):
+            p = bdist.build_partition(s, d, n, rank, world, device=device)
+            g, sp, n_own = p.graph, p.graph.halo_split, p.n_owned
+            csc, csr = g.csc, g.csr
+            # every position of the CSC exactly once, own-source and halo-source apart; CSR rows split at n_own
+            pos = torch.cat([sp["csc_own_pos"], sp["csc_halo_pos"]]).long().cpu()
+            assert torch.equal(torch.sort(pos).values, torch.arange(csc.nnz))
+            assert bool((csc.indices[sp["csc_own_pos"].long()] < n_own).all()) and bool((csc.indices[sp["csc_halo_pos"].long()] >= n_own).all())
+            assert torch.equal(sp["csc_halo"].indices.long().cpu() + n_own, csc.indices[sp["csc_halo_pos"].long()].long().cpu())
+            assert sp["csr_own"].n_rows == n_own and sp["csr_halo"].n_rows == g.number_of_nodes() - n_own
+            assert sp["csr_own"].nnz + sp["csr_halo"].nnz == csr.nnz
+            assert torch.equal(torch.cat([sp["csr_own_c2c"], sp["csr_halo_c2c"]]).cpu(), g.csr2csc.cpu())
+            glob = torch.cat([torch.arange(p.lo, p.hi), p.halo_global.cpu()])
+            xe = x[glob].to(device)
+            w_csc = a_e[p.edge_ids.cpu()][csc.eid.long().cpu()].to(device)           # the block's weights in CSC position order
+            one = _C.spmm(csc, xe, w_csc, None)
+            two = _C.spmm(sp["csc_own"], xe[:n_own], w_csc, sp["csc_own_pos"])
+            if sp["csc_halo"].nnz:
+                _C.spmm(sp["csc_halo"], xe[n_own:].contiguous(), w_csc, sp["csc_halo_pos"], out=two, addend=two)
+            assert torch.allclose(one, two, atol=1e-5, rtol=1e-5)
+            full[p.lo:p.hi] = two.cpu()
+            # fused backward: d x of every source row of the block and the per-edge dots, one pass vs halo rows + owned rows
+            dx = torch.randn(n_own, H, D, generator=gen).to(device)
+            ye = y[glob].to(device)
+            o1, dot1 = _C.spmm_dot(csr, dx, w_csc, g.csr2csc, ye)
+            dot2 = torch.full_like(dot1, float("nan"))
+            oh = torch.empty(g.number_of_nodes() - n_own, H, D, device=device)
+            if sp["csr_halo"].nnz:
+                _C.spmm_dot(sp["csr_halo"], dx, w_csc, sp["csr_halo_c2c"], ye[n_own:].contiguous(), out=oh, dot=dot2)
+            oo, _ = _C.spmm_dot(sp["csr_own"], dx, w_csc, sp["csr_own_c2c"], ye[:n_own].contiguous(), dot=dot2)
+            assert torch.allclose(torch.cat([oo, oh]), o1, atol=1e-5, rtol=1e-5) and torch.allclose(dot2, dot1, atol=1e-5, rtol=1e-5)
+        fwd_close(full, ref, 2e-5)

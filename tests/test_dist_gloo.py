@@ -50,7 +50,7 @@ def test_partition_plan_invariants(golden):
                 off += cnt
 
 
-def _worker(rank, world, port, kind, tmp, fuse=False, halves=False):
+def _worker(rank, world, port, kind, tmp, fuse=False, halves=False, overlap=True):
     import torch.distributed as dist
     import torch.nn.functional as F
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -62,6 +62,7 @@ def _worker(rank, world, port, kind, tmp, fuse=False, halves=False):
         import bot_amd
         from bot_amd.nn import fused
         fused.FORCE = fuse
+        fused.OVERLAP = overlap                              # merged-GEMM layers: exchange overlapped with the owned-source sweeps, or the one-exchange form
         from bot_amd import gemm
         gemm.FORCE = halves                                  # the projections on the fp16-halves path (emulated), both runs
         from bot_amd import dist as bdist
@@ -102,6 +103,7 @@ def _worker(rank, world, port, kind, tmp, fuse=False, halves=False):
         loss, pred = bdist.forward_backward(model, part, use_labels=True, loss="loge", n_classes=C, mask=mask_full[tr_own])
         assert (fused.CALLS > calls0) == (fuse and kind == "gat_plain"), (fused.CALLS, calls0)
         assert (fused.AGG_CALLS > 0) == (fuse and kind == "gat_plain")
+        assert (fused.OVERLAP_CALLS > 0) == (fuse and kind == "gat_plain" and overlap), fused.OVERLAP_CALLS
         assert not halves or gemm.STATS["split"] > 0
         assert abs(loss.item() - loss_ref.item()) < 1e-5, (loss.item(), loss_ref.item())
         np.testing.assert_allclose(pred.detach().numpy(), pred_ref.detach()[part.lo:part.hi].numpy(), rtol=1e-4, atol=1e-5)
@@ -114,11 +116,15 @@ def _worker(rank, world, port, kind, tmp, fuse=False, halves=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world,fuse,halves", [("gat", 2, False, False), ("gcn", 2, False, False), ("gat", 3, False, False),
-                                                    ("gat_plain", 2, True, False), ("gat_plain", 3, True, False),
-                                                    ("gat_plain", 2, False, False), ("gat_plain", 2, True, True)])
-def test_partitioned_step_matches_single_process(kind, world, fuse, halves, tmp_path):
-    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), fuse, halves), nprocs=world, join=True)
+@pytest.mark.parametrize("kind,world,fuse,halves,overlap", [("gat", 2, False, False, True), ("gcn", 2, False, False, True),
+                                                            ("gat", 3, False, False, True), ("gat_plain", 2, True, False, True),
+                                                            ("gat_plain", 3, True, False, True), ("gat_plain", 2, False, False, True),
+                                                            ("gat_plain", 2, True, True, True), ("gat_plain", 3, True, False, False)])
+def test_partitioned_step_matches_single_process(kind, world, fuse, halves, overlap, tmp_path):
+    """`overlap`: the merged-GEMM layers ship `el` first and the projected rows asynchronously, sweeping the owned-source edges
+    meanwhile (bot_amd/nn/fused.py OVERLAP) — per-destination sums then run owned-source edges first: same values to rounding;
+    False: the one-exchange form."""
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), fuse, halves, overlap), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 

@@ -189,6 +189,12 @@ def test_f4_community_partition_blocks_on_device(golden):
     PC.check_f4_community_partition_blocks(golden, DEV)
 
 
+def test_halo_split_sweeps_on_device(golden):
+    """The split structures and two-pass sweeps of the overlapped partitioned layer (bot_amd.nn.fused OVERLAP, Graph.halo_split) on the
+    real kernels: blocks of 2- and 3-way partitions side by side in one process."""
+    PC.check_halo_split_sweeps(golden, DEV)
+
+
 def test_proteins_golden(golden):
     PC.check_proteins_golden(golden, DEV)
 

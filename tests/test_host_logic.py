@@ -423,3 +423,7 @@ def test_workload_parity_procedure_emulated(cpu_backend, monkeypatch, name, scal
     else:
         assert r["ok"], r
     assert cpu["edges"] == r["edges"] > 0 and cpu["seconds"] > 0
+
+
+def test_halo_split_sweeps_emulated(golden, cpu_backend):
+    PC.check_halo_split_sweeps(golden, "cpu")
