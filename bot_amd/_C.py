@@ -183,6 +183,8 @@ def row_plan(indptr_cpu: torch.Tensor, chunk: int):
     indptr_cpu: CPU int32 [n_rows+1].  Returns CPU int32 tensors (items [n_items,4], long_rows, long_ptr)."""
     assert indptr_cpu.device.type == "cpu" and indptr_cpu.dtype == torch.int32 and indptr_cpu.is_contiguous()
     n_rows = indptr_cpu.numel() - 1
+    if n_rows == 0:     # a direction without rows (the halo rows of a 1-rank partition): an empty plan
+        return torch.empty((0, 4), dtype=torch.int32), torch.empty((0,), dtype=torch.int32), torch.zeros((1,), dtype=torch.int32), 0
     n_items, n_long, n_slots = c_int64(), c_int64(), c_int64()
     _check(_lib.bot_row_plan_size_host(indptr_cpu.data_ptr(), n_rows, chunk, ctypes.addressof(n_items),
                                        ctypes.addressof(n_long), ctypes.addressof(n_slots)), "row_plan_size")

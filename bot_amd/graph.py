@@ -318,7 +318,7 @@ class Graph:
         Per destination the sum then runs over the owned-source edges first and the halo-source edges second (each in edge-id
         order) — not the single-GPU order, by design; values agree to rounding, not bitwise."""
         if self._halo_split is None:
-            assert self.is_block, "halo_split applies to partitioned blocks"
+            assert self.halo is not None, "halo_split applies to the blocks of a partition"   # (a 1-rank partition has no halo rows)
             n_own = self._n_dst
             csc, csr = self.csc, self.csr
             own_pos = torch.nonzero(csc.indices < n_own).squeeze(1)

@@ -119,7 +119,8 @@ def _worker(rank, world, port, kind, tmp, fuse=False, halves=False, overlap=True
 @pytest.mark.parametrize("kind,world,fuse,halves,overlap", [("gat", 2, False, False, True), ("gcn", 2, False, False, True),
                                                             ("gat", 3, False, False, True), ("gat_plain", 2, True, False, True),
                                                             ("gat_plain", 3, True, False, True), ("gat_plain", 2, False, False, True),
-                                                            ("gat_plain", 2, True, True, True), ("gat_plain", 3, True, False, False)])
+                                                            ("gat_plain", 2, True, True, True), ("gat_plain", 3, True, False, False),
+                                                            ("gat_plain", 1, True, False, True)])   # one rank: no halo rows at all
 def test_partitioned_step_matches_single_process(kind, world, fuse, halves, overlap, tmp_path):
     """`overlap`: the merged-GEMM layers ship `el` first and the projected rows asynchronously, sweeping the owned-source edges
     meanwhile (bot_amd/nn/fused.py OVERLAP) — per-destination sums then run owned-source edges first: same values to rounding;
