@@ -9,6 +9,8 @@
 // adds them in chunk order (deterministic, no atomics).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace bot {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -145,7 +147,11 @@ static void tn_shape(int64_t n, int32_t kx, int32_t ky, int32_t batch, int64_t* 
     using namespace bot;
     *kxp = (kx + kTnBX - 1) / kTnBX * kTnBX, *kyp = (ky + kTnBY - 1) / kTnBY * kTnBY;
     const int64_t groups = (*kxp / kTnBX) * (*kyp / kTnBY) * batch;
-    int64_t c = (768 + groups - 1) / groups;                            // ~3 workgroups per CU in total
+    static const int64_t target = [] {                                  // workgroups in total (BOT_TN_WGS: measurements)
+        const char* e = getenv("BOT_TN_WGS");
+        return e ? (int64_t)atoi(e) : (int64_t)768;
+    }();
+    int64_t c = (target + groups - 1) / groups;                         // ~3 workgroups per CU in total
     const int64_t max_chunks = (n + 255) / 256;                         // at least 256 rows per chunk
     *chunks = c < 1 ? 1 : (c > max_chunks ? (max_chunks < 1 ? 1 : max_chunks) : c);
 }
