@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -61,8 +61,8 @@ _SIGS = {
     "bot_segment_sum_f32": (ctypes.c_int, [_P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, c_int32, _P, _P]),
     "bot_gather_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
     "bot_scatter_add_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
-    "bot_merge_weight_fwd_f32": (ctypes.c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
-    "bot_merge_weight_bwd_f32": (ctypes.c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "bot_merge_weight_fwd_f32": (ctypes.c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "bot_merge_weight_bwd_f32": (ctypes.c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     "bot_edge_mlp_workspace_floats": (c_int64, []),
     "bot_edge_mlp_fwd_f32": (ctypes.c_int, [_P, c_int32, _P, _P, c_int32, _P, c_int32, c_int64, _P, _P]),
     "bot_edge_mlp_bwd_f32": (ctypes.c_int, [_P, c_int32, _P, _P, c_int32, _P, c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
@@ -312,6 +312,8 @@ def spmm_dot(d, x, w, wperm, y, out=None, dot=None):
     partial = None
     if d.n_long:
         partial = torch.empty(int(_lib.bot_spmm_workspace_floats(d.n_slots, H, D)), dtype=torch.float32, device=x.device)
+    flat = SPMM_LAYOUT == "flat" or (SPMM_LAYOUT is None and getattr(d, "plan_order", "degree") == "xcd")
+    _lib.bot_spmm_set_layout(1 if flat else 0)     # thread-local speed hint (this may be the autograd thread); same values either way
     _check(_timed("spmm_dot", (H, D), lambda: _lib.bot_spmm_dot_f32(
         d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
         _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, w.data_ptr(), _ptr(_i32(wperm, "wperm")), y.data_ptr(), ldy, hsy,
@@ -866,8 +868,10 @@ def edge_mlp_bwd(ef, W1, b1, W2, dz):
 
 
 # ------------------------------------------------------------------------------------------------ merged projection weight
-def merge_weight_fwd(W, Wres, attn_l, attn_r, H, D, P, with_fc):
-    """[K, P] = [W^T (with_fc) | Wres^T | wl | wr | 0] (include/bot_gnn.h bot_merge_weight_fwd_f32)."""
+def merge_weight_fwd(W, Wres, attn_l, attn_r, H, D, P, with_fc, block=None):
+    """[K, P] = [W^T (with_fc) | Wres^T | wl | wr | 0] (include/bot_gnn.h bot_merge_weight_fwd_f32); `block`: column width of the two
+    copied blocks (default H*D)."""
+    block = H * D if block is None else int(block)
     _dev(W, Wres, attn_l, attn_r)
     W = _f32(W, "W").contiguous()
     Wres = None if Wres is None else _f32(Wres, "Wres").contiguous()
@@ -875,13 +879,14 @@ def merge_weight_fwd(W, Wres, attn_l, attn_r, H, D, P, with_fc):
     ar = None if attn_r is None else _f32(attn_r, "attn_r").contiguous()
     K = W.shape[1]
     out = torch.empty((K, P), dtype=torch.float32, device=W.device)
-    _check(_lib.bot_merge_weight_fwd_f32(W.data_ptr(), _ptr(Wres), al.data_ptr(), _ptr(ar), H, D, K, P, int(with_fc), out.data_ptr(),
+    _check(_lib.bot_merge_weight_fwd_f32(W.data_ptr(), _ptr(Wres), al.data_ptr(), _ptr(ar), H, D, K, P, int(with_fc), block, out.data_ptr(),
                                          _stream()), "merge_weight_fwd")
     return out
 
 
-def merge_weight_bwd(W, attn_l, attn_r, H, D, P, with_fc, has_res, dm):
+def merge_weight_bwd(W, attn_l, attn_r, H, D, P, with_fc, has_res, dm, block=None):
     _dev(W, attn_l, attn_r, dm)
+    block = H * D if block is None else int(block)
     W, al, dm = W.contiguous(), attn_l.contiguous(), _f32(dm, "d_merged").contiguous()
     ar = None if attn_r is None else attn_r.contiguous()
     K = W.shape[1]
@@ -889,6 +894,6 @@ def merge_weight_bwd(W, attn_l, attn_r, H, D, P, with_fc, has_res, dm):
     dWres = torch.empty_like(W) if has_res else None
     dal = torch.empty_like(al)
     dar = None if ar is None else torch.empty_like(ar)
-    _check(_lib.bot_merge_weight_bwd_f32(W.data_ptr(), al.data_ptr(), _ptr(ar), H, D, K, P, int(with_fc), dm.data_ptr(), dW.data_ptr(),
+    _check(_lib.bot_merge_weight_bwd_f32(W.data_ptr(), al.data_ptr(), _ptr(ar), H, D, K, P, int(with_fc), block, dm.data_ptr(), dW.data_ptr(),
                                          _ptr(dWres), dal.data_ptr(), _ptr(dar), _stream()), "merge_weight_bwd")
     return dW, dWres, dal, dar

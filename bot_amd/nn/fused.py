@@ -58,15 +58,22 @@ def sym_scales(graph):
     return c["sym_scales"]
 
 
+def block_width(HD: int) -> int:
+    """Column width of the `ft` and `res` blocks of the merged projection [ft | res | el | er | pad]: H*D rounded up to a multiple of 4,
+    so that the residual block — whose rows the fused backward sweep GATHERS — starts on a 16-byte boundary (3 x 250: 752)."""
+    return (HD + 3) // 4 * 4
+
+
 def cat_weight(conv):
     """[W_fc ; W_res ; wl ; wr ; 0-pad] with wl[h] = W_fc[h]^T attn_l[h]  (so that h @ wl^T == <fc(h)[h], attn_l[h]>,
     models.py:517,521).  Differentiable: the gradients reach fc.weight, res_fc.weight, attn_l, attn_r through these ops."""
     H, D = conv._num_heads, conv._out_feats
     W = conv.fc.weight
     Wh = W.view(H, D, -1)
-    rows = [W]
+    gap = block_width(H * D) - H * D                 # zero rows behind each of the two copied blocks (block_width)
+    rows = [W] + ([W.new_zeros(gap, W.shape[1])] if gap else [])
     if conv.res_fc is not None:
-        rows.append(conv.res_fc.weight)
+        rows += [conv.res_fc.weight] + ([W.new_zeros(gap, W.shape[1])] if gap else [])
     rows.append((Wh * conv.attn_l.view(H, D, 1)).sum(1))
     if conv.attn_r is not None:
         rows.append((Wh * conv.attn_r.view(H, D, 1)).sum(1))
@@ -83,18 +90,19 @@ class _MergeWeight(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, W, Wres, attn_l, attn_r, H, D, with_fc):
-        used = (H * D if with_fc else 0) + (H * D if Wres is not None else 0) + H + (H if attn_r is not None else 0)
+        blk = block_width(H * D) if with_fc else H * D      # the aggregate-first form has no `ft` block: `res` starts at column 0
+        used = (blk if with_fc else 0) + (blk if Wres is not None else 0) + H + (H if attn_r is not None else 0)
         P = used + (-used) % 128
         ctx.save_for_backward(W, attn_l, attn_r)
-        ctx.cfg = (H, D, P, with_fc, Wres is not None)
-        return _C.merge_weight_fwd(W, Wres, attn_l.reshape(-1), None if attn_r is None else attn_r.reshape(-1), H, D, P, with_fc)
+        ctx.cfg = (H, D, P, with_fc, Wres is not None, blk)
+        return _C.merge_weight_fwd(W, Wres, attn_l.reshape(-1), None if attn_r is None else attn_r.reshape(-1), H, D, P, with_fc, block=blk)
 
     @staticmethod
     def backward(ctx, dm):
         W, attn_l, attn_r = ctx.saved_tensors
-        H, D, P, with_fc, has_res = ctx.cfg
+        H, D, P, with_fc, has_res, blk = ctx.cfg
         dW, dWres, dal, dar = _C.merge_weight_bwd(W, attn_l.reshape(-1), None if attn_r is None else attn_r.reshape(-1), H, D, P,
-                                                  with_fc, has_res, dm)
+                                                  with_fc, has_res, dm, block=blk)
         return dW, dWres, dal.view_as(attn_l), (None if dar is None else dar.view_as(attn_r)), None, None, None
 
 
@@ -217,7 +225,8 @@ class _GATHidden(torch.autograd.Function):
         else:
             out = torch.mm(h, Wcat) if kp else torch.mm(h, Wcat.t())    # [N, P] = [ft | res | el | er | pad]
         ctx.halves = None if xh is None else (xh.n, xh.F, xh.piece)
-        c = 2 * HD if has_res else HD
+        B = block_width(HD)                                             # [ft (HD) pad -> B | res (HD) pad -> B | el | er | pad]
+        c = 2 * B if has_res else B
         ext = None
         ctx.overlap = graph.halo is not None and OVERLAP and not sym
         if ctx.overlap:                                                 # partitioned, overlapped: see OVERLAP above
@@ -232,7 +241,7 @@ class _GATHidden(torch.autograd.Function):
             ctx.zs = _C.zsign_buffer(csc, H, slope)
             ctx.adrop = (attn_p, new_dropout_seed(attn_p)) if attn_p > 0 else None
             a, a_d = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None, ctx.zs, drop=ctx.adrop or (0.0, 0))
-            res = out[:, HD:2 * HD].unflatten(1, (H, D)) if has_res else None
+            res = out[:, B:B + HD].unflatten(1, (H, D)) if has_res else None
             x3 = _C.spmm(sp["csc_own"], out[:, :HD].unflatten(1, (H, D)), a_d, sp["csc_own_pos"], addend=res)   # owned-source edges
             work.wait()
             del send_keep
@@ -268,7 +277,7 @@ class _GATHidden(torch.autograd.Function):
         a, a_d = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None, ctx.zs, drop=ctx.adrop or (0.0, 0))
         if sym:
             a_d = a_d * w_e                                             # the SpMM weights; d a below is scaled back by w_e
-        res = out[:, HD:2 * HD].unflatten(1, (H, D)) if has_res else None
+        res = out[:, B:B + HD].unflatten(1, (H, D)) if has_res else None
         if HD % 4 and bn is not None and sweep_is_row_kernel(graph, H, D):
             # rows of 750 floats: give the pre-BatchNorm tensor a row pitch of 752 so that its rows are 16-byte aligned — the
             # BatchNorm kernels read it four times per step and move 16-byte aligned operands at full width (dense.hip)
@@ -309,8 +318,13 @@ class _GATHidden(torch.autograd.Function):
             drop_p, seed, bn_training, sync, group, total = epi
         kp = ctx.kp
         N, HD, P = h.shape[0], H * D, Wcat.shape[1 if kp else 0]
+        B = block_width(HD)
         dout = torch.empty((N, P), dtype=dy.dtype, device=h.device)
-        dx = dout[:, HD:2 * HD] if has_res else torch.empty((N, HD), dtype=dy.dtype, device=h.device)
+        dx = dout[:, B:B + HD] if has_res else torch.empty((N, HD), dtype=dy.dtype, device=h.device)
+        if B != HD:                                                     # the pad columns meet zero weight rows: they must be finite
+            dout[:, HD:B].zero_()
+            if has_res:
+                dout[:, B + HD:2 * B].zero_()
         if epi is None:
             dx.copy_(dy)
         else:
@@ -322,7 +336,7 @@ class _GATHidden(torch.autograd.Function):
                 sg, sgx = both[0].contiguous(), both[1].contiguous()
             _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
                                 sgx if bn_training else None, total, out=dx)
-        c = 2 * HD if has_res else HD
+        c = 2 * B if has_res else B
         if ctx.overlap:
             # halo rows first — their gradients travel back while the owned rows are swept and the attention backward runs
             plan, sp = g.halo, g.halo_split
@@ -767,7 +781,8 @@ def gat_infer_layer(conv, epi, graph, h, relu, first=False):
                                                    lambda: gemm.split(W.t().contiguous() if WEIGHT_KP else W, 1)))
     else:
         out = torch.mm(h, W) if WEIGHT_KP else torch.mm(h, W.t())       # [N, P] = [ft | res | el | er | pad]
-    c = 2 * HD if has_res else HD
+    B = block_width(HD)
+    c = 2 * B if has_res else B
     if graph.halo is not None:                                          # partitioned: owned + halo source rows [ft | el]
         ext = _extend_forward(graph, out, HD, H, c)
         ft, el = ext[:, :HD], ext[:, HD:HD + H]
@@ -780,7 +795,7 @@ def gat_infer_layer(conv, epi, graph, h, relu, first=False):
         el = el * s_out.unsqueeze(1)
         ew = w_e
     scale, shift = eval_affine(epi)
-    res = out[:, HD:2 * HD].unflatten(1, (H, D)) if has_res else None
+    res = out[:, B:B + HD].unflatten(1, (H, D)) if has_res else None
     y = _C.gat_infer(graph.csc, ft.unflatten(1, (H, D)), el, er, None, ew, conv.leaky_relu.negative_slope, addend=res,
                      scale=scale, shift=shift, relu=relu)
     return y.view(N, HD)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 10
+#define BOT_ABI_VERSION 11
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -89,7 +89,7 @@ int bot_degrees_i64(const int32_t* indptr, int64_t n_rows, int64_t* deg, bot_str
  * the plan has no long rows).
  * ------------------------------------------------------------------------------------------- */
 int64_t bot_spmm_workspace_floats(int64_t n_slots, int32_t H, int32_t D);
-/* Layout hint for the calling thread's following bot_spmm_f32 calls on weighted multi-head slabs whose head width is not a multiple
+/* Layout hint for the calling thread's following bot_spmm_f32 / bot_spmm_dot_f32 calls on weighted multi-head slabs whose head width is not a multiple
  * of 4 floats (3 x 250) and whose rows are H*D contiguous floats on a 16-byte aligned pitch >= H*D rounded up to x4: 0 (default) =
  * head-segment lanes with 8-byte loads, 1 = flat 16-byte lanes (spmm_flat_kernel).  Results are bitwise identical; flat is faster when
  * the gathered rows are L2-resident (graphs numbered for locality), slightly slower when they are fabric-bound.  Speed only. */
@@ -370,14 +370,16 @@ int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int6
  * linear maps on its input — fc (models.py:490-492), res_fc (:558-560), and the attention scores folded through fc,
  * el = h . (W_h^T attn_l[h]) (:517), er likewise (:521) — become ONE GEMM against
  *     merged [K, P] = [ W_fc^T (with_fc) | W_res^T (Wres != NULL) | wl | wr (attn_r != NULL) | 0 ... ]
- * with wl[k,h] = sum_d W_fc[h*D+d, k] * attn_l[h*D+d].  W, Wres: [H*D, K] row-major; attn_l, attn_r: [H*D].  The backward
- * takes d merged and returns the gradients of the four parameters (dWres / d_attn_r NULL when absent).
+ * with wl[k,h] = sum_d W_fc[h*D+d, k] * attn_l[h*D+d].  W, Wres: [H*D, K] row-major; attn_l, attn_r: [H*D].  `block` >= H*D is the
+ * column width of each of the two copied blocks (zero padded): H*D rounded up to x4 puts the residual block of the GEMM output /
+ * gradient buffer on a 16-byte boundary (3 x 250: columns [0, 750) | 2 pad | [752, 1502) | 2 pad | scores).  The backward takes
+ * d merged and returns the gradients of the four parameters (dWres / d_attn_r NULL when absent).
  * ------------------------------------------------------------------------------------------- */
 int bot_merge_weight_fwd_f32(const float* W, const float* Wres, const float* attn_l, const float* attn_r, int32_t H, int32_t D,
-                             int32_t K, int32_t P, int32_t with_fc, float* merged, bot_stream_t stream);
+                             int32_t K, int32_t P, int32_t with_fc, int32_t block, float* merged, bot_stream_t stream);
 int bot_merge_weight_bwd_f32(const float* W, const float* attn_l, const float* attn_r, int32_t H, int32_t D, int32_t K,
-                             int32_t P, int32_t with_fc, const float* d_merged, float* dW, float* dWres, float* d_attn_l,
-                             float* d_attn_r, bot_stream_t stream);
+                             int32_t P, int32_t with_fc, int32_t block, const float* d_merged, float* dW, float* dWres,
+                             float* d_attn_l, float* d_attn_r, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Edge-feature attention term of the ogbn-proteins GAT, fused.  Replaces, per layer,
