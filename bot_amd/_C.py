@@ -312,8 +312,6 @@ def spmm_dot(d, x, w, wperm, y, out=None, dot=None):
     partial = None
     if d.n_long:
         partial = torch.empty(int(_lib.bot_spmm_workspace_floats(d.n_slots, H, D)), dtype=torch.float32, device=x.device)
-    flat = SPMM_LAYOUT == "flat" or (SPMM_LAYOUT is None and getattr(d, "plan_order", "degree") == "xcd")
-    _lib.bot_spmm_set_layout(1 if flat else 0)     # thread-local speed hint (this may be the autograd thread); same values either way
     _check(_timed("spmm_dot", (H, D), lambda: _lib.bot_spmm_dot_f32(
         d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
         _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, w.data_ptr(), _ptr(_i32(wperm, "wperm")), y.data_ptr(), ldy, hsy,

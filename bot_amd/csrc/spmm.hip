@@ -388,112 +388,6 @@ __global__ __launch_bounds__(kBlock) void spmm_flat_kernel(SpmmArgs a) {
     }
 }
 
-// The fused backward (spmm_dot_rows_kernel) in the flat 16-byte layout of spmm_flat_kernel: gathered rows x (the residual block of the
-// gradient buffer, on a 16-byte boundary since the merged layout pads its blocks to x4 columns), the row's own features y and the
-// output row are all H*D contiguous floats read / written as float4 lanes; a lane-chunk's four elements belong to at most two heads,
-// so its dot product is split into the part of head `ha` (first `ns` elements) and the part of head `hb`, which are added into
-// per-head sums, reduced over the wave four edges at a time and stored as one H-float record per edge.
-template <int NCHUNK, int HMAX>
-__global__ __launch_bounds__(kBlock) void spmm_dot_flat_kernel(SpmmArgs a) {
-    constexpr int U = 4;
-    const int lane = threadIdx.x & 63;
-    const int64_t item = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    if (item >= a.n_items) return;
-    const int4 it = a.items[item];
-    const int row = __builtin_amdgcn_readfirstlane(it.x), beg = __builtin_amdgcn_readfirstlane(it.y);
-    const int end = __builtin_amdgcn_readfirstlane(it.z), slot = __builtin_amdgcn_readfirstlane(it.w);
-    const int F = a.H * a.D;
-    int off[NCHUNK], ha[NCHUNK], hb[NCHUNK], ns[NCHUNK], nv[NCHUNK];
-    float acc[NCHUNK][4], yv[NCHUNK][4];
-    const float* yb = a.y + (int64_t)row * a.ldy;
-#pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-        const int e = (c * 64 + lane) * 4;
-        nv[c] = min(4, max(0, F - e));
-        off[c] = nv[c] > 0 ? e : 0;
-        const int h0 = min(off[c] / a.D, a.H - 1);
-        ha[c] = h0, hb[c] = min(h0 + 1, a.H - 1);
-        ns[c] = min(4, (h0 + 1) * a.D - off[c]);
-        vload<4>(yv[c], yb + off[c]);                   // (the tail float4 may reach past F: ldy >= roundup4(F), masked below)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acc[c][t] = 0.f;
-            if (t >= nv[c]) yv[c][t] = 0.f;
-        }
-    }
-    for (int k0 = beg; k0 < end; k0 += 64) {
-        const int k = k0 + lane;
-        int idx = 0, wp = 0;
-        if (k < end) {
-            idx = a.indices[k];
-            wp = a.wperm ? a.wperm[k] : k;
-        }
-        const int cnt = min(64, end - k0);
-        for (int i = 0; i < cnt; i += U) {
-            float v[U][NCHUNK][4], wh[U][HMAX], p[HMAX][U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = min(i + u, cnt - 1);      // past the end: re-read a valid neighbour with weight 0, result not stored
-                const int s = __builtin_amdgcn_readlane(idx, j);
-                const int ps = __builtin_amdgcn_readlane(wp, j);
-                const float* px = a.x + (int64_t)s * a.ldx;
-                const float* pw = a.w + (int64_t)ps * a.H;
-#pragma unroll
-                for (int c = 0; c < NCHUNK; ++c) vload<4>(v[u][c], px + off[c]);
-#pragma unroll
-                for (int h = 0; h < HMAX; ++h) wh[u][h] = (i + u < cnt && h < a.H) ? pw[h] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int h = 0; h < HMAX; ++h) p[h][u] = 0.f;
-#pragma unroll
-                for (int c = 0; c < NCHUNK; ++c) {
-                    float wa = wh[u][0], wb = wh[u][0];
-#pragma unroll
-                    for (int h = 1; h < HMAX; ++h) {
-                        wa = ha[c] == h ? wh[u][h] : wa;
-                        wb = hb[c] == h ? wh[u][h] : wb;
-                    }
-                    float da = 0.f, db = 0.f;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const bool first = t < ns[c];
-                        acc[c][t] = fmaf(first ? wa : wb, v[u][c][t], acc[c][t]);
-                        const float pr = v[u][c][t] * yv[c][t];
-                        da += first ? pr : 0.f;
-                        db += first ? 0.f : pr;
-                    }
-#pragma unroll
-                    for (int h = 0; h < HMAX; ++h) p[h][u] += (ha[c] == h ? da : 0.f) + (hb[c] == h ? db : 0.f);
-                }
-            }
-            const int mywp = __shfl(wp, i + (lane & 3));  // position whose dot products this lane holds after the reduction
-#pragma unroll
-            for (int h = 0; h < HMAX; ++h) {
-                const float tot = transpose_reduce4<64>(p[h], lane);
-                if (lane < U && i + lane < cnt && h < a.H) a.dot_out[(int64_t)mywp * a.H + h] = tot;
-            }
-        }
-    }
-    float* ob = slot < 0 ? a.out + (int64_t)row * a.ldo : a.partial + (int64_t)slot * a.ldp;
-    const bool o16 = ((reinterpret_cast<uintptr_t>(ob) & 15) == 0), o8 = ((reinterpret_cast<uintptr_t>(ob) & 7) == 0);
-#pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-        if (nv[c] <= 0) continue;
-        if (nv[c] == 4 && o16) vstore<4>(ob + off[c], acc[c]);
-        else if (o8 && (nv[c] & 1) == 0) {
-            float lo[2] = {acc[c][0], acc[c][1]}, hi[2] = {acc[c][2], acc[c][3]};
-            vstore<2>(ob + off[c], lo);
-            if (nv[c] == 4) vstore<2>(ob + off[c] + 2, hi);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (t < nv[c]) ob[off[c] + t] = acc[c][t];
-        }
-    }
-}
-
 template <int VEC, int LANES, int NCHUNK, bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs a) {
     constexpr int TILE = VEC * LANES * NCHUNK;
@@ -984,30 +878,6 @@ static bool dispatch_spmm_flat(const SpmmArgs& a, hipStream_t st) {
     return true;
 }
 
-static bool dispatch_spmm_dot_flat(const SpmmArgs& a, hipStream_t st) {
-    const int F = a.H * a.D;
-    const int64_t Fp = (F + 3) / 4 * 4;
-    if (!spmm_flat_wanted() || a.H < 2 || a.H > 4 || a.D % 4 == 0 || a.D < 4 || F > 1024) return false;
-    if (a.hsx != a.D || a.hso != a.D || a.hsy != a.D || !aligned(a.x, 16) || !aligned(a.y, 16) || a.ldx % 4 != 0 || a.ldy % 4 != 0 ||
-        a.ldx < Fp || a.ldy < Fp)
-        return false;
-    const int nchunk = (F + 255) / 256;
-    const int64_t blocks = (a.n_items * 64 + kBlock - 1) / kBlock;
-    if (blocks == 0) return true;
-    set_kernel("bot::spmm_dot_flat_kernel<%d,%d>", nchunk, a.H <= 3 ? 3 : 4);
-#define BOT_DFLAT(NC)                                                                                                 \
-    do {                                                                                                              \
-        if (a.H <= 3) hipLaunchKernelGGL((spmm_dot_flat_kernel<NC, 3>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a); \
-        else hipLaunchKernelGGL((spmm_dot_flat_kernel<NC, 4>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);         \
-    } while (0)
-    if (nchunk == 1) BOT_DFLAT(1);
-    else if (nchunk == 2) BOT_DFLAT(2);
-    else if (nchunk == 3) BOT_DFLAT(3);
-    else BOT_DFLAT(4);
-#undef BOT_DFLAT
-    return true;
-}
-
 template <int VEC>
 static void dispatch_spmm(SpmmArgs& a, hipStream_t st) {
     const int L = (a.D + VEC - 1) / VEC;  // lanes needed for one head slab
@@ -1098,8 +968,7 @@ int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_ro
     const int vec = pick_vec(D, {ldx, hsx, ldo, hso, ldy, hsy}, {x, out, partial, y});
     BOT_REQUIRE(D <= vec * 256, BOT_E_RANGE, "spmm_dot: D=%d exceeds the %d floats one launch tile covers (use bot_spmm_f32 + bot_sddmm_dot_f32)",
                 D, vec * 256);
-    const bool rows = dispatch_spmm_dot_flat(a, st) ||
-                      (vec == 4 ? dispatch_spmm_dot_rows<4>(a, st) : (vec == 2 ? dispatch_spmm_dot_rows<2>(a, st) : dispatch_spmm_dot_rows<1>(a, st)));
+    const bool rows = vec == 4 ? dispatch_spmm_dot_rows<4>(a, st) : (vec == 2 ? dispatch_spmm_dot_rows<2>(a, st) : dispatch_spmm_dot_rows<1>(a, st));
     if (!rows) {
         if (vec == 4) dispatch_spmm_dot<4>(a, st);
         else if (vec == 2) dispatch_spmm_dot<2>(a, st);

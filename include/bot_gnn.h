@@ -89,7 +89,7 @@ int bot_degrees_i64(const int32_t* indptr, int64_t n_rows, int64_t* deg, bot_str
  * the plan has no long rows).
  * ------------------------------------------------------------------------------------------- */
 int64_t bot_spmm_workspace_floats(int64_t n_slots, int32_t H, int32_t D);
-/* Layout hint for the calling thread's following bot_spmm_f32 / bot_spmm_dot_f32 calls on weighted multi-head slabs whose head width is not a multiple
+/* Layout hint for the calling thread's following bot_spmm_f32 calls on weighted multi-head slabs whose head width is not a multiple
  * of 4 floats (3 x 250) and whose rows are H*D contiguous floats on a 16-byte aligned pitch >= H*D rounded up to x4: 0 (default) =
  * head-segment lanes with 8-byte loads, 1 = flat 16-byte lanes (spmm_flat_kernel).  Results are bitwise identical; flat is faster when
  * the gathered rows are L2-resident (graphs numbered for locality), slightly slower when they are fabric-bound.  Speed only. */

@@ -636,33 +636,6 @@ def test_spmm_flat_16_byte_lanes():
             assert not _C._lib.bot_last_kernel().decode().startswith("bot::spmm_flat_kernel")
             _C.SPMM_LAYOUT = "flat"
             assert torch.equal(rows_out, _C.spmm(csc, x, w, None, addend=res, out=torch.empty(n, F, device=DEV).unflatten(1, (H, D))))
-    # the fused backward in the same layout (spmm_dot_flat_kernel): gathered rows, the row's own features and the output all slabs
-    # of 16-byte aligned buffers; against torch and against the head-segment kernel (the dot products reduce in another order: close,
-    # not bitwise; the row sums are bitwise)
-    g = bot_amd.Graph(s, d, n, chunk=8).to(DEV)
-    csr, c2c = g.csr, g.csr2csc
-    rows_r = torch.repeat_interleave(torch.arange(n, device=DEV), (csr.indptr[1:] - csr.indptr[:-1]).long())
-    for H, D in ((3, 250), (2, 250), (4, 30), (3, 6)):
-        F = H * D
-        Fp = (F + 3) // 4 * 4
-        big = torch.randn(n, 3 * Fp + 8, generator=gen).to(DEV)
-        dx = big[:, Fp:Fp + F].unflatten(1, (H, D))                    # the residual block of a padded merged layout
-        ft = big[:, :F].unflatten(1, (H, D))
-        w = torch.rand(csr.nnz, H, generator=gen).to(DEV)
-        outb = big[:, 2 * Fp:2 * Fp + F].unflatten(1, (H, D))
-        _C.SPMM_LAYOUT = "flat"
-        o_f, dot_f = _C.spmm_dot(csr, dx, w, c2c, ft, out=outb)
-        assert _C._lib.bot_last_kernel().decode().startswith("bot::spmm_dot_flat_kernel"), _C._lib.bot_last_kernel()
-        o_f, dot_f = o_f.clone(), dot_f.clone()
-        _C.SPMM_LAYOUT = "rows"
-        o_r, dot_r = _C.spmm_dot(csr, dx, w, c2c, ft)
-        assert not _C._lib.bot_last_kernel().decode().startswith("bot::spmm_dot_flat_kernel")
-        xs = dx[csr.indices.long()]
-        ref_o = torch.zeros(n, H, D, device=DEV).index_add_(0, rows_r, xs * w[c2c.long()].unsqueeze(-1))
-        ref_dot = torch.empty(csr.nnz, H, device=DEV)
-        ref_dot[c2c.long()] = (xs * ft[rows_r]).sum(-1)
-        assert torch.equal(o_f, o_r) and torch.allclose(o_f, ref_o, atol=2e-4, rtol=1e-5), (H, D)
-        assert torch.allclose(dot_f, ref_dot, atol=1e-4 * D ** 0.5, rtol=1e-5) and torch.allclose(dot_f, dot_r, atol=1e-4 * D ** 0.5, rtol=1e-5), (H, D)
     _C.SPMM_LAYOUT = None
     # default: the hint follows the plan order of the direction
     h = bot_amd.reorder_graph(bot_amd.Graph(s, d, n), "degree", plan_order="xcd").to(DEV)

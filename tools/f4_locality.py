@@ -67,8 +67,8 @@ def main():
                 n, E = g.number_of_nodes(), g.number_of_edges()
                 x, a, out = operands(g)
                 ms = timeit(lambda: _C.spmm(g.csc, x, a, None, out=out))
-                y = torch.randn(n, H, D, device=DEV)
-                ms_b = timeit(lambda: _C.spmm_dot(g.csr, x, a, g.csr2csc, y))
+                y, _, dout = operands(g)          # same pitch as x: the fused backward takes the flat layout when all three slabs allow it
+                ms_b = timeit(lambda: _C.spmm_dot(g.csr, x, a, g.csr2csc, y, out=dout))
                 el = torch.randn(n, H, device=DEV)
                 ms_i = timeit(lambda: _C.gat_infer(g.csc, x, el, out=out))
                 alg = 4 * (2 * n * H * D + E + n + 1 + E * H)
