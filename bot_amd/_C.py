@@ -664,11 +664,7 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     ldc = _ld(out) if ldc is None else ldc
     lda, ldb = _ld(a), _ld(b)
     key = f"{int(trans_a)}{int(trans_b)} m{m} n{n} k{k} lda{lda} ldb{ldb} ldc{ldc} b{batch} s{sa},{sb},{sc}"
-    index = -1
-    if beta == 0.0:
-        index = _gemm_algos().get(key, -1)
-        if index < 0 and ldc != n:      # recorded for the contiguous output: the same kernel serves a padded row pitch (validated by the library)
-            index = _gemm_algos().get(f"{int(trans_a)}{int(trans_b)} m{m} n{n} k{k} lda{lda} ldb{ldb} ldc{n} b{batch} s{sa},{sb},{sc}", -1)
+    index = _gemm_algos().get(key, -1) if beta == 0.0 else -1
     _check(_timed("gemm_halves", (m, n, k, batch), lambda: _lib.bot_gemm_halves_f32(
         int(trans_a), int(trans_b), m, n, k, alpha.data_ptr(), a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(),
         ldc, batch, sa, sb, sc, float(beta), ws.data_ptr(), ws.numel(), int(GEMM_TUNE), index, _stream())), "gemm_halves")
@@ -783,9 +779,7 @@ def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=None):
     _dev(x, mean, invstd)
     x = _mat(x, "x")
     n, F = x.shape
-    # rows of y on a 16-byte boundary (F = 750 -> pitch 752): the kernels move 16-byte aligned operands at full width, and y is read
-    # again only by kernels that take a row pitch (the next layer's GEMM reads the halves, or torch.mm a strided operand)
-    y = torch.empty((n, (F + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :F]
+    y = torch.empty((n, F), dtype=torch.float32, device=x.device)
     if halves is not None:
         hscale, piece = halves
         buf = torch.empty((n, 3 * piece), dtype=torch.float16, device=x.device)

@@ -305,8 +305,7 @@ class _GATHidden(torch.autograd.Function):
         import torch.distributed as dist
         H, D, has_res, has_er, slope, epi = ctx.cfg
         g = ctx.graph
-        if dy.stride(1) != 1:
-            dy = dy.contiguous()                                        # (a row pitch is fine: the next layer hands 16-byte aligned rows)
+        dy = dy.contiguous()
         d_bn_w = d_bn_b = None
         ft_halo = None
         saved = ctx.saved_tensors
@@ -394,20 +393,14 @@ class _GATHidden(torch.autograd.Function):
         if used < P:
             dout[:, used:].zero_()
         dW = dh = None
-        xh_cols = None
         if ctx.halves is not None:
             xh = gemm.Halves(h, ctx.xscale, *ctx.halves, 0)
-            xh_cols = xh.F                                              # h holds the halves buffer here: the input's width is xh.F
             dh_ = gemm.split(dout, 0)
             if ctx.needs_input_grad[1]:
                 dW = gemm.tn(xh, dh_)                                    # [K, P]
                 dW = dW if kp else dW.t().contiguous()
             if ctx.needs_input_grad[0]:
-                # rows of the input gradient on a 16-byte boundary (750 -> pitch 752): it is the previous layer's BatchNorm backward
-                # that reads it, twice, and those kernels move aligned operands at full width
-                K = h.shape[1] if xh_cols is None else xh_cols
-                dh = torch.empty((N, (K + 3) // 4 * 4), dtype=dy.dtype, device=dy.device)[:, :K]
-                gemm.mm_nt(dh_, gemm.split(Wcat if kp else Wcat.t().contiguous(), 1), out=dh)
+                dh = gemm.mm_nt(dh_, gemm.split(Wcat if kp else Wcat.t().contiguous(), 1))
         else:
             if ctx.needs_input_grad[1]:
                 dW = torch.mm(h.t(), dout) if kp else torch.mm(dout.t(), h)
@@ -532,8 +525,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         import torch.distributed as dist
         H, D, has_res, has_er, slope, epi = ctx.cfg
         g = ctx.graph
-        if dy.stride(1) != 1:
-            dy = dy.contiguous()
+        dy = dy.contiguous()
         d_bn_w = d_bn_b = None
         if epi is None:
             h, W, Wr, z, table, el, er, a, a_d = ctx.saved_tensors
