@@ -9,6 +9,8 @@ for W in cora reddit proteins products; do
   timeout 1500 python bench.py --workload $W --steps 10 --warmup 3 > $O/bench_$W.json 2> $O/bench_$W.err
   tail -c 300 $O/bench_$W.json
 done
+python tools/train_halves_vs_f32.py 60 > $O/train_halves_vs_f32.txt 2>&1; tail -4 $O/train_halves_vs_f32.txt
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -3 $O/smoke.txt
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof_b
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o r -- python3 /root/repo/bench.py --steps 20 --warmup 5 --cpu-baseline off --gemm halves > /tmp/b.log 2>&1
