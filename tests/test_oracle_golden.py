@@ -297,3 +297,44 @@ def test_edge_softmax_properties():
     s2 = torch.zeros(n, 3, 1, dtype=torch.float64).index_add(0, dst[eids], sub)
     has2 = torch.bincount(dst[eids], minlength=n) > 0
     assert torch.allclose(s2[has2], torch.ones_like(s2[has2]))
+
+
+def test_oracle_against_scipy_sparse(golden):
+    """A third, library-made restatement of the operators' arithmetic: SciPy's sparse matrices define SpMM unambiguously (parallel
+    edges are summed when a COO matrix is converted, as DGL sums messages of a multigraph).  oracle/ref_ops.py and the C kernels
+    (oracle/c_ops.py) must agree with `A^T x`, with the edge-weighted `A_w^T x`, and with a softmax taken over the stored entries of
+    each column — on the golden graphs and on a random multigraph with duplicate edges.  (This pins the arithmetic, not DGL's
+    conventions — edge-id order of `to_bidirected`, `eids` semantics — which stay anchored on the reference's call sites.)"""
+    import scipy.sparse as sp
+    from oracle import c_ops
+    gen = torch.Generator().manual_seed(77)
+    cases = [golden.graph("g64"), golden.graph("g300")]
+    n = 50
+    cases.append((torch.randint(0, n, (400,), generator=gen), torch.randint(0, n, (400,), generator=gen), n))   # duplicates, self-loops
+    for s, d, n in cases:
+        E = s.numel()
+        H, D = 3, 5
+        x = torch.randn(n, H, D, generator=gen, dtype=torch.float64)
+        w = torch.rand(E, H, generator=gen, dtype=torch.float64)
+        A = sp.coo_matrix((np.ones(E), (s.numpy(), d.numpy())), shape=(n, n)).tocsr()          # A[u, v] = multiplicity of u -> v
+        ref = (A.T @ x.reshape(n, H * D).numpy()).reshape(n, H, D)
+        np.testing.assert_allclose(R.copy_u_sum(s, d, n, x).numpy(), ref, rtol=1e-12, atol=1e-12)
+        cg = c_ops.CGraph(s, d, n)
+        np.testing.assert_allclose(c_ops.copy_u_sum(cg, x.float()).numpy(), ref, rtol=1e-5, atol=1e-5)
+        for h in range(H):
+            Aw = sp.coo_matrix((w[:, h].numpy(), (s.numpy(), d.numpy())), shape=(n, n)).tocsr()
+            np.testing.assert_allclose(R.u_mul_e_sum(s, d, n, x, w.unsqueeze(-1))[:, h].numpy(), Aw.T @ x[:, h].numpy(), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(R.copy_e_sum(d, n, w).numpy(),
+                                   np.stack([np.bincount(d.numpy(), weights=w[:, h].numpy(), minlength=n) for h in range(H)], 1), rtol=1e-12)
+        # edge_softmax: exp(e - max over the in-edges) / sum over the in-edges, per destination and head, with numpy's ufuncs
+        e = torch.randn(E, H, 1, generator=gen, dtype=torch.float64) * 4
+        a = R.edge_softmax(d, n, e).squeeze(-1).numpy()
+        mx = np.full((n, H), -np.inf)
+        np.maximum.at(mx, d.numpy(), e.squeeze(-1).numpy())
+        ex = np.exp(e.squeeze(-1).numpy() - mx[d.numpy()])
+        den = np.zeros((n, H))
+        np.add.at(den, d.numpy(), ex)
+        np.testing.assert_allclose(a, ex / den[d.numpy()], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(c_ops.edge_softmax(cg, e.float()).squeeze(-1).numpy(), ex / den[d.numpy()], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(torch.bincount(d, minlength=n).numpy(), np.asarray(A.sum(0)).ravel().astype(np.int64))       # in-degrees
+        assert np.array_equal(torch.bincount(s, minlength=n).numpy(), np.asarray(A.sum(1)).ravel().astype(np.int64))       # out-degrees
