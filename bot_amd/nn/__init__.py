@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import gemm, ops
+from .. import gemm, halo, ops
 from ..errors import DGLError
 
 __all__ = ["ElementWiseLinear", "GraphConv", "GATConv", "GCN", "GAT"]
@@ -146,12 +146,14 @@ class GraphConv(nn.Module):
             h = h * _bcast(degree_norm(graph, "out", -0.5), h)
         # graph.extend: identity on one GPU; in partitioned mode the halo rows arrive here, after the
         # narrowing GEMM when there is one (so the narrower tensor is what crosses xGMI)
+        # (bot_amd.halo: the exchange runs beside the sweep over the owned-source edges)
+        agg = (lambda t: halo.copy_u_sum(graph, t)) if halo.enabled(graph) else (lambda t: ops.copy_u_sum(graph, graph.extend(t)))
         if self._in_feats > self._out_feats:
             if w is not None:
                 h = gemm.matmul(h, w)
-            rst = ops.copy_u_sum(graph, graph.extend(h))
+            rst = agg(h)
         else:
-            rst = ops.copy_u_sum(graph, graph.extend(h))
+            rst = agg(h)
             if w is not None:
                 rst = gemm.matmul(rst, w)
         if self._norm == "both":
@@ -245,7 +247,11 @@ class GATConv(nn.Module):
             norm = degree_norm(graph, "out", -0.5)
             ft = ft * _bcast(norm, ft)
             el = el * norm.unsqueeze(-1)
-        ft = graph.extend(ft)  # identity on one GPU; appends the halo rows in partitioned mode
+        # partitioned mode: the halo rows of `el` (small) arrive here; those of `ft` travel while the attention is formed and the
+        # owned-source edges are swept (bot_amd.halo), or — BOT_HALO_OVERLAP=0 — in one exchange here
+        transfer = halo.start(graph, ft) if halo.enabled(graph) else None
+        if transfer is None:
+            ft = graph.extend(ft)  # identity on one GPU
         el = graph.extend(el).unsqueeze(-1)
         keep_order = "eid"
         if keep is None and self.training and self.edge_drop > 0:
@@ -253,7 +259,7 @@ class GATConv(nn.Module):
         a = ops.gat_attention(graph, el, er, keep=keep, negative_slope=self.leaky_relu.negative_slope, order="csc",
                               keep_order=keep_order)
         a = self.attn_drop(a)
-        rst = ops.u_mul_e_sum(graph, ft, a, order="csc")
+        rst = ops.u_mul_e_sum(graph, ft, a, order="csc") if transfer is None else halo.u_mul_e_sum(graph, ft, a, transfer=transfer)
         if self._use_symmetric_norm:
             rst = rst * _bcast(degree_norm(graph, "in", 0.5), rst)
         if self.res_fc is not None:  # residual folded into the GEMM epilogue (beta = 1)

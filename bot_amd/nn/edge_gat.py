@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import halo, ops
 from ..graph import take_rows
 from . import _bcast, _epilogue, _pair, degree_norm, has_zero_in_degree
 from . import fused as _fused
@@ -108,10 +108,16 @@ class GATConv(nn.Module):
                 res = pieces.pop(0).unflatten(1, (H, D))
             attn_src = pieces.pop(0).unsqueeze(-1)
             attn_dst = pieces.pop(0).unsqueeze(-1) if self.attn_dst_fc is not None else None
-        ft = graph.extend(ft)
+        infer = (not torch.is_grad_enabled() and not self.training and res is not None and (ft.is_cuda or _fused.FORCE) and H <= 8
+                 and self.activation is None and _fused.sweep_is_row_kernel(graph, H, D))
+        # partitioned mode: the halo rows of `attn_src` (small) arrive here; those of `ft` travel while the edge logits and the
+        # attention are formed and the owned-source edges are swept (bot_amd.halo), or in one exchange here (inference sweep,
+        # BOT_HALO_OVERLAP=0)
+        transfer = halo.start(graph, ft) if (halo.enabled(graph) and not infer) else None
+        if transfer is None:
+            ft = graph.extend(ft)
         attn_src = graph.extend(attn_src)
-        if (not torch.is_grad_enabled() and not self.training and res is not None and (ft.is_cuda or _fused.FORCE) and H <= 8
-                and self.activation is None and _fused.sweep_is_row_kernel(graph, H, D)):
+        if infer:
             # inference (evaluate(): eval mode under no_grad, ogbn-proteins/gat.py:136-160): logits + softmax + aggregation +
             # dst_fc residual (+ the stack's eval-mode BatchNorm and ReLU when it hands them in) in ONE sweep, nothing
             # edge-sized written beyond the edge logits of the edge-feature term (bot_gat_infer_f32)
@@ -130,7 +136,10 @@ class GATConv(nn.Module):
             keep_order = "csc" if (ee is None or ee_order == "csc") else "eid"
         a = ops.gat_attention(graph, attn_src, attn_dst, ee, keep=keep, negative_slope=self.leaky_relu.negative_slope,
                               order="csc", ee_order=ee_order, keep_order=keep_order)
-        rst = ops.u_mul_e_sum(graph, ft, self.attn_drop(a), order="csc", addend=res)
+        if transfer is None:
+            rst = ops.u_mul_e_sum(graph, ft, self.attn_drop(a), order="csc", addend=res)
+        else:
+            rst = halo.u_mul_e_sum(graph, ft, self.attn_drop(a), addend=res, transfer=transfer)
         if self._use_symmetric_norm:
             rst = rst * _bcast(degree_norm(graph, "in", 0.5), rst)
         if res is not None:

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _C, gemm
+from .. import _C, gemm, halo
 from ..graph import take_rows
 from ..ops import bn_batch_stats, new_dropout_seed
 
@@ -159,39 +159,10 @@ def _extend_backward(graph, dext, n_own):
 # start the big one ([n_halo, H*D] projected rows) ASYNCHRONOUSLY, and meanwhile run everything that does not need it: the attention
 # (scores only) and the aggregation over the in-edges whose source is owned; the halo-source edges follow into the same rows once the
 # transfer has landed (Graph.halo_split).  Backward likewise: the halo rows' gradients are swept first and sent while the owned rows
-# are swept and the attention backward runs.  `torch.distributed` runs the collective on its own stream; `work.wait()` orders the
-# consumer after it — no host synchronisation, capturable.  BOT_HALO_OVERLAP=0: the one-exchange form (`_extend_forward`).
-OVERLAP = os.environ.get("BOT_HALO_OVERLAP", "1") != "0"
+# are swept and the attention backward runs.  The exchange helpers and the switch (BOT_HALO_OVERLAP / `halo.OVERLAP`) live in
+# bot_amd/halo.py, which gives the modular layers the same form.
 OVERLAP_CALLS = 0   # layer forwards that took the overlapped form (tests assert the path was taken)
-
-
-def _ship_rows(plan, own2d, async_op=False):
-    """The rows of own2d [n_own, W] (row stride allowed) that other ranks need -> (halo [n_halo, W], work handle or None, send buffer:
-    keep it referenced until the work is waited on)."""
-    import torch.distributed as dist
-    W = own2d.shape[1]
-    send = _C.gather_rows(own2d, plan.send_rows) if plan.n_send else own2d.new_empty((0, W))
-    halo = torch.empty((plan.n_halo, W), dtype=own2d.dtype, device=own2d.device)
-    work = dist.all_to_all_single(halo, send, plan.recv_splits, plan.send_splits, group=plan.group, async_op=async_op)
-    return halo, (work if async_op else None), send
-
-
-def _return_rows(plan, dhalo, async_op=False):
-    """Reverse direction: gradients of the halo rows [n_halo, W] go back to their owners -> (back [n_send, W], work or None)."""
-    import torch.distributed as dist
-    back = torch.empty((plan.n_send, dhalo.shape[1]), dtype=dhalo.dtype, device=dhalo.device)
-    work = dist.all_to_all_single(back, dhalo, plan.send_splits, plan.recv_splits, group=plan.group, async_op=async_op)
-    return back, (work if async_op else None)
-
-
-def _fold_back(plan, own2d, back):
-    """own2d[send_rows] += back, peer by peer in rank order (each peer's rows are sorted-unique: one writer per row, deterministic)."""
-    off = 0
-    for cnt in plan.send_splits:
-        if cnt:
-            _C.scatter_add_rows(own2d, plan.send_rows[off:off + cnt], back[off:off + cnt])
-        off += cnt
-    return own2d
+_ship_rows, _return_rows, _fold_back = halo.ship_rows, halo.return_rows, halo.fold_back
 
 
 def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p):
@@ -228,7 +199,7 @@ class _GATHidden(torch.autograd.Function):
         B = block_width(HD)                                             # [ft (HD) pad -> B | res (HD) pad -> B | el | er | pad]
         c = 2 * B if has_res else B
         ext = None
-        ctx.overlap = graph.halo is not None and OVERLAP and not sym
+        ctx.overlap = halo.enabled(graph) and not sym
         if ctx.overlap:                                                 # partitioned, overlapped: see OVERLAP above
             global OVERLAP_CALLS
             OVERLAP_CALLS += 1

@@ -746,3 +746,73 @@ def check_halo_split_sweeps(golden, device):
             oo, _ = _C.spmm_dot(sp["csr_own"], dx, w_csc, sp["csr_own_c2c"], ye[:n_own].contiguous(), dot=dot2)
             assert torch.allclose(torch.cat([oo, oh]), o1, atol=1e-5, rtol=1e-5) and torch.allclose(dot2, dot1, atol=1e-5, rtol=1e-5)
         fwd_close(full, ref, 2e-5)
+
+
+def check_halo_sums(golden, device):
+    """bot_amd.halo's overlapped aggregations (what GraphConv, the modular GATConv and the edge-feature GATConvs call in partitioned
+    mode) on the blocks of a 2- and 3-way partition, one process: the exchange is replaced by indexing a global table (forward) and
+    by recording the halo rows' gradients (backward), everything else — split sweeps, weights taken per part, fused backward over
+    the halo rows and the owned rows, fold-back — is the real code.  Against the one-exchange form (`ops.*` on the extended table)
+    of the same block: values and all three gradients to rounding (the per-destination order differs by design)."""
+    from bot_amd import dist as bdist, halo, ops
+    s, d, n = golden.graph("g300")
+    gen = torch.Generator().manual_seed(47)
+    H, D, F = 2, 10, 41                                                              # F = 41: the 2-D form pads to 44 columns
+    x = torch.randn(n, H, D, generator=gen)
+    x2 = torch.randn(n, F, generator=gen)
+    orig = halo.ship_rows, halo.return_rows
+    calls0 = halo.CALLS
+    try:
+        for world in (2, 3):
+            for rank in range(world):
+                p = bdist.build_partition(s, d, n, rank, world, device=device)
+                g, n_own = p.graph, p.n_owned
+                hg = p.halo_global.cpu()
+                nnz = g.csc.nnz
+                a = torch.rand(nnz, H, 1, generator=gen).to(device)
+                res = torch.randn(n_own, H, D, generator=gen).to(device)
+                gout = torch.randn(n_own, H, D, generator=gen).to(device)
+                gout2 = torch.randn(n_own, F, generator=gen).to(device)
+                for table, weighted in ((x, True), (x2, False)):
+                    sent = []
+                    flat = table.reshape(n, -1)
+                    if not weighted:
+                        flat = torch.nn.functional.pad(flat, (0, 3))               # the 2-D form ships its rows padded to x4 columns
+
+                    def fake_ship(plan, own2d, async_op=False, flat=flat):
+                        assert torch.equal(own2d.cpu(), flat[p.lo:p.hi])
+                        return flat[hg].to(device), None, None
+
+                    def fake_return(plan, dhalo, async_op=False):
+                        sent.append(dhalo.clone())
+                        return torch.zeros((plan.n_send, dhalo.shape[1]), device=device), (_Done() if async_op else None)
+
+                    halo.ship_rows, halo.return_rows = fake_ship, fake_return
+                    own = table[p.lo:p.hi].to(device).requires_grad_()
+                    ext = torch.cat([table[p.lo:p.hi], table[hg]]).to(device).requires_grad_()
+                    if weighted:
+                        a1, a2 = a.clone().requires_grad_(), a.clone().requires_grad_()
+                        r1, r2 = res.clone().requires_grad_(), res.clone().requires_grad_()
+                        one = ops.u_mul_e_sum(g, ext, a1, order="csc", addend=r1)
+                        two = halo.u_mul_e_sum(g, own, a2, addend=r2, transfer=halo.start(g, own))
+                        (one * gout).sum().backward()
+                        (two * gout).sum().backward()
+                        assert torch.allclose(a1.grad, a2.grad, atol=1e-5, rtol=1e-5) and torch.equal(r1.grad, r2.grad)
+                    else:
+                        one = ops.copy_u_sum(g, ext)
+                        two = halo.copy_u_sum(g, own)
+                        (one * gout2).sum().backward()
+                        (two * gout2).sum().backward()
+                    assert one.shape == two.shape and torch.allclose(one, two, atol=1e-5, rtol=1e-5)
+                    assert torch.allclose(own.grad, ext.grad[:n_own], atol=1e-5, rtol=1e-5)
+                    assert len(sent) == 1
+                    got = sent[0].view(hg.numel(), -1)[:, :flat.shape[1] - (0 if weighted else 3)]
+                    assert torch.allclose(got, ext.grad[n_own:].reshape(hg.numel(), -1), atol=1e-5, rtol=1e-5)
+    finally:
+        halo.ship_rows, halo.return_rows = orig
+    assert halo.CALLS - calls0 == 2 * (2 + 3)
+
+
+class _Done:
+    def wait(self):
+        return True

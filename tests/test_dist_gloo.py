@@ -62,7 +62,8 @@ def _worker(rank, world, port, kind, tmp, fuse=False, halves=False, overlap=True
         import bot_amd
         from bot_amd.nn import fused
         fused.FORCE = fuse
-        fused.OVERLAP = overlap                              # merged-GEMM layers: exchange overlapped with the owned-source sweeps, or the one-exchange form
+        from bot_amd import halo
+        halo.OVERLAP = overlap                               # exchange overlapped with the owned-source sweeps, or the one-exchange form
         from bot_amd import gemm
         gemm.FORCE = halves                                  # the projections on the fp16-halves path (emulated), both runs
         from bot_amd import dist as bdist
@@ -104,6 +105,9 @@ def _worker(rank, world, port, kind, tmp, fuse=False, halves=False, overlap=True
         assert (fused.CALLS > calls0) == (fuse and kind == "gat_plain"), (fused.CALLS, calls0)
         assert (fused.AGG_CALLS > 0) == (fuse and kind == "gat_plain")
         assert (fused.OVERLAP_CALLS > 0) == (fuse and kind == "gat_plain" and overlap), fused.OVERLAP_CALLS
+        # the modular layers (GraphConv, GATConv outside the fused node) take bot_amd.halo's overlapped sums
+        modular = kind in ("gat", "gcn") or not fuse
+        assert (halo.CALLS > 0) == (modular and overlap), (halo.CALLS, kind, fuse, overlap)
         assert not halves or gemm.STATS["split"] > 0
         assert abs(loss.item() - loss_ref.item()) < 1e-5, (loss.item(), loss_ref.item())
         np.testing.assert_allclose(pred.detach().numpy(), pred_ref.detach()[part.lo:part.hi].numpy(), rtol=1e-4, atol=1e-5)
@@ -120,16 +124,18 @@ def _worker(rank, world, port, kind, tmp, fuse=False, halves=False, overlap=True
                                                             ("gat", 3, False, False, True), ("gat_plain", 2, True, False, True),
                                                             ("gat_plain", 3, True, False, True), ("gat_plain", 2, False, False, True),
                                                             ("gat_plain", 2, True, True, True), ("gat_plain", 3, True, False, False),
-                                                            ("gat_plain", 1, True, False, True)])   # one rank: no halo rows at all
+                                                            ("gat_plain", 1, True, False, True),    # one rank: no halo rows at all
+                                                            ("gcn", 3, False, False, False), ("gat", 2, False, False, False),
+                                                            ("gcn", 1, False, False, True)])
 def test_partitioned_step_matches_single_process(kind, world, fuse, halves, overlap, tmp_path):
     """`overlap`: the merged-GEMM layers ship `el` first and the projected rows asynchronously, sweeping the owned-source edges
-    meanwhile (bot_amd/nn/fused.py OVERLAP) — per-destination sums then run owned-source edges first: same values to rounding;
+    meanwhile (bot_amd/halo.py; the modular layers through halo.copy_u_sum / halo.u_mul_e_sum) — per-destination sums then run owned-source edges first: same values to rounding;
     False: the one-exchange form."""
     mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), fuse, halves, overlap), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
-def _worker_edge(rank, world, port, kind, tmp):
+def _worker_edge(rank, world, port, kind, tmp, overlap=True):
     """The edge-feature GAT stacks of BASELINE configs 4 / 5 (ogbn-proteins / ogbn-products models) on a 1-D partition:
     logits of the owned rows and the all-reduced parameter gradients equal the single-process ones."""
     import torch.distributed as dist
@@ -141,8 +147,9 @@ def _worker_edge(rank, world, port, kind, tmp):
         from tests import _oracle_backend
         _oracle_backend.install_direct()
         import bot_amd
-        from bot_amd import dist as bdist
+        from bot_amd import dist as bdist, halo
         from bot_amd.nn import edge_gat
+        halo.OVERLAP = overlap
         s, d, n = Golden().graph("g300")
         E = s.numel()
         gen = torch.Generator().manual_seed(11)
@@ -174,6 +181,7 @@ def _worker_edge(rank, world, port, kind, tmp):
         if kind == "proteins":
             pg.edata["feat"] = ef[part.edge_ids]
         logits = model(pg)
+        assert (halo.CALLS == 3) == overlap, halo.CALLS       # one overlapped aggregation per layer
         (logits * gout[part.lo:part.hi]).sum().backward()
         bdist.all_reduce_grads(model)
         np.testing.assert_allclose(logits.detach().numpy(), logits_ref.detach()[part.lo:part.hi].numpy(), rtol=1e-4, atol=1e-5)
@@ -189,9 +197,9 @@ def _worker_edge(rank, world, port, kind, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world", [("proteins", 2), ("products", 2), ("proteins", 3)])
-def test_partitioned_edge_gat_matches_single_process(kind, world, tmp_path):
-    mp.spawn(_worker_edge, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("kind,world,overlap", [("proteins", 2, True), ("products", 2, True), ("proteins", 3, True), ("products", 3, False)])
+def test_partitioned_edge_gat_matches_single_process(kind, world, overlap, tmp_path):
+    mp.spawn(_worker_edge, args=(world, _free_port(), kind, str(tmp_path), overlap), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 

@@ -195,6 +195,12 @@ def test_halo_split_sweeps_on_device(golden):
     PC.check_halo_split_sweeps(golden, DEV)
 
 
+def test_halo_sums_on_device(golden):
+    """bot_amd.halo's overlapped aggregations (what the modular layers call in partitioned mode) on the real kernels, the exchange
+    replaced by indexing: forward, all gradients and the returned halo-row gradients against the one-exchange form."""
+    PC.check_halo_sums(golden, DEV)
+
+
 def test_proteins_golden(golden):
     PC.check_proteins_golden(golden, DEV)
 

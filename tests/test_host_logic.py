@@ -427,3 +427,8 @@ def test_workload_parity_procedure_emulated(cpu_backend, monkeypatch, name, scal
 
 def test_halo_split_sweeps_emulated(golden, cpu_backend):
     PC.check_halo_split_sweeps(golden, "cpu")
+
+
+def test_halo_sums_emulated(golden, cpu_backend):
+    """bot_amd.halo's overlapped aggregations (GraphConv / GATConv / edge-feature GATConv in partitioned mode) over the emulated backend."""
+    PC.check_halo_sums(golden, "cpu")
