@@ -19,7 +19,6 @@ import os
 import torch
 
 from . import _C
-from .graph import take_rows
 
 OVERLAP = os.environ.get("BOT_HALO_OVERLAP", "1") != "0"
 CALLS = 0           # aggregations that took the overlapped form here (tests assert the path was taken)
@@ -94,6 +93,18 @@ def start(graph, x_own) -> Transfer:
     return Transfer(*ship_rows(graph.halo, x2, async_op=True))
 
 
+def _part_weights(sub, pos, a2, n_src, H, D):
+    """Weights of one part of the split CSC: through the position map `pos` (the row kernels take it), or — where the part is dense
+    enough for the L2-blocked sweep, which reads its weights in the part's own order — gathered into an array of their own
+    (E*H floats against the E*H*D the sweep gathers)."""
+    if a2 is None:
+        return None, None
+    from . import blocked
+    if blocked.plan_for(sub, n_src, H, D) is not None:
+        return _C.gather_rows(a2, pos), None
+    return a2, pos
+
+
 class _HaloSum(torch.autograd.Function):
     """out[v] = sum over the in-edges (u -> v) of a_e * x[u] (a None: plain sum) (+ addend[v]) on a partition block, x given for
     the OWNED rows only.  a: [E, H] in CSC position order."""
@@ -109,18 +120,16 @@ class _HaloSum(torch.autograd.Function):
         H, D = x3.shape[1], x3.shape[2]
         if transfer is None:
             transfer = start(g, x)
-        a2 = a_own = a_halo = None
-        if a is not None:
-            a2 = _flat2(a).contiguous()
-            # the parts' weights as arrays of their own (E*H floats): a sweep without a position map may take the L2-blocked kernel
-            a_own, a_halo = take_rows(a2, sp["csc_own_pos"]), take_rows(a2, sp["csc_halo_pos"])
+        a2 = None if a is None else _flat2(a).contiguous()
         ad3 = None
         if addend is not None:
             ad3 = _pad4(addend).unsqueeze(1) if two_d else (addend if addend.dim() == 3 else _flat2(addend).unsqueeze(1))
-        out = _C.spmm(sp["csc_own"], x3, a_own, None, addend=ad3)                       # owned-source edges
+        w, wp = _part_weights(sp["csc_own"], sp["csc_own_pos"], a2, n_own, H, D)
+        out = _C.spmm(sp["csc_own"], x3, w, wp, addend=ad3)                             # owned-source edges
         halo3 = transfer.wait().view(plan.n_halo, H, D)
         if sp["csc_halo"].nnz:                                                          # halo-source edges on top
-            out = _C.spmm(sp["csc_halo"], halo3, a_halo, None, addend=out)
+            w, wp = _part_weights(sp["csc_halo"], sp["csc_halo_pos"], a2, plan.n_halo, H, D)
+            out = _C.spmm(sp["csc_halo"], halo3, w, wp, addend=out)
         ctx.g, ctx.xshape, ctx.two_d, ctx.ashape = g, x.shape, two_d, (None if a is None else a.shape)
         ctx.has_addend = addend is not None
         ctx.save_for_backward(x3, halo3, a2)
