@@ -40,6 +40,7 @@ def ref_attention(src, dst, n, el, er, ee, keep, slope):
 
 
 blocked_hits = 0
+flat_hits = 0
 for t in range(trials):
     n = ri(1, 400)
     dense = ri(0, 2) == 0
@@ -134,6 +135,33 @@ for t in range(trials):
             ys = torch.randn(Hi, n, Di, generator=gen, dtype=torch.float64).to(DEV)
             refd = (xs[srcp].unsqueeze(1) * ys[:, dstp].permute(1, 0, 2)).sum(-1)
             assert close(_C.sddmm_dot_bcast(csc, xs.float(), ys.float()), refd, 1e-4), ("sddmm_dot_bcast", t, n, E, Hi, Di)
+    # --- flat 16-byte-lane forward SpMM (round 3): 2..4 heads of a width that is not a multiple of 4, contiguous rows on an x4
+    #     pitch — against fp64 and BITWISE against the head-segment kernel
+    Hf, Df = ri(2, 4), ri(5, 255)
+    if E and Df % 4 and Hf * Df <= 1024:
+        pitch = (Hf * Df + 3) // 4 * 4 + 4 * ri(0, 3)
+        xfb = torch.randn(n, pitch, generator=gen, dtype=torch.float64).to(DEV)
+        wf = torch.rand(E, Hf, generator=gen, dtype=torch.float64).to(DEV)
+        adf = torch.randn(n, pitch, generator=gen, dtype=torch.float64).to(DEV) if ri(0, 1) else None
+        csc = g.csc
+        srcp = csc.indices.long()
+        dstp = torch.repeat_interleave(torch.arange(n, device=DEV), (csc.indptr[1:] - csc.indptr[:-1]).long())
+        x3 = xfb[:, :Hf * Df].unflatten(1, (Hf, Df))
+        reff = torch.zeros(n, Hf, Df, device=DEV, dtype=torch.float64).index_add_(0, dstp, x3[srcp] * wf.unsqueeze(-1))
+        ad3 = None if adf is None else adf[:, :Hf * Df].unflatten(1, (Hf, Df))
+        if ad3 is not None:
+            reff = reff + ad3
+        xs32 = xfb.float()[:, :Hf * Df].unflatten(1, (Hf, Df))
+        ad32 = None if adf is None else adf.float()[:, :Hf * Df].unflatten(1, (Hf, Df))
+        outs = {}
+        for lay in ("flat", "segments"):
+            _C.SPMM_LAYOUT = lay
+            outs[lay] = _C.spmm(csc, xs32, wf.float(), torch.arange(E, dtype=torch.int32, device=DEV), addend=ad32)
+            if lay == "flat":
+                flat_hits += "flat" in _C._lib.bot_last_kernel().decode()
+        _C.SPMM_LAYOUT = None
+        assert close(outs["flat"], reff, 1e-4), ("spmm flat", t, n, E, Hf, Df, pitch)
+        assert torch.equal(outs["flat"], outs["segments"]), ("spmm flat vs segments", t, n, E, Hf, Df, pitch)
     # --- dense products of round 2: random shapes, strides, magnitudes (fp64 reference; errors relative to the largest entry)
     m, k, nn = ri(1, 3000), ri(1, 256), ri(1, 300)
     mag = 10.0 ** ri(-9, 4)
@@ -167,4 +195,4 @@ for t in range(trials):
         refw = X.double().t() @ Dm.double()
         gotw = gemm.tn(xs, gemm.split(Dm, 0))
         assert float((gotw.double() - refw).abs().max()) <= 4e-6 * amax(refw), ("gemm_halves tn", t, mm, k, nn, mag)
-print(f"fuzz ok: {trials} trials (seed {seed}), {blocked_hits} of them on the L2-blocked path")
+print(f"fuzz ok: {trials} trials (seed {seed}), {blocked_hits} of them on the L2-blocked path, {flat_hits} flat-lane SpMM launches")
