@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -40,7 +40,7 @@ _SIGS = {
     "bot_spmm_blocked_f32": (ctypes.c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P,
                                             c_int32, c_int32, _P, c_int64, _P, c_int64, _P]),
     "bot_spmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P,
-                                        _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P]),
+                                        _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P, _P]),
     "bot_spmm_bcast_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, _P, _P, c_int32,
                                           c_int32, _P, c_int64, c_int64, _P, _P]),
     "bot_spmm_dot_bcast_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P,
@@ -91,7 +91,10 @@ _SIGS = {
     "bot_bn_act_bwd_reduce_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
                                                  c_uint64, _P, _P, _P, _P, _P]),
     "bot_bn_act_bwd_apply_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
-                                                c_uint64, _P, _P, _P, c_double, _P, c_int64, _P]),
+                                                c_uint64, _P, _P, _P, c_double, _P, c_int64, _P, _P]),
+    "bot_absmax_slots": (c_int32, []),
+    "bot_absmax_slots_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P]),
+    "bot_halves_scale_from_slots_f32": (ctypes.c_int, [_P, _P, _P]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(_lib, _name)  # AttributeError here = header and library disagree
@@ -291,11 +294,12 @@ def spmm_dot_max_d(x):
     return 1024 if (x.shape[2] % 4 == 0 and x.stride(0) % 4 == 0) else (512 if x.shape[2] % 2 == 0 and x.stride(0) % 2 == 0 else 256)
 
 
-def spmm_dot(d, x, w, wperm, y, out=None, dot=None):
+def spmm_dot(d, x, w, wperm, y, out=None, dot=None, absmax=None):
     """Fused backward of u_mul_e_sum on direction `d`:  out[r,h,:] = sum_k w[wperm[k],h] x[indices[k],h,:]  and
     dot[wperm[k],h] = <y[r,h,:], x[indices[k],h,:]>.  Returns (out [n_rows,H,D], dot [nnz,H]).
     `dot`: write into this [E,H] array instead of a fresh one — `d` may be a PART of a larger direction (Graph.halo_split) whose
-    entries are reached through `wperm`; the parts of one direction fill disjoint rows of the same array."""
+    entries are reached through `wperm`; the parts of one direction fill disjoint rows of the same array.
+    `absmax`: `absmax_slots()` words that receive max|out| as a by-product (include/bot_gnn.h "Maxima as by-products")."""
     _dev(x, w, y, d.indptr)
     x, ldx, hsx = _slab(x, "x")
     y, ldy, hsy = _slab(y, "y")
@@ -315,7 +319,7 @@ def spmm_dot(d, x, w, wperm, y, out=None, dot=None):
     _check(_timed("spmm_dot", (H, D), lambda: _lib.bot_spmm_dot_f32(
         d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
         _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, w.data_ptr(), _ptr(_i32(wperm, "wperm")), y.data_ptr(), ldy, hsy,
-        H, D, out.data_ptr(), ldo, hso, dot.data_ptr(), _ptr(partial), _stream())), "spmm_dot")
+        H, D, out.data_ptr(), ldo, hso, dot.data_ptr(), _ptr(partial), _ptr(absmax), _stream())), "spmm_dot")
     return out, dot
 
 
@@ -583,6 +587,26 @@ def halves_scale(x):
     return scale
 
 
+def absmax_slots(device):
+    """Zeroed words for the producers' max|value| by-products (include/bot_gnn.h "Maxima as by-products")."""
+    return torch.zeros(int(_lib.bot_absmax_slots()), dtype=torch.int32, device=device)
+
+
+def absmax_into(x, slots):
+    """Fold max|x| of a (row-strided) [n,F] float32 matrix into the slots — for the columns no producer kernel covers."""
+    _dev(x, slots)
+    x = _mat(x, "x")
+    _check(_lib.bot_absmax_slots_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], slots.data_ptr(), _stream()), "absmax_slots")
+    return slots
+
+
+def halves_scale_from_slots(slots):
+    """scale [2] = (s, 1/s) from the by-product slots: what halves_scale finds with a pass over the matrix."""
+    scale = torch.empty(2, dtype=torch.float32, device=slots.device)
+    _check(_lib.bot_halves_scale_from_slots_f32(slots.data_ptr(), scale.data_ptr(), _stream()), "halves_scale_from_slots")
+    return scale
+
+
 def halves_split(x, scale, order, piece, out=None):
     """fp16 halves of x [n,F] scaled by scale[0]: [h1|h1|h2] (order 0) or [h1|h2|h1] (order 1), pieces `piece` columns wide."""
     _dev(x, scale)
@@ -808,9 +832,10 @@ def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed):
     return sg, sgx
 
 
-def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, out=None):
+def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, out=None, absmax=None):
     """dx of the fused BatchNorm+ReLU+dropout; sum_g/sum_gx None = statistics were constants (eval mode).
-    `out` may be a row-strided [n,F] view (e.g. a column slice of a wider gradient buffer)."""
+    `out` may be a row-strided [n,F] view (e.g. a column slice of a wider gradient buffer).  `absmax`: `absmax_slots()` words that
+    receive max|dx| as a by-product."""
     _dev(dy, x)
     dy, x = _mat(dy, "dy"), _mat(x, "x")
     n, F = x.shape
@@ -818,7 +843,8 @@ def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, su
     assert dx.stride(1) == 1 and dx.dtype == torch.float32
     _check(_lib.bot_bn_act_bwd_apply_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, F, mean.data_ptr(),
                                          invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p), int(seed), _seed_off(p),
-                                         _ptr(sum_g), _ptr(sum_gx), float(total_count), dx.data_ptr(), dx.stride(0), _stream()),
+                                         _ptr(sum_g), _ptr(sum_gx), float(total_count), dx.data_ptr(), dx.stride(0), _ptr(absmax),
+                                         _stream()),
            "bn_act_bwd_apply")
     return dx
 

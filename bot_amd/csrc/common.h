@@ -152,6 +152,28 @@ struct Philox {
     }
 };
 
+// |value| maxima as a by-product of the kernel that PRODUCES a matrix (round 3: the operand of a halves GEMM needs max|x| for its
+// scale; a separate pass over a 1 GB gradient buffer costs 0.2 ms).  Non-negative floats order like their bit patterns, so the
+// maximum is taken with INTEGER atomics on kAbsmaxSlots words (spread by workgroup id): exact, order-free, reproducible.
+// fmaxf drops NaNs, like absmax_partial_kernel does.  The caller zeroes the slots; bot_halves_scale_from_slots_f32 reads them.
+constexpr int kAbsmaxSlots = 64;
+#ifdef __HIPCC__
+__device__ __forceinline__ float wave_absmax(float m) {            // every lane of the wave must call this
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
+__device__ __forceinline__ void absmax_publish(float wave_max, uint32_t* slots) {   // wave_max: the wave-reduced value
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t bits = __float_as_uint(wave_max);
+        uint32_t* p = slots + (blockIdx.x & (kAbsmaxSlots - 1));
+        if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, bits);   // most waves stop at the load
+    }
+}
+#endif
+// max|x| of a strided [n, F] matrix into the slots (halves.hip): the fall-back where a producer has no by-product form
+void launch_absmax_slots(const float* x, int64_t ldx, int64_t n, int32_t F, uint32_t* slots, hipStream_t st);
+
 // fp16-halves operand format (halves.hip): the second half of a LEFT operand is stored times 2^11, the third piece of a RIGHT
 // operand is 2^-11 h1, so that the a2 b1 term keeps its bits for rows far below the matrix maximum.
 constexpr float kHalvesShift = 2048.f;

@@ -114,6 +114,7 @@ struct BnArgs {
     float* dx;
     int64_t lddx;
     float* part;  // [kRowBlocks][2][F]
+    uint32_t* absmax;      // optional by-product of the backward apply pass: max|dx| (common.h absmax_publish)
     bool wx, wy, wdy, wdx;  // quad launches: which operands have 16-byte aligned rows (load_cols / store_cols)
 };
 
@@ -387,49 +388,53 @@ template <int VEC>
 __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
     const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
     const int c = (blockIdx.x * kTX + tx) * VEC;
-    if (c >= a.F) return;
-    const int nv = min(VEC, a.F - c);
-    float mu[VEC], is[VEC], sc[VEC], sh[VEC], mg[VEC], mgx[VEC];
-    load_param<VEC>(mu, a.mean, c, a.F, 0.f);
-    load_param<VEC>(is, a.invstd, c, a.F, 0.f);
-    load_param<VEC>(sc, a.w, c, a.F, 1.f);
-    load_param<VEC>(sh, a.b, c, a.F, 0.f);
-    load_param<VEC>(mg, a.sum_g, c, a.F, 0.f);                    // NULL sums: eval mode (running statistics are constants)
-    load_param<VEC>(mgx, a.sum_gx, c, a.F, 0.f);
+    float amax = 0.f;
+    if (c < a.F) {                       // (no early return: every lane takes part in the absmax reduction below)
+        const int nv = min(VEC, a.F - c);
+        float mu[VEC], is[VEC], sc[VEC], sh[VEC], mg[VEC], mgx[VEC];
+        load_param<VEC>(mu, a.mean, c, a.F, 0.f);
+        load_param<VEC>(is, a.invstd, c, a.F, 0.f);
+        load_param<VEC>(sc, a.w, c, a.F, 1.f);
+        load_param<VEC>(sh, a.b, c, a.F, 0.f);
+        load_param<VEC>(mg, a.sum_g, c, a.F, 0.f);                    // NULL sums: eval mode (running statistics are constants)
+        load_param<VEC>(mgx, a.sum_gx, c, a.F, 0.f);
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) mg[t] *= a.inv_count, mgx[t] *= a.inv_count;
-    const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
-    const int64_t nquad = (a.F + 3) / 4;
-    const uint64_t seed = eff_seed(a.seed, a.seed_offset);
-    constexpr int UR = 4;
-    const int64_t step = (int64_t)gridDim.y * kTY;
-    for (int64_t r0 = (int64_t)blockIdx.y * kTY + ty; r0 < a.n; r0 += step * UR) {
-        float v[UR][VEC], g[UR][VEC];
+        for (int t = 0; t < VEC; ++t) mg[t] *= a.inv_count, mgx[t] *= a.inv_count;
+        const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+        const int64_t nquad = (a.F + 3) / 4;
+        const uint64_t seed = eff_seed(a.seed, a.seed_offset);
+        constexpr int UR = 4;
+        const int64_t step = (int64_t)gridDim.y * kTY;
+        for (int64_t r0 = (int64_t)blockIdx.y * kTY + ty; r0 < a.n; r0 += step * UR) {
+            float v[UR][VEC], g[UR][VEC];
 #pragma unroll
-        for (int u = 0; u < UR; ++u) {
-            const int64_t r = r0 + u * step;
-            if (r < a.n) {
-                load_cols<VEC>(v[u], a.x + r * a.ldx + c, a.wx, nv);
-                load_cols<VEC>(g[u], a.dy + r * a.lddy + c, a.wdy, nv);
+            for (int u = 0; u < UR; ++u) {
+                const int64_t r = r0 + u * step;
+                if (r < a.n) {
+                    load_cols<VEC>(v[u], a.x + r * a.ldx + c, a.wx, nv);
+                    load_cols<VEC>(g[u], a.dy + r * a.lddy + c, a.wdy, nv);
+                }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < UR; ++u) {
-            const int64_t r = r0 + u * step;
-            if (r >= a.n) break;
-            float f[VEC];
-            if (a.p > 0.f) drop_factors<VEC>(seed, r, c, nquad, a.p, scale, f);
+            for (int u = 0; u < UR; ++u) {
+                const int64_t r = r0 + u * step;
+                if (r >= a.n) break;
+                float f[VEC];
+                if (a.p > 0.f) drop_factors<VEC>(seed, r, c, nquad, a.p, scale, f);
 #pragma unroll
-            for (int t = 0; t < VEC; ++t) {
-                const float xh = (v[u][t] - mu[t]) * is[t];
-                float gg = g[u][t];
-                if (a.p > 0.f) gg *= f[t];
-                if (a.relu && !(fmaf(xh, sc[t], sh[t]) > 0.f)) gg = 0.f;
-                v[u][t] = sc[t] * is[t] * (gg - mg[t] - xh * mgx[t]);
+                for (int t = 0; t < VEC; ++t) {
+                    const float xh = (v[u][t] - mu[t]) * is[t];
+                    float gg = g[u][t];
+                    if (a.p > 0.f) gg *= f[t];
+                    if (a.relu && !(fmaf(xh, sc[t], sh[t]) > 0.f)) gg = 0.f;
+                    v[u][t] = sc[t] * is[t] * (gg - mg[t] - xh * mgx[t]);
+                    if (t < nv) amax = fmaxf(amax, fabsf(v[u][t]));
+                }
+                store_cols<VEC>(a.dx + r * a.lddx + c, v[u], a.wdx, nv);
             }
-            store_cols<VEC>(a.dx + r * a.lddx + c, v[u], a.wdx, nv);
         }
     }
+    if (a.absmax) absmax_publish(wave_absmax(amax), a.absmax);
 }
 
 // Launch width of the BatchNorm kernels.  16 / 8 / 4-byte lanes when EVERY operand allows them (pick_vec); otherwise, for even
@@ -610,7 +615,7 @@ int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int
 int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
                              const float* mean, const float* invstd, const float* weight, const float* bias, int32_t relu,
                              float p, uint64_t seed, const uint64_t* seed_offset, const float* sum_g, const float* sum_gx,
-                             double total_count, float* dx, int64_t lddx, bot_stream_t stream) {
+                             double total_count, float* dx, int64_t lddx, uint32_t* absmax_slots, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && lddy >= F && lddx >= F, BOT_E_RANGE, "bn_act_bwd_apply: n=%lld F=%d", (long long)n, F);
     if (n == 0) return 0;
@@ -620,7 +625,7 @@ int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int6
     BnArgs a{};
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
     a.seed = seed, a.seed_offset = seed_offset, a.dy = dy, a.lddy = lddy, a.sum_g = sum_g, a.sum_gx = sum_gx, a.inv_count = sum_g ? (float)(1.0 / total_count) : 0.f;
-    a.dx = dx, a.lddx = lddx;
+    a.dx = dx, a.lddx = lddx, a.absmax = absmax_slots;
     bool quad;
     const int vec = bn_vec(F, {ldx, lddy, lddx}, {x, dy, dx}, &quad);
     a.wx = !quad || rows16(x, ldx), a.wdy = !quad || rows16(dy, lddy), a.wdx = !quad || rows16(dx, lddx);

@@ -125,6 +125,25 @@ void launch_halves_scale(const float* part, int n, float* scale, hipStream_t st)
     hipLaunchKernelGGL(halves_scale_kernel, dim3(1), dim3(kWave), 0, st, part, n, scale);
 }
 
+// max|x| of a strided matrix into the by-product slots (common.h): the same reduction as absmax_partial_kernel, published with the
+// integer atomic instead of a partials array
+__global__ __launch_bounds__(kBlock) void absmax_slots_kernel(const float* x, int64_t ldx, int64_t n, int32_t F, uint32_t* slots) {
+    float m = 0.f;
+    const int64_t total = n * (int64_t)F;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / F;
+        m = fmaxf(m, fabsf(x[r * ldx + (i - r * F)]));
+    }
+    absmax_publish(wave_absmax(m), slots);
+}
+
+void launch_absmax_slots(const float* x, int64_t ldx, int64_t n, int32_t F, uint32_t* slots, hipStream_t st) {
+    const int64_t total = n * (int64_t)F;
+    if (total <= 0) return;
+    const int blocks = (int)max((int64_t)1, min((int64_t)kMaxBlocks, (total + kBlock * 8 - 1) / (kBlock * 8)));
+    hipLaunchKernelGGL(absmax_slots_kernel, dim3(blocks), dim3(kBlock), 0, st, x, ldx, n, F, slots);
+}
+
 }  // namespace bot
 
 extern "C" {
@@ -141,6 +160,24 @@ int bot_halves_scale_f32(const float* x, int64_t ldx, int64_t n, int32_t F, floa
     hipLaunchKernelGGL(absmax_partial_kernel, dim3(blocks), dim3(kBlock), 0, st, x, ldx, n, F, workspace);
     launch_halves_scale(workspace, blocks, scale, st);
     return hip_status("halves_scale launch");
+}
+
+int32_t bot_absmax_slots(void) { return bot::kAbsmaxSlots; }
+
+int bot_absmax_slots_f32(const float* x, int64_t ldx, int64_t n, int32_t F, uint32_t* slots, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F, BOT_E_RANGE, "absmax_slots: n=%lld F=%d ldx=%lld", (long long)n, F, (long long)ldx);
+    BOT_REQUIRE(slots && (x || n == 0), BOT_E_NULL, "absmax_slots: NULL pointer");
+    launch_absmax_slots(x, ldx, n, F, slots, (hipStream_t)stream);
+    return hip_status("absmax_slots launch");
+}
+
+int bot_halves_scale_from_slots_f32(const uint32_t* slots, float* scale, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(slots && scale, BOT_E_NULL, "halves_scale_from_slots: NULL pointer");
+    // a non-negative float and its bit pattern are the same word: the slots ARE an array of partial maxima
+    launch_halves_scale(reinterpret_cast<const float*>(slots), kAbsmaxSlots, scale, (hipStream_t)stream);
+    return hip_status("halves_scale_from_slots launch");
 }
 
 int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,

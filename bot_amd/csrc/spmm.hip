@@ -38,6 +38,8 @@ struct SpmmArgs {
     // optional epilogue of the forward SpMM: out[r,h,:] += addend[r,h,:] (the layer's residual branch, models.py:558-560)
     const float* addend;
     int64_t lda, hsa;
+    // optional by-product of the fused backward: max|out| into kAbsmaxSlots words (common.h absmax_publish)
+    uint32_t* absmax;
 };
 
 // Backward of u_mul_e_sum in ONE sweep over the out-edges (CSR direction) — each gathered row dx[v,h,:] is used twice:
@@ -217,6 +219,17 @@ __global__ __launch_bounds__(kBlock) void spmm_dot_rows_kernel(SpmmArgs a) {
                                  : a.partial + (int64_t)slot * a.ldp + (int64_t)hd[c] * a.D + el[c];
             vstore<VEC>(ob, acc[c]);
         }
+    if (a.absmax) {                      // wave-uniform; the chunks of a long row are finished (and measured) by spmm_combine_kernel
+        float m = 0.f;
+        if (slot < 0) {
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+                for (int t = 0; t < VEC; ++t)
+                    if (act[c]) m = fmaxf(m, fabsf(acc[c][t]));
+        }
+        absmax_publish(wave_absmax(m), a.absmax);
+    }
 }
 
 // The weighted forward SpMM in the same all-heads layout as spmm_dot_rows_kernel (one wavefront per work item, a head = HL
@@ -499,17 +512,20 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs a) {
 __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(const int32_t* long_rows, const int32_t* long_ptr,
                                                              int64_t n_long, int32_t H, int32_t D, const float* partial,
                                                              int64_t ldp, float* out, int64_t ldo, int64_t hso,
-                                                             const float* addend = nullptr, int64_t lda = 0, int64_t hsa = 0) {
+                                                             const float* addend = nullptr, int64_t lda = 0, int64_t hsa = 0,
+                                                             uint32_t* absmax = nullptr) {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t hd = (int64_t)H * D;
-    if (gid >= n_long * hd) return;
-    const int64_t i = gid / hd;
-    const int e = (int)(gid - i * hd);
-    const int h = e / D, d = e - h * D;
     float s = 0.f;
-    for (int p = long_ptr[i]; p < long_ptr[i + 1]; ++p) s += partial[(int64_t)p * ldp + e];
-    if (addend) s += addend[(int64_t)long_rows[i] * lda + (int64_t)h * hsa + d];
-    out[(int64_t)long_rows[i] * ldo + (int64_t)h * hso + d] = s;
+    if (gid < n_long * hd) {
+        const int64_t i = gid / hd;
+        const int e = (int)(gid - i * hd);
+        const int h = e / D, d = e - h * D;
+        for (int p = long_ptr[i]; p < long_ptr[i + 1]; ++p) s += partial[(int64_t)p * ldp + e];
+        if (addend) s += addend[(int64_t)long_rows[i] * lda + (int64_t)h * hsa + d];
+        out[(int64_t)long_rows[i] * ldo + (int64_t)h * hso + d] = s;
+    }
+    if (absmax) absmax_publish(wave_absmax(fabsf(s)), absmax);     // all 64 lanes arrive here (no early return above)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -951,7 +967,7 @@ int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_ro
                      int64_t n_items, const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, const float* x,
                      int64_t ldx, int64_t hsx, const float* w, const int32_t* wperm, const float* y, int64_t ldy, int64_t hsy,
                      int32_t H, int32_t D, float* out, int64_t ldo, int64_t hso, float* dot_out, float* partial,
-                     bot_stream_t stream) {
+                     uint32_t* absmax_slots, bot_stream_t stream) {
     using namespace bot;
     (void)indptr;
     BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_items >= 0 && n_long >= 0, BOT_E_RANGE, "spmm_dot: negative size");
@@ -968,6 +984,7 @@ int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_ro
     const int vec = pick_vec(D, {ldx, hsx, ldo, hso, ldy, hsy}, {x, out, partial, y});
     BOT_REQUIRE(D <= vec * 256, BOT_E_RANGE, "spmm_dot: D=%d exceeds the %d floats one launch tile covers (use bot_spmm_f32 + bot_sddmm_dot_f32)",
                 D, vec * 256);
+    a.absmax = absmax_slots;             // by-product of the all-heads kernel and of the long rows' combine pass
     const bool rows = vec == 4 ? dispatch_spmm_dot_rows<4>(a, st) : (vec == 2 ? dispatch_spmm_dot_rows<2>(a, st) : dispatch_spmm_dot_rows<1>(a, st));
     if (!rows) {
         if (vec == 4) dispatch_spmm_dot<4>(a, st);
@@ -978,8 +995,13 @@ int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_ro
     if (n_long > 0) {
         const int64_t n = n_long * H * D;
         hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows,
-                           long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso, (const float*)nullptr, (int64_t)0, (int64_t)0);
+                           long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso, (const float*)nullptr, (int64_t)0, (int64_t)0,
+                           rows ? absmax_slots : (uint32_t*)nullptr);
         if (int rc = hip_status("spmm_dot combine launch")) return rc;
+    }
+    if (absmax_slots && !rows) {         // the head-major kernel has no by-product form: one pass per head slab over the result
+        for (int h = 0; h < H; ++h) launch_absmax_slots(out + (int64_t)h * hso, ldo, n_rows, D, absmax_slots, st);
+        if (int rc = hip_status("spmm_dot absmax launch")) return rc;
     }
     return 0;
 }

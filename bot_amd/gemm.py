@@ -38,11 +38,13 @@ class Halves:
         self.buf, self.scale, self.n, self.F, self.piece, self.order = buf, scale, n, F, piece, order
 
 
-def split(x, order: int) -> Halves:
-    """order 0: left operand [h1 | h1 | 2^11 h2]; order 1: right operand [h1 | h2 | 2^-11 h1] (both reduce over their columns)."""
+def split(x, order: int, scale=None) -> Halves:
+    """order 0: left operand [h1 | h1 | 2^11 h2]; order 1: right operand [h1 | h2 | 2^-11 h1] (both reduce over their columns).
+    `scale`: the (s, 1/s) pair when the caller already has it (max|x| delivered by the kernels that wrote x)."""
     n, F = x.shape
     piece = (F + PIECE_ALIGN - 1) // PIECE_ALIGN * PIECE_ALIGN
-    scale = _C.halves_scale(x)
+    if scale is None:
+        scale = _C.halves_scale(x)
     return Halves(_C.halves_split(x, scale, order, piece), scale, n, F, piece, order)
 
 

@@ -27,6 +27,7 @@ from ..graph import take_rows
 from ..ops import bn_batch_stats, new_dropout_seed
 
 
+ABSMAX_BYPRODUCT = os.environ.get("BOT_ABSMAX_BYPRODUCT", "1") != "0"   # max|gradient| from its producers instead of a pass (_GATHidden.backward)
 SKINNY = os.environ.get("BOT_SKINNY", "1") != "0"   # the small-K products of the aggregate-first layer on bot_skinny_gemm_f32
 FORCE = False  # tests set this to run the fused node over the emulated (CPU) backend
 CALLS = 0      # number of fused-layer invocations (tests assert the path was actually taken)
@@ -292,6 +293,7 @@ class _GATHidden(torch.autograd.Function):
         B = block_width(HD)
         dout = torch.empty((N, P), dtype=dy.dtype, device=h.device)
         dx = dout[:, B:B + HD] if has_res else torch.empty((N, HD), dtype=dy.dtype, device=h.device)
+        slots = None
         if B != HD:                                                     # the pad columns meet zero weight rows: they must be finite
             dout[:, HD:B].zero_()
             if has_res:
@@ -305,8 +307,12 @@ class _GATHidden(torch.autograd.Function):
                 both = torch.stack([sg, sgx])
                 dist.all_reduce(both, group=group)
                 sg, sgx = both[0].contiguous(), both[1].contiguous()
+            # the gradient buffer becomes a halves-GEMM operand below: its two big producers (this pass: dx, the fused sweep: d ft)
+            # deliver max|value| as they write, instead of a separate 1 GB pass (include/bot_gnn.h "Maxima as by-products")
+            if ctx.halves is not None and has_res and not ctx.overlap and g.halo is None and ABSMAX_BYPRODUCT:
+                slots = _C.absmax_slots(dy.device)
             _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
-                                sgx if bn_training else None, total, out=dx)
+                                sgx if bn_training else None, total, out=dx, absmax=slots)
         c = 2 * B if has_res else B
         if ctx.overlap:
             # halo rows first — their gradients travel back while the owned rows are swept and the attention backward runs
@@ -339,7 +345,7 @@ class _GATHidden(torch.autograd.Function):
         else:
             dft_dst = dout[:, :HD].unflatten(1, (H, D))
         if not skip_sweep:
-            _, da = _C.spmm_dot(g.csr, dx.unflatten(1, (H, D)), a_d, g.csr2csc, ft, out=dft_dst)
+            _, da = _C.spmm_dot(g.csr, dx.unflatten(1, (H, D)), a_d, g.csr2csc, ft, out=dft_dst, absmax=slots)
             if ctx.sym:
                 s_out, w_e = sym_scales(g)
                 da = da * w_e
@@ -366,7 +372,11 @@ class _GATHidden(torch.autograd.Function):
         dW = dh = None
         if ctx.halves is not None:
             xh = gemm.Halves(h, ctx.xscale, *ctx.halves, 0)
-            dh_ = gemm.split(dout, 0)
+            if slots is not None:                                        # + the few score columns no big producer covers
+                _C.absmax_into(dout[:, c:used], slots)
+                dh_ = gemm.split(dout, 0, scale=_C.halves_scale_from_slots(slots))
+            else:
+                dh_ = gemm.split(dout, 0)
             if ctx.needs_input_grad[1]:
                 dW = gemm.tn(xh, dh_)                                    # [K, P]
                 dW = dW if kp else dW.t().contiguous()

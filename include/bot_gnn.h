@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 11
+#define BOT_ABI_VERSION 12
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -136,6 +136,8 @@ int bot_spmm_blocked_f32(const int32_t* tile_rows, const int32_t* ptr, const int
  *
  * so a GAT layer's backward needs one E*H*D gather instead of the two of bot_spmm_f32 + bot_sddmm_dot_f32.
  * y is the layer's forward input slab (row-local).  D <= 1024 (16-byte aligned slabs) / 512 / 256.
+ * absmax_slots (optional, NULL = off): max|out| is folded into these bot_absmax_slots() words as a by-product (see
+ * "Maxima as by-products" below) — `out` then needs no separate pass before it becomes a halves-GEMM operand.
  * ------------------------------------------------------------------------------------------- */
 int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
                      const int32_t* items, int64_t n_items,
@@ -145,7 +147,7 @@ int bot_spmm_dot_f32(const int32_t* indptr, const int32_t* indices, int64_t n_ro
                      const float* y, int64_t ldy, int64_t hsy,
                      int32_t H, int32_t D,
                      float* out, int64_t ldo, int64_t hso,
-                     float* dot_out, float* partial, bot_stream_t stream);
+                     float* dot_out, float* partial, uint32_t* absmax_slots, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Aggregate-before-project forms of u_mul_e_sum (models.py:547) for layers whose input is narrower than H*D — the
@@ -363,7 +365,8 @@ int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int
 int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
                              const float* mean, const float* invstd, const float* weight, const float* bias,
                              int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, const float* sum_g,
-                             const float* sum_gx, double total_count, float* dx, int64_t lddx, bot_stream_t stream);
+                             const float* sum_gx, double total_count, float* dx, int64_t lddx, uint32_t* absmax_slots /* optional: max|dx|,
+                             "Maxima as by-products" */, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Merged projection weight of a GAT layer (host-side convenience of the fused layer node, not a DGL operator): the layer's
@@ -440,6 +443,15 @@ int bot_random_keep_u8(int64_t n, int64_t n_keep, uint64_t seed, uint8_t* keep, 
  * ------------------------------------------------------------------------------------------- */
 int64_t bot_halves_workspace_floats(void);
 int bot_halves_scale_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* scale, float* workspace, bot_stream_t stream);
+/* Maxima as by-products (v12).  The scale of an operand only needs max|x|; when x is a gradient buffer that several kernels have just
+ * written, they can deliver it: bot_spmm_dot_f32 and bot_bn_act_bwd_apply_f32 take `absmax_slots`, an array of bot_absmax_slots()
+ * uint32 words that the CALLER ZEROES; every workgroup folds the largest |value| it stored into one of them as a bit pattern
+ * (non-negative floats order like unsigned integers: an integer atomic max — exact, independent of the order of arrival; NaNs are
+ * skipped as in halves_scale).  bot_absmax_slots_f32 adds a strided matrix the slow way (the few columns no producer covers);
+ * bot_halves_scale_from_slots_f32 turns the slots into the same (s, 1/s) pair bot_halves_scale_f32 would have found. */
+int32_t bot_absmax_slots(void);
+int bot_absmax_slots_f32(const float* x, int64_t ldx, int64_t n, int32_t F, uint32_t* slots, bot_stream_t stream);
+int bot_halves_scale_from_slots_f32(const uint32_t* slots, float* scale, bot_stream_t stream);
 int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
                          int64_t ldo, int32_t piece, bot_stream_t stream);
 int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, const float* alpha, const uint16_t* A,

@@ -41,12 +41,13 @@ def spmm_dot_max_d(x):
     return 1024
 
 
-def spmm_dot(d, x, w, wperm, y, out=None, dot=None):
+def spmm_dot(d, x, w, wperm, y, out=None, dot=None, absmax=None):
     res = spmm(d, x, w, wperm)
     if out is not None:
         out.copy_(res)
     else:
         out = res
+    _fold_absmax(absmax, res)
     val = (x[d.indices.long()] * y[_rows(d)]).sum(-1)
     if dot is None:
         dot = torch.empty_like(val)
@@ -240,6 +241,27 @@ def halves_scale(x):
     return _pow2_scale(float(x.abs().max()) if x.numel() else 0.0)
 
 
+# maxima as by-products (include/bot_gnn.h): int32 words holding the bit patterns of non-negative floats; one slot suffices here
+def absmax_slots(device):
+    return torch.zeros(64, dtype=torch.int32, device=device)
+
+
+def _fold_absmax(slots, t):
+    if slots is not None and t.numel():
+        m = t.detach().float().abs()
+        m = m[~torch.isnan(m)].max() if bool((~torch.isnan(m)).any()) else m.new_zeros(())
+        slots[0] = torch.maximum(slots[0], m.reshape(1).view(torch.int32)[0])
+
+
+def absmax_into(x, slots):
+    _fold_absmax(slots, x)
+    return slots
+
+
+def halves_scale_from_slots(slots):
+    return _pow2_scale(float(slots.max().reshape(1).view(torch.float32)[0]))
+
+
 def halves_split(x, scale, order, piece, out=None):
     n, F = x.shape
     z = x.float() * (float(scale[0]) if scale is not None else 1.0)
@@ -296,11 +318,12 @@ def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed):
     return g.sum(0), (g * xh).sum(0)
 
 
-def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, out=None):
+def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, out=None, absmax=None):
     xh, o = _bn_gate(x, mean, invstd, weight, bias, relu, p)
     g = torch.where(o > 0, dy, torch.zeros_like(dy)) if relu else dy
     w = weight if weight is not None else 1.0
     res = w * invstd * g if sum_g is None else w * invstd * (g - sum_g / total_count - xh * sum_gx / total_count)
+    _fold_absmax(absmax, res)
     if out is not None:
         out.copy_(res)
         return out
@@ -330,7 +353,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -816,3 +816,67 @@ def check_halo_sums(golden, device):
 class _Done:
     def wait(self):
         return True
+
+
+def check_absmax_byproducts(golden, device):
+    """include/bot_gnn.h "Maxima as by-products": the fused backward sweep (all-heads kernel, long rows through the combine pass, and
+    the head-major fall-back) and the BatchNorm backward deliver max|what they wrote| exactly; the scale made from the slots equals
+    the scale of a pass over the assembled matrix; and a fused GAT stack's gradients are BITWISE the same with the by-products as
+    with the separate pass (a power-of-two scale that is equal gives equal halves)."""
+    from bot_amd import _C, gemm
+    from bot_amd.nn import fused
+    s, d, n = golden.graph("g300")
+    gen = torch.Generator().manual_seed(53)
+    as_f32 = lambda slots: slots.view(torch.float32).max()
+    for chunk, H, D in ((8, 3, 250), (None, 3, 250), (8, 1, 40), (8, 2, 10), (None, 9, 7)):
+        g = bot_amd.Graph(s, d, n, chunk=chunk).to(device)
+        x = torch.randn(n, H, D, generator=gen).to(device) * 3.0
+        y = torch.randn(n, H, D, generator=gen).to(device)
+        w = torch.rand(g.csr.nnz, H, generator=gen).to(device)
+        slots = _C.absmax_slots(device)
+        out, _ = _C.spmm_dot(g.csr, x, w, g.csr2csc, y, absmax=slots)
+        assert float(as_f32(slots)) == float(out.abs().max()), (chunk, H, D)
+        out2, _ = _C.spmm_dot(g.csr, x, w, g.csr2csc, y)
+        assert torch.equal(out, out2)
+    # BatchNorm backward into a column block of a wider buffer, odd width, dropout on
+    nrow, Fw = 1000, 750
+    xx, dy = torch.randn(nrow, Fw, generator=gen).to(device), torch.randn(nrow, Fw, generator=gen).to(device)
+    mean, var = xx.mean(0), xx.var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    bw, bb = torch.rand(Fw, generator=gen).to(device) + 0.5, torch.randn(Fw, generator=gen).to(device)
+    pdrop = 0.25 if str(device) != "cpu" else 0.0                                   # (the CPU emulation has no Philox stream)
+    sg, sgx = _C.bn_act_bwd_reduce(dy, xx, mean, invstd, bw, bb, True, pdrop, 7)
+    buf = torch.zeros(nrow, 2 * 752 + 8, device=device)
+    slots = _C.absmax_slots(device)
+    _C.bn_act_bwd_apply(dy, xx, mean, invstd, bw, bb, True, pdrop, 7, sg, sgx, float(nrow), out=buf[:, 752:752 + Fw], absmax=slots)
+    assert float(as_f32(slots)) == float(buf.abs().max()) > 0
+    buf[:, 1504:1510] = torch.randn(nrow, 6, generator=gen).to(device) * 40.0
+    _C.absmax_into(buf[:, 1504:1510], slots)
+    assert float(as_f32(slots)) == float(buf.abs().max())
+    assert torch.equal(_C.halves_scale_from_slots(slots).cpu(), _C.halves_scale(buf).cpu())
+    assert torch.equal(_C.halves_scale_from_slots(_C.absmax_slots(device)).cpu(), torch.tensor([1.0, 1.0]))   # nothing recorded: s = 1
+    # a fused stack, projections on the halves path: same gradients bit for bit, and the by-product form is the one that ran
+    g = bot_amd.Graph(s, d, n).to(device)
+    fin, C = 20, 5
+    cfg = dict(n_layers=3, n_heads=3, n_hidden=16, norm="batch", non_interactive_attn=True, use_symmetric_norm=False, linear=True,
+               residual=False)
+    feat, gout = torch.randn(n, fin, generator=gen).to(device), torch.randn(n, C, generator=gen).to(device)
+    grads = {}
+    force0, by0, ff0 = gemm.FORCE, fused.ABSMAX_BYPRODUCT, fused.FORCE
+    calls = []
+    orig = _C.halves_scale_from_slots
+    try:
+        gemm.FORCE = fused.FORCE = True                                             # (the fused nodes / halves path at this size and on the emulated backend)
+        _C.halves_scale_from_slots = lambda sl: (calls.append(1), orig(sl))[1]
+        for by in (True, False):
+            fused.ABSMAX_BYPRODUCT = by
+            torch.manual_seed(11)
+            model = bnn.GAT(dim_node=fin, dim_edge=0, dim_output=C, activation=F.relu, **cfg).train().to(device)
+            n0 = len(calls)
+            (model(g, feat) * gout).sum().backward()
+            assert (len(calls) > n0) == by
+            grads[by] = {k: p.grad.clone() for k, p in model.named_parameters()}
+    finally:
+        gemm.FORCE, fused.ABSMAX_BYPRODUCT, fused.FORCE, _C.halves_scale_from_slots = force0, by0, ff0, orig
+    for k in grads[True]:
+        assert torch.equal(grads[True][k], grads[False][k]), k

@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 11
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 12
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
@@ -193,6 +193,12 @@ def test_halo_split_sweeps_on_device(golden):
     """The split structures and two-pass sweeps of the overlapped partitioned layer (bot_amd.nn.fused OVERLAP, Graph.halo_split) on the
     real kernels: blocks of 2- and 3-way partitions side by side in one process."""
     PC.check_halo_split_sweeps(golden, DEV)
+
+
+def test_absmax_byproducts_on_device(golden):
+    """max|value| delivered by the kernels that write the gradient buffer (fused backward sweep incl. long rows and the head-major
+    fall-back, BatchNorm backward) is exact, and a fused stack's gradients are bitwise unchanged by it."""
+    PC.check_absmax_byproducts(golden, DEV)
 
 
 def test_halo_sums_on_device(golden):

@@ -429,6 +429,11 @@ def test_halo_split_sweeps_emulated(golden, cpu_backend):
     PC.check_halo_split_sweeps(golden, "cpu")
 
 
+def test_absmax_byproducts_emulated(golden, cpu_backend):
+    """The by-product maxima of the gradient buffer's producers (host plumbing over the emulated backend; the kernels: GPU suite)."""
+    PC.check_absmax_byproducts(golden, "cpu")
+
+
 def test_halo_sums_emulated(golden, cpu_backend):
     """bot_amd.halo's overlapped aggregations (GraphConv / GATConv / edge-feature GATConv in partitioned mode) over the emulated backend."""
     PC.check_halo_sums(golden, "cpu")
