@@ -166,7 +166,7 @@ __device__ __forceinline__ float wave_absmax(float m) {            // every lane
 __device__ __forceinline__ void absmax_publish(float wave_max, uint32_t* slots) {   // wave_max: the wave-reduced value
     if ((threadIdx.x & 63) == 0) {
         const uint32_t bits = __float_as_uint(wave_max);
-        uint32_t* p = slots + (blockIdx.x & (kAbsmaxSlots - 1));
+        uint32_t* p = slots + ((blockIdx.x + 7 * blockIdx.y) & (kAbsmaxSlots - 1));   // 2-D grids (BatchNorm: 3 x 256 blocks) spread too
         if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, bits);   // most waves stop at the load
     }
 }
