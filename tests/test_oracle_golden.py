@@ -338,3 +338,49 @@ def test_oracle_against_scipy_sparse(golden):
         np.testing.assert_allclose(c_ops.edge_softmax(cg, e.float()).squeeze(-1).numpy(), ex / den[d.numpy()], rtol=1e-5, atol=1e-6)
         assert np.array_equal(torch.bincount(d, minlength=n).numpy(), np.asarray(A.sum(0)).ravel().astype(np.int64))       # in-degrees
         assert np.array_equal(torch.bincount(s, minlength=n).numpy(), np.asarray(A.sum(1)).ravel().astype(np.int64))       # out-degrees
+
+
+def test_oracle_backward_against_torch_sparse_autograd(golden):
+    """The BACKWARD of the operators, pinned by a library's own derivation: torch.sparse (`torch.sparse.mm`, `torch.sparse.softmax` and
+    their autograd) computes the same aggregation and the same per-destination softmax on a sparse [dst, src] matrix without any of
+    this repository's code.  oracle/ref_ops.py (autograd through index ops) and the C kernels' hand-written backward (oracle/c_ops.py)
+    must give the same forward values AND the same gradients with respect to the node features, the edge weights and the edge logits.
+    Simple graphs (torch coalesces duplicate entries; DGL's multigraph semantics are covered by the SciPy test above)."""
+    from oracle import c_ops
+    gen = torch.Generator().manual_seed(91)
+    rs, rd = torch.randint(0, 60, (500,), generator=gen), torch.randint(0, 60, (500,), generator=gen)
+    key = torch.unique(rs * 60 + rd)                                       # a random simple digraph with self-loops
+    cases = [golden.graph("g64"), golden.graph("g300"), (key // 60, key % 60, 60)]
+    for s, d, n in cases:
+        assert torch.unique(s * n + d).numel() == s.numel()                # no parallel edges
+        E, D = s.numel(), 6
+        idx = torch.stack([d, s])                                          # row = destination, column = source
+        x0 = torch.randn(n, D, generator=gen, dtype=torch.float64)
+        w0 = torch.rand(E, generator=gen, dtype=torch.float64) + 0.1
+        e0 = torch.randn(E, generator=gen, dtype=torch.float64) * 3
+        gout = torch.randn(n, D, generator=gen, dtype=torch.float64)
+        ga = torch.randn(E, generator=gen, dtype=torch.float64)
+
+        def lib_side():
+            x, w, e = (t.clone().requires_grad_() for t in (x0, w0, e0))
+            out = torch.sparse.mm(torch.sparse_coo_tensor(idx, w, (n, n)), x)                       # u_mul_e_sum
+            sm = torch.sparse.softmax(torch.sparse_coo_tensor(idx, e, (n, n)).coalesce(), dim=1)     # softmax over each destination's in-edges
+            order = torch.argsort(d * n + s)                                                         # coalesced order -> edge order
+            a = torch.empty_like(e0).index_put((order,), sm.values())
+            ((out * gout).sum() + (a * ga).sum()).backward()
+            return out.detach(), a.detach(), x.grad, w.grad, e.grad
+
+        def oracle_side(dtype, ops_mod, graph):
+            x, w, e = (t.clone().to(dtype).requires_grad_() for t in (x0, w0, e0))
+            out = ops_mod.u_mul_e_sum(*graph, x.view(n, 1, D), w.view(E, 1, 1)).view(n, D)
+            a = (ops_mod.edge_softmax(d, n, e.view(E, 1, 1)) if ops_mod is R else ops_mod.edge_softmax(graph[0], e.view(E, 1, 1))).view(E)
+            ((out * gout.to(dtype)).sum() + (a * ga.to(dtype)).sum()).backward()
+            return out.detach(), a.detach(), x.grad, w.grad, e.grad
+
+        want = lib_side()
+        got = oracle_side(torch.float64, R, (s, d, n))
+        for g_, w_, name in zip(got, want, ("out", "a", "dx", "dw", "de")):
+            np.testing.assert_allclose(g_.numpy(), w_.numpy(), rtol=1e-10, atol=1e-12, err_msg=f"ref_ops {name}")
+        got = oracle_side(torch.float32, c_ops, (c_ops.CGraph(s, d, n),))
+        for g_, w_, name in zip(got, want, ("out", "a", "dx", "dw", "de")):
+            np.testing.assert_allclose(g_.double().numpy(), w_.numpy(), rtol=2e-4, atol=2e-5, err_msg=f"c_ops {name}")
