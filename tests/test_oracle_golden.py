@@ -384,3 +384,27 @@ def test_oracle_backward_against_torch_sparse_autograd(golden):
         got = oracle_side(torch.float32, c_ops, (c_ops.CGraph(s, d, n),))
         for g_, w_, name in zip(got, want, ("out", "a", "dx", "dw", "de")):
             np.testing.assert_allclose(g_.double().numpy(), w_.numpy(), rtol=2e-4, atol=2e-5, err_msg=f"c_ops {name}")
+
+
+def test_preprocess_edge_set_against_scipy(golden):
+    """`preprocess` (run.py:133-148: to_bidirected, remove_self_loop, add_self_loop) as SET algebra done by SciPy: the edge set must be
+    the symmetric closure of the raw edges without the diagonal, plus every self-loop exactly once — whatever the raw list holds
+    (duplicates, self-loops, one-directional and already-bidirectional pairs).  The ORDER of the edges (DGL's convention: sorted pairs,
+    self-loops appended last) is what the golden fixtures and the reference's call sites pin; this pins the set and the multiplicities."""
+    import scipy.sparse as sp
+    gen = torch.Generator().manual_seed(5)
+    for n, e in ((1, 0), (7, 0), (40, 300), (300, 900), (64, 64 * 64)):
+        s = torch.randint(0, n, (e,), generator=gen)
+        d = torch.randint(0, n, (e,), generator=gen)
+        ps, pd = R.preprocess_edges(s, d, n)
+        A = sp.coo_matrix((np.ones(e), (s.numpy(), d.numpy())), shape=(n, n)).tocsr()
+        S = ((A + A.T) != 0).astype(np.int64).tolil()
+        S.setdiag(1)
+        want = S.tocoo()
+        got = sp.coo_matrix((np.ones(ps.numel()), (ps.numpy(), pd.numpy())), shape=(n, n)).tocsr()
+        assert got.max() <= 1 if ps.numel() else True                               # no parallel edges
+        assert ps.numel() == want.nnz
+        assert (got != want.tocsr()).nnz == 0
+        # self-loops come last, one per node in node order (run.py:146-147 `remove_self_loop().add_self_loop()`)
+        assert torch.equal(ps[-n:], torch.arange(n)) and torch.equal(pd[-n:], torch.arange(n))
+        assert bool((ps[:-n] != pd[:-n]).all())
