@@ -797,21 +797,23 @@ def bn_stats_halves(x, eps, momentum, running_mean, running_var, num_batches_tra
     return mean, invstd, hscale
 
 
-def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=None):
+def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=None, want_y=True):
     """y = dropout_p(relu?((x - mean) * invstd * weight + bias)); Philox mask from `seed`.
-    halves = (hscale [2], piece): also returns y's fp16 halves [n, 3 * piece] scaled by hscale[0] -> (y, buf)."""
+    halves = (hscale [2], piece): also returns y's fp16 halves [n, 3 * piece] scaled by hscale[0] -> (y, buf).
+    want_y=False (with halves): only the halves are written; the returned y is None."""
     _dev(x, mean, invstd)
     x = _mat(x, "x")
     n, F = x.shape
-    y = torch.empty((n, F), dtype=torch.float32, device=x.device)
     if halves is not None:
         hscale, piece = halves
+        y = torch.empty((n, F), dtype=torch.float32, device=x.device) if want_y else None
         buf = torch.empty((n, 3 * piece), dtype=torch.float16, device=x.device)
         _check(_timed("bn_act_fwd", (F,), lambda: _lib.bot_bn_act_fwd_halves_f32(
             x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p),
-            int(seed), _seed_off(p), y.data_ptr(), y.stride(0), hscale.data_ptr(), buf.data_ptr(), buf.stride(0), piece, _stream())),
+            int(seed), _seed_off(p), _ptr(y), F, hscale.data_ptr(), buf.data_ptr(), buf.stride(0), piece, _stream())),
             "bn_act_fwd_halves")
         return y, buf
+    y = torch.empty((n, F), dtype=torch.float32, device=x.device)
     _check(_timed("bn_act_fwd", (F,), lambda: _lib.bot_bn_act_fwd_f32(
         x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p),
         int(seed), _seed_off(p), y.data_ptr(), y.stride(0), _stream())), "bn_act_fwd")

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
                 if (a.p > 0.f) o *= f[t];
                 v[u][t] = o;
             }
-            store_cols<VEC>(a.y + r * a.ldy + c, v[u], a.wy, nv);
+            if (a.y) store_cols<VEC>(a.y + r * a.ldy + c, v[u], a.wy, nv);     // NULL: only the halves are wanted (bot_bn_act_fwd_halves_f32)
             if constexpr (VEC == 4) {
                 if (a.hout) {
                     __half h1[4], h2[4];
@@ -549,10 +549,11 @@ static int bn_act_fwd_impl(const float* x, int64_t ldx, int64_t n, int32_t F, co
                            const uint64_t* seed_offset, float* y, int64_t ldy, const float* hscale, uint16_t* hout, int64_t ldh,
                            int32_t piece, bot_stream_t stream) {
     using namespace bot;
+    if (!y) ldy = ldx;                   // halves only (hout != NULL): y puts no constraint on the launch width
     BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && ldy >= F, BOT_E_RANGE, "bn_act_fwd: n=%lld F=%d", (long long)n, F);
     BOT_REQUIRE(p >= 0.f && p < 1.f, BOT_E_RANGE, "bn_act_fwd: dropout p=%f must be in [0,1)", (double)p);
     if (n == 0) return 0;
-    BOT_REQUIRE(x && mean && invstd && y, BOT_E_NULL, "bn_act_fwd: NULL pointer");
+    BOT_REQUIRE(x && mean && invstd && (y || hout), BOT_E_NULL, "bn_act_fwd: NULL pointer");
     BnArgs a{};
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
     a.seed = seed, a.seed_offset = seed_offset, a.y = y, a.ldy = ldy;

@@ -65,6 +65,11 @@ def take(x, order: int):
     if h is not None and ref() is not None and h.order == order:    # a dead y: the address was recycled for another tensor
         STATS["taken"] += 1
         return h
+    if x.dim() == 2 and x.shape[0] > 1 and x.stride(0) == 0:
+        # a HANDLE (bot_amd.nn.fused._epilogue_forward: the hidden state was stored as halves only) whose halves are gone: its
+        # values are placeholders, never an operand
+        raise RuntimeError("bot_amd.gemm.take: this hidden state exists only as fp16 halves and they are no longer stashed "
+                           "(it was produced for exactly one halves-GEMM consumer); set BOT_SKIP_Y=0 to store fp32 hidden states")
     STATS["split"] += 1
     return split(x, order)
 

@@ -357,7 +357,14 @@ class GAT(nn.Module):
             norm = None if last else (self.norms[i] if len(self.norms) else False)
             if (self.fuse_layers and norm is not False and (h.is_cuda or fused.FORCE)
                     and fused.can_fuse(self.convs[i], norm, self.activation, graph, self.training, self.residual)):
-                h = fused.gat_hidden_layer(self.convs[i], norm, graph, h, self.dropout.p, self.training)
+                # does the NEXT layer read this one's output only as the halves its epilogue stashes?  then the fp32 copy is not stored
+                y_needed = True
+                if not last and norm is not None:
+                    nxt_last = i + 1 == self.n_layers - 1
+                    nxt_norm = None if nxt_last else (self.norms[i + 1] if len(self.norms) else False)
+                    y_needed = nxt_norm is False or not fused.halves_only_consumer(
+                        self.convs[i + 1], nxt_norm, self.activation, graph, self.training, self.residual, h.shape[0], h.is_cuda)
+                h = fused.gat_hidden_layer(self.convs[i], norm, graph, h, self.dropout.p, self.training, y_needed=y_needed)
                 if last:
                     h = h.view(h.shape[0], self.convs[i]._num_heads, -1)
                 else:

@@ -28,6 +28,8 @@ from ..ops import bn_batch_stats, new_dropout_seed
 
 
 ABSMAX_BYPRODUCT = os.environ.get("BOT_ABSMAX_BYPRODUCT", "1") != "0"   # max|gradient| from its producers instead of a pass (_GATHidden.backward)
+SKIP_Y = os.environ.get("BOT_SKIP_Y", "1") != "0"   # hidden states whose one consumer is a halves GEMM exist as halves only (_epilogue_forward)
+HANDLES = 0    # epilogues that returned a handle instead of a stored fp32 tensor (tests)
 SKINNY = os.environ.get("BOT_SKINNY", "1") != "0"   # the small-K products of the aggregate-first layer on bot_skinny_gemm_f32
 FORCE = False  # tests set this to run the fused node over the emulated (CPU) backend
 CALLS = 0      # number of fused-layer invocations (tests assert the path was actually taken)
@@ -166,16 +168,24 @@ OVERLAP_CALLS = 0   # layer forwards that took the overlapped form (tests assert
 _ship_rows, _return_rows, _fold_back = halo.ship_rows, halo.return_rows, halo.fold_back
 
 
-def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p):
+def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed=True):
     """BatchNorm statistics + the fused BatchNorm / ReLU / dropout pass.  When the next projection runs on fp16 halves
-    (bot_amd.gemm) the pass writes them too and the scale comes from the statistics pass: y is not read again before its GEMM."""
+    (bot_amd.gemm) the pass writes them too and the scale comes from the statistics pass: y is not read again before its GEMM.
+    y_needed=False (the caller KNOWS the one consumer of y is such a projection, `halves_only_consumer`): the fp32 y is not stored at
+    all — 508 MB per hidden layer at config 2 that nobody would read (this pass's backward reads x) — and the returned tensor is a
+    HANDLE: zeros of y's shape on ONE element (stride 0), which carries the autograd edge and the key of the stashed halves.
+    `gemm.take` refuses a handle without its halves, so a handle can never be split into a GEMM operand by mistake."""
     HD = x.shape[1]
     piece = gemm.epilogue_piece(HD, x) if bn_training else None
     seed = new_dropout_seed(drop_p)
     if piece is not None:
         mean, invstd, total, sync, group, hscale = bn_batch_stats(x, bn, bn_training, halves_p=drop_p)
         if hscale is not None:
-            y, buf = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed, halves=(hscale, piece))
+            y, buf = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed, halves=(hscale, piece), want_y=y_needed)
+            if y is None:
+                global HANDLES
+                HANDLES += 1
+                y = x.new_zeros(1).expand(x.shape[0], HD)
             gemm.stash(y, gemm.Halves(buf, hscale, x.shape[0], HD, piece, 0))
             return y, mean, invstd, total, sync, group, seed
     else:
@@ -185,7 +195,7 @@ def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p):
 
 class _GATHidden(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, Wcat, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp, sym):
+    def forward(ctx, h, Wcat, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp, sym, y_needed=True):
         N, HD = h.shape[0], H * D
         csc = graph.csc
         ctx.sym = sym                                                   # symmetric normalisation folded into the edge weights
@@ -228,7 +238,7 @@ class _GATHidden(torch.autograd.Function):
                 ctx.save_for_backward(*keep)
                 ctx.cfg = (H, D, has_res, has_er, slope, None)
                 return x
-            y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p)
+            y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed)
             ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
             ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
             return y
@@ -267,7 +277,7 @@ class _GATHidden(torch.autograd.Function):
             ctx.save_for_backward(*keep)
             ctx.cfg = (H, D, has_res, has_er, slope, None)
             return x
-        y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p)
+        y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed)
         ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
         ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
         return y
@@ -388,7 +398,7 @@ class _GATHidden(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dh = torch.mm(dout, Wcat.t()) if kp else torch.mm(dout, Wcat)
         return (dh, dW, d_bn_w if ctx.needs_input_grad[2] else None, d_bn_b if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def cat_weight_aggfirst(conv):
@@ -431,7 +441,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
     a batched GEMM over heads on the aggregated slab [H, N, Fin], and in partitioned mode the halo rows are [x | el]."""
 
     @staticmethod
-    def forward(ctx, h, W, Wr, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp, sym):
+    def forward(ctx, h, W, Wr, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp, sym, y_needed=True):
         N, Fin, HD = h.shape[0], h.shape[1], H * D
         csc = graph.csc
         ctx.sym = sym
@@ -496,7 +506,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             ctx.save_for_backward(*keep)
             ctx.cfg = (H, D, has_res, has_er, slope, None)
             return x
-        y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p)
+        y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed)
         ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
         ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
         return y
@@ -590,12 +600,20 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         if need_dh:
             dh = torch.addmm(dh_g, dout2, Wr.t() if kp else Wr)
         return (dh, dW, dWr, d_bn_w if ctx.needs_input_grad[3] else None, d_bn_b if ctx.needs_input_grad[4] else None,
-                None, None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
-def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
+def halves_only_consumer(conv, norm, activation, graph, training, stack_residual, n_rows, on_device) -> bool:
+    """Will `gat_hidden_layer(conv, norm, ...)` read its input ONLY as the fp16 halves the previous layer's epilogue stashed?  True for the
+    merged-GEMM node on the halves path (not the aggregate-first node, which gathers the fp32 rows; not the modular fallback).  The
+    stack asks this BEFORE it runs the previous layer, which may then skip storing its fp32 output (`_epilogue_forward`)."""
+    return (SKIP_Y and (on_device or FORCE) and can_fuse(conv, norm, activation, graph, training, stack_residual) and not use_agg_first(conv)
+            and gemm.MODE == "halves" and (gemm.FORCE or (on_device and n_rows >= gemm.MIN_ROWS)))
+
+
+def gat_hidden_layer(conv, bn, graph, h, dropout_p, training, y_needed=True):
     """`dropout(relu(bn(conv(graph, h).flatten(1))))` as one autograd node (bn None: just `conv(graph, h).flatten(1)`,
-    the stack's output layer).  h: [N, Fin] -> [N, H*D]."""
+    the stack's output layer).  h: [N, Fin] -> [N, H*D].  y_needed=False: see `_epilogue_forward`."""
     from . import has_zero_in_degree
     if not conv._allow_zero_in_degree:
         assert not has_zero_in_degree(graph), "0-in-degree nodes (models.py:477-479)"
@@ -612,7 +630,7 @@ def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
         return _GATHiddenAggFirst.apply(h, conv.fc.weight, merged_weight(conv, with_fc=False), bn_w, bn_b, graph, bn, H, D,
                                         conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
                                         attn_p, dropout_p if training and bn is not None else 0.0, bn_training, WEIGHT_KP,
-                                        conv._use_symmetric_norm)
+                                        conv._use_symmetric_norm, y_needed)
     if bn is None:
         return _GATHidden.apply(h, merged_weight(conv), None, None, graph, None, H, D, conv.res_fc is not None,
                                 conv.attn_r is not None, conv.leaky_relu.negative_slope, attn_p, 0.0, False, WEIGHT_KP,
@@ -620,7 +638,7 @@ def gat_hidden_layer(conv, bn, graph, h, dropout_p, training):
     return _GATHidden.apply(h, merged_weight(conv), bn.weight if bn.affine else None, bn.bias if bn.affine else None, graph, bn,
                             H, D, conv.res_fc is not None, conv.attn_r is not None, conv.leaky_relu.negative_slope,
                             conv.attn_drop.p if training else 0.0, dropout_p if training else 0.0, bn_training, WEIGHT_KP,
-                            conv._use_symmetric_norm)
+                            conv._use_symmetric_norm, y_needed)
 
 
 # ------------------------------------------------------------------------------------------------ inference-only forward (f3)

@@ -350,7 +350,9 @@ int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const 
  * bn_stats_halves also tracks the column extremes and derives hscale = (s, 1/s) from the bound
  * max_c (|weight_c| max(|max_c - mean_c|, |min_c - mean_c|) invstd_c + |bias_c|) / (1 - p) >= max |y| — no pass over y;
  * bn_act_fwd_halves writes y AND its halves [h1 | h1 | 2^11 h2] (pieces of `piece` = F rounded up to x64 columns, zero padded), so the
- * separate halves_scale / halves_split passes over y disappear.  Needs the 4-column form (even F, 8-byte aligned rows). */
+ * separate halves_scale / halves_split passes over y disappear.  Needs the 4-column form (even F, 8-byte aligned rows).
+ * y == NULL (v12): ONLY the halves are written — for a hidden state whose one consumer is the next projection GEMM (the backward
+ * of this pass reads x, never y), which saves the fp32 store of an [n, F] matrix nobody reads. */
 int bot_bn_stats_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float eps, float momentum, float* mean, float* invstd,
                             float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* weight,
                             const float* bias, float p, float* hscale, float* workspace, bot_stream_t stream);

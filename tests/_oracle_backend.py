@@ -216,12 +216,12 @@ def _bn_gate(x, mean, invstd, weight, bias, relu, p):
     return xh, o
 
 
-def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=None):
+def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=None, want_y=True):
     _, o = _bn_gate(x, mean, invstd, weight, bias, relu, p)
     y = torch.relu(o) if relu else o
-    if halves is not None:                      # bot_bn_act_fwd_halves_f32: the output also as fp16 halves
+    if halves is not None:                      # bot_bn_act_fwd_halves_f32: the output also as fp16 halves (want_y False: only them)
         hscale, piece = halves
-        return y, halves_split(y, hscale, 0, piece)
+        return (y if want_y else None), halves_split(y, hscale, 0, piece)
     return y
 
 

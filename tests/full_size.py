@@ -118,7 +118,9 @@ def tap_kinks():
         relu_taps.append((y.detach() > 0).to(torch.uint8).cpu())
         return y
 
-    def hid(conv, bn, graph, h, dropout_p, training):
+    def hid(conv, bn, graph, h, dropout_p, training, **kw):
+        # the tap reads the layer's fp32 output: keep it stored here (y_needed; `check_halves_only_hidden_states` asserts that the
+        # halves-only form changes no bit of the results)
         y = orig_f(conv, bn, graph, h, dropout_p, training)
         if bn is not None:
             relu_taps.append((y.detach() > 0).to(torch.uint8).cpu())

@@ -8,6 +8,7 @@ Tolerances: integers bit-exact; fp32 forward within 1e-4 absolute of the referen
 import ast
 
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -880,3 +881,58 @@ def check_absmax_byproducts(golden, device):
         gemm.FORCE, fused.ABSMAX_BYPRODUCT, fused.FORCE, _C.halves_scale_from_slots = force0, by0, ff0, orig
     for k in grads[True]:
         assert torch.equal(grads[True][k], grads[False][k]), k
+
+
+def check_halves_only_hidden_states(golden, device):
+    """`fused._epilogue_forward(y_needed=False)`: a hidden state whose one consumer is the next layer's halves GEMM is stored as fp16
+    halves only and travels as a handle (zeros on one element, stride 0).  Logits, every gradient and the BatchNorm running statistics
+    of a config-2-style stack are BITWISE those of the stack that stores its fp32 hidden states; the handle is what the next layer
+    received; and a handle that lost its halves is refused by `gemm.take`, never split."""
+    from bot_amd import gemm
+    from bot_amd.nn import fused
+    s, d, n = golden.graph("g300")
+    g = bot_amd.Graph(s, d, n).to(device)
+    fin, C = 9, 5                                                                   # 9 <= 16: layer 0 is the aggregate-first node
+    cfg = dict(n_layers=4, n_heads=3, n_hidden=16, norm="batch", non_interactive_attn=True, use_symmetric_norm=False, linear=True,
+               residual=False)
+    gen = torch.Generator().manual_seed(61)
+    feat, gout = torch.randn(n, fin, generator=gen).to(device), torch.randn(n, C, generator=gen).to(device)
+    saved = gemm.FORCE, fused.FORCE, fused.SKIP_Y
+    res = {}
+    try:
+        gemm.FORCE = fused.FORCE = True
+        for skip in (True, False):
+            fused.SKIP_Y = skip
+            torch.manual_seed(11)
+            model = bnn.GAT(dim_node=fin, dim_edge=0, dim_output=C, activation=F.relu, **cfg).train().to(device)
+            seen = []
+            orig = fused.gat_hidden_layer
+
+            def spy(conv, bn, graph, h, *a, **kw):
+                seen.append((tuple(h.shape), h.stride(0), kw.get("y_needed", True)))
+                return orig(conv, bn, graph, h, *a, **kw)
+
+            fused.gat_hidden_layer = spy
+            h0 = fused.HANDLES
+            try:
+                logits = model(g, feat)
+            finally:
+                fused.gat_hidden_layer = orig
+            (logits * gout).sum().backward()
+            res[skip] = (logits.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()},
+                         {k: b.clone() for k, b in model.named_buffers()})
+            # 4 layers: outputs of layers 0, 1, 2 feed merged-GEMM layers 1, 2, 3 -> three handles; layer 0 reads the real features
+            assert fused.HANDLES - h0 == (3 if skip else 0)
+            assert [t[1] == 0 for t in seen] == [False, skip, skip, skip], seen
+            assert [t[2] for t in seen] == [not skip, not skip, not skip, True], seen
+        assert torch.equal(res[True][0], res[False][0])
+        for k in res[True][1]:
+            assert torch.equal(res[True][1][k], res[False][1][k]), k
+        for k in res[True][2]:
+            assert torch.equal(res[True][2][k], res[False][2][k]), k
+        # a handle without its halves is refused
+        handle = torch.zeros(1, device=device).expand(50, 8)
+        with pytest.raises(RuntimeError, match="exists only as fp16 halves"):
+            gemm.take(handle, 0)
+    finally:
+        gemm.FORCE, fused.FORCE, fused.SKIP_Y = saved

@@ -201,6 +201,11 @@ def test_absmax_byproducts_on_device(golden):
     PC.check_absmax_byproducts(golden, DEV)
 
 
+def test_halves_only_hidden_states_on_device(golden):
+    """Hidden states that only a halves GEMM reads are stored as halves only: bitwise the results of the stack that stores them."""
+    PC.check_halves_only_hidden_states(golden, DEV)
+
+
 def test_halo_sums_on_device(golden):
     """bot_amd.halo's overlapped aggregations (what the modular layers call in partitioned mode) on the real kernels, the exchange
     replaced by indexing: forward, all gradients and the returned halo-row gradients against the one-exchange form."""
