@@ -57,7 +57,7 @@ _SIGS = {
     "bot_gat_infer_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "bot_gat_infer_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                          _P, c_int64, _P, c_int64, _P, _P, c_float, c_int32, c_int32, _P, c_int64, c_int64, _P, _P,
-                                         c_int32, _P, c_int64, c_int64, _P, _P]),
+                                         c_int32, _P, c_int64, c_int64, _P, _P, _P]),
     "bot_segment_sum_f32": (ctypes.c_int, [_P, c_int64, c_int64, _P, c_int64, c_int32, _P, _P, c_int32, _P, _P]),
     "bot_gather_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
     "bot_scatter_add_rows_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int32, _P, c_int64, _P]),
@@ -462,7 +462,7 @@ def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der, 
     return dz, der
 
 
-def gat_infer(d, x, el=None, er=None, ee=None, ew=None, slope=0.2, addend=None, scale=None, shift=None, relu=False, out=None):
+def gat_infer(d, x, el=None, er=None, ee=None, ew=None, slope=0.2, addend=None, scale=None, shift=None, relu=False, out=None, absmax=None):
     """Inference-only GAT layer in one sweep (include/bot_gnn.h bot_gat_infer_f32):
         out[r,h,:] = act((sum_k softmax_k(leaky(el[src] + er[r] + ee[k]))[h] * ew[k] * x[src,h,:] + addend[r,h,:]) * scale + shift)
     x: [n_src,H,D] (strided slab); el [n_src,H] / er [n_rows,H]: row-strided views allowed; ee [nnz,H], ew [nnz]: position order;
@@ -503,7 +503,7 @@ def gat_infer(d, x, el=None, er=None, ee=None, ew=None, slope=0.2, addend=None, 
         d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
         _ptr(d.long_ptr), d.n_long, d.n_slots, x.data_ptr(), ldx, hsx, _ptr(el), ldel, _ptr(er), lder, _ptr(ee), _ptr(ew),
         float(slope), H, D, _ptr(addend), lda, hsa, _ptr(scale), _ptr(shift), int(bool(relu)), out.data_ptr(), ldo, hso, _ptr(ws),
-        _stream())), "gat_infer")
+        _ptr(absmax), _stream())), "gat_infer")
     return out
 
 

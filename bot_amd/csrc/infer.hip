@@ -50,6 +50,7 @@ struct InferArgs {
     int64_t ldp;
     const int32_t* long_rows;
     const int32_t* long_ptr;
+    uint32_t* absmax;  // optional by-product: max|out| into kAbsmaxSlots words (common.h absmax_publish)
 };
 
 __device__ __forceinline__ float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(kBlock) void gat_infer_rows_kernel(InferArgs a) {
         }
     }
     // normalise (whole rows), epilogue, store
+    float amax = 0.f;
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
         if (!act[c]) continue;
@@ -233,10 +235,13 @@ __global__ __launch_bounds__(kBlock) void gat_infer_rows_kernel(InferArgs a) {
             }
             infer_epilogue<VEC>(a, row, hd[c], el[c], acc[c]);
             vstore<VEC>(a.out + (int64_t)row * a.ldo + (int64_t)hd[c] * a.hso + el[c], acc[c]);
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) amax = fmaxf(amax, fabsf(acc[c][t]));
         } else {
             vstore<VEC>(a.partial + (int64_t)slot * a.ldp + (int64_t)hd[c] * a.D + el[c], acc[c]);
         }
     }
+    if (a.absmax) absmax_publish(wave_absmax(amax), a.absmax);     // (long rows: gat_infer_combine_kernel)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -394,15 +399,17 @@ __global__ __launch_bounds__(kBlock) void gat_infer_rowstat_kernel(InferArgs a) 
 __global__ __launch_bounds__(kBlock) void gat_infer_combine_kernel(InferArgs a, int64_t n_long) {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t hd = (int64_t)a.H * a.D;
-    if (gid >= n_long * hd) return;
-    const int64_t i = gid / hd;
-    const int e = (int)(gid - i * hd);
-    const int h = e / a.D, d = e - h * a.D;
     float acc[1] = {0.f};
-    for (int p = a.long_ptr[i]; p < a.long_ptr[i + 1]; ++p) acc[0] += a.partial[(int64_t)p * a.ldp + e];
-    const int row = a.long_rows[i];
-    infer_epilogue<1>(a, row, h, d, acc);
-    a.out[(int64_t)row * a.ldo + (int64_t)h * a.hso + d] = acc[0];
+    if (gid < n_long * hd) {
+        const int64_t i = gid / hd;
+        const int e = (int)(gid - i * hd);
+        const int h = e / a.D, d = e - h * a.D;
+        for (int p = a.long_ptr[i]; p < a.long_ptr[i + 1]; ++p) acc[0] += a.partial[(int64_t)p * a.ldp + e];
+        const int row = a.long_rows[i];
+        infer_epilogue<1>(a, row, h, d, acc);
+        a.out[(int64_t)row * a.ldo + (int64_t)h * a.hso + d] = acc[0];
+    }
+    if (a.absmax) absmax_publish(wave_absmax(fabsf(acc[0])), a.absmax);    // every lane arrives here
 }
 
 template <int VEC, int HL, int NCHUNK, int CPH>
@@ -476,7 +483,7 @@ int bot_gat_infer_f32(const int32_t* indptr, const int32_t* indices, int64_t n_r
                       const float* x, int64_t ldx, int64_t hsx, const float* el, int64_t ldel, const float* er, int64_t lder,
                       const float* ee, const float* ew, float slope, int32_t H, int32_t D, const float* addend, int64_t lda,
                       int64_t hsa, const float* scale, const float* shift, int32_t relu, float* out, int64_t ldo, int64_t hso,
-                      float* workspace, bot_stream_t stream) {
+                      float* workspace, uint32_t* absmax_slots, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_items >= 0 && n_long >= 0 && n_slots >= 0, BOT_E_RANGE, "gat_infer: negative size");
     BOT_REQUIRE(nnz < INT32_MAX && n_rows < INT32_MAX, BOT_E_RANGE, "gat_infer: int32 index range exceeded");
@@ -507,8 +514,10 @@ int bot_gat_infer_f32(const int32_t* indptr, const int32_t* indices, int64_t n_r
         hipLaunchKernelGGL(gat_infer_rowstat_kernel, dim3((unsigned)n_long), dim3(kBlock), 0, st, a);
         if (int rc = hip_status("gat_infer rowstat launch")) return rc;
     }
+    a.absmax = absmax_slots;            // by-product of the all-heads kernel and of the long rows' combine pass
     const bool rows = vec == 4 ? dispatch_infer_rows<4>(a, st) : (vec == 2 ? dispatch_infer_rows<2>(a, st) : dispatch_infer_rows<1>(a, st));
     if (!rows) {
+        a.absmax = nullptr;             // the head-major kernel has no by-product form: a pass over the result below
         if (vec == 4) dispatch_infer_heads<4>(a, st);
         else if (vec == 2) dispatch_infer_heads<2>(a, st);
         else dispatch_infer_heads<1>(a, st);
@@ -518,6 +527,10 @@ int bot_gat_infer_f32(const int32_t* indptr, const int32_t* indices, int64_t n_r
         const int64_t n = n_long * H * D;
         hipLaunchKernelGGL(gat_infer_combine_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, a, n_long);
         if (int rc = hip_status("gat_infer combine launch")) return rc;
+    }
+    if (absmax_slots && !rows) {
+        for (int h = 0; h < H; ++h) launch_absmax_slots(out + (int64_t)h * hso, ldo, n_rows, D, absmax_slots, st);
+        if (int rc = hip_status("gat_infer absmax launch")) return rc;
     }
     return 0;
 }

@@ -60,6 +60,21 @@ def stash(y, h: Halves):
     STATS["stashed"] += 1
 
 
+_SCALES = {}
+
+
+def stash_scale(y, scale):
+    """max|y| was delivered by the kernel that wrote y (include/bot_gnn.h "Maxima as by-products"): the (s, 1/s) pair for the split
+    of y that follows — the inference layers, whose output is split by the next layer.  One entry, consumed by `split_with_stash`."""
+    _SCALES.clear()
+    _SCALES[(y.data_ptr(), y._version, tuple(y.shape))] = (weakref.ref(y), scale)
+
+
+def split_with_stash(x, order: int) -> Halves:
+    ref, scale = _SCALES.pop((x.data_ptr(), x._version, tuple(x.shape)), (None, None))
+    return split(x, order, scale=scale if (scale is not None and ref() is not None) else None)
+
+
 def take(x, order: int):
     ref, h = _STASH.pop((x.data_ptr(), x._version, tuple(x.shape)), (None, None))
     if h is not None and ref() is not None and h.order == order:    # a dead y: the address was recycled for another tensor

@@ -776,7 +776,7 @@ def gat_infer_layer(conv, epi, graph, h, relu, first=False):
         out = torch.addmm(ctx.store["base"], h[:, F0:], Wk[F0:])
     elif gemm.enabled(h):                                               # fp32 GEMM on the fp16 matrix cores (bot_amd.gemm)
         # the weight's halves live and die with the merged weight they were split from: same key (the parameters' versions)
-        out = gemm.mm_nt(gemm.split(h, 0), _cached(conv, "infer_halves", _infer_key(conv),
+        out = gemm.mm_nt(gemm.split_with_stash(h, 0), _cached(conv, "infer_halves", _infer_key(conv),
                                                    lambda: gemm.split(W.t().contiguous() if WEIGHT_KP else W, 1)))
     else:
         out = torch.mm(h, W) if WEIGHT_KP else torch.mm(h, W.t())       # [N, P] = [ft | res | el | er | pad]
@@ -795,6 +795,11 @@ def gat_infer_layer(conv, epi, graph, h, relu, first=False):
         ew = w_e
     scale, shift = eval_affine(epi)
     res = out[:, B:B + HD].unflatten(1, (H, D)) if has_res else None
+    # a hidden layer's output is the next layer's GEMM operand: the sweep delivers max|y| as it stores y (no pass for the halves' scale)
+    slots = _C.absmax_slots(h.device) if (relu and ABSMAX_BYPRODUCT and gemm.enabled(h)) else None
     y = _C.gat_infer(graph.csc, ft.unflatten(1, (H, D)), el, er, None, ew, conv.leaky_relu.negative_slope, addend=res,
-                     scale=scale, shift=shift, relu=relu)
-    return y.view(N, HD)
+                     scale=scale, shift=shift, relu=relu, absmax=slots)
+    y = y.view(N, HD)
+    if slots is not None:
+        gemm.stash_scale(y, _C.halves_scale_from_slots(slots))
+    return y

@@ -285,7 +285,7 @@ int bot_gat_infer_f32(const int32_t* indptr, const int32_t* indices, int64_t n_r
                       const float* addend, int64_t lda, int64_t hsa,
                       const float* scale, const float* shift, int32_t relu,
                       float* out, int64_t ldo, int64_t hso,
-                      float* workspace, bot_stream_t stream);
+                      float* workspace, uint32_t* absmax_slots /* optional: max|out|, "Maxima as by-products" */, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Segment sum of edge values.  Replaces update_all(fn.copy_e, fn.sum) — copy_e_sum
@@ -446,7 +446,7 @@ int bot_random_keep_u8(int64_t n, int64_t n_keep, uint64_t seed, uint8_t* keep, 
 int64_t bot_halves_workspace_floats(void);
 int bot_halves_scale_f32(const float* x, int64_t ldx, int64_t n, int32_t F, float* scale, float* workspace, bot_stream_t stream);
 /* Maxima as by-products (v12).  The scale of an operand only needs max|x|; when x is a gradient buffer that several kernels have just
- * written, they can deliver it: bot_spmm_dot_f32 and bot_bn_act_bwd_apply_f32 take `absmax_slots`, an array of bot_absmax_slots()
+ * written, they can deliver it: bot_spmm_dot_f32, bot_bn_act_bwd_apply_f32 and bot_gat_infer_f32 take `absmax_slots`, an array of bot_absmax_slots()
  * uint32 words that the CALLER ZEROES; every workgroup folds the largest |value| it stored into one of them as a bit pattern
  * (non-negative floats order like unsigned integers: an integer atomic max — exact, independent of the order of arrival; NaNs are
  * skipped as in halves_scale).  bot_absmax_slots_f32 adds a strided matrix the slow way (the few columns no producer covers);

@@ -141,7 +141,7 @@ def gat_attn_bwd(d, el, er, ee, eperm, slope, H, a, da, aperm, zperm, want_der, 
     return dz, der
 
 
-def gat_infer(d, x, el=None, er=None, ee=None, ew=None, slope=0.2, addend=None, scale=None, shift=None, relu=False, out=None):
+def gat_infer(d, x, el=None, er=None, ee=None, ew=None, slope=0.2, addend=None, scale=None, shift=None, relu=False, out=None, absmax=None):
     """include/bot_gnn.h bot_gat_infer_f32, restated with plain torch ops."""
     H, D = x.shape[1], x.shape[2]
     rows = _rows(d)
@@ -164,6 +164,7 @@ def gat_infer(d, x, el=None, er=None, ee=None, ew=None, slope=0.2, addend=None, 
     if relu:
         r = torch.relu(r)
     r = r.view(d.n_rows, H, D)
+    _fold_absmax(absmax, r)
     if out is not None:
         out.copy_(r)
         return out

@@ -839,6 +839,16 @@ def check_absmax_byproducts(golden, device):
         assert float(as_f32(slots)) == float(out.abs().max()), (chunk, H, D)
         out2, _ = _C.spmm_dot(g.csr, x, w, g.csr2csc, y)
         assert torch.equal(out, out2)
+    # the inference sweep (all-heads kernel with long rows, head-major fall-back): max|y| of what it stored
+    for chunk, H, D in ((8, 3, 250), (None, 2, 10), (8, 9, 7)):
+        g = bot_amd.Graph(s, d, n, chunk=chunk).to(device)
+        x = torch.randn(n, H, D, generator=gen).to(device)
+        el, er = torch.randn(n, H, generator=gen).to(device), torch.randn(n, H, generator=gen).to(device)
+        sc, sh = (torch.rand(H * D, generator=gen) + 0.5).to(device), torch.randn(H * D, generator=gen).to(device)
+        slots = _C.absmax_slots(device)
+        y = _C.gat_infer(g.csc, x, el, er, None, None, 0.2, scale=sc, shift=sh, relu=True, absmax=slots)
+        assert float(as_f32(slots)) == float(y.abs().max()) > 0, (chunk, H, D)
+        assert torch.equal(y, _C.gat_infer(g.csc, x, el, er, None, None, 0.2, scale=sc, shift=sh, relu=True))
     # BatchNorm backward into a column block of a wider buffer, odd width, dropout on
     nrow, Fw = 1000, 750
     xx, dy = torch.randn(nrow, Fw, generator=gen).to(device), torch.randn(nrow, Fw, generator=gen).to(device)
@@ -881,6 +891,24 @@ def check_absmax_byproducts(golden, device):
         gemm.FORCE, fused.ABSMAX_BYPRODUCT, fused.FORCE, _C.halves_scale_from_slots = force0, by0, ff0, orig
     for k in grads[True]:
         assert torch.equal(grads[True][k], grads[False][k]), k
+    # evaluate(): the inference layers hand the next layer's split its scale — same logits bit for bit, and the scale was used
+    preds = {}
+    used = []
+    orig_split = gemm.split
+    try:
+        gemm.FORCE = fused.FORCE = True
+        gemm.split = lambda x, order, scale=None: (used.append(scale is not None), orig_split(x, order, scale=scale))[1]
+        torch.manual_seed(11)
+        model = bnn.GAT(dim_node=fin, dim_edge=0, dim_output=C, activation=F.relu, **cfg).eval().to(device)
+        for by in (True, False):
+            fused.ABSMAX_BYPRODUCT = by
+            n0 = len(used)
+            with torch.no_grad():
+                preds[by] = model(g, feat).clone()
+            assert sum(used[n0:]) == (2 if by else 0), used[n0:]          # the two hidden states of the 3-layer stack
+    finally:
+        gemm.FORCE, fused.ABSMAX_BYPRODUCT, fused.FORCE, gemm.split = force0, by0, ff0, orig_split
+    assert torch.equal(preds[True], preds[False])
 
 
 def check_halves_only_hidden_states(golden, device):
