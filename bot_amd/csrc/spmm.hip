@@ -521,7 +521,16 @@ __global__ __launch_bounds__(kBlock) void spmm_combine_kernel(const int32_t* lon
         const int64_t i = gid / hd;
         const int e = (int)(gid - i * hd);
         const int h = e / D, d = e - h * D;
-        for (int p = long_ptr[i]; p < long_ptr[i + 1]; ++p) s += partial[(int64_t)p * ldp + e];
+        int p = long_ptr[i];
+        const int p1 = long_ptr[i + 1];
+        for (; p + 4 <= p1; p += 4) {       // four loads in flight, added in slot order
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = partial[(int64_t)(p + j) * ldp + e];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += v[j];
+        }
+        for (; p < p1; ++p) s += partial[(int64_t)p * ldp + e];
         if (addend) s += addend[(int64_t)long_rows[i] * lda + (int64_t)h * hsa + d];
         out[(int64_t)long_rows[i] * ldo + (int64_t)h * hso + d] = s;
     }

@@ -134,8 +134,17 @@ __global__ __launch_bounds__(kBlock) void tn_reduce_kernel(const float* part, in
     if (idx >= (int64_t)kx * ky) return;
     const int r = (int)(idx / ky), c = (int)(idx % ky);
     const float* p = part + ((int64_t)z * chunks * kxp + r) * kyp + c;
+    const int64_t step = (int64_t)kxp * kyp;
     float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += p[(int64_t)k * kxp * kyp];
+    int k = 0;
+    for (; k + 8 <= chunks; k += 8) {      // eight loads in flight, added in chunk order (a dependent load per term ran at 0.5 TB/s)
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(k + j) * step];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; k < chunks; ++k) s += p[k * step];
     out[z * so + (transposed ? (int64_t)c * ldo + r : (int64_t)r * ldo + c)] = s;
 }
 
