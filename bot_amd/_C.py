@@ -92,6 +92,7 @@ _SIGS = {
                                                  c_uint64, _P, _P, _P, _P, _P]),
     "bot_bn_act_bwd_apply_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
                                                 c_uint64, _P, _P, _P, c_double, _P, c_int64, _P, _P]),
+    "bot_halves_tn_combine_f32": (ctypes.c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P]),
     "bot_absmax_slots": (c_int32, []),
     "bot_absmax_slots_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P]),
     "bot_halves_scale_from_slots_f32": (ctypes.c_int, [_P, _P, _P]),
@@ -605,6 +606,25 @@ def halves_scale_from_slots(slots):
     scale = torch.empty(2, dtype=torch.float32, device=slots.device)
     _check(_lib.bot_halves_scale_from_slots_f32(slots.data_ptr(), scale.data_ptr(), _stream()), "halves_scale_from_slots")
     return scale
+
+
+def halves_tn_combine(a, b, P, rem_a=None, rem_b=None):
+    """out [K, P] = sum_c a[c][:, :P] + (sum_c a[c][:, PP:PP+P] + sum_c b[c][:, :P]) * 2^-11 for a [C, K, 2 PP], b [C, K, PP] contiguous
+    (+ remainder chunks rem_a [K, 2 PP] / rem_b [K, PP]) — include/bot_gnn.h bot_halves_tn_combine_f32."""
+    _dev(a, b)
+    a, b = _f32(a, "a").contiguous(), _f32(b, "b").contiguous()
+    if a.dim() == 2:
+        a, b = a.unsqueeze(0), b.unsqueeze(0)
+    C, K, PP2 = a.shape
+    PP = PP2 // 2
+    assert b.shape == (C, K, PP) and P <= PP
+    if rem_a is not None:
+        rem_a, rem_b = rem_a.contiguous(), rem_b.contiguous()
+        assert rem_a.shape == (K, PP2) and rem_b.shape == (K, PP)
+    out = torch.empty((K, P), dtype=torch.float32, device=a.device)
+    _check(_lib.bot_halves_tn_combine_f32(a.data_ptr(), b.data_ptr(), C, K, PP, P, _ptr(rem_a), _ptr(rem_b), out.data_ptr(), P, _stream()),
+           "halves_tn_combine")
+    return out
 
 
 def halves_split(x, scale, order, piece, out=None):

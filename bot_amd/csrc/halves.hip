@@ -137,6 +137,32 @@ __global__ __launch_bounds__(kBlock) void absmax_slots_kernel(const float* x, in
     absmax_publish(wave_absmax(m), slots);
 }
 
+// The weight gradient x^T d of two LEFT-layout halves operands arrives as chunked partial products (bot_amd/gemm.py:tn):
+//   a[s] = x1_s^T [d1_s | 2^11 d2_s]  ([K, 2 PP] per row chunk s),   b[s] = (2^11 x2_s)^T d1_s  ([K, PP]),  optional remainders ra / rb.
+// out[k, p] = sum_s a[s][k][p] + (sum_s a[s][k][PP + p] + sum_s b[s][k][p]) * 2^-11 — the chunk sums in chunk order, eight loads in flight.
+__global__ __launch_bounds__(kBlock) void tn_combine_kernel(const float* a, const float* b, int32_t S, int32_t K, int32_t PP, int32_t P,
+                                                           const float* ra, const float* rb, float* out, int64_t ldo) {
+    const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= (int64_t)K * P) return;
+    const int k = (int)(idx / P), p = (int)(idx - (int64_t)k * P);
+    const int64_t sa = (int64_t)K * 2 * PP, sb = (int64_t)K * PP;
+    const float* a1 = a + (int64_t)k * 2 * PP + p;
+    const float* a2 = a1 + PP;
+    const float* b1 = b + (int64_t)k * PP + p;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+        float v1[4], v2[4], v3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v1[j] = a1[(s + j) * sa], v2[j] = a2[(s + j) * sa], v3[j] = b1[(s + j) * sb];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s1 += v1[j], s2 += v2[j], s3 += v3[j];
+    }
+    for (; s < S; ++s) s1 += a1[s * sa], s2 += a2[s * sa], s3 += b1[s * sb];
+    if (ra) s1 += ra[(int64_t)k * 2 * PP + p], s2 += ra[(int64_t)k * 2 * PP + PP + p], s3 += rb[(int64_t)k * PP + p];
+    out[(int64_t)k * ldo + p] = s1 + (s2 + s3) * (1.f / kHalvesShift);
+}
+
 void launch_absmax_slots(const float* x, int64_t ldx, int64_t n, int32_t F, uint32_t* slots, hipStream_t st) {
     const int64_t total = n * (int64_t)F;
     if (total <= 0) return;
@@ -178,6 +204,18 @@ int bot_halves_scale_from_slots_f32(const uint32_t* slots, float* scale, bot_str
     // a non-negative float and its bit pattern are the same word: the slots ARE an array of partial maxima
     launch_halves_scale(reinterpret_cast<const float*>(slots), kAbsmaxSlots, scale, (hipStream_t)stream);
     return hip_status("halves_scale_from_slots launch");
+}
+
+int bot_halves_tn_combine_f32(const float* a, const float* b, int32_t chunks, int32_t K, int32_t PP, int32_t P, const float* rem_a,
+                              const float* rem_b, float* out, int64_t ldo, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(chunks >= 1 && K >= 1 && P >= 1 && PP >= P && ldo >= P, BOT_E_RANGE, "halves_tn_combine: chunks=%d K=%d PP=%d P=%d ldo=%lld", chunks, K, PP,
+                P, (long long)ldo);
+    BOT_REQUIRE(a && b && out && ((rem_a == nullptr) == (rem_b == nullptr)), BOT_E_NULL, "halves_tn_combine: NULL pointer (the remainders go together)");
+    const int64_t total = (int64_t)K * P;
+    hipLaunchKernelGGL(tn_combine_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a, b, chunks, K, PP, P,
+                       rem_a, rem_b, out, ldo);
+    return hip_status("halves_tn_combine launch");
 }
 
 int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,

@@ -128,15 +128,13 @@ def tn(x: Halves, d: Halves):
 
     a = part(x1, d12, 2 * PP, R, S, 0)
     b = part(x2, d1, PP, R, S, 0)
-    if S > 1:
-        a, b = a.sum(0), b.sum(0)
-    # both operands are LEFT layouts here: x1^T d1 + (x1^T [2^11 d2] + [2^11 x2]^T d1) / 2^11
-    out = a[:, :P] + (a[:, PP:PP + P] + b[:, :P]) * (1.0 / SHIFT)
+    ra = rb = None
     if S * R < N:
         ra = part(x1, d12, 2 * PP, N - S * R, 1, S * R)
         rb = part(x2, d1, PP, N - S * R, 1, S * R)
-        out = out + ra[:, :P] + (ra[:, PP:PP + P] + rb[:, :P]) * (1.0 / SHIFT)
-    return out
+    # both operands are LEFT layouts here: x1^T d1 + (x1^T [2^11 d2] + [2^11 x2]^T d1) / 2^11, the chunks added in chunk order —
+    # one launch (bot_halves_tn_combine_f32) instead of two library reductions and the element-wise passes
+    return _C.halves_tn_combine(a, b, P, ra, rb)
 
 
 

@@ -456,6 +456,12 @@ int bot_absmax_slots_f32(const float* x, int64_t ldx, int64_t n, int32_t F, uint
 int bot_halves_scale_from_slots_f32(const uint32_t* slots, float* scale, bot_stream_t stream);
 int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
                          int64_t ldo, int32_t piece, bot_stream_t stream);
+/* The weight gradient x^T d of two LEFT-layout operands, formed by the caller from row chunks (batched gemm_halves calls): a [chunks][K][2 PP]
+ * = x1^T [d1 | 2^11 d2] and b [chunks][K][PP] = (2^11 x2)^T d1 per chunk, contiguous, plus optional remainder chunks rem_a [K][2 PP] / rem_b [K][PP]:
+ *   out[k, p] = sum_c a[c][k][p] + (sum_c a[c][k][PP + p] + sum_c b[c][k][p]) * 2^-11      (chunk order, p < P <= PP)
+ * one launch instead of two library reductions and four element-wise passes. */
+int bot_halves_tn_combine_f32(const float* a, const float* b, int32_t chunks, int32_t K, int32_t PP, int32_t P, const float* rem_a,
+                              const float* rem_b, float* out, int64_t ldo, bot_stream_t stream);
 int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, int64_t k, const float* alpha, const uint16_t* A,
                         int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t batch, int64_t stride_a,
                         int64_t stride_b, int64_t stride_c, float beta, void* workspace, int64_t workspace_bytes, int32_t tune,

@@ -242,6 +242,16 @@ def halves_scale(x):
     return _pow2_scale(float(x.abs().max()) if x.numel() else 0.0)
 
 
+def halves_tn_combine(a, b, P, rem_a=None, rem_b=None):
+    if a.dim() == 2:
+        a, b = a.unsqueeze(0), b.unsqueeze(0)
+    PP = a.shape[2] // 2
+    s1, s2, s3 = a[:, :, :P].sum(0), a[:, :, PP:PP + P].sum(0), b[:, :, :P].sum(0)
+    if rem_a is not None:
+        s1, s2, s3 = s1 + rem_a[:, :P], s2 + rem_a[:, PP:PP + P], s3 + rem_b[:, :P]
+    return s1 + (s2 + s3) * (1.0 / 2048.0)
+
+
 # maxima as by-products (include/bot_gnn.h): int32 words holding the bit patterns of non-negative floats; one slot suffices here
 def absmax_slots(device):
     return torch.zeros(64, dtype=torch.int32, device=device)
@@ -354,7 +364,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 
