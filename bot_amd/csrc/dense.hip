@@ -19,6 +19,8 @@
 
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace bot {
 
 constexpr int kTX = 64;   // lanes across columns (x VEC floats each)
@@ -330,6 +332,60 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
     }
 }
 
+// Row-segment form of the forward pass when the halves are written (round 3): one workgroup per kRowSeg CONSECUTIVE rows, a thread per 4
+// columns of the whole padded row — the launch shape of halves_split_kernel.  The column-tiled kernel above (256 row blocks striding
+// through the matrix) wrote the three pieces at 3.7 TB/s; 21 k small workgroups that each stream 24 KB in and 36 KB out reach 5.4 TB/s
+// (0.349 -> 0.237 ms at [169 343, 752]; 1, 2, 4, 16 rows per workgroup and looping workgroups of 16 ... 256 rows all measured slower;
+// the backward apply pass in the same shape measured 0.302 vs 0.305 ms: it writes ONE contiguous row, and stays column-tiled).
+constexpr int kRowSeg = 8;
+__global__ __launch_bounds__(256) void bn_act_fwd_rowseg_kernel(BnArgs a) {
+    const int c = threadIdx.x * 4;
+    if (c >= a.piece) return;
+    const bool live = c < a.F;
+    const int nv = live ? min(4, a.F - c) : 0;
+    const float hs = a.hscale[0];
+    float mu[4], sc[4], sh[4], wv[4];
+    load_param<4>(mu, a.mean, c, a.F, 0.f);
+    load_param<4>(sc, a.invstd, c, a.F, 0.f);
+    load_param<4>(wv, a.w, c, a.F, 1.f);
+    load_param<4>(sh, a.b, c, a.F, 0.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sc[t] *= wv[t];
+    const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+    const int64_t nquad = (a.F + 3) / 4;
+    const uint64_t seed = eff_seed(a.seed, a.seed_offset);
+    const int64_t r0 = (int64_t)blockIdx.x * kRowSeg;
+    float v[kRowSeg][4];
+#pragma unroll
+    for (int u = 0; u < kRowSeg; ++u)
+        if (live && r0 + u < a.n) load_cols<4>(v[u], a.x + (r0 + u) * a.ldx + c, a.wx, nv);
+#pragma unroll
+    for (int u = 0; u < kRowSeg; ++u) {
+        const int64_t r = r0 + u;
+        if (r >= a.n) break;
+        __half h1[4], h2[4];
+        float f[4];
+        if (live && a.p > 0.f) drop_factors<4>(seed, r, c, nquad, a.p, scale, f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float o = 0.f;
+            if (t < nv) {
+                o = fmaf(v[u][t] - mu[t], sc[t], sh[t]);
+                if (a.relu) o = fmaxf(o, 0.f);
+                if (a.p > 0.f) o *= f[t];
+            }
+            const float z = o * hs;
+            h1[t] = __float2half_rn(z);
+            h2[t] = __float2half_rn((z - __half2float(h1[t])) * kHalvesShift);   // left operand: [h1 | h1 | 2^11 h2]
+            v[u][t] = o;
+        }
+        if (a.y && live) store_cols<4>(a.y + r * a.ldy + c, v[u], a.wy, nv);
+        __half* o = a.hout + r * a.ldh + c;
+        const uint2 hi = *reinterpret_cast<const uint2*>(h1), lo = *reinterpret_cast<const uint2*>(h2);
+        *reinterpret_cast<uint2*>(o) = hi, *reinterpret_cast<uint2*>(o + a.piece) = hi, *reinterpret_cast<uint2*>(o + 2 * (int64_t)a.piece) = lo;
+    }
+}
+
 // g = dy * keep/(1-p) * [bn > 0];  partial column sums of g and g*xhat
 template <int VEC>
 __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_reduce_kernel(BnArgs a) {
@@ -579,6 +635,10 @@ static int bn_act_fwd_impl(const float* x, int64_t ldx, int64_t n, int32_t F, co
     a.wx = !quad || rows16(x, ldx), a.wy = !quad || rows16(y, ldy);
     const dim3 grid = bn_grid(F, vec, n);
     hipStream_t st = (hipStream_t)stream;
+    if (hout && piece <= 1024) {         // (vec == 4 was required above) the row-segment form: see bn_act_fwd_rowseg_kernel
+        hipLaunchKernelGGL(bn_act_fwd_rowseg_kernel, dim3((unsigned)((n + kRowSeg - 1) / kRowSeg)), dim3((piece / 4 + 63) / 64 * 64), 0, st, a);
+        return hip_status("bn_act_fwd rowseg launch");
+    }
     if (vec == 4) hipLaunchKernelGGL((bn_act_fwd_kernel<4>), grid, dim3(kTX * kTY), 0, st, a);
     else if (vec == 2) hipLaunchKernelGGL((bn_act_fwd_kernel<2>), grid, dim3(kTX * kTY), 0, st, a);
     else hipLaunchKernelGGL((bn_act_fwd_kernel<1>), grid, dim3(kTX * kTY), 0, st, a);
