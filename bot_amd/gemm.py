@@ -60,6 +60,25 @@ def stash(y, h: Halves):
     STATS["stashed"] += 1
 
 
+_HANDLES = {}   # data_ptr of a handle's one-element base -> weak reference to the base (alive as long as any view of it is)
+
+
+def make_handle(like, n: int, F: int):
+    """The stand-in for a hidden state that exists as fp16 halves only (bot_amd.nn.fused._epilogue_forward): zeros of shape [n, F] on
+    ONE element (strides 0, 0) — initialised memory, the autograd edge and the key of the stashed halves.  Registered by the address
+    of its base, so that `take` tells it from a caller's own broadcast tensor."""
+    for k in [k for k, r in _HANDLES.items() if r() is None]:
+        del _HANDLES[k]
+    base = like.new_zeros(1)
+    _HANDLES[base.data_ptr()] = weakref.ref(base)
+    return base.expand(n, F)
+
+
+def is_handle(x) -> bool:
+    r = _HANDLES.get(x.data_ptr()) if (x.dim() == 2 and x.stride(0) == 0 and x.stride(1) == 0) else None
+    return r is not None and r() is not None
+
+
 _SCALES = {}
 
 
@@ -80,7 +99,7 @@ def take(x, order: int):
     if h is not None and ref() is not None and h.order == order:    # a dead y: the address was recycled for another tensor
         STATS["taken"] += 1
         return h
-    if x.dim() == 2 and x.shape[0] > 1 and x.stride(0) == 0:
+    if is_handle(x):
         # a HANDLE (bot_amd.nn.fused._epilogue_forward: the hidden state was stored as halves only) whose halves are gone: its
         # values are placeholders, never an operand
         raise RuntimeError("bot_amd.gemm.take: this hidden state exists only as fp16 halves and they are no longer stashed "

@@ -959,8 +959,13 @@ def check_halves_only_hidden_states(golden, device):
         for k in res[True][2]:
             assert torch.equal(res[True][2][k], res[False][2][k]), k
         # a handle without its halves is refused
-        handle = torch.zeros(1, device=device).expand(50, 8)
+        handle = gemm.make_handle(feat, 50, 8)
+        assert gemm.is_handle(handle) and handle.stride() == (0, 0) and float(handle.abs().max()) == 0.0
         with pytest.raises(RuntimeError, match="exists only as fp16 halves"):
             gemm.take(handle, 0)
+        # a caller's own broadcast tensor is not a handle: it is split like any other operand
+        mine = torch.ones(1, device=device).expand(64, 8)
+        assert not gemm.is_handle(mine)
+        assert gemm.take(mine, 0).buf.shape[0] == 64
     finally:
         gemm.FORCE, fused.FORCE, fused.SKIP_Y = saved
