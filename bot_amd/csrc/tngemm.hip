@@ -54,30 +54,30 @@ __global__ __launch_bounds__(kTnThreads) void tn_gemm_kernel(TnArgs a) {
     const int xcols = a.kx - gxc * kTnBX, ycols = a.ky - gy * kTnBY;      // valid columns of this block (may exceed the block width)
     const int64_t r_begin = (int64_t)chunk * a.rows_per_chunk;
     const int64_t r_end = r_begin + a.rows_per_chunk < a.n ? r_begin + a.rows_per_chunk : a.n;
-    constexpr int NX = kTnStage * kTnBX / kTnThreads, NY = kTnStage * kTnBY / kTnThreads;    // 8 and 6 elements per thread and stage
-    float xr[NX], yr[NY];
-    auto gload = [&](int64_t r0) {
+    // Staging map: thread t moves column t % B of rows t / B + (512 / B) q of a stage — X: 256 columns, rows {0,1} + 2 q, q < 8; Y: 192
+    // columns on threads 0..383, rows {0,1} + 2 q, q < 8 — so a thread's loads differ by a wave-uniform row stride (one 32-bit offset each).
+    constexpr int NX = 8, NY = 8;
+    const int xc = threadIdx.x & 255, xr0 = threadIdx.x >> 8;
+    const int yc = threadIdx.x % kTnBY, yr0 = threadIdx.x / kTnBY;           // yr0 == 2: idle for Y (threads 384..511)
+    const bool xok = xc < xcols, yok = yr0 < 2 && yc < ycols;
+    // TWO stages of global loads in flight (round 3): with one, a workgroup's 1.3 us of MFMAs per stage did not cover a load's latency —
+    // the kernel moved 850 MB at 1.4 TB/s.  Register sets A / B alternate (static indexing: the loop body is written out twice).
+    float xa_[NX], ya_[NY], xb_[NX], yb_[NY];
+    auto gload = [&](float (&xr)[NX], float (&yr)[NY], int64_t r0) {
+        const float* xp = X + (r0 + xr0) * a.ldx + xc;
+        const float* yp = Y + (r0 + yr0) * a.ldy + yc;
+        const int nrow = (int)(r_end - r0);                                   // rows of this stage that exist (>= 1)
 #pragma unroll
-        for (int q = 0; q < NX; ++q) {
-            const int idx = threadIdx.x + q * kTnThreads, row = idx / kTnBX, col = idx % kTnBX;
-            xr[q] = (r0 + row < r_end && col < xcols) ? X[(r0 + row) * a.ldx + col] : 0.f;
-        }
+        for (int q = 0; q < NX; ++q) xr[q] = (xok && xr0 + 2 * q < nrow) ? xp[(int64_t)(2 * q) * a.ldx] : 0.f;
 #pragma unroll
-        for (int q = 0; q < NY; ++q) {
-            const int idx = threadIdx.x + q * kTnThreads, row = idx / kTnBY, col = idx % kTnBY;
-            yr[q] = (r0 + row < r_end && col < ycols) ? Y[(r0 + row) * a.ldy + col] : 0.f;
-        }
+        for (int q = 0; q < NY; ++q) yr[q] = (yok && yr0 + 2 * q < nrow) ? yp[(int64_t)(2 * q) * a.ldy] : 0.f;
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const float (&xr)[NX], const float (&yr)[NY], int buf) {
 #pragma unroll
-        for (int q = 0; q < NX; ++q) {
-            const int idx = threadIdx.x + q * kTnThreads;
-            xs[buf][idx / kTnBX][idx % kTnBX] = xr[q];
-        }
+        for (int q = 0; q < NX; ++q) xs[buf][xr0 + 2 * q][xc] = xr[q];
+        if (yr0 < 2) {
 #pragma unroll
-        for (int q = 0; q < NY; ++q) {
-            const int idx = threadIdx.x + q * kTnThreads;
-            ys[buf][idx / kTnBY][idx % kTnBY] = yr[q];
+            for (int q = 0; q < NY; ++q) ys[buf][yr0 + 2 * q][yc] = yr[q];
         }
     };
     f32x16 acc[kTnTI][kTnTJ];
@@ -87,16 +87,8 @@ __global__ __launch_bounds__(kTnThreads) void tn_gemm_kernel(TnArgs a) {
         for (int j = 0; j < kTnTJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    if (r_begin < r_end) {
-        gload(r_begin);
-        lstore(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += kTnStage, buf ^= 1) {
-        const bool more = r0 + kTnStage < r_end;
-        if (more) gload(r0 + kTnStage);
-#pragma unroll
+    auto compute = [&](int buf) {
+#pragma unroll 2
         for (int ks = 0; ks < kTnStage / 2; ++ks) {
             float xa[kTnTI], ya[kTnTJ];
 #pragma unroll
@@ -108,7 +100,31 @@ __global__ __launch_bounds__(kTnThreads) void tn_gemm_kernel(TnArgs a) {
 #pragma unroll
                 for (int j = 0; j < kTnTJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i], ya[j], acc[i][j], 0, 0, 0);
         }
-        if (more) lstore(buf ^ 1);
+    };
+    // stage s covers rows r_begin + s * kTnStage ...; LDS buffer s & 1 holds stage s while it is multiplied; the register set that holds
+    // stage s + 1 was loaded one stage earlier and is stored to the other buffer after the products; stage s + 2 is requested first.
+    const int64_t nst = (r_end - r_begin + kTnStage - 1) / kTnStage;
+    if (nst > 0) {
+        gload(xa_, ya_, r_begin);
+        lstore(xa_, ya_, 0);
+        if (nst > 1) gload(xb_, yb_, r_begin + kTnStage);            // stage 1 -> set B
+    }
+    __syncthreads();
+    for (int64_t s0 = 0; s0 < nst; s0 += 2) {
+        // even stage s0: LDS buffer 0; set B holds stage s0 + 1; request stage s0 + 2 into set A
+        if (s0 + 2 < nst) gload(xa_, ya_, r_begin + (s0 + 2) * kTnStage);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s0 + 1 < nst) lstore(xb_, yb_, 1);
+        __syncthreads();
+        if (s0 + 1 >= nst) break;
+        // odd stage s0 + 1: LDS buffer 1; set A holds stage s0 + 2; request stage s0 + 3 into set B
+        if (s0 + 3 < nst) gload(xb_, yb_, r_begin + (s0 + 3) * kTnStage);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s0 + 2 < nst) lstore(xa_, ya_, 0);
         __syncthreads();
     }
     // C/D map: column (j) = lane & 31, row (i) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
