@@ -60,23 +60,23 @@ def stash(y, h: Halves):
     STATS["stashed"] += 1
 
 
-_HANDLES = {}   # data_ptr of a handle's one-element base -> weak reference to the base (alive as long as any view of it is)
+_HANDLES = {}   # data_ptr of a handle's one-element base -> the base (held: its address cannot be recycled while it is listed)
+_MAX_HANDLES = 64  # a handle lives from one layer's epilogue to the next layer's projection; older bases are dropped
 
 
 def make_handle(like, n: int, F: int):
     """The stand-in for a hidden state that exists as fp16 halves only (bot_amd.nn.fused._epilogue_forward): zeros of shape [n, F] on
     ONE element (strides 0, 0) — initialised memory, the autograd edge and the key of the stashed halves.  Registered by the address
     of its base, so that `take` tells it from a caller's own broadcast tensor."""
-    for k in [k for k, r in _HANDLES.items() if r() is None]:
-        del _HANDLES[k]
+    while len(_HANDLES) >= _MAX_HANDLES:
+        del _HANDLES[next(iter(_HANDLES))]
     base = like.new_zeros(1)
-    _HANDLES[base.data_ptr()] = weakref.ref(base)
+    _HANDLES[base.data_ptr()] = base
     return base.expand(n, F)
 
 
 def is_handle(x) -> bool:
-    r = _HANDLES.get(x.data_ptr()) if (x.dim() == 2 and x.stride(0) == 0 and x.stride(1) == 0) else None
-    return r is not None and r() is not None
+    return x.dim() == 2 and x.stride(0) == 0 and x.stride(1) == 0 and x.data_ptr() in _HANDLES
 
 
 _SCALES = {}
