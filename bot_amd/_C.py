@@ -71,6 +71,7 @@ _SIGS = {
     "bot_halves_workspace_floats": (c_int64, []),
     "bot_halves_scale_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
     "bot_halves_split_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int32, _P, c_int64, c_int32, _P]),
+    "bot_halves_split_cols_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int32, _P, c_int64, c_int32, c_int32, _P]),
     "bot_gemm_halves_f32": (ctypes.c_int, [c_int32, c_int32, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int64,
                                            c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, c_int32, _P]),
     "bot_gemm_halves_last_algo": (ctypes.c_int, [_P, _P]),
@@ -637,6 +638,18 @@ def halves_split(x, scale, order, piece, out=None):
     _check(_lib.bot_halves_split_f16(x.data_ptr(), x.stride(0), n, F, _ptr(scale), order, out.data_ptr(), out.stride(0), piece, _stream()),
            "halves_split")
     return out
+
+
+def halves_split_cols(x, scale, order, buf, piece, col, width):
+    """Split x [n,F] into columns [col, col + width) of the three pieces of the halves operand `buf` [n, 3 * piece] (zeros behind
+    the F columns of x): several matrices side by side as ONE operand under one scale — bot_halves_split_cols_f16."""
+    _dev(x, scale, buf)
+    x = _mat(x, "x")
+    n, F = x.shape
+    assert buf.dtype == torch.float16 and buf.shape == (n, 3 * piece) and buf.stride(1) == 1 and col % 2 == 0 and col + width <= piece
+    _check(_lib.bot_halves_split_cols_f16(x.data_ptr(), x.stride(0), n, F, _ptr(scale), order, buf.data_ptr() + 2 * col, buf.stride(0), piece,
+                                          width, _stream()), "halves_split_cols")
+    return buf
 
 
 _GEMM_WS = {}

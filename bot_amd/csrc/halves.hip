@@ -87,12 +87,13 @@ __global__ __launch_bounds__(kWave) void halves_scale_kernel(const float* part, 
     }
 }
 
+// `width` columns of each piece are written starting at `out` (F from x, zeros behind them); the three pieces are `piece` apart
 template <int ORDER>
 __global__ __launch_bounds__(128) void halves_split_kernel(const float* x, int64_t ldx, int32_t F, const float* scale, __half* out,
-                                                           int64_t ldo, int32_t piece, bool wide) {
+                                                           int64_t ldo, int32_t piece, bool wide, int32_t width) {
     const int64_t r = blockIdx.x;
     const int c = (blockIdx.y * 128 + threadIdx.x) * 2;
-    if (c >= piece) return;
+    if (c >= width) return;
     const float s = scale ? scale[0] : 1.f;
     float v0 = 0.f, v1 = 0.f;
     const float* xr = x + r * ldx;
@@ -130,9 +131,28 @@ void launch_halves_scale(const float* part, int n, float* scale, hipStream_t st)
 __global__ __launch_bounds__(kBlock) void absmax_slots_kernel(const float* x, int64_t ldx, int64_t n, int32_t F, uint32_t* slots) {
     float m = 0.f;
     const int64_t total = n * (int64_t)F;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t r = i / F;
-        m = fmaxf(m, fabsf(x[r * ldx + (i - r * F)]));
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    if (ldx == F && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {      // contiguous, 16-byte aligned: float4 lanes, four loads in flight
+        const int64_t nq = total >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        for (; i + 3 * stride < nq; i += 4 * stride) {
+            const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                               fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))),
+                               fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+        }
+        for (; i < nq; i += stride) {
+            const float4 a = x4[i];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        }
+        for (int64_t j = (nq << 2) + (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total; j += stride) m = fmaxf(m, fabsf(x[j]));
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+            const int64_t r = i / F;
+            m = fmaxf(m, fabsf(x[r * ldx + (i - r * F)]));
+        }
     }
     absmax_publish(wave_absmax(m), slots);
 }
@@ -218,9 +238,23 @@ int bot_halves_tn_combine_f32(const float* a, const float* b, int32_t chunks, in
     return hip_status("halves_tn_combine launch");
 }
 
+static int halves_split_impl(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
+                             int64_t ldo, int32_t piece, int32_t width, bot_stream_t stream);
+
 int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
                          int64_t ldo, int32_t piece, bot_stream_t stream) {
+    return halves_split_impl(x, ldx, n, F, scale, order, out, ldo, piece, piece, stream);
+}
+
+int bot_halves_split_cols_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
+                              int64_t ldo, int32_t piece, int32_t width, bot_stream_t stream) {
+    return halves_split_impl(x, ldx, n, F, scale, order, out, ldo, piece, width, stream);
+}
+
+static int halves_split_impl(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
+                             int64_t ldo, int32_t piece, int32_t width, bot_stream_t stream) {
     using namespace bot;
+    BOT_REQUIRE(width >= F && width <= piece && width % 2 == 0, BOT_E_RANGE, "halves_split: width=%d (F=%d piece=%d)", width, F, piece);
     BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && piece >= F && ldo >= 3 * (int64_t)piece, BOT_E_RANGE,
                 "halves_split: n=%lld F=%d ldx=%lld piece=%d ldo=%lld", (long long)n, F, (long long)ldx, piece, (long long)ldo);
     BOT_REQUIRE(order == 0 || order == 1, BOT_E_RANGE, "halves_split: order=%d", order);
@@ -230,9 +264,9 @@ int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, cons
     BOT_REQUIRE((x && out) || n == 0, BOT_E_NULL, "halves_split: NULL pointer");
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)n, (unsigned)((piece / 2 + 127) / 128));
-    if (order == 0) hipLaunchKernelGGL(halves_split_kernel<0>, grid, dim3(128), 0, st, x, ldx, F, scale, (__half*)out, ldo, piece, wide);
-    else hipLaunchKernelGGL(halves_split_kernel<1>, grid, dim3(128), 0, st, x, ldx, F, scale, (__half*)out, ldo, piece, wide);
+    const dim3 grid((unsigned)n, (unsigned)((width / 2 + 127) / 128));
+    if (order == 0) hipLaunchKernelGGL(halves_split_kernel<0>, grid, dim3(128), 0, st, x, ldx, F, scale, (__half*)out, ldo, piece, wide, width);
+    else hipLaunchKernelGGL(halves_split_kernel<1>, grid, dim3(128), 0, st, x, ldx, F, scale, (__half*)out, ldo, piece, wide, width);
     return hip_status("halves_split launch");
 }
 

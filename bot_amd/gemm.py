@@ -19,6 +19,7 @@ import torch
 from . import _C
 
 MODE = os.environ.get("BOT_GEMM", "halves")
+LINEAR_BLOCKS = os.environ.get("BOT_LINEAR_BLOCKS", "1") != "0"   # merged projections hand their column blocks' gradients over without a `cat`
 FORCE = False              # tests set this to run the halves path over the emulated (CPU) backend at any row count
 MIN_ROWS = 8192            # below this many rows the fp32 GEMM is launch-bound anyway
 PIECE_ALIGN = 64
@@ -178,6 +179,56 @@ class _Matmul(torch.autograd.Function):
             dw = tn(Halves(buf, scale, *ctx.meta, 0), dh)               # [K, P]
             dw = dw if kp else dw.t().contiguous()
         return dx, dw, None
+
+
+class _MergedLinear(torch.autograd.Function):
+    """(x w^T)[:, block_i] for a weight [P, K] made of row blocks (several Linears on one input, bot_amd.nn.edge_gat): the column blocks of
+    ONE GEMM come back as separate tensors, and in the backward their gradients go side by side into ONE halves operand — each block split
+    in place into its column range under a common scale (bot_halves_split_cols_f16) — instead of being copied into one [n, P] buffer
+    first (autograd's `cat` for a `split`: 9.5 GB read + written per layer at S-products)."""
+
+    @staticmethod
+    def forward(ctx, x, w, sizes):
+        xh = take(x, 0)
+        ctx.sizes, ctx.meta = sizes, (xh.n, xh.F, xh.piece)
+        ctx.save_for_backward(xh.buf, xh.scale, w)
+        y = mm_nt(xh, split(w, 1))
+        return tuple(torch.split(y, sizes, dim=1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        buf, scale, w = ctx.saved_tensors
+        sizes = ctx.sizes
+        n, P = buf.shape[0], sum(sizes)
+        piece = (P + PIECE_ALIGN - 1) // PIECE_ALIGN * PIECE_ALIGN
+        grads = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
+        slots = _C.absmax_slots(buf.device)
+        for g in grads:
+            if g is not None:
+                _C.absmax_into(g, slots)
+        dscale = _C.halves_scale_from_slots(slots)
+        dbuf = torch.empty((n, 3 * piece), dtype=torch.float16, device=buf.device)
+        off = 0
+        for i, (g, wd) in enumerate(zip(grads, sizes)):
+            width = wd if i + 1 < len(sizes) else piece - off                        # the last block also zeroes the operand's padding
+            if g is None:
+                for k in range(3):
+                    dbuf[:, k * piece + off:k * piece + off + width].zero_()
+            else:
+                _C.halves_split_cols(g, dscale, 0, dbuf, piece, off, width)
+            off += wd
+        dh = Halves(dbuf, dscale, n, P, piece, 0)
+        dx = mm_nt(dh, split(w.t().contiguous(), 1)) if ctx.needs_input_grad[0] else None
+        dw = tn(Halves(buf, scale, *ctx.meta, 0), dh).t().contiguous() if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+def linear_blocks(x, weight, sizes):
+    """The column blocks `sizes` of x [N, K] @ weight[P, K]^T as separate tensors through one GEMM and one halves operand in the backward;
+    None when the shapes do not pay or a block would start on an odd column (the caller keeps `linear` + `torch.split`)."""
+    if not LINEAR_BLOCKS or not worth(x, weight.shape[1], weight.shape[0]) or any(s % 2 for s in sizes[:-1]):
+        return None
+    return _MergedLinear.apply(x, weight, tuple(sizes))
 
 
 def worth(x, K: int, P: int) -> bool:

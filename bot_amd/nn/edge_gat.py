@@ -97,12 +97,19 @@ class GATConv(nn.Module):
             parts.append(self.attn_src_fc.weight), biases.append(None)
             if self.attn_dst_fc is not None:
                 parts.append(self.attn_dst_fc.weight), biases.append(None)
-            bias = None
-            if any(b is not None for b in biases):
-                bias = torch.cat([b if b is not None else w.new_zeros(w.shape[0]) for w, b in zip(parts, biases)])
-            proj = ops.linear(feat_src, torch.cat(parts), bias) if feat_src.dim() == 2 and (feat_src.is_cuda or _fused.FORCE) \
-                else F.linear(feat_src, torch.cat(parts), bias)
-            pieces = list(torch.split(proj, [w.shape[0] for w in parts], dim=1))
+            # only dst_fc has a bias: it is added to ITS columns after the GEMM — a bias vector over the whole merged output (zeros
+            # elsewhere) was a 19 GB element-wise pass per layer at S-products for 480 of 968 columns that needed it
+            sizes = [w.shape[0] for w in parts]
+            pieces = None
+            if feat_src.dim() == 2 and (feat_src.is_cuda or _fused.FORCE):
+                from .. import gemm
+                pieces = gemm.linear_blocks(feat_src, torch.cat(parts), sizes)          # halves path: the blocks' gradients never meet in a `cat`
+                if pieces is None:
+                    pieces = torch.split(ops.linear(feat_src, torch.cat(parts)), sizes, dim=1)
+            else:
+                pieces = torch.split(F.linear(feat_src, torch.cat(parts)), sizes, dim=1)
+            pieces = list(pieces)
+            pieces = [p if b is None else ops.add_bias(p, b) for p, b in zip(pieces, biases)]
             ft = pieces.pop(0).unflatten(1, (H, D))
             if self.dst_fc is not None:
                 res = pieces.pop(0).unflatten(1, (H, D))

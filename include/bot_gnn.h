@@ -456,6 +456,12 @@ int bot_absmax_slots_f32(const float* x, int64_t ldx, int64_t n, int32_t F, uint
 int bot_halves_scale_from_slots_f32(const uint32_t* slots, float* scale, bot_stream_t stream);
 int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
                          int64_t ldo, int32_t piece, bot_stream_t stream);
+/* The same split into a COLUMN RANGE of a wider halves operand: `out` points at the range's first column of piece 0, `width` (even,
+ * F <= width <= piece) columns of each of the three pieces are written — F from x, zeros behind them — the pieces stay `piece` apart.
+ * Lets several matrices that are one operand side by side (the gradients of a merged projection's column blocks) be split in place,
+ * under ONE scale, without first copying them into one buffer. */
+int bot_halves_split_cols_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
+                              int64_t ldo, int32_t piece, int32_t width, bot_stream_t stream);
 /* The weight gradient x^T d of two LEFT-layout operands, formed by the caller from row chunks (batched gemm_halves calls): a [chunks][K][2 PP]
  * = x1^T [d1 | 2^11 d2] and b [chunks][K][PP] = (2^11 x2)^T d1 per chunk, contiguous, plus optional remainder chunks rem_a [K][2 PP] / rem_b [K][PP]:
  *   out[k, p] = sum_c a[c][k][p] + (sum_c a[c][k][PP + p] + sum_c b[c][k][p]) * 2^-11      (chunk order, p < P <= PP)

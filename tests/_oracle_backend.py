@@ -242,6 +242,14 @@ def halves_scale(x):
     return _pow2_scale(float(x.abs().max()) if x.numel() else 0.0)
 
 
+def halves_split_cols(x, scale, order, buf, piece, col, width):
+    n, F = x.shape
+    tmp = halves_split(torch.nn.functional.pad(x.float(), (0, width - F)), scale, order, width)      # [n, 3 * width]
+    for k in range(3):
+        buf[:, k * piece + col:k * piece + col + width] = tmp[:, k * width:(k + 1) * width]
+    return buf
+
+
 def halves_tn_combine(a, b, P, rem_a=None, rem_b=None):
     if a.dim() == 2:
         a, b = a.unsqueeze(0), b.unsqueeze(0)
@@ -364,7 +372,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

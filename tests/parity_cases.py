@@ -969,3 +969,49 @@ def check_halves_only_hidden_states(golden, device):
         assert gemm.take(mine, 0).buf.shape[0] == 64
     finally:
         gemm.FORCE, fused.FORCE, fused.SKIP_Y = saved
+
+
+def check_merged_linear_blocks(golden, device):
+    """`gemm.linear_blocks` (the four Linears of an edge-feature GATConv as ONE GEMM whose column blocks come back separately, their
+    gradients split side by side into one halves operand — no `cat`): the ogbn-products / ogbn-proteins stacks on the halves path give
+    the logits and gradients of the stock-fp32 path (the halves GEMMs are fp32-accurate), and the in-place column splits did run."""
+    from bot_amd import _C, gemm
+    from bot_amd.nn import edge_gat, fused
+    s, d, n = golden.graph("g300")
+    E = s.numel()
+    gen = torch.Generator().manual_seed(71)
+    nf, ef = torch.randn(n, 9, generator=gen), torch.rand(E, 8, generator=gen)
+    gout = torch.randn(n, 6, generator=gen).to(device)
+    saved = gemm.FORCE, fused.FORCE
+    calls = []
+    orig = _C.halves_split_cols
+    try:
+        fused.FORCE = True
+        _C.halves_split_cols = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        for kind in ("proteins", "products"):
+            res = {}
+            for halves in (True, False):
+                gemm.FORCE = halves
+                torch.manual_seed(5)
+                if kind == "proteins":
+                    model = edge_gat.ProteinsGAT(node_feats=9, edge_feats=8, n_classes=6, n_layers=3, n_heads=2, n_hidden=64, edge_emb=16,
+                                                 activation=F.relu, dropout=0.0, input_drop=0.0, attn_drop=0.0, edge_drop=0.0)
+                else:
+                    model = edge_gat.ProductsGAT(node_feats=9, edge_feats=0, n_classes=6, n_layers=3, n_heads=2, n_hidden=64, edge_emb=0,
+                                                 activation=F.relu, dropout=0.0, input_drop=0.0, attn_drop=0.0, edge_drop=0.0, residual=True)
+                model = model.train().to(device)
+                g = bot_amd.Graph(s, d, n).to(device)
+                g.ndata["feat"] = nf.to(device)
+                if kind == "proteins":
+                    g.edata["feat"] = ef.to(device)
+                n0 = len(calls)
+                logits = model(g)
+                (logits * gout).sum().backward()
+                assert (len(calls) > n0) == halves, (kind, halves, len(calls) - n0)
+                res[halves] = (logits.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+            fwd_close(res[True][0], res[False][0].cpu().numpy(), 1e-4)
+            for k, gref in res[False][1].items():
+                grad_close(res[True][1][k], gref.cpu().numpy(), 3e-4)
+    finally:
+        gemm.FORCE, fused.FORCE = saved
+        _C.halves_split_cols = orig

@@ -206,6 +206,11 @@ def test_halves_only_hidden_states_on_device(golden):
     PC.check_halves_only_hidden_states(golden, DEV)
 
 
+def test_merged_linear_blocks_on_device(golden):
+    """The edge-feature GATConvs' merged projection on the halves path: column blocks out, gradients split in place into one operand."""
+    PC.check_merged_linear_blocks(golden, DEV)
+
+
 def test_halo_sums_on_device(golden):
     """bot_amd.halo's overlapped aggregations (what the modular layers call in partitioned mode) on the real kernels, the exchange
     replaced by indexing: forward, all gradients and the returned halo-row gradients against the one-exchange form."""

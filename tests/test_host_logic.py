@@ -438,6 +438,10 @@ def test_halves_only_hidden_states_emulated(golden, cpu_backend):
     PC.check_halves_only_hidden_states(golden, "cpu")
 
 
+def test_merged_linear_blocks_emulated(golden, cpu_backend):
+    PC.check_merged_linear_blocks(golden, "cpu")
+
+
 def test_halo_sums_emulated(golden, cpu_backend):
     """bot_amd.halo's overlapped aggregations (GraphConv / GATConv / edge-feature GATConv in partitioned mode) over the emulated backend."""
     PC.check_halo_sums(golden, "cpu")
