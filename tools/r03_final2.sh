@@ -1,8 +1,8 @@
 # Round 3, closing run at the final code (bot_amd/halo.py, by-product maxima, halves-only hidden states; ABI 12): GPU suite, one bench line per BASELINE config,
-# smoke, kernel trace of the headline command, PMC traffic of the headline SpMM -> gpurun_out/r03q/
+# smoke, kernel trace of the headline command, PMC traffic of the headline SpMM -> gpurun_out/r03n/
 set -x
 cd /root/repo
-O=gpurun_out/r03q; mkdir -p $O
+O=gpurun_out/r03n; mkdir -p $O
 python -m pytest tests -m gpu -x -q --durations=8 > $O/gpu_tests.log 2>&1; echo rc=$? >> $O/gpu_tests.log; tail -4 $O/gpu_tests.log
 python bench.py --steps 20 --warmup 5 > $O/bench_arxiv.json 2> $O/bench_arxiv.err; tail -c 200 $O/bench_arxiv.json
 for W in cora reddit proteins products; do
