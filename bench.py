@@ -16,7 +16,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -29,7 +32,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak of one MI355X (/opt/skill
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md "Chip-level parameters"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -59,9 +62,117 @@ def parse():
                          "(configs 1-3; works partitioned too, RCCL collectives are captured).  Default off: the roofline object "
                          "needs HIP events around individual launches inside the timed region, which a replay has none of; "
                          "measured at config 2 on one GPU: 19.74 ms captured vs 19.80 ms eager (the step is GPU-bound)")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0,
+                    help="N > 1 started without a launcher: seconds after which the self-started torch.distributed.run child is killed")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the ranks through torch.distributed.run even for N = 1 (what N > 1 does by itself; lets a 1-GPU box "
+                         "exercise the launcher, the relay and - with --force-partitioned - RCCL initialisation end to end)")
+    ap.add_argument("--collective-timeout", type=float, default=120.0,
+                    help="N > 1: seconds a rank waits for init_process_group and for the first all-to-all before it exits non-zero")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the 1-D partitioned code path even with one rank (exercises the RCCL plumbing on a 1-GPU box)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ self-launch (N > 1)
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def is_result_line(line: str) -> bool:
+    """The rank-0 JSON line of this script (held back by the relay so that it is the LAST line of the parent's stdout)."""
+    t = line.strip()
+    if not (t.startswith("{") and t.endswith("}") and '"metric"' in t):
+        return False
+    try:
+        return "metric" in json.loads(t)
+    except ValueError:
+        return False
+
+
+def relay_child(cmd, env=None, timeout=None, out=None) -> int:
+    """Run `cmd` as a fresh CHILD process (never an exec: a process that replaces itself after touching the GPU takes the box down),
+    pass its stdout through line by line, hold result lines back and print the last one at the very end; stderr is inherited.
+    Returns the child's return code (124 if `timeout` seconds passed: the child's own process group — the one started here — is
+    killed)."""
+    out = out if out is not None else sys.stdout
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1, start_new_session=True)
+    timed_out = []
+
+    def expire():
+        timed_out.append(True)
+        try:
+            os.killpg(p.pid, 9)      # the exact group started above (start_new_session), nothing matched by name
+        except OSError:
+            pass
+
+    timer = threading.Timer(timeout, expire) if timeout else None
+    if timer:
+        timer.daemon = True
+        timer.start()
+    result = None
+    try:
+        for line in p.stdout:
+            if is_result_line(line):
+                result = line
+                continue
+            out.write(line)
+            out.flush()
+        rc = p.wait()
+    finally:
+        if timer:
+            timer.cancel()
+    if result is not None:
+        out.write(result if result.endswith("\n") else result + "\n")
+        out.flush()
+    if timed_out:
+        print(f"bench.py: the {len(cmd)}-word launch command did not finish in {timeout} s; its process group was killed", file=sys.stderr)
+        return 124
+    return rc
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves, exactly as the
+    driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    <same arguments>`), as a child process, BEFORE anything in this process touches the GPU.  (The reference pins one device,
+    src/no-sampling/run.py:524-527; nothing to mirror there.)"""
+    have = torch.cuda.device_count()      # counting devices does not initialise the GPU on this image
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this node has {have}", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool: RCCL's intra-node transport needs it
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr)
+    return relay_child(cmd, env=env, timeout=args.launch_timeout)
+
+
+class Watchdog:
+    """`with Watchdog(120, "init_process_group"):` — if the block has not finished in time the rank prints what hung and exits
+    non-zero (os._exit: a stuck collective cannot be interrupted from Python; it never re-execs anything), so that a wedged
+    rendezvous or a dead xGMI link ends the run with a message instead of a hang."""
+
+    def __init__(self, seconds, what, code=3):
+        self.seconds, self.what, self.code = seconds, what, code
+        self.done = threading.Event()
+
+    def _watch(self):
+        if not self.done.wait(self.seconds):
+            print(f"bench.py rank {os.environ.get('RANK', '0')}: {self.what} did not complete in {self.seconds} s - exiting", file=sys.stderr,
+                  flush=True)
+            os._exit(self.code)
+
+    def __enter__(self):
+        threading.Thread(target=self._watch, daemon=True).start()
+        return self
+
+    def __exit__(self, *exc):
+        self.done.set()
+        return False
 
 
 def spmm_alg_bytes(n, e, H, D, weighted):
@@ -139,20 +250,40 @@ def cpu_baseline_and_parity_sample(name, dev, scale):
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if (args.gpus > 1 or args.self_launch) and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process only launches the ranks and relays their output (no GPU call before this)
+        sys.exit(launch_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() <= local:
+        sys.exit(f"bench.py rank {rank}: needs {max(args.gpus, local + 1)} GPUs, this node has {torch.cuda.device_count()}")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     partitioned = world > 1 or args.force_partitioned
+    rccl = None
     if partitioned:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        with Watchdog(args.collective_timeout, "init_process_group(nccl)"):
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        with Watchdog(args.collective_timeout, "the first all-to-all (RCCL over xGMI)"):
+            # every pair of ranks exchanges one row before any real work: a dead link or a wedged peer shows up here, by name
+            probe = torch.full((world, 4), float(rank), device=dev)
+            got = torch.empty_like(probe)
+            dist.all_to_all_single(got, probe)
+            torch.cuda.synchronize()
+            assert got[:, 0].tolist() == [float(r) for r in range(world)], f"rank {rank}: all-to-all probe returned {got[:, 0].tolist()}"
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            rccl = "unknown"
 
     from bot_amd import _C, gemm, tuning, workloads
     if args.gemm is not None:
@@ -307,7 +438,8 @@ def main():
             H, D, _ = wl.dominant_shape
             widths = wl.halo_widths if getattr(wl, "halo_widths", None) else [H * D]
             per_rank_bytes = [4 * 2 * sum(w * (g["halo_rows"] + g["send_rows"]) for w in widths) for g in gathered]
-            part_info = {"ranks": gathered, "exchange_row_widths_per_layer": widths,
+            assert len(gathered) == world and [g["rank"] for g in gathered] == list(range(world))
+            part_info = {"n_ranks": len(gathered), "rccl_version": rccl, "ranks": gathered, "exchange_row_widths_per_layer": widths,
                          "exchange_bytes_per_rank_per_step": per_rank_bytes,
                          "note": "forward all-to-all of halo source rows + reverse all-to-all of their gradients per layer (RCCL); "
                                  "bytes = 4 * 2 directions * sum over layers of width * (rows received + rows sent)"}

@@ -1418,3 +1418,27 @@ def test_bench_line_contract():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["roofline"] is not None and line["cpu_baseline"]["value"] > 0 and "S-cora" in line["cpu_baseline"]["sample"]
     assert line["parity"]["ok"] is True and line["parity"]["criterion"] == "abs" and "sample" in line["parity"]
+
+
+def test_bench_self_launch_chain_on_one_gpu():
+    """`python bench.py --gpus N` starts its own ranks.  On the 1-GPU box the same chain — this process launches
+    `python -m torch.distributed.run ... bench.py <same arguments>` as a child BEFORE touching the GPU, the rank initialises RCCL
+    (watchdogged), runs the partitioned step, and the relay keeps rank 0's JSON line last — is exercised with `--self-launch
+    --force-partitioned` at N = 1; and `--gpus 2` ends with a message and rc 2 instead of an assertion or a hang."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--self-launch", "--force-partitioned", "--steps", "2",
+                          "--warmup", "1", "--scale", "0.1", "--cpu-baseline", "off"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "torch.distributed.run" in out.stderr                      # the launcher announced its child
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    part = line["config"]["partition"]
+    assert line["n_gpus"] == 1 and part["n_ranks"] == 1 and part["rccl_version"] not in (None, "unknown") and len(part["ranks"]) == 1
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                             cwd=root, env=env)
+        assert out.returncode == 2 and "needs 2 GPUs" in out.stderr and out.stdout.strip() == ""
