@@ -168,7 +168,17 @@ def hip_step(g, feat, labels, train_idx, mask, sd, cfg, n_classes, loss="loge", 
         _, pred, _ = T.forward_backward(model, g, feat, labels, train_idx, train_idx[:0], train_idx[:0], use_labels=True,
                                         loss=loss, n_classes=n_classes, mask=mask.to(dev))
     assert len(relu_gates) == cfg["n_layers"] - 1 and len(leaky_gates) == cfg["n_layers"]
-    return pred.detach(), {k: p.grad.detach() for k, p in model.named_parameters()}, (relu_gates, leaky_gates)
+    pred, grads = pred.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    # the tap keeps every hidden state stored in fp32 (it reads them), so the step above is not the production path
+    # (hidden states as fp16 halves only, bot_amd.nn.fused `y_needed=False`).  The SAME step once more with no tap — what bench.py
+    # times — must give the same logits and gradients, bit for bit, so that the parity verdict below covers the production path.
+    model.zero_grad(set_to_none=True)
+    _, pred2, _ = T.forward_backward(model, g, feat, labels, train_idx, train_idx[:0], train_idx[:0], use_labels=True,
+                                     loss=loss, n_classes=n_classes, mask=mask.to(dev))
+    assert torch.equal(pred2.detach(), pred), "the untapped (production) step gives different logits from the tapped one"
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, grads[k]), f"the untapped (production) step gives a different gradient for {k}"
+    return pred, grads, (relu_gates, leaky_gates)
 
 
 def rank_against_exact(grads_hip, grads_ref, grads_exact, zero_grads=None):
@@ -339,8 +349,10 @@ def workload_parity(name, dev, scale=1.0, exact="auto", timed=False):
     Returns (parity dict incl. "criterion" / "ok", {"seconds", "threads", "edges", "nodes"} of the fp32 oracle step).
     Config 2 (arxiv) has its own entry points (oracle_step / hip_step: label mask, fused / modular variants)."""
     from bot_amd import workloads
+    t_start = time.perf_counter()
     wl = workloads.build(name, dev, drop=False, scale=scale)
     model, g, ds = wl.model, wl.graph, wl.dataset
+    t_built = time.perf_counter()
     s, d = (t.cpu() for t in g.edges())
     n = g.number_of_nodes()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -360,6 +372,7 @@ def workload_parity(name, dev, scale=1.0, exact="auto", timed=False):
         kw = dict(n_layers=6 if prot else 3, n_heads=6 if prot else 4, n_hidden=80 if prot else 120,
                   node_loss=workloads._bce if prot else workloads._loge, use_node_encoder=prot, residual=prot)
         pred, grads, gates = edge_gat_hip_step(model, g, ds.labels, ds.train_idx, kw["node_loss"])
+        t_hip = time.perf_counter()
         args = (s, d, n, ds.feat.cpu(), None if ds.efeat is None else ds.efeat.cpu(), ds.labels.cpu(), ds.train_idx.cpu(), sd)
         # products: Linear weight gradients of the ORACLE accumulated in fp64 (its sgemm over 2.45 M rows is 2.1e-4 off, see
         # oracle.ref_models.linear_f64grad); dst_fc biases sit in front of a training-mode BatchNorm (exact gradient 0)
@@ -370,9 +383,12 @@ def workload_parity(name, dev, scale=1.0, exact="auto", timed=False):
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(2) as pool:
                 f32 = pool.submit(edge_gat_oracle_step, *args, gates=gates, f64_weight_grads=not prot, **kw)
-                f64 = pool.submit(edge_gat_oracle_step, *args, gates=gates, dtype=torch.float64, **kw)
+                f64 = pool.submit(edge_gat_oracle_step, *args, gates=gates, dtype=torch.float64,
+                                  threads=_oracle_threads(int(os.environ.get("BOT_ORACLE_THREADS_F64", 32))), **kw)
                 rp, rg, secs, gstats = f32.result()
-                xp, xg, _, _ = f64.result()
+                xp, xg, secs64, _ = f64.result()
+            print(f"workload_parity({name}): build {t_built - t_start:.1f} s, HIP step + taps {t_hip - t_built:.1f} s, fp32 oracle {secs:.1f} s || "
+                  f"fp64 oracle {secs64:.1f} s (side by side), total so far {time.perf_counter() - t_start:.1f} s")
         else:
             rp, rg, secs, gstats = edge_gat_oracle_step(*args, gates=gates, f64_weight_grads=not prot, **kw)
             if exact:

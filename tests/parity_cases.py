@@ -19,7 +19,8 @@ from oracle import ref_models as RM
 from oracle import ref_ops as R
 
 FWD_ATOL = 1e-4
-GRAD_RTOL = 1e-4
+import os
+GRAD_RTOL = float(os.environ.get("BOT_TEST_GRAD_RTOL", "1e-4"))
 
 
 def fwd_close(a, b, atol=FWD_ATOL, rtol=0.0):
@@ -29,11 +30,24 @@ def fwd_close(a, b, atol=FWD_ATOL, rtol=0.0):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
+GRAD_NOISE = 1e-5         # a gradient that is analytically ZERO (a bias in front of a BatchNorm: the reference holds its own fp32
+                          # cancellation noise there, 1e-7 .. 1e-6) has no entry to be relative to: both sides must be below this
+WORST = []                # max|a - b| / max|b| of every gradient checked (tools / tests read the largest)
+NOISE_SEEN = []           # (max|reference|, max|tested|) of every gradient that took the noise branch (tests print / bound the count)
+
+
 def grad_close(a, b, rtol=GRAD_RTOL):
+    """Every entry within rtol of the reference gradient's LARGEST entry: |a - b| <= rtol * max|b|, nothing else (round 4: the scale
+    used to be max(1, max|b|), which made the check absolute for the many gradients whose largest entry is below 1)."""
     a = a.detach().cpu().double().numpy()
     b = np.asarray(b, dtype=np.float64)
-    scale = max(1.0, float(np.abs(b).max()))
-    np.testing.assert_allclose(a, b, rtol=rtol * 10, atol=rtol * scale)
+    scale = float(np.abs(b).max()) if b.size else 0.0
+    if scale < GRAD_NOISE:
+        NOISE_SEEN.append((scale, float(np.abs(a).max()) if a.size else 0.0))
+        assert a.shape == b.shape and (a.size == 0 or float(np.abs(a).max()) < GRAD_NOISE), (scale, float(np.abs(a).max()))
+        return
+    WORST.append(float(np.abs(a - b).max()) / scale)
+    np.testing.assert_allclose(a, b, rtol=0.0, atol=rtol * scale)
 
 
 def leaf(t, device="cpu"):
@@ -252,9 +266,10 @@ def build_stack(kind, cfg, fin=11, C=5):
     return bnn.GAT(dim_node=fin, dim_edge=0, dim_output=C, activation=F.relu, **cfg)
 
 
-def check_stacks_golden(golden, device, fuse=True):
+def check_stacks_golden(golden, device, fuse=True, grad_rtol=GRAD_RTOL):
     """`fuse=True`: hidden GAT layers run as the single fused autograd node where their options allow
-    (bot_amd/nn/fused.py); `fuse=False`: the modular path everywhere.  Both must reproduce the reference."""
+    (bot_amd/nn/fused.py); `fuse=False`: the modular path everywhere.  Both must reproduce the reference.
+    Gradients within `grad_rtol` = 1e-4 of the reference gradient's largest entry (round 4: was 3e-4 of max(1, largest))."""
     from bot_amd.nn import fused
     calls0, infer_seen = fused.CALLS, [0]
     for c in golden.cases("stacks"):
@@ -272,9 +287,9 @@ def check_stacks_golden(golden, device, fuse=True):
             assert fused.CALLS - before == cfg["n_layers"]  # symmetric normalisation folded into the edge weights: fused too
         fwd_close(logits, c["logits"])
         (logits * c.t("gout").to(device)).sum().backward()
-        grad_close(feat.grad, c["dfeat"], 3e-4)
+        grad_close(feat.grad, c["dfeat"], grad_rtol)
         for k, p in model.named_parameters():
-            grad_close(p.grad, c[f"g.{k}"], 3e-4)
+            grad_close(p.grad, c[f"g.{k}"], grad_rtol)
         if not bool(int(training)):
             # f3: the same eval-mode logits from the inference-only path (`evaluate()` runs the stack under no_grad, run.py:291):
             # one GEMM + one fused sweep per layer where the stack's options allow, the generic path otherwise
@@ -333,7 +348,7 @@ def check_proteins_golden(golden, device):
         (logits * c.t("gout").to(device)).sum().backward()
         for k, p in model.named_parameters():
             if f"g.{k}" in c:
-                grad_close(p.grad, c[f"g.{k}"], 3e-4)
+                grad_close(p.grad, c[f"g.{k}"])
         if not training:   # evaluate()'s forward: the layers' inference-only sweep (inter-layer residual: BatchNorm stays outside)
             from bot_amd.nn import fused
             n0 = fused.INFER_CALLS
@@ -372,7 +387,7 @@ def check_products_golden(golden, device):
             (logits * c.t("gout").to(device)).sum().backward()
             for k, p in model.named_parameters():
                 if f"g.{k}" in c and p.grad is not None:
-                    grad_close(p.grad, c[f"g.{k}"], 3e-4)
+                    grad_close(p.grad, c[f"g.{k}"])
             if not training:   # evaluate()'s forward (eval mode, no_grad): the inference-only sweep, BatchNorm + ReLU folded in
                 from bot_amd.nn import fused
                 n0 = fused.INFER_CALLS
@@ -425,7 +440,7 @@ def check_train_step_golden(golden, device):
                                   n_label_iters=int(n_label_iters), loss=loss_name, n_classes=C, mask=mask)
         assert abs(loss.item() - float(c["loss"])) < 1e-4 * max(1.0, abs(float(c["loss"])))
         for k, p in model.named_parameters():
-            grad_close(p.grad, c[f"g.{k}"], 3e-4)
+            grad_close(p.grad, c[f"g.{k}"])
         for k, v in model.state_dict().items():  # post-step parameters and BN buffers
             if v.is_floating_point():
                 np.testing.assert_allclose(v.cpu().numpy(), c[f"p1.{k}"], rtol=2e-3, atol=2e-4, err_msg=k)
@@ -473,7 +488,7 @@ def check_agg_first_against_oracle(golden, device):
         fwd_close(logits, ref.detach().numpy())
         got = dict(model.named_parameters())
         for k, rg in zip(names, ref_grads):
-            grad_close(got[k].grad, rg.numpy(), 3e-4)
+            grad_close(got[k].grad, rg.numpy())
 
 
 def check_keep_mask_orders(golden, device):
@@ -620,9 +635,9 @@ def check_f4_layers_in_original_order(golden, device):
                     logits = model(h, feat)                                   # node tensors in ORIGINAL order in and out
                     fwd_close(logits, c["logits"])
                     (logits * c.t("gout").to(device)).sum().backward()
-                    grad_close(feat.grad, c["dfeat"], 3e-4)
+                    grad_close(feat.grad, c["dfeat"])
                     for k, p in model.named_parameters():
-                        grad_close(p.grad, c[f"g.{k}"], 3e-4)
+                        grad_close(p.grad, c[f"g.{k}"])
                     if not bool(int(training)):
                         with torch.no_grad():
                             fwd_close(model(h, feat.detach()), c["logits"])  # the inference-only sweep on the renumbered graph
@@ -640,7 +655,7 @@ def check_f4_layers_in_original_order(golden, device):
                 fwd_close(logits, sref.detach().numpy())
                 got = dict(model.named_parameters())
                 for k, rg in zip(names, sref_grads):
-                    grad_close(got[k].grad, rg.numpy(), 3e-4)
+                    grad_close(got[k].grad, rg.numpy())
 
 
 def check_f4_community_partition_blocks(golden, device, worlds=(2, 3)):
@@ -1011,7 +1026,7 @@ def check_merged_linear_blocks(golden, device):
                 res[halves] = (logits.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
             fwd_close(res[True][0], res[False][0].cpu().numpy(), 1e-4)
             for k, gref in res[False][1].items():
-                grad_close(res[True][1][k], gref.cpu().numpy(), 3e-4)
+                grad_close(res[True][1][k], gref.cpu().numpy())
     finally:
         gemm.FORCE, fused.FORCE = saved
         _C.halves_split_cols = orig

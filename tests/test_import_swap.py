@@ -136,9 +136,9 @@ def test_reference_stacks_on_bot_amd(golden, ref_models):
         logits = model(g, feat)
         PC.fwd_close(logits, c["logits"])
         (logits * c.t("gout")).sum().backward()
-        PC.grad_close(feat.grad, c["dfeat"], 3e-4)
+        PC.grad_close(feat.grad, c["dfeat"])
         for k, p in model.named_parameters():
-            PC.grad_close(p.grad, c[f"g.{k}"], 3e-4)
+            PC.grad_close(p.grad, c[f"g.{k}"])
         # the same state_dict drives bot_amd's own modules: identical keys, identical logits
         mine = PC.build_stack(kind, cfg)
         mine.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in c.sub("p.").items()}, strict=True)
