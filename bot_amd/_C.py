@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -74,6 +74,8 @@ _SIGS = {
     "bot_halves_split_cols_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int32, _P, c_int64, c_int32, c_int32, _P]),
     "bot_gemm_halves_f32": (ctypes.c_int, [c_int32, c_int32, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int64,
                                            c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, c_int32, _P]),
+    "bot_gemm_halves3_nt_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64,
+                                               c_int32, _P]),
     "bot_gemm_halves_last_algo": (ctypes.c_int, [_P, _P]),
     "bot_gemm_halves_library_version": (ctypes.c_int, [_P, _P]),
     "bot_tn_gemm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32, c_int32]),
@@ -736,6 +738,19 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
         idx, ms = ctypes.c_int32(-1), ctypes.c_float(0.0)
         _lib.bot_gemm_halves_last_algo(ctypes.byref(idx), ctypes.byref(ms))
         GEMM_SEEN[key] = (idx.value, ms.value)
+    return out
+
+
+def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0):
+    """out[m, n] = scale_a[1] scale_b[1] (a1 b1^T + a1 b2^T + a2 b1^T) from a LEFT operand buffer a [m, 3 piece_a] and a RIGHT operand
+    buffer b [n, 3 piece_b] (bot_amd.gemm.Halves.buf / .scale), k = the common piece width used (bot_gemm_halves3_nt_f32)."""
+    _dev(a, b, scale_a, scale_b)
+    m, n = a.shape[0], b.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    _check(_timed("gemm_halves", (m, n, 3 * k, 1), lambda: _lib.bot_gemm_halves3_nt_f32(
+        m, n, k, scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), 2 * piece_a, b.data_ptr(), _ld(b), piece_b, out.data_ptr(),
+        _ld(out), int(mode), _stream())), "gemm_halves3_nt")
     return out
 
 

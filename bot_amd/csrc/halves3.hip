@@ -1,0 +1,321 @@
+// bot_gemm_halves3_nt_f32 — the fp32 projection  C[m, n] = alpha[n] * sum_k x[m, k] w[n, k]  on the fp16 matrix cores from the two-term
+// operand halves of halves.hip, hand-written for gfx950 (round 4).
+//
+// hipBLASLt (gemm.cpp) evaluates  a1 b1 + a1 b2 + a2 b1  as ONE fp16 GEMM over a three-fold reduction axis, A' = [a1 | a1 | 2^11 a2],
+// B' = [b1 | b2 | 2^-11 b1]: every k-step of the library kernel stages a1 and b1 twice.  This kernel stages each operand's two halves
+// ONCE per k-step (4 pieces instead of 6 through global -> LDS -> registers) and issues the three MFMAs per fragment pair from them:
+//
+//   acc += a1 . b1;   acc += a1 . b2;   acc += (2^11 a2) . (2^-11 b1)         (the last factor is a v_pk_mul_f16 of the b1 fragment:
+//                                                                               exact, bit for bit the third piece of a right operand)
+//
+// Geometry: 256 x 256 output tile per 512-thread workgroup (8 waves as 2 (M) x 4 (N), 128 x 64 per wave), BK = 32 halves per piece per
+// k-step, v_mfma_f32_16x16x32_f16 (96 per wave per k-step), two LDS stages of 4 pieces x 16 KB = 128 KB filled by global_load_lds_dwordx4
+// (LDS-DMA: no staging registers) one k-step ahead; ONE raw s_barrier per k-step with the DMA of the next stage in flight across the
+// whole MFMA phase.  LDS image per piece: [256 rows][64 B], the 16-byte chunk index XOR-swizzled with f(row quad) = (-(row >> 2)) & 3 so
+// that each 16-lane group of a ds_read_b128 (MI355X_MICROARCH.md "LDS") covers all 64 banks; the DMA writes lane-linear, so the swizzle is
+// applied to its per-lane SOURCE address (cdna_hip_programming.md rule 21).  The MFMA operands are swapped (D = W-fragment x X-fragment)
+// so that a lane holds 4 CONSECUTIVE output columns of one row: float4 stores.  Workgroup -> tile order is XCD-aware: the column tiles of
+// one row block run on one XCD (blocks b, b + 8, ... share an L2), so the X tile leaves HBM once.
+//
+// Reference call sites: the projections of src/no-sampling/models.py:490-492 and :558-560 (fc / res_fc, merged) and their input gradients.
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "common.h"
+
+namespace bot {
+namespace {
+
+constexpr int BK = 32;                          // halves per piece per k-step: one v_mfma_f32_16x16x32_f16 deep
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct H3Args {
+    const _Float16* A;      // [M, lda]: a1 at column 0, 2^11 a2 at column a2_off
+    const _Float16* B;      // [N, ldb]: b1 at column 0, b2 at column b2_off
+    const float* scale_a;   // (s, 1/s) pairs of the two operands (halves_scale): alpha = scale_a[1] * scale_b[1]
+    const float* scale_b;
+    float* C;               // [M, ldc]
+    int64_t lda, ldb, ldc;
+    int M, N, K;            // K: columns per piece, a multiple of BK
+    int a2_off, b2_off;
+    int tiles_m, tiles_n;
+    int mode;               // 0 = the product.  Measurement switches (tools/exp_halves3.py): bit 0 no output stores; bit 2 / 3 B / A never
+                            // advance along k; bit 5 the plain loop (barrier at the end of a k-step) and, in it, bit 6 no barrier / wait,
+                            // bit 7 no DMA inside the loop, bit 8 one A fragment pair per k-step
+};
+
+// LDS-DMA, 16 bytes per lane: buffer_load_dwordx4 ... lds with the tile's resource descriptor in SGPRs, a per-lane 32-bit byte offset and a
+// wave-uniform byte offset (SGPR).  (The buffer builtins exist in the device pass only: the host pass needs just the kernel's stub.)
+__device__ __forceinline__ void dma16(const void* tile_base, unsigned char* lptr, uint32_t voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tile_base), 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lptr, 16, voff, soff, 0, 0);
+#endif
+}
+
+// One BM x BN output tile per workgroup of WM x WN waves (wave tile MT x NT MFMA tiles of 16 x 16).  LDS: two stages of
+// [a1 | a2 | b1 | b2], each piece [rows][64 B] with the 16-byte chunk index XOR-swizzled by f(row quad) = (-(row >> 2)) & 3.
+template <int BM, int BN, int WM, int WN, bool PIPE>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p) {
+    constexpr int kWaves = WM * WN;
+    constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
+    constexpr int kABytes = BM * BK * 2, kBBytes = BN * BK * 2;             // one piece of each operand
+    constexpr int kStageBytes = 2 * kABytes + 2 * kBBytes;
+    constexpr int GA = BM / 16 / kWaves, GB = BN / 16 / kWaves;              // 16-row groups (1 KB = one wave DMA instruction) per wave and piece
+    static_assert(GA >= 1 && GB >= 1 && GA * kWaves * 16 == BM && GB * kWaves * 16 == BN, "tile / wave shape");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kStageBytes];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // XCD-aware tile order: blocks b and b + 8 share an XCD (and its L2); XCD x takes the row blocks 8 q + x and walks their column tiles
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
+    if (tm >= p.tiles_m) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const float alpha = p.scale_a[1] * p.scale_b[1];
+
+    // LDS-DMA plan: lane i of a wave instruction lands at byte 16 i of its 1 KB row group: row i >> 2, stored chunk i & 3, which holds
+    // the row's chunk (i & 3) ^ f(row quad) - the swizzle is applied to the per-lane SOURCE address (the DMA writes lane-linear)
+    const int lr = lane >> 2, cq = (lane & 3) ^ ((-(lane >> 4)) & 3);
+    // Addresses as a wave-uniform base (SGPR pair, advanced by a scalar add per k-step) + a per-lane 32-bit byte offset that never
+    // changes: the DMA instruction then carries 4 bytes of address per lane instead of 8 and the loop has no address arithmetic on the
+    // vector unit (an LDS-DMA's issue occupies the SIMD's vector issue port, which its partner wave's MFMAs need).  Offsets are
+    // relative to the tile's first row, so they stay below 256 rows x the row pitch whatever the operand's size.
+    // (buffer_load_dwordx4 ... lds: resource descriptor of the tile's first row in SGPRs + constant VGPR offset + SGPR k offset)
+    const _Float16* tileA = p.A + (int64_t)m0 * p.lda;
+    const _Float16* tileB = p.B + (int64_t)n0 * p.ldb;
+    uint32_t offA[2 * GA], offB[2 * GB];
+#pragma unroll
+    for (int h = 0; h < GA; ++h) {
+        const uint32_t r = (uint32_t)(min(m0 + (w + kWaves * h) * 16 + lr, p.M - 1) - m0) * (uint32_t)p.lda + cq * 8;
+        offA[h] = r * 2, offA[GA + h] = (r + p.a2_off) * 2;
+    }
+#pragma unroll
+    for (int h = 0; h < GB; ++h) {
+        const uint32_t r = (uint32_t)(min(n0 + (w + kWaves * h) * 16 + lr, p.N - 1) - n0) * (uint32_t)p.ldb + cq * 8;
+        offB[h] = r * 2, offB[GB + h] = (r + p.b2_off) * 2;
+    }
+    const int stepA = (p.mode & 8) ? 0 : BK * 2, stepB = (p.mode & 4) ? 0 : BK * 2;     // ablations: an operand re-read from its first k-step
+    // DMA instruction i of a k-step (0 .. kDma - 1): a1 groups, a2 groups, b1 groups, b2 groups; `kt` = the k-step being fetched
+    constexpr int kDma = 2 * GA + 2 * GB;
+    auto issue_one = [&](int i, int stage, int kt) {
+        unsigned char* base = lds + stage * kStageBytes + w * 1024;
+        if (i < 2 * GA) {
+            const int q = i / GA, h = i % GA;
+            dma16(tileA, base + q * kABytes + h * kWaves * 1024, offA[i], kt * stepA);
+        } else {
+            const int k = i - 2 * GA, q = k / GB, h = k % GB;
+            dma16(tileB, base + 2 * kABytes + q * kBBytes + h * kWaves * 1024, offB[k], kt * stepB);
+        }
+    };
+    auto issue = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < kDma; ++i) issue_one(i, stage, kt);
+    };
+
+    // fragment addresses: lane l reads row (l & 15) of a 16-row tile, chunk l >> 4, stored at chunk ^ f(row quad)
+    const int wr = w / WN, wc = w % WN;
+    const int frow = lane & 15, fch = (lane >> 4) ^ ((-(frow >> 2)) & 3);
+    const int a_off = (wr * MT * 16 + frow) * 64 + fch * 16;                      // + mt * 1024
+    const int b_off = 2 * kABytes + (wc * NT * 16 + frow) * 64 + fch * 16;        // + nt * 1024
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int T = p.K / BK;
+    auto mfma12 = [&](int mt, const half8& a1, const half8& a2, const half8 (&b1)[NT], const half8 (&b2)[NT], const half8 (&b1s)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            // operands swapped: D[i = output column within the tile][j = output row] -> a lane holds 4 consecutive columns of one row
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[nt], a1, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2[nt], a1, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1s[nt], a2, acc[mt][nt], 0, 0, 0);
+        }
+    };
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (!PIPE) {
+        auto kstep = [&](int t, auto more_tag) {
+            constexpr bool more = decltype(more_tag)::value;     // the last k-step is peeled: no branch around the DMA inside the MFMA phase
+            const int nstage = (t + 1) & 1;
+            const unsigned char* st = lds + (t & 1) * kStageBytes;
+            half8 b1[NT], b2[NT], b1s[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                b1[nt] = *reinterpret_cast<const half8*>(st + b_off + nt * 1024);
+                b2[nt] = *reinterpret_cast<const half8*>(st + b_off + kBBytes + nt * 1024);
+                b1s[nt] = b1[nt] * (_Float16)(1.0f / kHalvesShift);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int am = (p.mode & 256) ? 0 : mt;                 // ablation: one A fragment pair per k-step instead of MT
+                const half8 a1 = *reinterpret_cast<const half8*>(st + a_off + am * 1024);
+                const half8 a2 = *reinterpret_cast<const half8*>(st + a_off + kABytes + am * 1024);
+                // the DMA of the next stage is spread over the MFMA phase (one or two instructions per row of MFMA tiles)
+                if (more && !(p.mode & 128)) {                          // ablation: no LDS-DMA in the loop
+#pragma unroll
+                    for (int i = mt * kDma / MT; i < (mt + 1) * kDma / MT; ++i) issue_one(i, nstage, t + 1);
+                }
+                mfma12(mt, a1, a2, b1, b2, b1s);
+            }
+            if (!(p.mode & 64)) {                                       // ablation: no wait, no barrier
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        };
+        for (int t = 0; t + 1 < T; ++t) kstep(t, std::true_type{});
+        kstep(T - 1, std::false_type{});
+    } else {
+        // Software-pipelined across the barrier.  The ONE barrier of a k-step sits in front of the step's LAST row of MFMA tiles: by then
+        // every read of the step's stage has returned (lgkmcnt(0)) and this wave's share of the next stage has landed (vmcnt(0)), so
+        // behind it (a) the next step's B fragments and first A fragments are requested, (b) the DMA of the step after next starts into
+        // the stage just freed - and the 12 MFMAs of the last tile row, whose operands are in registers, cover the LDS latency that a
+        // barrier at the END of the step exposes on both waves of a SIMD at once.  DMA instructions of step s: two behind the barrier
+        // of step s - 2, two each beside tile rows 0 .. 2 of step s - 1 (landed long before the next barrier).
+        static_assert(kDma == 8 && MT >= 4, "DMA schedule of the pipelined loop");
+        half8 b1[NT], b2[NT], b1s[NT], a1, a2;
+        auto read_b = [&](const unsigned char* st, half8 (&x1)[NT], half8 (&x2)[NT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                x1[nt] = *reinterpret_cast<const half8*>(st + b_off + nt * 1024);
+                x2[nt] = *reinterpret_cast<const half8*>(st + b_off + kBBytes + nt * 1024);
+            }
+        };
+        if (T > 1) {
+            issue_one(0, 1, 1);
+            issue_one(1, 1, 1);
+        }
+        read_b(lds, b1, b2);
+        a1 = *reinterpret_cast<const half8*>(lds + a_off);
+        a2 = *reinterpret_cast<const half8*>(lds + a_off + kABytes);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b1s[nt] = b1[nt] * (_Float16)(1.0f / kHalvesShift);
+        for (int t = 0; t < T; ++t) {
+            const bool more = t + 1 < T, more2 = t + 2 < T;
+            const unsigned char* st = lds + (t & 1) * kStageBytes;
+            const unsigned char* sn = lds + ((t + 1) & 1) * kStageBytes;
+#pragma unroll
+            for (int mt = 0; mt < MT - 1; ++mt) {
+                const half8 an1 = *reinterpret_cast<const half8*>(st + a_off + (mt + 1) * 1024);
+                const half8 an2 = *reinterpret_cast<const half8*>(st + a_off + kABytes + (mt + 1) * 1024);
+                if (more && mt < 3) {
+                    issue_one(2 + 2 * mt, (t + 1) & 1, t + 1);
+                    issue_one(3 + 2 * mt, (t + 1) & 1, t + 1);
+                }
+                mfma12(mt, a1, a2, b1, b2, b1s);
+                a1 = an1, a2 = an2;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            half8 b1n[NT], b2n[NT], an1 = a1, an2 = a2;
+            if (more2) {
+                issue_one(0, t & 1, t + 2);
+                issue_one(1, t & 1, t + 2);
+            }
+            if (more) {
+                read_b(sn, b1n, b2n);
+                an1 = *reinterpret_cast<const half8*>(sn + a_off);
+                an2 = *reinterpret_cast<const half8*>(sn + a_off + kABytes);
+            }
+            mfma12(MT - 1, a1, a2, b1, b2, b1s);
+            if (more) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    b1[nt] = b1n[nt], b2[nt] = b2n[nt];
+                    b1s[nt] = b1n[nt] * (_Float16)(1.0f / kHalvesShift);
+                }
+                a1 = an1, a2 = an2;
+            }
+        }
+        __builtin_amdgcn_s_barrier();       // the epilogue reuses the stages: every wave is past its last fragment read
+    }
+
+    // epilogue: acc[mt][nt][r] = C[m0 + wr MT 16 + mt 16 + (lane & 15)][n0 + wc NT 16 + nt 16 + (lane >> 4) 4 + r]
+    if (p.mode & 1) {
+        if (acc[0][0][0] == 1.2345e-33f) p.C[0] = acc[MT - 1][NT - 1][3] + acc[MT / 2][1][2];      // keeps the accumulators live
+        return;
+    }
+    const bool vec_ok = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+    const bool vec2_ok = (p.ldc % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 7) == 0);
+    // Through LDS, so that a store instruction writes 4 rows x 256 contiguous bytes (full 128-byte lines) instead of 16 rows x 64 bytes:
+    // the accumulator layout gives a lane 4 consecutive columns of ONE row per tile, 16 rows per instruction (measured with the
+    // full-line address pattern as an ablation: -0.06 ... -0.14 ms of 1.1).  All stages are free after the last barrier; every wave
+    // stages its own 32-row slabs (2 rows of MFMA tiles) in a private region, pitch NT 16 + 4 floats: conflict-free ds_write_b128.
+    static_assert(MT % 2 == 0 && NT == 4, "epilogue staging assumes 64-column wave tiles, an even number of tile rows");
+    constexpr int P = NT * 16 + 4;
+    static_assert(32 * P * 4 <= 2 * kStageBytes / kWaves, "staging slab does not fit the wave's share of the LDS");
+    float* stg = reinterpret_cast<float*>(lds + w * (2 * kStageBytes / kWaves));
+    const int q4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int col = n0 + wc * NT * 16 + l15 * 4;
+#pragma unroll
+    for (int pass = 0; pass < MT / 2; ++pass) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 v = acc[pass * 2 + mm][nt] * alpha;
+                *reinterpret_cast<f32x4*>(stg + (mm * 16 + l15) * P + nt * 16 + q4) = v;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = i * 4 + (lane >> 4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * P + l15 * 4);
+            const int row = m0 + wr * MT * 16 + pass * 32 + r;
+            if (row < p.M) {
+                float* c = p.C + (int64_t)row * p.ldc + col;
+                if (vec_ok && col + 3 < p.N) {
+                    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (vec2_ok && col + 3 < p.N) {          // rows on an 8-byte pitch (the [N, 750] input gradient)
+                    *reinterpret_cast<float2*>(c) = make_float2(v[0], v[1]);
+                    *reinterpret_cast<float2*>(c + 2) = make_float2(v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < p.N) c[e] = v[e];
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool PIPE>
+void launch_h3(H3Args p, int64_t m, int64_t n, hipStream_t st) {
+    p.tiles_m = (int)((m + BM - 1) / BM), p.tiles_n = (int)((n + BN - 1) / BN);
+    const int groups = (p.tiles_m + 7) / 8;
+    hipLaunchKernelGGL((gemm_halves3_nt_kernel<BM, BN, WM, WN, PIPE>), dim3(groups * 8 * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+}
+
+}  // namespace
+}  // namespace bot
+
+extern "C" int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
+                                       int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t mode,
+                                       bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(m > 0 && n > 0 && k > 0 && k % BK == 0, -1, "gemm_halves3_nt: m, n > 0 and k a positive multiple of %d (got %lld %lld %lld)", BK,
+                (long long)m, (long long)n, (long long)k);
+    BOT_REQUIRE(scale_a && scale_b && A && B && C, -1, "gemm_halves3_nt: null pointer");
+    BOT_REQUIRE(aligned(A, 16) && aligned(B, 16) && lda % 8 == 0 && ldb % 8 == 0 && a2_off % 8 == 0 && b2_off % 8 == 0, -1,
+                "gemm_halves3_nt: operands, row pitches and piece offsets must be 16-byte aligned");
+    BOT_REQUIRE(a2_off + k <= lda && b2_off + k <= ldb && ldc >= n && m < (1ll << 31) - 256 && n < (1ll << 31) - 256, -1, "gemm_halves3_nt: bad pitches");
+    H3Args p;
+    p.A = reinterpret_cast<const _Float16*>(A), p.B = reinterpret_cast<const _Float16*>(B), p.scale_a = scale_a, p.scale_b = scale_b, p.C = C;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldc, p.M = (int)m, p.N = (int)n, p.K = (int)k, p.a2_off = (int)a2_off, p.b2_off = (int)b2_off;
+    p.tiles_m = p.tiles_n = 0;
+    p.mode = mode;
+    if (mode & 32) {        // measurement builds only: one barrier at the END of a k-step, with the ablation switches
+        set_kernel("bot::gemm_halves3_nt_kernel<256,256,2,4,plain>");
+        launch_h3<256, 256, 2, 4, false>(p, m, n, (hipStream_t)stream);
+    } else {
+        set_kernel("bot::gemm_halves3_nt_kernel<256,256,2,4,pipelined>");
+        launch_h3<256, 256, 2, 4, true>(p, m, n, (hipStream_t)stream);
+    }
+    return hip_status("gemm_halves3_nt");
+}

@@ -19,6 +19,9 @@ import torch
 from . import _C
 
 MODE = os.environ.get("BOT_GEMM", "halves")
+NT_KERNEL = os.environ.get("BOT_GEMM_NT", "halves3")   # NT products (forward, input gradient): "halves3" = csrc/halves3.hip (each operand
+                                                       # half staged once, three MFMAs per fragment pair), "lib" = hipBLASLt over the 3x-concatenated axis
+NT_MIN_COLS = 192                                      # narrower outputs (the 40-class output layer) leave most of a 256-column tile empty: library
 LINEAR_BLOCKS = os.environ.get("BOT_LINEAR_BLOCKS", "1") != "0"   # merged projections hand their column blocks' gradients over without a `cat`
 FORCE = False              # tests set this to run the halves path over the emulated (CPU) backend at any row count
 MIN_ROWS = 8192            # below this many rows the fp32 GEMM is launch-bound anyway
@@ -126,6 +129,8 @@ def _alpha(a: Halves, b: Halves, n=None):
 def mm_nt(a: Halves, b: Halves, out=None):
     """a [n, F] (order 0) times b [p, F]^T (order 1) -> fp32 [n, p]."""
     assert a.order == 0 and b.order == 1 and a.F == b.F and a.piece == b.piece
+    if NT_KERNEL == "halves3" and b.n >= NT_MIN_COLS:
+        return _C.gemm_halves3_nt(a.buf, b.buf, a.scale, b.scale, a.piece, b.piece, a.piece, out=out)
     return _C.gemm_halves(a.buf, b.buf, _alpha(a, b, b.n), trans_b=True, out=out)
 
 

@@ -179,6 +179,7 @@ def build(name: str, device, *, rank=0, world=1, partitioned=False, seed=0, scal
     describe = (f"S-{name}: power-law graph N={n} E={E} (raw {ds.raw_edges}), F={0 if ds.feat is None else ds.feat.shape[1]}, C={C}; {desc}")
     wl = Workload(name, describe, n, E, ds.raw_edges, step, model, ("spmm", shape), shape, n_local, e_local, ds, g)
     wl.captured = captured
+    wl.optimizer = opt
     # row widths (floats) of the halo tables one step exchanges, per layer: the GAT's aggregate-first layer 0 ships [x | el], the
     # other layers [ft | el] (bot_amd/nn/fused.py:_ext_width); the GCN ships the narrower side of every GraphConv
     if name == "arxiv":

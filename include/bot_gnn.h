@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 13
+#define BOT_ABI_VERSION 14
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -472,6 +472,18 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
                         int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t batch, int64_t stride_a,
                         int64_t stride_b, int64_t stride_c, float beta, void* workspace, int64_t workspace_bytes, int32_t tune,
                         int32_t algo_index, bot_stream_t stream);
+/* v14: the NT product of two halves operands, hand-written for gfx950 (csrc/halves3.hip) instead of the library call above:
+ *   C[m, n] = scale_a[1] scale_b[1] * sum_k ( a1[m,k] b1[n,k] + a1[m,k] b2[n,k] + (2^11 a2)[m,k] (2^-11 b1)[n,k] )
+ * scale_a / scale_b: the operands' (s, 1/s) device pairs from halves_scale (read by the kernel: no alpha vector, no launch to form it);
+ * mode 0 (anything else is an ablation switch of the measurement tools).
+ * A: a LEFT operand's buffer (row pitch lda halves; a1 at column 0, 2^11 a2 at column a2_off = 2 * piece), B: a RIGHT operand's buffer
+ * (b1 at column 0, b2 at column b2_off = piece); k = the piece width (a multiple of 32).  Each operand half is staged through LDS once
+ * per k-step and serves all three MFMAs (the library formulation concatenates the reduction axis three-fold and stages a1 and b1 twice).
+ * Same operands, same three products, fp32 accumulation: results differ from bot_gemm_halves_f32 only in summation order.
+ * Replaces the projections x W^T of src/no-sampling/models.py:490-492, :558-560 (forward) and their input gradients d W. */
+int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
+                            int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t mode,
+                            bot_stream_t stream);
 /* solution index (hipblaslt_ext::getIndexFromAlgo) and search time in ms of the kernel the last gemm_halves call used; what
  * tools/tune_halves_gemm.py records into bot_amd/tuning/halves_gemm.json and passes back as `algo_index` (-1: none) */
 int bot_gemm_halves_last_algo(int32_t* index, float* ms);

@@ -324,6 +324,18 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     return out
 
 
+def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0):
+    """include/bot_gnn.h bot_gemm_halves3_nt_f32: a1 b1^T + a1 b2^T + (2^11 a2) (2^-11 b1)^T from a LEFT and a RIGHT operand buffer."""
+    a1, a2 = a[:, :k].float(), a[:, 2 * piece_a:2 * piece_a + k].float()
+    b1, b2 = b[:, :k].float(), b[:, piece_b:piece_b + k].float()
+    b1s = (b[:, :k] * torch.tensor(2.0 ** -11, dtype=torch.float16)).float()          # the kernel's v_pk_mul_f16: exact or rounded into fp16 subnormals
+    res = (a1 @ b1.t() + a1 @ b2.t() + a2 @ b1s.t()) * (scale_a[1] * scale_b[1])
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
+
+
 def bn_stats_halves(x, eps, momentum, running_mean, running_var, num_batches_tracked, weight, bias, p):
     mean, invstd = bn_stats(x, eps, momentum, running_mean, running_var, num_batches_tracked)
     dev = torch.maximum((x.max(0).values - mean).abs(), (x.min(0).values - mean).abs()) * invstd
@@ -372,7 +384,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -340,12 +340,15 @@ def edge_gat_hip_step(model, g, labels, train_idx, node_loss):
 PARITY_SCALE = {"cora": 1.0, "arxiv": 1.0, "reddit": 1.0, "proteins": 0.125, "products": 0.125}   # bench.py's bounded CPU sample
 
 
-def workload_parity(name, dev, scale=1.0, exact="auto", timed=False):
+def workload_parity(name, dev, scale=1.0, exact="auto", timed=False, warm=False, gpu_steps=0):
     """One train step (drop rates 0) of BASELINE config `name` (bot_amd.workloads) on the HIP path against the oracle's C
     kernels on the host cores, graph of the workload's generator at `scale` (1.0 = the size the bench line is quoted on; the
     density — mean degree — does not depend on it).  The oracle runs at the HIP run's ReLU / leaky-ReLU gates (KinkGates).
     `exact`: also run the step in fp64 and rank the two fp32 runs against it ("auto": config 4, whose logits reach 125).
     `timed`: the fp32 oracle step's seconds are reported as a CPU baseline — run it alone, not beside the fp64 leg.
+    `warm`: with `timed`, the oracle step runs TWICE and the second one is the timing (first-touch page faults of its GB-sized
+    temporaries are in the first).  `gpu_steps` > 0: that many train steps of the SAME graph on the HIP path are timed too
+    (after 2 warm-ups, drop rates 0) and come back as "gpu_seconds_per_step" — the GPU rate on the graph the CPU number is from.
     Returns (parity dict incl. "criterion" / "ok", {"seconds", "threads", "edges", "nodes"} of the fp32 oracle step).
     Config 2 (arxiv) has its own entry points (oracle_step / hip_step: label mask, fused / modular variants)."""
     from bot_amd import workloads
@@ -413,4 +416,20 @@ def workload_parity(name, dev, scale=1.0, exact="auto", timed=False):
     r["gate_tolerance"] = gate_tol
     ok = ok and r.get("max_abs_preact_at_differing_gate", 0.0) <= gate_tol
     r.update(criterion=crit, criterion_text=CRITERIA[crit], ok=bool(ok), edges=int(s.numel()), scale=scale)
-    return r, {"seconds": secs, "threads": threads, "edges": int(s.numel()), "nodes": n}
+    cpu = {"seconds": secs, "threads": threads, "edges": int(s.numel()), "nodes": n, "warm": False}
+    if timed and warm:
+        if name in ("cora", "reddit"):
+            cpu["seconds"] = gcn_oracle_step(s, d, n, ds.feat.cpu(), ds.labels.cpu(), ds.train_idx.cpu(), sd, cfg, gates=gates)[2]
+        else:
+            cpu["seconds"] = edge_gat_oracle_step(*args, gates=gates, f64_weight_grads=not prot, **kw)[2]
+        cpu["warm"], cpu["first_step_seconds"] = True, secs
+    if gpu_steps > 0:
+        for _ in range(2):
+            wl.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(gpu_steps):
+            wl.step()
+        torch.cuda.synchronize()
+        cpu["gpu_seconds_per_step"] = (time.perf_counter() - t0) / gpu_steps
+    return r, cpu

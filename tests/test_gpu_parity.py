@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 13
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 14
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
@@ -1391,3 +1391,157 @@ def test_bench_self_launch_chain_on_one_gpu():
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
                              cwd=root, env=env)
         assert out.returncode == 2 and "needs 2 GPUs" in out.stderr and out.stdout.strip() == ""
+
+
+# ---------------------------------------------------------------------------------------------- replays, at length
+def _replay_case(kind, part_group=None):
+    """(eager step fn, captured step object, eager model, captured model) of one stack on a small graph of its BASELINE shape, every
+    drop rate 0 and a FIXED label mask, both models from the same state."""
+    import copy
+    import torch.nn.functional as F
+    from bot_amd import nn as bnn, synth, train as T
+    name, scale = {"arxiv": ("arxiv", 0.2), "cora": ("cora", 1.0), "reddit": ("reddit", 0.04), "arxiv-1rank": ("arxiv", 0.2)}[kind]
+    ds = synth.make_dataset(name, device=DEV, seed=0, scale=scale)
+    g, C = ds.graph, ds.n_classes
+    g.create_formats_()
+    mask = torch.rand(ds.train_idx.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(3)) < 0.5
+
+    def make():
+        torch.manual_seed(0)
+        if name == "arxiv":
+            m = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, n_layers=3, n_heads=3, n_hidden=64,
+                        norm="batch", dropout=0.0, input_drop=0.0, attn_drop=0.0, linear=True).to(DEV)
+            return m, torch.optim.RMSprop(m.parameters(), lr=0.002, capturable=True), dict(use_labels=True, loss="loge", n_classes=C)
+        hid, layers = (16, 2) if name == "cora" else (256, 3)
+        m = bnn.GCN(in_feats=ds.feat.shape[1], n_classes=C, n_hidden=hid, n_layers=layers, activation=F.relu,
+                    norm="none" if name == "cora" else "batch", norm_adj="symm", dropout=0.0).to(DEV)
+        return m, torch.optim.Adam(m.parameters(), lr=0.01, capturable=True), dict(use_labels=False, loss="logit", n_classes=C)
+
+    m1, o1, kw = make()
+    m2, o2, _ = make()
+    m2.load_state_dict(copy.deepcopy(m1.state_dict()))
+    if kind == "arxiv-1rank":
+        from bot_amd import dist as bdist
+        part = bdist.partition_dataset(ds, 0, 1, DEV, part_group)
+        m1, m2 = bdist.wrap_model(m1, part_group), bdist.wrap_model(m2, part_group)
+
+        def eager():
+            return bdist.train_step(m1, part, o1, mask=mask, group=part_group, **kw)
+
+        def body():
+            m2.train()
+            o2.zero_grad(set_to_none=True)
+            loss, pred = bdist.forward_backward(m2, part, mask=mask, group=part_group, **kw)
+            o2.step()
+            return loss, pred
+        cap = T.CapturedTrainStep(body, DEV, warmup=3)
+    else:
+        def eager():
+            return T.train_step(m1, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o1, mask=mask, **kw)
+        cap = T.captured_train_step(m2, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o2, warmup=3, mask=mask, **kw)
+    return eager, cap, m1, m2
+
+
+@pytest.fixture
+def one_rank_rccl():
+    import socket
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        yield None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["arxiv", "cora", "reddit", "arxiv-1rank"])
+def test_captured_step_twelve_replays_bitwise(kind, request):
+    """round 3 found torch's multi-workgroup reductions returning wrong sums from the FOURTH replay of a captured
+    step on, and rerouted the three call sites that showed it.  This replays each capturable stack — the config-2 GAT, the config-1 and
+    config-3 GCNs and the 1-rank partitioned form (RCCL collectives captured) — TWELVE times and compares the loss, the logits and
+    EVERY parameter gradient with the eager step from the same state after every replay, bit for bit, then the parameters and
+    buffers at the end: any reduction (or anything else) that goes wrong under replay shows up as the first differing tensor."""
+    group = request.getfixturevalue("one_rank_rccl") if kind == "arxiv-1rank" else None
+    eager, cap, m1, m2 = _replay_case(kind, group)
+    for _ in range(3):                    # the capture ran 3 warm-up steps on m2 (the capture pass itself does not execute)
+        eager()
+    for it in range(12):
+        le, pe = eager()
+        lc, pc = cap()
+        torch.cuda.synchronize()
+        assert torch.equal(lc, le), (kind, it, float(lc), float(le))
+        assert torch.equal(pc, pe), (kind, it)
+        for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert torch.equal(a.grad, b.grad), (kind, it, k, float((a.grad - b.grad).abs().max()))
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), (kind, k)
+    from bot_amd import _C
+    _C.SEED_OFFSET = None
+
+
+@pytest.mark.parametrize("kind", ["arxiv", "cora", "reddit", "arxiv-1rank"])
+def test_no_multi_workgroup_torch_reduction_in_capturable_steps(kind, request, tmp_path):
+    """The other half of the same ADVICE item: whatever the root cause of the wrong replayed sums is, no capturable step may contain
+    a torch reduction that spans several workgroups (the kind that stages partials behind a memset-zeroed semaphore): the kernel
+    trace of one eager step of each stack — same launches as its captured form — must show `at::native::reduce_kernel` with a
+    one workgroup per output (grid.y == 1) only; every N-sized sum goes through the library's fixed-order kernels (bot_colsum_f32 and friends)."""
+    import json
+    from torch.profiler import ProfilerActivity, profile
+    group = request.getfixturevalue("one_rank_rccl") if kind == "arxiv-1rank" else None
+    eager, cap, m1, m2 = _replay_case(kind, group)
+    eager()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        eager()
+        torch.cuda.synchronize()
+    path = str(tmp_path / "trace.json")
+    prof.export_chrome_trace(path)
+    evs = [e for e in json.load(open(path))["traceEvents"] if e.get("cat") == "kernel"]
+    assert len(evs) > 10, "no kernel records in the trace"
+    red = [e for e in evs if "at::native::reduce_kernel" in e["name"]]
+    with_grid = [e for e in red if "grid" in e.get("args", {})]
+    # ATen/native/cuda/Reduce.cuh: grid = (output blocks, ctas_per_output); ctas_per_output > 1 <=> should_global_reduce() <=> partials in
+    # a staging buffer + the memset-zeroed semaphore.  (grid.x > 1 alone is one workgroup per slice of outputs: no cross-workgroup sum.)
+    multi = [(e["name"][:120], e["args"]["grid"]) for e in with_grid if int(e["args"]["grid"][1]) > 1]
+    print(f"{kind}: {len(evs)} kernels, {len(red)} torch reduce_kernel launches ({len(with_grid)} with grid info), multi-workgroup: {multi}")
+    assert len(with_grid) == len(red), "the trace carries no grid sizes: cannot tell single- from multi-workgroup reductions"
+    assert not multi, multi
+    from bot_amd import _C
+    _C.SEED_OFFSET = None
+
+
+def test_gemm_halves3_nt_kernel():
+    """csrc/halves3.hip (round 4): the hand-written NT product of two halves operands — each operand half staged once, three MFMAs per
+    fragment pair — against fp64 next to the hipBLASLt formulation of the same three products, on ragged shapes (row / column / k
+    remainders, outputs narrower than a tile, odd output pitches incl. the [N, 750] input gradient's 8-byte rows and a strided `out`),
+    bitwise run to run and bitwise equal to its own plain-loop build (same terms, same order), and refusing bad arguments."""
+    from bot_amd import gemm
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    for (m, K, P, ldc) in ((1000, 96, 300, None), (513, 750, 1536, None), (20000, 1536, 750, None), (4099, 64, 40, None), (777, 250, 257, 301),
+                           (300, 33, 5, None), (9000, 750, 1536, 1540)):
+        x = torch.randn(m, K, device=DEV, generator=gen) * 3
+        x[:, ::5] = 0
+        w = torch.randn(P, K, device=DEV, generator=gen) * 0.05
+        xs, ws = gemm.split(x, 0), gemm.split(w, 1)
+        ref = x.double() @ w.double().t()
+        lib = _C.gemm_halves(xs.buf, ws.buf, gemm._alpha(xs, ws, P), trans_b=True)
+        out = None
+        if ldc is not None:
+            backing = torch.full((m, ldc), 7.0, device=DEV)
+            out = backing[:, :P]
+        got = _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, xs.piece, out=out)
+        if ldc is not None:
+            assert bool((backing[:, P:] == 7.0).all()), "wrote outside the output columns"
+        again = _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, xs.piece)
+        plain = _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, xs.piece, mode=32)
+        sc = float(ref.abs().max())
+        e, el = float((got.double() - ref).abs().max()) / sc, float((lib.double() - ref).abs().max()) / sc
+        print(f"gemm_halves3_nt m={m} K={K} P={P}: err {e:.2e} (hipBLASLt, same operands: {el:.2e})")
+        assert e <= max(4e-6, 1.5 * el), (m, K, P, e, el)
+        assert torch.equal(got, again) and torch.equal(got, plain)
+    assert gemm.NT_KERNEL == "halves3"          # the default route of gemm.mm_nt (forward + input gradient of the merged projections)
+    with pytest.raises(_C.BotKernelError):
+        _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, 40)       # k not a multiple of 32
