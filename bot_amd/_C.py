@@ -76,6 +76,10 @@ _SIGS = {
                                            c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, c_int32, _P]),
     "bot_gemm_halves3_nt_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64,
                                                c_int32, _P]),
+    "bot_label_split_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, _P, c_float, c_uint64, _P, c_int32, _P, _P, _P, _P, _P]),
+    "bot_build_input_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_int32, _P, c_float, c_uint64, _P, _P, c_int64, _P]),
+    "bot_node_loss_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P, c_int32, c_float, _P, c_int64, _P, c_int64, _P]),
+    "bot_rmsprop_step_f32": (ctypes.c_int, [c_int32, _P, _P, _P, _P, c_float, _P, c_float, c_float, c_float, _P]),
     "bot_gemm_halves_last_algo": (ctypes.c_int, [_P, _P]),
     "bot_gemm_halves_library_version": (ctypes.c_int, [_P, _P]),
     "bot_tn_gemm_workspace_floats": (c_int64, [c_int64, c_int32, c_int32, c_int32]),
@@ -752,6 +756,63 @@ def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=
         m, n, k, scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), 2 * piece_a, b.data_ptr(), _ld(b), piece_b, out.data_ptr(),
         _ld(out), int(mode), _stream())), "gemm_halves3_nt")
     return out
+
+
+def label_split(train_idx, labels, mask, mask_rate, seed, use_labels, code, wn):
+    """include/bot_gnn.h bot_label_split_f32: writes code / wn at the training nodes, returns count (1-element float tensor on the device)."""
+    _dev(train_idx, labels, wn)
+    count = torch.empty(1, dtype=torch.float32, device=wn.device)
+    ws = torch.empty(128, dtype=torch.int32, device=wn.device)
+    lab = labels.reshape(labels.shape[0], -1)
+    m = None
+    if mask is not None:
+        m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    _check(_lib.bot_label_split_f32(train_idx.data_ptr(), train_idx.numel(), lab.data_ptr(), lab.stride(0), _ptr(m), float(mask_rate), int(seed),
+                                    _seed_off(1.0), int(bool(use_labels)), _ptr(code), wn.data_ptr(), count.data_ptr(), ws.data_ptr(), _stream()), "label_split")
+    return count
+
+
+def build_input(feat, code, n_classes, p, seed):
+    """include/bot_gnn.h bot_build_input_f32: dropout_p([feat | onehot(code)]) as a new [N, F + C] tensor."""
+    _dev(feat)
+    _f32(feat, "feat")
+    n, F = feat.shape
+    out = torch.empty((n, F + n_classes), dtype=torch.float32, device=feat.device)
+    _check(_lib.bot_build_input_f32(feat.data_ptr(), _ld(feat), n, F, n_classes, _ptr(code), float(p), int(seed), _seed_off(p), out.data_ptr(), _ld(out),
+                                    _stream()), "build_input")
+    return out
+
+
+LOSS_KINDS = {"logit": 0, "loge": 1, "savage": 2}
+
+
+def node_loss(x, labels, wn, count, kind, eps, want_grad=True):
+    """include/bot_gnn.h bot_node_loss_f32: (y [n_pad] with n_pad = n rounded up to 64, zero beyond n and where wn == 0; dx [n, C] or None)."""
+    _dev(x, labels, wn, count)
+    _f32(x, "x")
+    n, C = x.shape
+    n_pad = (n + 63) // 64 * 64
+    y = torch.empty(n_pad, dtype=torch.float32, device=x.device)
+    dx = torch.empty((n, C), dtype=torch.float32, device=x.device) if want_grad else None
+    lab = labels.reshape(labels.shape[0], -1)
+    _check(_lib.bot_node_loss_f32(x.data_ptr(), _ld(x), n, C, lab.data_ptr(), lab.stride(0), wn.data_ptr(), count.data_ptr(), LOSS_KINDS[kind], float(eps),
+                                  y.data_ptr(), n_pad, _ptr(dx), C, _stream()), "node_loss")
+    return y, dx
+
+
+def rmsprop_step(params, grads, square_avgs, lr, alpha, eps, weight_decay, lr_dev=None):
+    """include/bot_gnn.h bot_rmsprop_step_f32 over lists of contiguous float32 tensors (48 per launch)."""
+    for i in range(0, len(params), 48):
+        ps, gs, sq = params[i:i + 48], grads[i:i + 48], square_avgs[i:i + 48]
+        k = len(ps)
+        for t in (*ps, *gs, *sq):
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise BotKernelError("rmsprop_step: contiguous float32 tensors only")
+        P = (c_void_p * k)(*[t.data_ptr() for t in ps])
+        G = (c_void_p * k)(*[t.data_ptr() for t in gs])
+        S = (c_void_p * k)(*[t.data_ptr() for t in sq])
+        Nn = (c_int64 * k)(*[t.numel() for t in ps])
+        _check(_lib.bot_rmsprop_step_f32(k, P, G, S, Nn, float(lr), _ptr(lr_dev), float(alpha), float(eps), float(weight_decay), _stream()), "rmsprop_step")
 
 
 def skinny_gemm(a, b, *, b_is_kn, out, accumulate=False, batch=1, strides=(0, 0, 0), m=None, n=None, k=None, ldc=None):

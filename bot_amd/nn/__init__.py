@@ -294,7 +294,9 @@ class GCN(nn.Module):
         self.activation = activation
 
     def forward(self, graph, feat):
-        h = self.input_drop(graph.to_internal(feat))  # identity unless the graph was renumbered (bot_amd.reorder_graph)
+        h = graph.to_internal(feat)  # identity unless the graph was renumbered (bot_amd.reorder_graph)
+        if not fused.take_input_dropped():  # bot_amd.train assembles the input with the dropout applied (one pass) and says so
+            h = self.input_drop(h)
         h_last = None
         for i in range(self.n_layers):
             conv = self.convs[i](graph, h)
@@ -342,7 +344,9 @@ class GAT(nn.Module):
 
     def forward(self, graph, feat):
         from . import fused
-        h = self.input_drop(graph.to_internal(feat))  # identity unless the graph was renumbered (bot_amd.reorder_graph)
+        h = graph.to_internal(feat)  # identity unless the graph was renumbered (bot_amd.reorder_graph)
+        if not fused.take_input_dropped():  # bot_amd.train assembles the input with the dropout applied (one pass) and says so
+            h = self.input_drop(h)
         h_last = None
         infer = self.fuse_layers and not self.training and not torch.is_grad_enabled() and (h.is_cuda or fused.FORCE)
         for i in range(self.n_layers):

@@ -611,6 +611,31 @@ def halves_only_consumer(conv, norm, activation, graph, training, stack_residual
             and gemm.MODE == "halves" and (gemm.FORCE or (on_device and n_rows >= gemm.MIN_ROWS)))
 
 
+_INPUT_DROPPED = [False]
+
+
+class input_already_dropped:
+    """While active, the NEXT stack forward skips its input dropout (models.py:711 / GCN's `input_drop`): bot_amd.train assembled the
+    layer-0 operand with the dropout applied in the same pass (bot_build_input_f32).  Consumed by the first stack that asks."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        _INPUT_DROPPED[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _INPUT_DROPPED[0] = False
+        return False
+
+
+def take_input_dropped() -> bool:
+    v = _INPUT_DROPPED[0]
+    _INPUT_DROPPED[0] = False
+    return v
+
+
 def gat_hidden_layer(conv, bn, graph, h, dropout_p, training, y_needed=True):
     """`dropout(relu(bn(conv(graph, h).flatten(1))))` as one autograd node (bn None: just `conv(graph, h).flatten(1)`,
     the stack's output layer).  h: [N, Fin] -> [N, H*D].  y_needed=False: see `_epilogue_forward`."""

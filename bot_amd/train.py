@@ -5,11 +5,72 @@ logit / loge / savage losses (run.py:229-237), RMSprop warm-up (run.py:246-249).
 from __future__ import annotations
 
 import math
+import os
+import weakref
 
 import torch
 import torch.nn.functional as F
 
 EPSILON = 1 - math.log(2)  # run.py:34
+# One launch each for the label / prediction split, the input assembly (+ input dropout), the per-node loss with its gradient, and
+# (bot_amd.optim.RMSprop) the optimizer update, instead of ~45 small tensor ops (include/bot_gnn.h "the train step's glue").
+# BOT_FUSED_STEP=0 restores the tensor-op form of the same step (kept: label reuse takes it, and the tests compare the two).
+FUSED_STEP = os.environ.get("BOT_FUSED_STEP", "1") != "0"
+_SPLIT = {}   # (device, N) -> (weakref to the train_idx tensor it was initialised for, code int32 [N], wn float32 [N])
+
+
+def _split_buffers(train_idx, n):
+    """`code` (-1) and `wn` (0) arrays of bot_label_split_f32: entries of non-training nodes are never written, so they are
+    initialised once per train_idx TENSOR (identity, not address: a recycled address with other contents must not reuse them)."""
+    key = (train_idx.device, n)
+    ent = _SPLIT.get(key)
+    if ent is None or ent[0]() is not train_idx or ent[3] != train_idx._version:
+        ent = (weakref.ref(train_idx), torch.full((n,), -1, dtype=torch.int32, device=train_idx.device),
+               torch.zeros(n, dtype=torch.float32, device=train_idx.device), train_idx._version)
+        _SPLIT[key] = ent
+    return ent[1], ent[2]
+
+
+class _NodeLoss(torch.autograd.Function):
+    """mean over the prediction nodes of the per-node loss (run.py:229-237 on pred[train_pred_idx]) as ONE kernel that also
+    leaves the gradient: sum_n wn[n] y_n / count."""
+
+    @staticmethod
+    def forward(ctx, pred, labels, wn, count, kind):
+        from . import _C
+        y, dx = _C.node_loss(pred, labels, wn, count, kind, EPSILON, want_grad=pred.requires_grad)
+        ctx.save_for_backward(dx)
+        return _C.colsum(y.view(-1, 64)).sum() / count[0]      # fixed-order two-stage sum, then 64 values in one workgroup
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None, None, None, None
+
+
+def _fused_forward_backward(model, graph, feat, labels, train_idx, *, use_labels, mask_rate, loss, n_classes, mask):
+    from . import _C
+    from .nn import fused
+    from .ops import new_dropout_seed
+    n = feat.shape[0]
+    code, wn = _split_buffers(train_idx, n)
+    count = _C.label_split(train_idx, labels, mask, mask_rate, new_dropout_seed(1.0) if mask is None else 0, use_labels,
+                           code if use_labels else None, wn)
+    from . import nn as bnn
+    # only stacks known to honour `input_already_dropped` hand their input dropout over; any other model keeps its own
+    drop = getattr(model, "input_drop", None) if isinstance(model, (bnn.GAT, bnn.GCN)) else None
+    if use_labels:
+        # layer 0's operand in one pass: features, one-hot label block of the input-label nodes, input dropout (models.py:711) —
+        # the stack is told not to drop it again
+        p = float(drop.p) if (drop is not None and model.training) else 0.0
+        feat = _C.build_input(feat, code, n_classes, p, new_dropout_seed(p))
+        with fused.input_already_dropped(drop is not None):
+            pred = model(graph, feat)
+    else:
+        pred = model(graph, feat)
+    out = _NodeLoss.apply(pred, labels, wn, count, loss)
+    out.backward()
+    return out, pred, wn
 
 
 def add_labels(feat, labels, idx, n_classes):
@@ -50,13 +111,17 @@ def compute_acc(pred, labels):
 def forward_backward(model, graph, feat, labels, train_idx, val_idx, test_idx, *, use_labels=True, mask_rate=0.5,
                      n_label_iters=0, loss="logit", n_classes=None, mask=None):
     """Forward + loss + backward of `train()` — run.py:252-284 without the optimizer step.
-    Returns (loss tensor, pred, w) with w the 0/1 weight of every training node in the loss (1 = a prediction node of this
-    step, run.py:259-261 / :267).  `mask` overrides the random split of run.py:258.
+    Returns (loss tensor, pred, w) with w the 0/1 loss weights (1 = a prediction node of this step, run.py:259-261 / :267): per
+    training node in the tensor-op form, per NODE ([N], zero outside the training set) in the fused form.  `mask` overrides the
+    random split of run.py:258.
 
     Written with FIXED shapes: the reference's `train_idx[mask]` / `train_idx[~mask]` (boolean indexing) makes the host wait
     for the device and gives tensors whose size changes from step to step; here the one-hot label block is written with the
     mask as its values and the loss is the weighted mean over ALL training nodes — the same sets, the same numbers (up to the
     summation order of a mean), no synchronisation, and a launch sequence a hipGraph can capture (CapturedTrainStep)."""
+    if FUSED_STEP and n_label_iters == 0 and feat.dtype == torch.float32 and loss in ("logit", "loge", "savage"):
+        return _fused_forward_backward(model, graph, feat, labels, train_idx, use_labels=use_labels, mask_rate=mask_rate, loss=loss,
+                                       n_classes=n_classes, mask=mask)
     if mask is None:
         mask = torch.rand(train_idx.shape, device=train_idx.device) < mask_rate
     if use_labels:

@@ -104,7 +104,8 @@ def build(name: str, device, *, rank=0, world=1, partitioned=False, seed=0, scal
         cfg = dict(ARXIV_GAT, use_symmetric_norm=norm_adj == "symm")
         cfg.update(dropout=0.75 * k, input_drop=0.25 * k, attn_drop=0.1 * k)
         model = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, **cfg).to(dev)
-        opt = torch.optim.RMSprop(model.parameters(), lr=0.002, capturable=capture)
+        from . import optim as boptim
+        opt = boptim.RMSprop(model.parameters(), lr=0.002, capturable=capture)      # torch.optim.RMSprop's update in one launch
         kw = dict(use_labels=True, mask_rate=0.5, loss="loge", n_classes=C)
         shape, desc = (3, 250, True), (f"GAT 3 layers x 3 heads x 250, --labels --loss=loge --linear --norm=batch"
                                        f"{' --norm-adj=symm' if norm_adj == 'symm' else ''}, dropout 0.75/0.25/0.1, RMSprop step included")
@@ -112,20 +113,20 @@ def build(name: str, device, *, rank=0, world=1, partitioned=False, seed=0, scal
         hid, layers = (16, 2) if name == "cora" else (256, 3)
         model = bnn.GCN(in_feats=ds.feat.shape[1], n_classes=C, n_hidden=hid, n_layers=layers, activation=F.relu,
                         norm="none" if name == "cora" else "batch", norm_adj="symm", dropout=0.5 * k).to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=capture)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=capture, fused=dev.type == "cuda")
         kw = dict(use_labels=False, mask_rate=0.5, loss="logit", n_classes=C)   # run.py:265-267: the mask split also without --labels
         shape, desc = (1, hid, False), f"GCN {layers} layers x {hid}, norm_adj=symm, dropout 0.5, logit loss, Adam step included"
     elif name == "proteins":
         model = edge_gat.ProteinsGAT(node_feats=8, edge_feats=8, n_classes=C, n_layers=6, n_heads=6, n_hidden=80, edge_emb=16,
                                      activation=F.relu, dropout=0.25 * k, input_drop=0.1 * k, attn_drop=0.0, edge_drop=0.1 * k,
                                      allow_zero_in_degree=True).to(dev)
-        opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=0)
+        opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=0, fused=dev.type == "cuda")
         shape, desc = (6, 80, True), ("edge-feature GAT 6 layers x 6 heads x 80, 8-d edge features, edge_emb 16, dropout 0.25/0.1, "
                                       "edge drop 0.1, BCE-with-logits over 112 tasks, AdamW step included")
     else:
         model = edge_gat.ProductsGAT(node_feats=ds.feat.shape[1], edge_feats=0, n_classes=C, n_layers=3, n_heads=4, n_hidden=120,
                                      edge_emb=0, activation=F.relu, dropout=0.5 * k, input_drop=0.1 * k, attn_drop=0.0, edge_drop=0.1 * k).to(dev)
-        opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=0)
+        opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=0, fused=dev.type == "cuda")
         shape, desc = (4, 120, True), ("GAT 3 layers x 4 heads x 120, dropout 0.5/0.1, edge drop 0.1, loge loss, AdamW step included")
 
     if name == "proteins":  # node features = sum of the incident edge features over the WHOLE graph (ogbn-proteins/gat.py:58)

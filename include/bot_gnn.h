@@ -484,6 +484,37 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
 int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
                             int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t mode,
                             bot_stream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * v14: the train step's glue (csrc/step.hip) — what src/no-sampling/run.py does around the model with a dozen small tensor ops per
+ * step, as four launches.  Deterministic (fixed-order reductions, no atomics); Philox streams as in bot_bn_act_fwd_f32 (`seed`,
+ * optional device word `seed_offset` for hipGraph replays).
+ *
+ *   label_split   run.py:256-267.  keep_i = mask[i] (uint8, may be NULL) or u_i < mask_rate.  use_labels != 0: code[train_idx[i]] =
+ *                 keep_i ? label : -1 (the node's label is an input feature this step, run.py:259-263) and wn[train_idx[i]] = !keep_i
+ *                 (it is a prediction node); use_labels == 0: wn[train_idx[i]] = keep_i (run.py:265-267).  count[0] = sum of the wn written.
+ *                 `code` / `wn` are [N] arrays the CALLER initialised once to -1 / 0 (entries of non-training nodes never change);
+                 `workspace`: 128 int32 words (per-workgroup counts, folded in slot order: two launches).
+ *   build_input   `add_labels` (run.py:240-243) + the stack's input dropout (models.py:711) in one pass:
+ *                 out[n, :] = dropout_p([feat[n, :F] | onehot(code[n])[:C]]), survivors scaled by 1 / (1 - p); C may be 0.
+ *   node_loss     run.py:229-236 per node and its gradient: ce = logsumexp(x) - x[label]; kind 0 logit: y = ce, 1 loge: y = log(eps + ce)
+ *                 - log eps, 2 savage: y = (1 - exp(-ce))^2;  y_out[n] = wn[n] > 0 ? y : 0 (entries n .. n_pad - 1 are zeroed: pad to a
+ *                 multiple of 64 for the fixed-order sum that follows);  dx[n, c] = wn[n] > 0 ? y'(ce) (softmax(x)[c] - [c == label]) /
+ *                 count[0] : 0 (dx may be NULL).  Labels of nodes with wn = 0 may be placeholders (clamped into range, never used).
+ *   rmsprop_step  torch.optim.RMSprop (run.py:331-333; momentum 0, not centered) for n_tensors <= 48 parameters in ONE launch:
+ *                 g += weight_decay p; sq = alpha sq + (1 - alpha) g^2; p -= lr g / (sqrt(sq) + eps).  `params` / `grads` / `square_avg`
+ *                 / `numel` are HOST arrays (of device pointers / element counts), copied into the launch; lr_dev (may be NULL): a device
+ *                 scalar that overrides `lr` (captured steps).
+ * ------------------------------------------------------------------------------------------- */
+int bot_label_split_f32(const int64_t* train_idx, int64_t n_train, const int64_t* labels, int64_t ldl, const uint8_t* mask, float mask_rate,
+                        uint64_t seed, const uint64_t* seed_offset, int32_t use_labels, int32_t* code, float* wn, float* count, int32_t* workspace,
+                        bot_stream_t stream);
+int bot_build_input_f32(const float* feat, int64_t ldf, int64_t n, int32_t F, int32_t C, const int32_t* code, float p, uint64_t seed,
+                        const uint64_t* seed_offset, float* out, int64_t ldo, bot_stream_t stream);
+int bot_node_loss_f32(const float* x, int64_t ldx, int64_t n, int32_t C, const int64_t* labels, int64_t ldl, const float* wn, const float* count,
+                      int32_t kind, float eps, float* y, int64_t n_pad, float* dx, int64_t lddx, bot_stream_t stream);
+int bot_rmsprop_step_f32(int32_t n_tensors, float* const* params, const float* const* grads, float* const* square_avg, const int64_t* numel,
+                         float lr, const float* lr_dev, float alpha, float eps, float weight_decay, bot_stream_t stream);
+
 /* solution index (hipblaslt_ext::getIndexFromAlgo) and search time in ms of the kernel the last gemm_halves call used; what
  * tools/tune_halves_gemm.py records into bot_amd/tuning/halves_gemm.json and passes back as `algo_index` (-1: none) */
 int bot_gemm_halves_last_algo(int32_t* index, float* ms);

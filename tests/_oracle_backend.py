@@ -336,6 +336,66 @@ def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=
     return out
 
 
+# ---- the train step's glue (include/bot_gnn.h v14: label_split / build_input / node_loss / rmsprop_step), restated with torch CPU ops.
+# Dropout and the random split draw from torch's generator here (the kernels' Philox streams are a GPU matter: the GPU suite checks
+# their rates and reproducibility); with p = 0 and a given mask everything is exact.
+def label_split(train_idx, labels, mask, mask_rate, seed, use_labels, code, wn):
+    keep = mask.bool() if mask is not None else torch.rand(train_idx.shape, generator=torch.Generator().manual_seed(int(seed) % (2 ** 31))) < mask_rate
+    pred = ~keep if use_labels else keep
+    if code is not None:
+        code[train_idx] = torch.where(keep, labels.reshape(labels.shape[0], -1)[train_idx, 0], torch.full_like(train_idx, -1)).to(torch.int32)
+    wn[train_idx] = pred.to(torch.float32)
+    return pred.sum().to(torch.float32).reshape(1)
+
+
+def build_input(feat, code, n_classes, p, seed):
+    n, F = feat.shape
+    onehot = torch.zeros(n, n_classes)
+    if n_classes:
+        rows = torch.nonzero(code >= 0)[:, 0]
+        onehot[rows, code[rows].long()] = 1.0
+    x = torch.cat([feat, onehot], 1)
+    if p > 0:
+        keep = torch.rand(x.shape, generator=torch.Generator().manual_seed(int(seed) % (2 ** 31))) >= p
+        x = torch.where(keep, x / (1.0 - p), torch.zeros_like(x))
+    return x
+
+
+def node_loss(x, labels, wn, count, kind, eps, want_grad=True):
+    import math
+    n, C = x.shape
+    lab = labels.reshape(labels.shape[0], -1)[:, 0].clamp(0, C - 1)
+    xd = x.detach()
+    lse = torch.logsumexp(xd, 1)
+    ce = lse - xd.gather(1, lab[:, None])[:, 0]
+    if kind == "loge":
+        y, dy = torch.log(eps + ce) - math.log(eps), 1.0 / (eps + ce)
+    elif kind == "savage":
+        e = torch.exp(-ce)
+        y, dy = (1 - e) ** 2, 2 * (1 - e) * e
+    else:
+        y, dy = ce, torch.ones_like(ce)
+    on = wn > 0
+    n_pad = (n + 63) // 64 * 64
+    yo = torch.zeros(n_pad)
+    yo[:n] = torch.where(on, y, torch.zeros_like(y))
+    dx = None
+    if want_grad:
+        sm = torch.exp(xd - lse[:, None])
+        sm[torch.arange(n), lab] -= 1.0
+        dx = torch.where(on[:, None], sm * (dy / count[0])[:, None], torch.zeros_like(sm))
+    return yo, dx
+
+
+def rmsprop_step(params, grads, square_avgs, lr, alpha, eps, weight_decay, lr_dev=None):
+    lr = float(lr_dev) if lr_dev is not None else lr
+    for p, g, sq in zip(params, grads, square_avgs):
+        if weight_decay != 0:
+            g = g.add(p, alpha=weight_decay)
+        sq.mul_(alpha).addcmul_(g, g, value=1 - alpha)
+        p.addcdiv_(g, sq.sqrt().add_(eps), value=-lr)
+
+
 def bn_stats_halves(x, eps, momentum, running_mean, running_var, num_batches_tracked, weight, bias, p):
     mean, invstd = bn_stats(x, eps, momentum, running_mean, running_var, num_batches_tracked)
     dev = torch.maximum((x.max(0).values - mean).abs(), (x.min(0).values - mean).abs()) * invstd
@@ -384,7 +444,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -427,7 +427,9 @@ def check_train_step_golden(golden, device):
                             norm_adj="symm", use_linear=True)
         model = load_params(model, c, device, prefix="p0.")
         lr = 0.01
-        opt = (torch.optim.RMSprop if optim_name == "rmsprop" else torch.optim.Adam)(model.parameters(), lr=lr)
+        from bot_amd import optim as boptim
+        # RMSprop: the product's one-launch update (bot_amd.optim), pinned here against the reference's post-step parameters
+        opt = (boptim.RMSprop if optim_name == "rmsprop" else torch.optim.Adam)(model.parameters(), lr=lr)
         if optim_name == "rmsprop":
             T.adjust_learning_rate(opt, lr, int(epoch))
         assert abs(opt.param_groups[0]["lr"] - float(c["lr"])) < 1e-12

@@ -1545,3 +1545,117 @@ def test_gemm_halves3_nt_kernel():
     assert gemm.NT_KERNEL == "halves3"          # the default route of gemm.mm_nt (forward + input gradient of the merged projections)
     with pytest.raises(_C.BotKernelError):
         _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, 40)       # k not a multiple of 32
+
+
+def test_step_glue_kernels():
+    """include/bot_gnn.h v14 "the train step's glue" (csrc/step.hip), each kernel against the tensor ops it replaces (run.py:229-267,
+    :240-243, models.py:711, torch.optim.RMSprop), then one whole fused train step against the tensor-op form of the same step."""
+    import math
+    import torch.nn.functional as F
+    from bot_amd import nn as bnn, optim as boptim, synth, train as T
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    n, Fin, C = 5003, 7, 5
+    feat = torch.randn(n, Fin, device=DEV, generator=gen)
+    labels = torch.randint(0, C, (n, 1), device=DEV, generator=gen)
+    tr = torch.randperm(n, device=DEV, generator=gen)[:2700]
+    mask = torch.rand(2700, device=DEV, generator=gen) < 0.5
+    # --- label_split with a given mask, both modes
+    for use_labels in (True, False):
+        code = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+        wn = torch.zeros(n, device=DEV)
+        cnt = _C.label_split(tr, labels, mask, 0.5, 0, use_labels, code if use_labels else None, wn)
+        w_ref = torch.zeros(n, device=DEV)
+        w_ref[tr] = ((~mask) if use_labels else mask).float()
+        assert torch.equal(wn, w_ref) and float(cnt) == float(w_ref.sum())
+        if use_labels:
+            c_ref = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+            c_ref[tr[mask]] = labels[tr[mask], 0].int()
+            assert torch.equal(code, c_ref)
+    # --- its own random split: rate, reproducibility, a different stream per seed
+    outs = []
+    for seed in (11, 11, 12):
+        code = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+        wn = torch.zeros(n, device=DEV)
+        cnt = _C.label_split(tr, labels, None, 0.3, seed, True, code, wn)
+        outs.append((code.clone(), float(cnt)))
+    assert torch.equal(outs[0][0], outs[1][0]) and not torch.equal(outs[0][0], outs[2][0])
+    assert abs(outs[0][1] / 2700 - 0.7) < 0.04 and int((outs[0][0] >= 0).sum()) + int(outs[0][1]) == 2700
+    # --- build_input: exact without dropout; dropout rate / scaling / reproducibility with it
+    code = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    code[tr[mask]] = labels[tr[mask], 0].int()
+    ref = T.add_labels(feat, labels, tr[mask], C)
+    assert torch.equal(_C.build_input(feat, code, C, 0.0, 0), ref)
+    assert torch.equal(_C.build_input(feat, None, 0, 0.0, 0), feat)
+    a, b, c = (_C.build_input(feat, code, C, 0.25, s) for s in (3, 3, 4))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    kept = a != 0
+    assert abs(float(kept[:, :Fin].float().mean()) - 0.75) < 0.01
+    assert torch.allclose(a[kept], (ref / 0.75)[kept], rtol=1e-6, atol=0)
+    # --- node_loss (three kinds) against autograd of the tensor-op form; labels outside the prediction set may be placeholders
+    wn = torch.zeros(n, device=DEV)
+    wn[tr[~mask]] = 1.0
+    cnt = wn.sum().reshape(1)
+    bad = labels.clone()
+    bad[wn == 0] = -1
+    for kind in ("logit", "loge", "savage"):
+        x = (torch.randn(n, C, device=DEV, generator=gen) * 3).requires_grad_()
+        y_ref = T.per_node_loss(x, labels, kind)
+        (torch.where(wn > 0, y_ref, torch.zeros_like(y_ref)).sum() / cnt[0]).backward()
+        y, dx = _C.node_loss(x.detach(), bad, wn, cnt, kind, T.EPSILON)
+        assert y.numel() % 64 == 0 and not y[n:].any()
+        assert torch.allclose(y[:n], torch.where(wn > 0, y_ref.detach(), torch.zeros_like(y_ref)), rtol=2e-5, atol=2e-6), kind
+        assert float((dx - x.grad).abs().max()) <= 1e-5 * float(x.grad.abs().max()) + 1e-12, kind
+    # --- rmsprop_step against torch.optim.RMSprop (ragged sizes, weight decay, warm-up learning rates)
+    sizes = [(1,), (1023,), (1025,), (40, 7), (3, 250, 168), (64,)]
+    for wd in (0.0, 0.01):
+        p1 = [torch.randn(*s, device=DEV, generator=gen).requires_grad_() for s in sizes]
+        p2 = [p.detach().clone().requires_grad_() for p in p1]
+        o1, o2 = torch.optim.RMSprop(p1, lr=0.002, weight_decay=wd), boptim.RMSprop(p2, lr=0.002, weight_decay=wd)
+        for epoch in range(1, 6):
+            T.adjust_learning_rate(o1, 0.002, epoch), T.adjust_learning_rate(o2, 0.002, epoch)
+            for a_, b_ in zip(p1, p2):
+                g = torch.randn(a_.shape, device=DEV, generator=gen)
+                a_.grad, b_.grad = g.clone(), g.clone()
+            o1.step(), o2.step()
+        for a_, b_ in zip(p1, p2):
+            assert torch.allclose(a_, b_, rtol=1e-6, atol=1e-7)
+        assert set(o2.state_dict()["state"][0]) == {"step", "square_avg"}
+    with pytest.raises(NotImplementedError):
+        boptim.RMSprop(p2, momentum=0.9)
+    # --- one whole step: fused glue vs tensor ops (drop rates 0, fixed mask), GAT with labels and GCN without
+    ds = synth.make_dataset("arxiv", device=DEV, seed=0, scale=0.05)
+    g, Cc = ds.graph, ds.n_classes
+    g.create_formats_()
+    m_ = torch.rand(ds.train_idx.shape, device=DEV, generator=gen) < 0.5
+    for kind in ("gat", "gcn"):
+        res = []
+        for fusedstep in (True, False):
+            torch.manual_seed(0)
+            if kind == "gat":
+                model = bnn.GAT(dim_node=ds.feat.shape[1] + Cc, dim_edge=0, dim_output=Cc, activation=F.relu, n_layers=3, n_heads=3, n_hidden=32,
+                                norm="batch", linear=True).to(DEV)
+                kw = dict(use_labels=True, loss="loge", n_classes=Cc)
+            else:
+                model = bnn.GCN(in_feats=ds.feat.shape[1], n_classes=Cc, n_hidden=32, n_layers=2, activation=F.relu, norm="batch").to(DEV)
+                kw = dict(use_labels=False, loss="logit", n_classes=Cc)
+            opt = boptim.RMSprop(model.parameters(), lr=0.002)
+            T.FUSED_STEP = fusedstep
+            try:
+                loss, pred = T.train_step(model, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, opt, mask=m_, **kw)
+            finally:
+                T.FUSED_STEP = True
+            res.append((loss.detach(), pred.detach(), [p.grad.clone() for p in model.parameters()]))
+        assert abs(float(res[0][0]) - float(res[1][0])) <= 2e-6 * max(1.0, abs(float(res[1][0]))), kind
+        assert torch.equal(res[0][1], res[1][1]), kind                           # same forward: same operand, no dropout
+        for ga, gb in zip(res[0][2], res[1][2]):
+            assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()) + 1e-12, kind
+        # (post-step parameters are not compared here: the FIRST RMSprop update is lr * g / (0.1 |g| + eps), a sign function of
+        # entries near zero; the update kernel is held to torch.optim.RMSprop on identical gradients above)
+    # with the reference's input dropout the fused step draws its own (Philox) mask: finite loss, a different input every step
+    torch.manual_seed(1)
+    model = bnn.GAT(dim_node=ds.feat.shape[1] + Cc, dim_edge=0, dim_output=Cc, activation=F.relu, n_layers=2, n_heads=2, n_hidden=16, norm="batch",
+                    input_drop=0.25, dropout=0.5, linear=True).to(DEV)
+    opt = boptim.RMSprop(model.parameters(), lr=0.002)
+    ls = [float(T.train_step(model, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, opt, use_labels=True, loss="loge", n_classes=Cc)[0])
+          for _ in range(3)]
+    assert all(math.isfinite(v) for v in ls) and len(set(ls)) == 3
