@@ -11,10 +11,10 @@ import torch
 ENABLED = True
 MIN_MEAN_DEGREE = 96       # below this a (row, block) visit holds < 1 edge: nothing to reuse
 L2_BLOCK_BYTES = 2 << 20   # source rows per column block * row bytes (half of the 4 MiB L2 of an XCD; 1 / 2 / 4 / 8 MiB: 7.80 / 6.54 / 6.44 / 7.95 ms on S-reddit)
-# The fused backward (spmm_dot) has NO blocked form.  Round 2 built one (two [T, H*D] tiles in LDS: accumulators and the tile's own
-# rows) and measured it at S-proteins, H=6 D=80: 34.4 / 28.6 / 25.3 / 23.5 / 22.7 ms with 1 / 2 / 4 / 8 / 16 MiB column blocks against
-# 21.9 ms for the all-heads row kernel — T = 32 rows leave ~9 edges per wave between two workgroup barriers, the sweep is latency-bound
-# long before L2 residency pays.  It never won, so round 3 removed it (profiles/r02_blocked_dot_proteins.txt keeps the numbers).
+# The fused backward (spmm_dot) has NO blocked form.  Round 2 built one with two [T, H*D] tiles in LDS (T = 32: 34.4 ... 22.7 ms with
+# 1 ... 16 MiB column blocks against 21.9 ms for the row kernel at S-proteins, profiles/r02_blocked_dot_proteins.txt); round 4 built five
+# register-resident forms (T = 64, accumulators and the tile's own rows in VGPRs, 8 or 16 waves, with and without a software pipeline):
+# 22.2 - 26.5 ms at 2 - 4 MiB blocks against 22.0 ms (profiles/r04_blocked_dot_proteins.txt).  None won; both were removed.
 TILE_ROWS = 128            # destination rows per workgroup (32 / 64 / 128; 256 when rows are gathered by lane groups)
 TILE_LDS_BYTES = 128 * 1024  # LDS per workgroup: one 16-wave workgroup per CU
 WAVES = 16                 # wavefronts per workgroup (bot_amd/csrc/blocked.hip kBWaves)
