@@ -92,33 +92,44 @@ __global__ __launch_bounds__(256) void build_input_kernel(const float* feat, int
     }
 }
 
-// ---- per-node loss of run.py:229-236 and its gradient, one wave per node (lanes over the classes):
+// ---- per-node loss of run.py:229-236 and its gradient, 16 lanes per node (4 nodes per wave; a lane holds classes l, l + 16, ...):
 //   ce = logsumexp(x) - x[label];  kind 0: y = ce;  1 (loge): y = log(eps + ce) - log(eps);  2 (savage): y = (1 - exp(-ce))^2
 //   y_out[n] = wn[n] > 0 ? y : 0;   dx[n, c] = wn[n] > 0 ? (dy/dce) (softmax(x)[c] - [c == label]) / count : 0
 // Nodes with wn = 0 contribute nothing whatever their label holds (placeholders: clamped into range before use).
+// (One wave per node, lanes over 40 classes: 65 us at N = 169 343 - 169 k waves for 27 MB; this form: 4x fewer, every exp computed once.)
+constexpr int kLossMaxPerLane = 8;          // classes per lane: C <= 128
 __global__ __launch_bounds__(256) void node_loss_kernel(const float* x, int64_t ldx, int64_t n, int C, const int64_t* labels, int64_t ldl, const float* wn,
                                                         const float* count, int kind, float eps, float* y_out, float* dx, int64_t lddx, int64_t n_pad) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int l16 = threadIdx.x & 15;
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     if (row >= n_pad) return;
     if (row >= n) {                 // padding of y_out up to a multiple of 64 (the fixed-order sum that follows reads whole rows of 64)
-        if (lane == 0) y_out[row] = 0.f;
+        if (l16 == 0) y_out[row] = 0.f;
         return;
     }
     const bool on = wn[row] > 0.f;
     const float* xr = x + row * ldx;
+    float v[kLossMaxPerLane];
     float m = -INFINITY;
-    for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    for (int k = 0; k < kLossMaxPerLane; ++k) {
+        const int c = l16 + 16 * k;
+        v[k] = c < C ? xr[c] : -INFINITY;
+        m = fmaxf(m, v[k]);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
     float se = 0.f;
-    for (int c = lane; c < C; c += 64) se += expf(xr[c] - m);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    for (int k = 0; k < kLossMaxPerLane; ++k) {
+        v[k] = l16 + 16 * k < C ? expf(v[k] - m) : 0.f;          // e^(x - max), reused for the softmax below
+        se += v[k];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 16);
     int lab = (int)labels[row * ldl];
     lab = min(max(lab, 0), C - 1);
-    const float lse = m + logf(se);
-    const float ce = lse - xr[lab];
+    const float ce = m + logf(se) - xr[lab];
     float y, dydce;
     if (kind == 1) {
         y = logf(eps + ce) - logf(eps);
@@ -131,11 +142,16 @@ __global__ __launch_bounds__(256) void node_loss_kernel(const float* x, int64_t 
         y = ce;
         dydce = 1.f;
     }
-    if (lane == 0) y_out[row] = on ? y : 0.f;
+    if (l16 == 0) y_out[row] = on ? y : 0.f;
     if (dx) {
         const float g = on ? dydce / count[0] : 0.f;
+        const float inv = 1.f / se;
         float* dr = dx + row * lddx;
-        for (int c = lane; c < C; c += 64) dr[c] = g * (expf(xr[c] - lse) - (c == lab ? 1.f : 0.f));
+#pragma unroll
+        for (int k = 0; k < kLossMaxPerLane; ++k) {
+            const int c = l16 + 16 * k;
+            if (c < C) dr[c] = g * (v[k] * inv - (c == lab ? 1.f : 0.f));
+        }
     }
 }
 
@@ -205,9 +221,10 @@ extern "C" int bot_build_input_f32(const float* feat, int64_t ldf, int64_t n, in
 extern "C" int bot_node_loss_f32(const float* x, int64_t ldx, int64_t n, int32_t C, const int64_t* labels, int64_t ldl, const float* wn, const float* count,
                                  int32_t kind, float eps, float* y, int64_t n_pad, float* dx, int64_t lddx, bot_stream_t stream) {
     using namespace bot;
-    BOT_REQUIRE(n >= 0 && C > 0 && x && labels && wn && count && y && n_pad >= n && kind >= 0 && kind <= 2 && (!dx || lddx >= C), -1, "node_loss: bad arguments");
+    BOT_REQUIRE(n >= 0 && C > 0 && C <= 16 * kLossMaxPerLane && x && labels && wn && count && y && n_pad >= n && kind >= 0 && kind <= 2 && (!dx || lddx >= C),
+                -1, "node_loss: bad arguments (1 <= C <= %d)", 16 * kLossMaxPerLane);
     if (n_pad == 0) return 0;
-    hipLaunchKernelGGL(node_loss_kernel, dim3((unsigned)((n_pad * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, n, (int)C, labels, ldl, wn,
+    hipLaunchKernelGGL(node_loss_kernel, dim3((unsigned)((n_pad * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, n, (int)C, labels, ldl, wn,
                        count, (int)kind, eps, y, dx, lddx, n_pad);
     return hip_status("node_loss");
 }

@@ -68,7 +68,12 @@ def _fused_forward_backward(model, graph, feat, labels, train_idx, *, use_labels
             pred = model(graph, feat)
     else:
         pred = model(graph, feat)
-    out = _NodeLoss.apply(pred, labels, wn, count, loss)
+    if pred.shape[1] <= 128:
+        out = _NodeLoss.apply(pred, labels, wn, count, loss)
+    else:       # wider than the loss kernel's 128 classes: the same weighted mean with tensor ops
+        from .ops import sum_all
+        y = per_node_loss(pred, labels.clamp(0, pred.shape[1] - 1), loss)
+        out = sum_all(torch.where(wn > 0, y, torch.zeros_like(y))) / count[0]
     out.backward()
     return out, pred, wn
 

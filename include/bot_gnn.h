@@ -499,7 +499,7 @@ int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const float* scale_
  *   node_loss     run.py:229-236 per node and its gradient: ce = logsumexp(x) - x[label]; kind 0 logit: y = ce, 1 loge: y = log(eps + ce)
  *                 - log eps, 2 savage: y = (1 - exp(-ce))^2;  y_out[n] = wn[n] > 0 ? y : 0 (entries n .. n_pad - 1 are zeroed: pad to a
  *                 multiple of 64 for the fixed-order sum that follows);  dx[n, c] = wn[n] > 0 ? y'(ce) (softmax(x)[c] - [c == label]) /
- *                 count[0] : 0 (dx may be NULL).  Labels of nodes with wn = 0 may be placeholders (clamped into range, never used).
+ *                 count[0] : 0 (dx may be NULL); C <= 128.  Labels of nodes with wn = 0 may be placeholders (clamped into range, never used).
  *   rmsprop_step  torch.optim.RMSprop (run.py:331-333; momentum 0, not centered) for n_tensors <= 48 parameters in ONE launch:
  *                 g += weight_decay p; sq = alpha sq + (1 - alpha) g^2; p -= lr g / (sqrt(sq) + eps).  `params` / `grads` / `square_avg`
  *                 / `numel` are HOST arrays (of device pointers / element counts), copied into the launch; lr_dev (may be NULL): a device
