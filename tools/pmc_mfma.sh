@@ -13,7 +13,7 @@ agg = collections.defaultdict(list)
 for f in glob.glob("/tmp/pmc_m_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if any(t in k for t in ("skinny_gemm", "tn_gemm", "Cijk_", "edge_mlp")):
+        if any(t in k for t in ("skinny_gemm", "tn_gemm", "Cijk_", "edge_mlp", "gemm_halves3")):
             agg[(k.split("(")[0].replace("void ", "")[:90], r["Counter_Name"])].append(float(r["Counter_Value"]))
 print("kernel,counter,launches,avg_per_launch")
 for (k, c), v in sorted(agg.items()):

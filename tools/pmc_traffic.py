@@ -17,7 +17,8 @@ kernel = bench["roofline"]["kernel"].split(" (")[0]
 # one resident wave of workgroups): counters are summed over the kernel launches of a call.  Calls in the profiled run = calls per
 # step (from the bench line: launches_timed / steps) x steps run (timed + warm-up + the 3 extra steps that time the halves GEMMs).
 calls_per_step = bench["roofline"]["launches_timed"] / bench["steps"]
-steps_run = bench["steps"] + bench["warmup"] + (3 if bench["roofline"].get("dense_projections") else 0)
+# (+ the 3 extra steps that time optimizer.step(), round 4: every un-captured run has them)
+steps_run = bench["steps"] + bench["warmup"] + (3 if bench["roofline"].get("dense_projections") else 0) + (3 if bench.get("optimizer_ms") is not None else 0)
 calls = calls_per_step * steps_run
 norm = lambda k: k.replace(" ", "")
 rows = {r["counter"]: r for r in csv.DictReader(open(summary)) if norm(r["kernel"]) == norm(kernel)}

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round 4 closing run: one bench line per BASELINE config, kernel trace of the headline command, PMC traffic of each dominant SpMM,
+# MFMA-busy of the dense kernels, the GPU suite.  Everything lands in gpurun_out/r04f/ (copied to profiles/ by hand).
+cd /root/repo
+O=gpurun_out/r04f; mkdir -p $O
+python bench.py --steps 20 --warmup 5 > $O/bench_arxiv.json 2> $O/bench_arxiv.err
+tail -c 300 $O/bench_arxiv.json; echo
+for W in cora reddit proteins products; do
+  timeout 1500 python bench.py --workload $W --steps 10 --warmup 3 > $O/bench_$W.json 2> $O/bench_$W.err
+  tail -c 300 $O/bench_$W.json; echo
+done
+cd /tmp; export TMPDIR=/tmp
+rm -rf /tmp/prof_b
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o r -- python3 /root/repo/bench.py --steps 20 --warmup 5 --cpu-baseline off --gemm halves > /tmp/b.log 2>&1
+find /tmp/prof_b -name "*kernel_stats.csv" -exec cp {} /root/repo/$O/bench_arxiv_kernel_stats.csv \;
+tail -1 /tmp/b.log | cut -c1-200
+cd /root/repo
+for W in arxiv reddit proteins products; do
+  bash tools/pmc_bench.sh $W r04 2>&1 | tail -12
+done
+cp gpurun_out/pmc/r04_* $O/ 2>/dev/null
+bash tools/pmc_halves3.sh > /dev/null 2>&1; cp gpurun_out/r04/pmc_halves3.csv $O/ 2>/dev/null
+bash tools/pmc_mfma.sh > $O/pmc_mfma.log 2>&1; cp gpurun_out/r03m/r03_pmc_mfma.csv $O/r04_pmc_mfma.csv 2>/dev/null
+ls -la $O
