@@ -76,6 +76,9 @@ _SIGS = {
                                            c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, c_int32, _P]),
     "bot_gemm_halves3_nt_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64,
                                                c_int32, _P]),
+    "bot_gemm_halves3_tn_workspace_floats": (c_int64, [c_int64, c_int64, c_int64]),
+    "bot_gemm_halves3_tn_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P,
+                                               c_int64, _P, c_int32, _P]),
     "bot_label_split_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, _P, c_float, c_uint64, _P, c_int32, _P, _P, _P, _P, _P]),
     "bot_build_input_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_int32, _P, c_float, c_uint64, _P, _P, c_int64, _P]),
     "bot_node_loss_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P, c_int32, c_float, _P, c_int64, _P, c_int64, _P]),
@@ -755,6 +758,19 @@ def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=
     _check(_timed("gemm_halves", (m, n, 3 * k, 1), lambda: _lib.bot_gemm_halves3_nt_f32(
         m, n, k, scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), 2 * piece_a, b.data_ptr(), _ld(b), piece_b, out.data_ptr(),
         _ld(out), int(mode), _stream())), "gemm_halves3_nt")
+    return out
+
+
+def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0):
+    """out[k, p] = scale_x[1] scale_d[1] (x1^T d1 + x1^T d2 + x2^T d1) from two LEFT operand buffers x [n, 3 piece_x], d [n, 3 piece_d]
+    (include/bot_gnn.h bot_gemm_halves3_tn_f32): the weight gradient of a projection, reduced over the n rows."""
+    _dev(x, d, scale_x, scale_d)
+    n = x.shape[0]
+    out = torch.empty((k, p), dtype=torch.float32, device=x.device)
+    ws = torch.empty(int(_lib.bot_gemm_halves3_tn_workspace_floats(n, piece_x, piece_d)), dtype=torch.float32, device=x.device)
+    _check(_timed("gemm_halves", (k, p, 3 * n, 1), lambda: _lib.bot_gemm_halves3_tn_f32(
+        n, k, p, piece_x, piece_d, scale_x.data_ptr(), scale_d.data_ptr(), x.data_ptr(), _ld(x), 2 * piece_x, d.data_ptr(), _ld(d), 2 * piece_d,
+        out.data_ptr(), _ld(out), ws.data_ptr(), int(mode), _stream())), "gemm_halves3_tn")
     return out
 
 

@@ -285,6 +285,271 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p)
     }
 }
 
+// ============================================================================================================================
+// TN: the weight gradient  dW[k, p] = sum_n x[n, k] d[n, p]  of two LEFT-layout operands (x: [N, 3 KP], d: [N, 3 PP]; h1 at piece 0,
+// 2^11 h2 at piece 2), a reduction over the N ~ 1.7e5 node rows with a small result:
+//
+//   dW = x1^T d1 + x1^T d2 + x2^T d1 = sum_n  d1 x1 + (2^11 d2)(2^-11 x1) + (2^-11 d1)(2^11 x2)
+//
+// Same staging idea as the NT kernel (each operand's two halves cross global -> LDS once per step of 32 rows and serve three MFMAs per
+// fragment pair; the 2^-11 factors are v_pk_mul_f16 of fragments), but the reduction index runs along the ROWS of both operands, so an
+// MFMA fragment (8 consecutive n of one column) is a column segment of a row-major tile: it is read with gfx950's transposing LDS read
+// ds_read_b64_tr_b16 (lane t of a 16-lane group passes the address of row t >> 2, columns 4 (t & 3) .. + 3 of a 4 x 16 block and
+// receives column t's four rows; probed with integer data, tools/probe_ds_read_tr.hip) — two per fragment.
+//
+// Decomposition: 192 (k) x 192 (p) output tiles and split-K over row ranges, so that ONE split of the config-2 shape (768 x 1536) is
+// 4 x 8 = 32 tiles = the 32 CUs of one XCD: all workgroups that share an x or d tile share an L2, and every operand row leaves HBM once
+// (256 x 256 tiles give 18 per split: 42 % L2 hits and 1.28 ms, measured).  Three LDS stages of 48 KB with the DMA two steps ahead and a
+// COUNTED vmcnt wait: most loads miss the L2 by design (each row block is new) and need more than one MFMA phase to land (with the DMA
+// one step ahead and issued late in the step the 256 x 256 form took 1.83 ms).  LDS image per piece and stage: columns 0 .. 127 as
+// [32 rows][256 B] and columns 128 .. 191 as [32 rows][128 B] (a DMA instruction writes 1 KB linearly: 4 or 8 whole rows), the 32-byte
+// chunk index XOR-swizzled with key8(n) = (n & 3) | ((n >> 1) & 4) resp. key4(n) = ((n >> 1) & 1) | ((n >> 2) & 2) so that the 8 rows a
+// 32-lane half reads at once land on 8 different 32-byte bank groups (zero conflicts, PMC); the swizzle rides on the DMA's per-lane
+// SOURCE column.  Every workgroup writes its fp32 partial tile; tn_reduce_h3_kernel adds the splits in split order and applies 1 / (s_x s_d).
+constexpr int TBK = 32;                          // rows of n per step
+constexpr int TT = 192;                          // tile edge (k and p)
+constexpr int kTnSubA = TBK * 256, kTnSubB = TBK * 128;      // bytes: columns 0..127 / 128..191 of one piece
+constexpr int kTnPiece = kTnSubA + kTnSubB;      // 12 KB
+constexpr int kTnStage = 4 * kTnPiece;           // x1 | x2 | d1 | d2 : 48 KB
+constexpr int kTnStages = 3;
+
+struct TnArgs3 {
+    const _Float16* X;      // [N, ldx]: x1 at column 0, 2^11 x2 at column x2_off
+    const _Float16* D;      // [N, ldd]: d1 at column 0, 2^11 d2 at column d2_off
+    float* part;            // [splits][KP][PP] partial sums
+    int64_t ldx, ldd;
+    int N, K, P, KP, PP;    // K, P: valid columns; KP, PP: piece widths (multiples of 64)
+    int x2_off, d2_off;
+    int tiles_k, tiles_p, splits, rows_per_split;       // rows_per_split: a multiple of TBK
+    int mode;               // 0 = the product; measurement switches (tools/exp_halves3.py): bit 0 no DMA in the loop, bit 1 no barrier / wait
+};
+
+__device__ __forceinline__ int tn_key8(int n) { return (n & 3) | ((n >> 1) & 4); }
+__device__ __forceinline__ int tn_key4(int n) { return ((n >> 1) & 1) | ((n >> 2) & 2); }
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+struct TrLane {             // per-lane constants of the two transposing reads of a fragment (rows rA = 8 g + (t >> 2) and rA + 4)
+    int a0, a1, b0, b1;     // row byte offsets in the 256-byte-pitch / 128-byte-pitch sub-image (+ 8 (t & 3))
+    int k80, k81, k40, k41; // swizzle keys of the two rows
+};
+
+// byte offset inside a piece of transposing read r (0 / 1) of the fragment of 16-column chunk `chunk` (0 .. 11) for this lane
+__device__ __forceinline__ int tr_off(const TrLane& L, int chunk, int r) {
+    if (chunk < 8) return (r ? L.a1 : L.a0) + ((chunk ^ (r ? L.k81 : L.k80)) << 5);
+    return kTnSubA + (r ? L.b1 : L.b0) + (((chunk - 8) ^ (r ? L.k41 : L.k40)) << 5);
+}
+
+// 8 consecutive n (rows 8 g .. 8 g + 7 of the stage) of one column: two transposing reads at per-lane LDS byte addresses a0 / a1 (+ the
+// compile-time piece offset).  Inline asm, NOT the __builtin_amdgcn_ds_read_tr16_b64 intrinsic: behind an LDS-DMA the compiler puts an
+// s_waitcnt vmcnt(0) in front of every use of that intrinsic (it cannot tell the read from the DMA's destination), which drains the whole
+// prefetch pipeline once per tile row (measured: 1.46 -> 2.04 ms when the DMA moved into the MFMA phase).  The caller waits for the reads
+// with tr_wait() before the first use.
+typedef int v2i __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void tr_issue(v2i& lo, v2i& hi, unsigned a0, unsigned a1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF));
+#endif
+}
+__device__ __forceinline__ void tr_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);        // no MFMA may be hoisted above the wait (cdna_hip_programming.md rule 18)
+#endif
+}
+__device__ __forceinline__ half8 tr_pack(const v2i& lo, const v2i& hi) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i q = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(half8, q);
+}
+
+__global__ __launch_bounds__(512) void gemm_halves3_tn_kernel(TnArgs3 p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[kTnStages * kTnStage];
+    // (readfirstlane: the compiler must KNOW the wave index is uniform, or every DMA instruction - whose LDS address goes through M0 - is
+    // wrapped in a waterfall loop and every LDS read behind it waits for vmcnt(0))
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // blocks b, b + 8, ... share an XCD: XCD x takes the splits x, x + 8, ... and walks their tiles (all tiles of a split on one L2)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tps = p.tiles_k * p.tiles_p;
+    const int split = (j / tps) * 8 + xcd, tile = j % tps;
+    if (split >= p.splits) return;
+    const int tk = tile / p.tiles_p, tp = tile % p.tiles_p;
+    const int row0 = split * p.rows_per_split;
+    const int rows = min(p.rows_per_split, p.N - row0);          // > 0 by construction of the splits
+    const int T = (rows + TBK - 1) / TBK;
+
+    // LDS-DMA plan: 48 instructions of 1 KB per step (12 per piece: 8 x [4 rows x 256 B], 4 x [8 rows x 128 B]), six per wave.  Rows past the operand's end (the last split's last step) are outside the descriptor and arrive as zeros.
+    const _Float16* tileX = p.X + (int64_t)row0 * p.ldx + tk * TT;
+    const _Float16* tileD = p.D + (int64_t)row0 * p.ldd + tp * TT;
+    // (plain integer arithmetic: HIP's min<int64_t> goes through double, which makes the descriptor a VGPR value -> waterfall loops)
+    const int64_t bytesX = ((int64_t)rows * p.ldx - tk * TT) * 2, bytesD = ((int64_t)rows * p.ldd - tp * TT) * 2;
+    const uint32_t limX = bytesX > 0x7fffffff ? 0x7fffffffu : (uint32_t)bytesX;
+    const uint32_t limD = bytesD > 0x7fffffff ? 0x7fffffffu : (uint32_t)bytesD;
+    // Instruction i of wave w:  i = 0 .. 3: rows 4 w .. 4 w + 3 of the 256-byte sub-image of piece i (x1, x2, d1, d2);  i = 4 / 5: rows
+    // 8 (w & 3) .. + 7 of the 128-byte sub-image of x piece (w >> 2) / d piece (w >> 2).  WHICH operand an instruction reads is a
+    // compile-time property of i (its resource descriptor must be known uniform: a descriptor picked by a run-time select is a VGPR value
+    // and the compiler wraps the load in a waterfall loop).
+    uint32_t voff[6];       // per-lane source byte offset
+    int loff[6];            // LDS byte offset inside a stage (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const bool isx = i < 2 || i == 4;
+        int q, row, col, lo;
+        if (i < 4) {
+            q = i;
+            row = 4 * w + (lane >> 4);
+            const int sl = lane & 15;
+            col = (((sl >> 1) ^ tn_key8(row)) << 4) + (sl & 1) * 8;
+            lo = q * kTnPiece + w * 1024;
+        } else {
+            q = (i == 4 ? 0 : 2) + (w >> 2);
+            row = 8 * (w & 3) + (lane >> 3);
+            const int sl = lane & 7;
+            col = 128 + (((sl >> 1) ^ tn_key4(row)) << 4) + (sl & 1) * 8;
+            lo = q * kTnPiece + kTnSubA + (w & 3) * 1024;
+        }
+        const int64_t ld = isx ? p.ldx : p.ldd;
+        const int po = (q & 1) ? (isx ? p.x2_off : p.d2_off) : 0;
+        voff[i] = (uint32_t)((int64_t)row * ld + po + col) * 2;
+        loff[i] = lo;
+    }
+    const int stepX = TBK * (int)p.ldx * 2, stepD = TBK * (int)p.ldd * 2;
+    auto issue_one = [&](int i, int stage, int kt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned char* base = lds + stage * kTnStage;
+        if (i < 2 || i == 4) {
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(tileX), 0, (int)limX, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(base + loff[i]), 16, voff[i], kt * stepX, 0, 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(tileD), 0, (int)limD, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(base + loff[i]), 16, voff[i], kt * stepD, 0, 0);
+        }
+#endif
+    };
+    auto issue = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) issue_one(i, stage, kt);
+    };
+
+    // fragment addressing: lane l = (t = l & 15, g = l >> 4) wants rows 8 g .. 8 g + 7 of column t of a 16-column chunk
+    const int wr = w >> 2, wc = w & 3;                    // wave tile: 96 of the p columns (wr: 6 chunks) x 48 of the k columns (wc: 3 chunks)
+    const int t = lane & 15, g = lane >> 4;
+    const int rA = 8 * g + (t >> 2), rB = rA + 4, sub = 8 * (t & 3);
+    TrLane L;
+    L.a0 = rA * 256 + sub, L.a1 = rB * 256 + sub, L.b0 = rA * 128 + sub, L.b1 = rB * 128 + sub;
+    L.k80 = tn_key8(rA), L.k81 = tn_key8(rB), L.k40 = tn_key4(rA), L.k41 = tn_key4(rB);
+    // the swizzle makes a fragment's address lane-dependent in a way no immediate can carry: 18 per-lane offsets, computed once
+    int xo[3][2], dofs[6][2];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) xo[nt][0] = tr_off(L, wc * 3 + nt, 0), xo[nt][1] = tr_off(L, wc * 3 + nt, 1);
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt) dofs[mt][0] = tr_off(L, wr * 6 + mt, 0), dofs[mt][1] = tr_off(L, wr * 6 + mt, 1);
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    f32x4 acc[6][3];                                      // [mt: 16 p columns each][nt: 16 k columns each]
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const _Float16 sh = (_Float16)(1.0f / kHalvesShift);
+
+    issue(0, 0);
+    if (T > 1) issue(1, 1);
+    if (T > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // step 0 landed, step 1 may still be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int kt = 0; kt < T; ++kt) {
+        const int s2 = stage >= 1 ? stage - 1 : 2;        // (stage + 2) % 3: free since the barrier that ended step kt - 1
+        const bool ahead = kt + 2 < T && !(p.mode & 1);      // this step issues the DMA of step kt + 2, one instruction per tile row: six
+        // at once right behind the barrier cost every wave ~900 cycles of issue before its first MFMA (0.55 of 1.46 ms, ablation)
+        // the k-column fragments (x: the MFMA's B operand after the swap) of this wave's 48 columns: x1, 2^11 x2, 2^-11 x1
+        const unsigned sb = lds_base + stage * kTnStage;
+        v2i xl[3][2], xh[3][2], dl[2][2], dh[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            tr_issue<0>(xl[nt][0], xh[nt][0], sb + xo[nt][0], sb + xo[nt][1]);
+            tr_issue<kTnPiece>(xl[nt][1], xh[nt][1], sb + xo[nt][0], sb + xo[nt][1]);
+        }
+        tr_issue<2 * kTnPiece>(dl[0][0], dh[0][0], sb + dofs[0][0], sb + dofs[0][1]);
+        tr_issue<3 * kTnPiece>(dl[0][1], dh[0][1], sb + dofs[0][0], sb + dofs[0][1]);
+        tr_wait();
+        half8 x1[3], x2[3], x1s[3];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            x1[nt] = tr_pack(xl[nt][0], xh[nt][0]);
+            x2[nt] = tr_pack(xl[nt][1], xh[nt][1]);
+            x1s[nt] = x1[nt] * sh;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const half8 d1 = tr_pack(dl[mt & 1][0], dh[mt & 1][0]);
+            const half8 d2 = tr_pack(dl[mt & 1][1], dh[mt & 1][1]);
+            const half8 d1s = d1 * sh;
+            if (mt + 1 < 6) {                 // the next tile row's fragments, requested before this row's MFMAs
+                tr_issue<2 * kTnPiece>(dl[(mt + 1) & 1][0], dh[(mt + 1) & 1][0], sb + dofs[mt + 1][0], sb + dofs[mt + 1][1]);
+                tr_issue<3 * kTnPiece>(dl[(mt + 1) & 1][1], dh[(mt + 1) & 1][1], sb + dofs[mt + 1][0], sb + dofs[mt + 1][1]);
+            }
+            if (ahead) issue_one(mt, s2, kt + 2);
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                // D[i = p column][j = k column]: a lane holds 4 consecutive p of one k (float4 stores along p)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, x1[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d2, x1s[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1s, x2[nt], acc[mt][nt], 0, 0, 0);
+            }
+            if (mt + 1 < 6) tr_wait();
+        }
+        // step kt + 1 must have landed before anyone reads it; step kt + 2 (this wave's 6 youngest instructions) may stay in flight
+        if (!(p.mode & 2)) {
+            if (ahead) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    // acc[mt][nt][r] = partial of dW[k = tk 192 + wc 48 + nt 16 + (lane & 15)][p = tp 192 + wr 96 + mt 16 + (lane >> 4) 4 + r]
+    float* out = p.part + (int64_t)split * p.KP * p.PP;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int k = tk * TT + wc * 48 + nt * 16 + (lane & 15);
+        if (k >= p.KP) continue;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const int pc = tp * TT + wr * 96 + mt * 16 + (lane >> 4) * 4;
+            if (pc < p.PP) *reinterpret_cast<float4*>(out + (int64_t)k * p.PP + pc) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+        }
+    }
+}
+
+// out[k, p] = scale_x[1] scale_d[1] * sum_s part[s][k][p]   (split order), k < K, p < P
+__global__ __launch_bounds__(256) void tn_reduce_h3_kernel(const float* part, int splits, int K, int P, int KP, int PP, const float* scale_x,
+                                                           const float* scale_d, float* out, int64_t ldo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int p4 = (P + 3) >> 2;
+    if (i >= (int64_t)K * p4) return;
+    const int k = (int)(i / p4), pc = (int)(i - (int64_t)k * p4) * 4;
+    const float alpha = scale_x[1] * scale_d[1];
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = part + (int64_t)k * PP + pc;
+    constexpr int U = 4;                                    // loads in flight; added in split order
+    for (int s0 = 0; s0 < splits; s0 += U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = s0 + u < splits ? *reinterpret_cast<const float4*>(src + (int64_t)(s0 + u) * KP * PP) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < U; ++u) s4.x += v[u].x, s4.y += v[u].y, s4.z += v[u].z, s4.w += v[u].w;
+    }
+    float* o = out + (int64_t)k * ldo + pc;
+    const float r[4] = {s4.x * alpha, s4.y * alpha, s4.z * alpha, s4.w * alpha};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (pc + e < P) o[e] = r[e];
+}
+
 template <int BM, int BN, int WM, int WN, bool PIPE>
 void launch_h3(H3Args p, int64_t m, int64_t n, hipStream_t st) {
     p.tiles_m = (int)((m + BM - 1) / BM), p.tiles_n = (int)((n + BN - 1) / BN);
@@ -318,4 +583,40 @@ extern "C" int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const fl
         launch_h3<256, 256, 2, 4, true>(p, m, n, (hipStream_t)stream);
     }
     return hip_status("gemm_halves3_nt");
+}
+
+namespace bot {
+namespace {
+// splits: whole multiples of 8 (one per XCD at a time) while a split keeps >= 4096 rows; fewer for short operands
+int tn_splits(int64_t n_rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(8, n_rows / 4096)); }
+}  // namespace
+}  // namespace bot
+
+extern "C" int64_t bot_gemm_halves3_tn_workspace_floats(int64_t n_rows, int64_t kp, int64_t pp) { return (int64_t)bot::tn_splits(n_rows) * kp * pp; }
+
+extern "C" int bot_gemm_halves3_tn_f32(int64_t n_rows, int64_t k, int64_t p, int64_t kp, int64_t pp, const float* scale_x, const float* scale_d,
+                                       const uint16_t* X, int64_t ldx, int64_t x2_off, const uint16_t* D, int64_t ldd, int64_t d2_off, float* out,
+                                       int64_t ldo, float* workspace, int32_t mode, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n_rows > 0 && k > 0 && p > 0 && kp >= k && pp >= p && kp % 64 == 0 && pp % 64 == 0, -1,
+                "gemm_halves3_tn: need n, k, p > 0 and piece widths >= k, p that are multiples of 64");
+    BOT_REQUIRE(scale_x && scale_d && X && D && out && workspace, -1, "gemm_halves3_tn: null pointer");
+    BOT_REQUIRE(aligned(X, 16) && aligned(D, 16) && ldx % 8 == 0 && ldd % 8 == 0 && x2_off % 8 == 0 && d2_off % 8 == 0 && x2_off + kp <= ldx &&
+                    d2_off + pp <= ldd && ldo >= p && n_rows < (1ll << 31) - 4096, -1, "gemm_halves3_tn: bad alignment or pitches");
+    TnArgs3 a;
+    a.X = reinterpret_cast<const _Float16*>(X), a.D = reinterpret_cast<const _Float16*>(D), a.part = workspace, a.ldx = ldx, a.ldd = ldd;
+    a.N = (int)n_rows, a.K = (int)k, a.P = (int)p, a.KP = (int)kp, a.PP = (int)pp, a.x2_off = (int)x2_off, a.d2_off = (int)d2_off;
+    a.tiles_k = (int)((kp + TT - 1) / TT), a.tiles_p = (int)((pp + TT - 1) / TT);
+    int splits = tn_splits(n_rows);
+    const int rps = (int)(((n_rows + splits - 1) / splits + TBK - 1) / TBK * TBK);
+    splits = (int)((n_rows + rps - 1) / rps);             // no empty split (never more than tn_splits: the workspace holds them)
+    a.splits = splits, a.rows_per_split = rps;
+    a.mode = mode;
+    BOT_REQUIRE((int64_t)rps * std::max(ldx, ldd) * 2 < (1ll << 31), -1, "gemm_halves3_tn: a split of %d rows exceeds the 2 GiB a buffer descriptor spans", rps);
+    set_kernel("bot::gemm_halves3_tn_kernel");
+    hipLaunchKernelGGL(gemm_halves3_tn_kernel, dim3(((splits + 7) / 8) * 8 * a.tiles_k * a.tiles_p), dim3(512), 0, (hipStream_t)stream, a);
+    const int64_t n4 = k * ((p + 3) / 4);
+    hipLaunchKernelGGL(tn_reduce_h3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits, (int)k, (int)p,
+                       (int)kp, (int)pp, scale_x, scale_d, out, ldo);
+    return hip_status("gemm_halves3_tn");
 }

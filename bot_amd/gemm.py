@@ -21,6 +21,9 @@ from . import _C
 MODE = os.environ.get("BOT_GEMM", "halves")
 NT_KERNEL = os.environ.get("BOT_GEMM_NT", "halves3")   # NT products (forward, input gradient): "halves3" = csrc/halves3.hip (each operand
                                                        # half staged once, three MFMAs per fragment pair), "lib" = hipBLASLt over the 3x-concatenated axis
+TN_KERNEL = os.environ.get("BOT_GEMM_TN", "halves3")   # weight gradients (reduction over the node rows): "halves3" = the hand-written split-K
+                                                       # kernel of csrc/halves3.hip, "lib" = batched hipBLASLt products over row chunks + combine
+TN_MIN_OUT = 512 * 1024                                # smaller results (the 40-class output layer: 768 x 128) stay on the library
 NT_MIN_COLS = 192                                      # narrower outputs (the 40-class output layer) leave most of a 256-column tile empty: library
 LINEAR_BLOCKS = os.environ.get("BOT_LINEAR_BLOCKS", "1") != "0"   # merged projections hand their column blocks' gradients over without a `cat`
 FORCE = False              # tests set this to run the halves path over the emulated (CPU) backend at any row count
@@ -140,6 +143,8 @@ def tn(x: Halves, d: Halves):
     afterwards — faster than one long-K GEMM and a pairwise-style summation (bot_amd.ops.weight_grad)."""
     assert x.order == 0 and d.order == 0 and x.n == d.n
     N, K, P, KP, PP = x.n, x.F, d.F, x.piece, d.piece
+    if TN_KERNEL == "halves3" and KP * PP >= TN_MIN_OUT:      # enough 256 x 256 output tiles x row splits to fill the chip
+        return _C.gemm_halves3_tn(x.buf, d.buf, x.scale, d.scale, KP, PP, K, P)
     alpha = _alpha(x, d, 2 * PP)                # one value per output column; the narrower products take a prefix
     S = max(1, N // CHUNK_ROWS)
     R = N // S

@@ -484,6 +484,17 @@ int bot_gemm_halves_f32(int32_t trans_a, int32_t trans_b, int64_t m, int64_t n, 
 int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
                             int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t mode,
                             bot_stream_t stream);
+/* v14: the weight gradient  out[k, p] = scale_x[1] scale_d[1] * sum_n (x1 + x2)[n, k] (d1 + d2)[n, p]  (without the x2 d2 term) of two LEFT
+ * operand buffers X [n_rows, ldx] (x1 at column 0, 2^11 x2 at column x2_off = 2 * piece) and D [n_rows, ldd], hand-written for gfx950
+ * (csrc/halves3.hip: the reduction index runs along the ROWS of both operands; fragments by the transposing LDS read ds_read_b64_tr_b16;
+ * 192 x 192 tiles, three LDS stages, split-K over row ranges with one split per XCD, partials added in split order).  kp / pp: the piece widths (multiples of 64, zero padded beyond k / p);
+ * workspace: bot_gemm_halves3_tn_workspace_floats(n_rows, kp, pp) floats; mode 0 (other values: ablation switches of the measurement tools).  Replaces the batched library products + bot_halves_tn_combine_f32
+ * for the weight gradients of `fc` / `res_fc` (backward of src/no-sampling/models.py:490-492, 558-560). */
+int64_t bot_gemm_halves3_tn_workspace_floats(int64_t n_rows, int64_t kp, int64_t pp);
+int bot_gemm_halves3_tn_f32(int64_t n_rows, int64_t k, int64_t p, int64_t kp, int64_t pp, const float* scale_x, const float* scale_d,
+                            const uint16_t* X, int64_t ldx, int64_t x2_off, const uint16_t* D, int64_t ldd, int64_t d2_off, float* out,
+                            int64_t ldo, float* workspace, int32_t mode, bot_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * v14: the train step's glue (csrc/step.hip) — what src/no-sampling/run.py does around the model with a dozen small tensor ops per
  * step, as four launches.  Deterministic (fixed-order reductions, no atomics); Philox streams as in bot_bn_act_fwd_f32 (`seed`,

@@ -336,6 +336,15 @@ def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=
     return out
 
 
+def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0):
+    """include/bot_gnn.h bot_gemm_halves3_tn_f32: x1^T d1 + x1^T d2 + x2^T d1 of two LEFT operand buffers ([h1 | h1 | 2^11 h2])."""
+    sh = torch.tensor(2.0 ** -11, dtype=torch.float16)
+    x1, x2s = x[:, :k], x[:, 2 * piece_x:2 * piece_x + k]
+    d1, d2s = d[:, :p], d[:, 2 * piece_d:2 * piece_d + p]
+    res = x1.float().t() @ d1.float() + (x1 * sh).float().t() @ d2s.float() + x2s.float().t() @ (d1 * sh).float()
+    return res * (scale_x[1] * scale_d[1])
+
+
 # ---- the train step's glue (include/bot_gnn.h v14: label_split / build_input / node_loss / rmsprop_step), restated with torch CPU ops.
 # Dropout and the random split draw from torch's generator here (the kernels' Philox streams are a GPU matter: the GPU suite checks
 # their rates and reproducibility); with p = 0 and a given mask everything is exact.
@@ -444,7 +453,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["gemm_halves3_tn", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

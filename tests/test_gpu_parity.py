@@ -1543,6 +1543,28 @@ def test_gemm_halves3_nt_kernel():
         assert e <= max(4e-6, 1.5 * el), (m, K, P, e, el)
         assert torch.equal(got, again) and torch.equal(got, plain)
     assert gemm.NT_KERNEL == "halves3"          # the default route of gemm.mm_nt (forward + input gradient of the merged projections)
+    # --- TN: the weight gradient x^T d of two LEFT operands (192 x 192 tiles, transposing LDS reads, split-K, three LDS stages), against
+    # fp64 next to the library formulation (batched chunk products + combine): ragged row counts (the last step of the last split is
+    # zero-filled by the buffer descriptor), piece widths that are not multiples of the tile, narrow and wide results, one and eight splits
+    assert gemm.TN_KERNEL == "halves3"
+    for (n, K, P) in ((4099, 750, 1536), (20000, 1536, 750), (33, 64, 40), (50001, 168, 250), (40000, 100, 968), (169343 // 4, 750, 1536)):
+        x = torch.randn(n, K, device=DEV, generator=gen) * 3
+        d = torch.randn(n, P, device=DEV, generator=gen) * 1e-3
+        d[:, ::3] = 0
+        xs, ds = gemm.split(x, 0), gemm.split(d, 0)
+        ref = x.double().t() @ d.double()
+        got = _C.gemm_halves3_tn(xs.buf, ds.buf, xs.scale, ds.scale, xs.piece, ds.piece, K, P)
+        again = _C.gemm_halves3_tn(xs.buf, ds.buf, xs.scale, ds.scale, xs.piece, ds.piece, K, P)
+        gemm.TN_KERNEL = "lib"
+        try:
+            lib = gemm.tn(xs, ds)
+        finally:
+            gemm.TN_KERNEL = "halves3"
+        sc = float(ref.abs().max())
+        e, el = float((got.double() - ref).abs().max()) / sc, float((lib.double() - ref).abs().max()) / sc
+        print(f"gemm_halves3_tn n={n} K={K} P={P}: err {e:.2e} (library formulation: {el:.2e})")
+        assert got.shape == (K, P) and e <= max(4e-6, 3 * el), (n, K, P, e, el)
+        assert torch.equal(got, again)
     with pytest.raises(_C.BotKernelError):
         _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, 40)       # k not a multiple of 32
 

@@ -30,6 +30,16 @@ def h3(xs, ws, out=None, mode=0):
     return _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, xs.piece, out=out, mode=mode)
 
 
+if "--pmc-tn" in sys.argv:   # a few launches of the TN kernel on the config-2 shape
+    N = 169343
+    x = torch.randn(N, 750, device=dev, generator=gen)
+    d = torch.randn(N, 1536, device=dev, generator=gen) * 1e-3
+    xs, ds = gemm.split(x, 0), gemm.split(d, 0)
+    for _ in range(3):
+        gemm.tn(xs, ds)
+    torch.cuda.synchronize()
+    sys.exit(0)
+
 if "--pmc" in sys.argv:      # a few launches of each kernel on the forward shape, nothing else (tools/pmc_halves3.sh)
     m, K, P = 169343, 750, 1536
     x = torch.randn(m, K, device=dev, generator=gen)
@@ -55,6 +65,44 @@ for (m, K, P) in ((1000, 96, 300), (513, 750, 1536), (20000, 1536, 750), (4099, 
     sc = ref.abs().max()
     print(f"m={m} K={K} P={P}: halves3 err {float((mine.double() - ref).abs().max() / sc):.2e}  hipBLASLt err {float((lib.double() - ref).abs().max() / sc):.2e}  "
           f"bitwise run-to-run {same}  bitwise == plain loop {torch.equal(mine, plain)}  max|halves3 - lib| {float((mine - lib).abs().max() / sc):.2e}")
+
+# TN (weight gradient): correctness on ragged shapes, then the config-2 shape against the library formulation
+for (n, K, P) in ((1000, 96, 300), (4099, 750, 1536), (50001, 168, 250), (33, 64, 40), (20000, 1536, 750)):
+    x = torch.randn(n, K, device=dev, generator=gen) * 3
+    d = torch.randn(n, P, device=dev, generator=gen) * 1e-3
+    xs, ds = gemm.split(x, 0), gemm.split(d, 0)
+    ref = x.double().t() @ d.double()
+    gemm.TN_KERNEL = "lib"
+    lib = gemm.tn(xs, ds)
+    gemm.TN_KERNEL = "halves3"
+    mine = gemm.tn(xs, ds)
+    same = all(torch.equal(gemm.tn(xs, ds), mine) for _ in range(3))
+    sc = ref.abs().max()
+    print(f"TN n={n} K={K} P={P}: halves3 err {float((mine.double() - ref).abs().max() / sc):.2e}  library err {float((lib.double() - ref).abs().max() / sc):.2e}  "
+          f"bitwise run-to-run {same}")
+N = 169343
+x = torch.randn(N, 750, device=dev, generator=gen)
+d = torch.randn(N, 1536, device=dev, generator=gen) * 1e-3
+xs, ds = gemm.split(x, 0), gemm.split(d, 0)
+
+
+def tn_with(kind):
+    gemm.TN_KERNEL = kind
+    return gemm.tn(xs, ds)
+
+
+for _ in range(3):
+    tn_with("lib"), tn_with("halves3")
+rounds = [(t_ms(lambda: tn_with("lib")), t_ms(lambda: tn_with("halves3"))) for _ in range(5)]
+fl = 2.0 * N * 3 * 768 * 1536
+a, b = (sorted(r[i] for r in rounds)[2] for i in range(2))
+print(f"dW x^T d [750,N]x[N,1536]: hipBLASLt (batched chunks + combine) {a:.3f} ms ({fl / a / 1e9:.0f} TF)   halves3 TN {b:.3f} ms ({fl / b / 1e9:.0f} TF)   rounds {[tuple(round(v, 3) for v in r) for r in rounds]}")
+gemm.TN_KERNEL = "halves3"
+if "--ablate" in sys.argv:
+    for md, what in ((1, "no DMA in the loop"), (2, "no barrier / vmcnt wait"), (3, "neither")):
+        f = lambda md=md: _C.gemm_halves3_tn(xs.buf, ds.buf, xs.scale, ds.scale, xs.piece, ds.piece, 750, 1536, mode=md)
+        f()
+        print(f"   TN ablation {what}: {t_ms(f):.3f} ms")
 
 # timing at the config-2 shapes
 N = 169343
