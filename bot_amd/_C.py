@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -96,7 +96,7 @@ _SIGS = {
     "bot_bn_stats_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "bot_bn_stats_halves_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "bot_bn_act_fwd_halves_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, _P, c_int64,
-                                                 _P, _P, c_int64, c_int32, _P]),
+                                                 _P, _P, c_int64, c_int32, c_int32, _P]),
     "bot_bn_act_fwd_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, _P, c_int64, _P]),
     "bot_bn_act_bwd_reduce_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
                                                  c_uint64, _P, _P, _P, _P, _P]),
@@ -638,12 +638,13 @@ def halves_tn_combine(a, b, P, rem_a=None, rem_b=None):
 
 
 def halves_split(x, scale, order, piece, out=None):
-    """fp16 halves of x [n,F] scaled by scale[0]: [h1|h1|h2] (order 0) or [h1|h2|h1] (order 1), pieces `piece` columns wide."""
+    """fp16 halves of x [n,F] scaled by scale[0]: [h1|h1|h2] (order 0), [h1|h2|h1] (order 1) or [h1|h2] (order 2: a left operand without
+    the duplicate piece), pieces `piece` columns wide."""
     _dev(x, scale)
     x = _mat(x, "x")
     n, F = x.shape
     if out is None:
-        out = torch.empty((n, 3 * piece), dtype=torch.float16, device=x.device)
+        out = torch.empty((n, (2 if order == 2 else 3) * piece), dtype=torch.float16, device=x.device)
     _check(_lib.bot_halves_split_f16(x.data_ptr(), x.stride(0), n, F, _ptr(scale), order, out.data_ptr(), out.stride(0), piece, _stream()),
            "halves_split")
     return out
@@ -748,20 +749,21 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     return out
 
 
-def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0):
-    """out[m, n] = scale_a[1] scale_b[1] (a1 b1^T + a1 b2^T + a2 b1^T) from a LEFT operand buffer a [m, 3 piece_a] and a RIGHT operand
-    buffer b [n, 3 piece_b] (bot_amd.gemm.Halves.buf / .scale), k = the common piece width used (bot_gemm_halves3_nt_f32)."""
+def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None):
+    """out[m, n] = scale_a[1] scale_b[1] (a1 b1^T + a1 b2^T + a2 b1^T) from a LEFT operand buffer a [m, 3 piece_a] (or [m, 2 piece_a]
+    without the duplicate piece: a2_off = piece_a) and a RIGHT operand buffer b [n, 3 piece_b] (bot_amd.gemm.Halves.buf / .scale), k =
+    the common piece width used (bot_gemm_halves3_nt_f32)."""
     _dev(a, b, scale_a, scale_b)
     m, n = a.shape[0], b.shape[0]
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     _check(_timed("gemm_halves", (m, n, 3 * k, 1), lambda: _lib.bot_gemm_halves3_nt_f32(
-        m, n, k, scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), 2 * piece_a, b.data_ptr(), _ld(b), piece_b, out.data_ptr(),
-        _ld(out), int(mode), _stream())), "gemm_halves3_nt")
+        m, n, k, scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), 2 * piece_a if a2_off is None else a2_off, b.data_ptr(), _ld(b),
+        piece_b, out.data_ptr(), _ld(out), int(mode), _stream())), "gemm_halves3_nt")
     return out
 
 
-def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0):
+def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0, x2_off=None, d2_off=None):
     """out[k, p] = scale_x[1] scale_d[1] (x1^T d1 + x1^T d2 + x2^T d1) from two LEFT operand buffers x [n, 3 piece_x], d [n, 3 piece_d]
     (include/bot_gnn.h bot_gemm_halves3_tn_f32): the weight gradient of a projection, reduced over the n rows."""
     _dev(x, d, scale_x, scale_d)
@@ -769,7 +771,8 @@ def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0):
     out = torch.empty((k, p), dtype=torch.float32, device=x.device)
     ws = torch.empty(int(_lib.bot_gemm_halves3_tn_workspace_floats(n, piece_x, piece_d)), dtype=torch.float32, device=x.device)
     _check(_timed("gemm_halves", (k, p, 3 * n, 1), lambda: _lib.bot_gemm_halves3_tn_f32(
-        n, k, p, piece_x, piece_d, scale_x.data_ptr(), scale_d.data_ptr(), x.data_ptr(), _ld(x), 2 * piece_x, d.data_ptr(), _ld(d), 2 * piece_d,
+        n, k, p, piece_x, piece_d, scale_x.data_ptr(), scale_d.data_ptr(), x.data_ptr(), _ld(x), 2 * piece_x if x2_off is None else x2_off,
+        d.data_ptr(), _ld(d), 2 * piece_d if d2_off is None else d2_off,
         out.data_ptr(), _ld(out), ws.data_ptr(), int(mode), _stream())), "gemm_halves3_tn")
     return out
 
@@ -924,18 +927,20 @@ def bn_stats_halves(x, eps, momentum, running_mean, running_var, num_batches_tra
 
 def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=None, want_y=True):
     """y = dropout_p(relu?((x - mean) * invstd * weight + bias)); Philox mask from `seed`.
-    halves = (hscale [2], piece): also returns y's fp16 halves [n, 3 * piece] scaled by hscale[0] -> (y, buf).
+    halves = (hscale [2], piece[, pieces]): also returns y's fp16 halves [n, pieces * piece] scaled by hscale[0] -> (y, buf); pieces 3 (default):
+    [h1 | h1 | 2^11 h2], 2: [h1 | 2^11 h2].
     want_y=False (with halves): only the halves are written; the returned y is None."""
     _dev(x, mean, invstd)
     x = _mat(x, "x")
     n, F = x.shape
     if halves is not None:
-        hscale, piece = halves
+        hscale, piece = halves[:2]
+        pieces = halves[2] if len(halves) > 2 else 3
         y = torch.empty((n, F), dtype=torch.float32, device=x.device) if want_y else None
-        buf = torch.empty((n, 3 * piece), dtype=torch.float16, device=x.device)
+        buf = torch.empty((n, pieces * piece), dtype=torch.float16, device=x.device)
         _check(_timed("bn_act_fwd", (F,), lambda: _lib.bot_bn_act_fwd_halves_f32(
             x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p),
-            int(seed), _seed_off(p), _ptr(y), F, hscale.data_ptr(), buf.data_ptr(), buf.stride(0), piece, _stream())),
+            int(seed), _seed_off(p), _ptr(y), F, hscale.data_ptr(), buf.data_ptr(), buf.stride(0), piece, pieces, _stream())),
             "bn_act_fwd_halves")
         return y, buf
     y = torch.empty((n, F), dtype=torch.float32, device=x.device)

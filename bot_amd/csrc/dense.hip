@@ -101,7 +101,8 @@ struct BnArgs {
     uint64_t seed;
     const uint64_t* seed_offset;  // optional device word mixed into the seed at run time (hipGraph replays: see eff_seed)
     // fwd
-    __half* hout;          // optional: the output also as fp16 halves [h1 | h1 | 2^11 h2] (halves.hip), scaled by hscale[0]
+    __half* hout;          // optional: the output also as fp16 halves [h1 | h1 | 2^11 h2] or, `hpieces` == 2, [h1 | 2^11 h2] (halves.hip), scaled by hscale[0]
+    int32_t hpieces;       // 3: with the duplicate h1 piece the library's concatenated-axis GEMM reads; 2: without (csrc/halves3.hip reads only two)
     int64_t ldh;
     int32_t piece;
     const float* hscale;
@@ -273,7 +274,8 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
                 for (int64_t r = (int64_t)blockIdx.y * kTY + ty; r < a.n; r += (int64_t)gridDim.y * kTY) {
                     __half* o = a.hout + r * a.ldh + c;
                     const uint2 z = make_uint2(0u, 0u);
-                    *reinterpret_cast<uint2*>(o) = z, *reinterpret_cast<uint2*>(o + a.piece) = z, *reinterpret_cast<uint2*>(o + 2 * (int64_t)a.piece) = z;
+                    *reinterpret_cast<uint2*>(o) = z, *reinterpret_cast<uint2*>(o + a.piece) = z;
+                    if (a.hpieces == 3) *reinterpret_cast<uint2*>(o + 2 * (int64_t)a.piece) = z;
                 }
             return;
         }
@@ -325,7 +327,9 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_fwd_kernel(BnArgs a) {
                     }
                     __half* o = a.hout + r * a.ldh + c;
                     const uint2 hi = *reinterpret_cast<const uint2*>(h1), lo = *reinterpret_cast<const uint2*>(h2);
-                    *reinterpret_cast<uint2*>(o) = hi, *reinterpret_cast<uint2*>(o + a.piece) = hi, *reinterpret_cast<uint2*>(o + 2 * (int64_t)a.piece) = lo;
+                    *reinterpret_cast<uint2*>(o) = hi;
+                    if (a.hpieces == 3) *reinterpret_cast<uint2*>(o + a.piece) = hi, *reinterpret_cast<uint2*>(o + 2 * (int64_t)a.piece) = lo;
+                    else *reinterpret_cast<uint2*>(o + a.piece) = lo;
                 }
             }
         }
@@ -382,7 +386,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_rowseg_kernel(BnArgs a) {
         if (a.y && live) store_cols<4>(a.y + r * a.ldy + c, v[u], a.wy, nv);
         __half* o = a.hout + r * a.ldh + c;
         const uint2 hi = *reinterpret_cast<const uint2*>(h1), lo = *reinterpret_cast<const uint2*>(h2);
-        *reinterpret_cast<uint2*>(o) = hi, *reinterpret_cast<uint2*>(o + a.piece) = hi, *reinterpret_cast<uint2*>(o + 2 * (int64_t)a.piece) = lo;
+        *reinterpret_cast<uint2*>(o) = hi;
+        if (a.hpieces == 3) *reinterpret_cast<uint2*>(o + a.piece) = hi, *reinterpret_cast<uint2*>(o + 2 * (int64_t)a.piece) = lo;
+        else *reinterpret_cast<uint2*>(o + a.piece) = lo;
     }
 }
 
@@ -612,7 +618,7 @@ int bot_bn_stats_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, f
 static int bn_act_fwd_impl(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
                            const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
                            const uint64_t* seed_offset, float* y, int64_t ldy, const float* hscale, uint16_t* hout, int64_t ldh,
-                           int32_t piece, bot_stream_t stream) {
+                           int32_t piece, int32_t pieces, bot_stream_t stream) {
     using namespace bot;
     if (!y) ldy = ldx;                   // halves only (hout != NULL): y puts no constraint on the launch width
     BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && ldy >= F, BOT_E_RANGE, "bn_act_fwd: n=%lld F=%d", (long long)n, F);
@@ -622,12 +628,13 @@ static int bn_act_fwd_impl(const float* x, int64_t ldx, int64_t n, int32_t F, co
     BnArgs a{};
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
     a.seed = seed, a.seed_offset = seed_offset, a.y = y, a.ldy = ldy;
-    a.hout = reinterpret_cast<__half*>(hout), a.ldh = ldh, a.piece = piece, a.hscale = hscale;
+    a.hout = reinterpret_cast<__half*>(hout), a.ldh = ldh, a.piece = piece, a.hscale = hscale, a.hpieces = pieces;
     bool quad;
     const int vec = bn_vec(F, {ldx, ldy}, {x, y}, &quad);
     if (hout) {
         BOT_REQUIRE(hscale, BOT_E_NULL, "bn_act_fwd_halves: NULL scale");
-        BOT_REQUIRE(vec == 4 && piece >= F && piece % 4 == 0 && piece <= (int64_t)((F + kTX * 4 - 1) / (kTX * 4)) * kTX * 4 && ldh >= 3 * (int64_t)piece &&
+        BOT_REQUIRE(vec == 4 && piece >= F && piece % 4 == 0 && piece <= (int64_t)((F + kTX * 4 - 1) / (kTX * 4)) * kTX * 4 && (pieces == 2 || pieces == 3) &&
+                        ldh >= pieces * (int64_t)piece &&
                         ldh % 4 == 0 && aligned(hout, 8),
                     BOT_E_ALIGN, "bn_act_fwd_halves: needs the 4-column form (even F, 8-byte aligned rows) and piece = F rounded up to x64 "
                                  "(F=%d piece=%d ldh=%lld)", F, piece, (long long)ldh);
@@ -648,15 +655,15 @@ static int bn_act_fwd_impl(const float* x, int64_t ldx, int64_t n, int32_t F, co
 int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
                        const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
                        const uint64_t* seed_offset, float* y, int64_t ldy, bot_stream_t stream) {
-    return bn_act_fwd_impl(x, ldx, n, F, mean, invstd, weight, bias, relu, p, seed, seed_offset, y, ldy, nullptr, nullptr, 0, 0, stream);
+    return bn_act_fwd_impl(x, ldx, n, F, mean, invstd, weight, bias, relu, p, seed, seed_offset, y, ldy, nullptr, nullptr, 0, 0, 3, stream);
 }
 
 int bot_bn_act_fwd_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
                               const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
                               const uint64_t* seed_offset, float* y, int64_t ldy, const float* hscale, uint16_t* hout, int64_t ldh,
-                              int32_t piece, bot_stream_t stream) {
+                              int32_t piece, int32_t pieces, bot_stream_t stream) {
     BOT_REQUIRE(hout, BOT_E_NULL, "bn_act_fwd_halves: NULL output");
-    return bn_act_fwd_impl(x, ldx, n, F, mean, invstd, weight, bias, relu, p, seed, seed_offset, y, ldy, hscale, hout, ldh, piece, stream);
+    return bn_act_fwd_impl(x, ldx, n, F, mean, invstd, weight, bias, relu, p, seed, seed_offset, y, ldy, hscale, hout, ldh, piece, pieces, stream);
 }
 
 int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,

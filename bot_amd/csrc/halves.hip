@@ -115,6 +115,8 @@ __global__ __launch_bounds__(128) void halves_split_kernel(const float* x, int64
     if (ORDER == 0) {   // [h1 | h1 | 2^11 h2]
         *reinterpret_cast<__half2*>(o + piece) = hi;
         *reinterpret_cast<__half2*>(o + 2 * (int64_t)piece) = __halves2half2(__float2half_rn(r0 * kHalvesShift), __float2half_rn(r1 * kHalvesShift));
+    } else if (ORDER == 2) {   // [h1 | 2^11 h2]: a left operand without the duplicate piece (read by csrc/halves3.hip only)
+        *reinterpret_cast<__half2*>(o + piece) = __halves2half2(__float2half_rn(r0 * kHalvesShift), __float2half_rn(r1 * kHalvesShift));
     } else {            // [h1 | h2 | 2^-11 h1]
         *reinterpret_cast<__half2*>(o + piece) = __halves2half2(__float2half_rn(r0), __float2half_rn(r1));
         *reinterpret_cast<__half2*>(o + 2 * (int64_t)piece) =
@@ -255,9 +257,9 @@ static int halves_split_impl(const float* x, int64_t ldx, int64_t n, int32_t F, 
                              int64_t ldo, int32_t piece, int32_t width, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(width >= F && width <= piece && width % 2 == 0, BOT_E_RANGE, "halves_split: width=%d (F=%d piece=%d)", width, F, piece);
-    BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && piece >= F && ldo >= 3 * (int64_t)piece, BOT_E_RANGE,
+    BOT_REQUIRE(order == 0 || order == 1 || order == 2, BOT_E_RANGE, "halves_split: order=%d", order);
+    BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && piece >= F && ldo >= (order == 2 ? 2 : 3) * (int64_t)piece, BOT_E_RANGE,
                 "halves_split: n=%lld F=%d ldx=%lld piece=%d ldo=%lld", (long long)n, F, (long long)ldx, piece, (long long)ldo);
-    BOT_REQUIRE(order == 0 || order == 1, BOT_E_RANGE, "halves_split: order=%d", order);
     BOT_REQUIRE(piece % 2 == 0 && ldo % 2 == 0 && aligned(x, 4) && aligned(out, 4), BOT_E_ALIGN,
                 "halves_split: piece and ldo must be even, x and out 4-byte aligned");
     const bool wide = ldx % 2 == 0 && aligned(x, 8);
@@ -266,6 +268,7 @@ static int halves_split_impl(const float* x, int64_t ldx, int64_t n, int32_t F, 
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)n, (unsigned)((width / 2 + 127) / 128));
     if (order == 0) hipLaunchKernelGGL(halves_split_kernel<0>, grid, dim3(128), 0, st, x, ldx, F, scale, (__half*)out, ldo, piece, wide, width);
+    else if (order == 2) hipLaunchKernelGGL(halves_split_kernel<2>, grid, dim3(128), 0, st, x, ldx, F, scale, (__half*)out, ldo, piece, wide, width);
     else hipLaunchKernelGGL(halves_split_kernel<1>, grid, dim3(128), 0, st, x, ldx, F, scale, (__half*)out, ldo, piece, wide, width);
     return hip_status("halves_split launch");
 }

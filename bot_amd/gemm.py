@@ -23,6 +23,12 @@ NT_KERNEL = os.environ.get("BOT_GEMM_NT", "halves3")   # NT products (forward, i
                                                        # half staged once, three MFMAs per fragment pair), "lib" = hipBLASLt over the 3x-concatenated axis
 TN_KERNEL = os.environ.get("BOT_GEMM_TN", "halves3")   # weight gradients (reduction over the node rows): "halves3" = the hand-written split-K
                                                        # kernel of csrc/halves3.hip, "lib" = batched hipBLASLt products over row chunks + combine
+# Left operands WITHOUT their duplicate h1 piece ([h1 | 2^11 h2], "order 2"): only the library's concatenated-axis NT GEMM reads the
+# duplicate, so with both hand-written kernels in place wide operands are written with two pieces (a third less to write and to hold:
+# 0.5 GB per split of the config-2 gradient buffer).  Narrow operands (piece < NODUP_MIN_PIECE) keep three: their products are the ones
+# that still go to the library.
+LEFT_NODUP = NT_KERNEL == "halves3" and TN_KERNEL == "halves3" and os.environ.get("BOT_HALVES_DUP", "0") != "1"
+NODUP_MIN_PIECE = 256
 TN_MIN_OUT = 512 * 1024                                # smaller results (the 40-class output layer: 768 x 128) stay on the library
 NT_MIN_COLS = 192                                      # narrower outputs (the 40-class output layer) leave most of a 256-column tile empty: library
 LINEAR_BLOCKS = os.environ.get("BOT_LINEAR_BLOCKS", "1") != "0"   # merged projections hand their column blocks' gradients over without a `cat`
@@ -38,11 +44,26 @@ def enabled(x) -> bool:
 
 
 class Halves:
-    """fp16 halves of an fp32 matrix [n, F]: `buf` [n, 3 * piece] fp16, `scale` [2] = (s, 1/s) on the device."""
+    """fp16 halves of an fp32 matrix [n, F]: `buf` [n, 3 * piece] fp16 (order 2: [n, 2 * piece]), `scale` [2] = (s, 1/s) on the device.
+    order 0: left [h1 | h1 | 2^11 h2]; 1: right [h1 | h2 | 2^-11 h1]; 2: left without the duplicate, [h1 | 2^11 h2]."""
     __slots__ = ("buf", "scale", "n", "F", "piece", "order")
 
     def __init__(self, buf, scale, n, F, piece, order):
         self.buf, self.scale, self.n, self.F, self.piece, self.order = buf, scale, n, F, piece, order
+
+    @property
+    def left(self):
+        return self.order != 1
+
+    @property
+    def h2_off(self):
+        """column of the second half (2^11 h2) of a left operand"""
+        return self.piece if self.order == 2 else 2 * self.piece
+
+
+def left_order(piece: int) -> int:
+    """The layout new LEFT operands of this piece width are written in (0: with the duplicate piece, 2: without)."""
+    return 2 if (LEFT_NODUP and piece >= NODUP_MIN_PIECE) else 0
 
 
 def split(x, order: int, scale=None) -> Halves:
@@ -50,6 +71,8 @@ def split(x, order: int, scale=None) -> Halves:
     `scale`: the (s, 1/s) pair when the caller already has it (max|x| delivered by the kernels that wrote x)."""
     n, F = x.shape
     piece = (F + PIECE_ALIGN - 1) // PIECE_ALIGN * PIECE_ALIGN
+    if order == 0:
+        order = left_order(piece)
     if scale is None:
         scale = _C.halves_scale(x)
     return Halves(_C.halves_split(x, scale, order, piece), scale, n, F, piece, order)
@@ -103,7 +126,7 @@ def split_with_stash(x, order: int) -> Halves:
 
 def take(x, order: int):
     ref, h = _STASH.pop((x.data_ptr(), x._version, tuple(x.shape)), (None, None))
-    if h is not None and ref() is not None and h.order == order:    # a dead y: the address was recycled for another tensor
+    if h is not None and ref() is not None and h.left == (order != 1):    # a dead y: the address was recycled for another tensor
         STATS["taken"] += 1
         return h
     if is_handle(x):
@@ -131,26 +154,27 @@ def _alpha(a: Halves, b: Halves, n=None):
 
 def mm_nt(a: Halves, b: Halves, out=None):
     """a [n, F] (order 0) times b [p, F]^T (order 1) -> fp32 [n, p]."""
-    assert a.order == 0 and b.order == 1 and a.F == b.F and a.piece == b.piece
-    if NT_KERNEL == "halves3" and b.n >= NT_MIN_COLS:
-        return _C.gemm_halves3_nt(a.buf, b.buf, a.scale, b.scale, a.piece, b.piece, a.piece, out=out)
+    assert a.left and b.order == 1 and a.F == b.F and a.piece == b.piece
+    if NT_KERNEL == "halves3" and (b.n >= NT_MIN_COLS or a.order == 2):      # (an operand without the duplicate piece has no library form)
+        return _C.gemm_halves3_nt(a.buf, b.buf, a.scale, b.scale, a.piece, b.piece, a.piece, out=out, a2_off=a.h2_off)
+    assert a.order == 0
     return _C.gemm_halves(a.buf, b.buf, _alpha(a, b, b.n), trans_b=True, out=out)
 
 
 def tn(x: Halves, d: Halves):
-    """x^T d for two LEFT-operand layouts x [N, K], d [N, P] (order 0 both): the weight gradient, a reduction over the N rows.
+    """x^T d for two LEFT-operand layouts x [N, K], d [N, P] (order 0 or 2 each): the weight gradient, a reduction over the N rows.
     Row chunks of CHUNK_ROWS are batch entries (x1^T [d1 | d2] and x2^T d1 per chunk), the partial products are added
     afterwards — faster than one long-K GEMM and a pairwise-style summation (bot_amd.ops.weight_grad)."""
-    assert x.order == 0 and d.order == 0 and x.n == d.n
+    assert x.left and d.left and x.n == d.n
     N, K, P, KP, PP = x.n, x.F, d.F, x.piece, d.piece
-    if TN_KERNEL == "halves3" and KP * PP >= TN_MIN_OUT:      # enough 256 x 256 output tiles x row splits to fill the chip
-        return _C.gemm_halves3_tn(x.buf, d.buf, x.scale, d.scale, KP, PP, K, P)
+    if TN_KERNEL == "halves3" and KP * PP >= TN_MIN_OUT:      # enough 192 x 192 output tiles x row splits to fill the chip
+        return _C.gemm_halves3_tn(x.buf, d.buf, x.scale, d.scale, KP, PP, K, P, x2_off=x.h2_off, d2_off=d.h2_off)
     alpha = _alpha(x, d, 2 * PP)                # one value per output column; the narrower products take a prefix
     S = max(1, N // CHUNK_ROWS)
     R = N // S
     ldx, ldd = x.buf.stride(0), d.buf.stride(0)
-    x1, x2 = x.buf[:, :K], x.buf[:, 2 * KP:2 * KP + K]
-    d12, d1 = d.buf[:, PP:3 * PP], d.buf[:, :PP]
+    x1, x2 = x.buf[:, :K], x.buf[:, x.h2_off:x.h2_off + K]
+    d12, d1 = d.buf[:, d.h2_off - PP:d.h2_off + PP], d.buf[:, :PP]       # [h1 | 2^11 h2]: the last two pieces, or all of an order-2 buffer
 
     def part(xa, db, n, rows, batch, r0):
         return _C.gemm_halves(xa[r0:], db[r0:], alpha[:n], trans_a=True, m=K, n=n, k=rows, batch=batch,
@@ -174,7 +198,7 @@ class _Matmul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, kp):
         xh = take(x, 0)
-        ctx.kp, ctx.meta = kp, (xh.n, xh.F, xh.piece)
+        ctx.kp, ctx.meta = kp, (xh.n, xh.F, xh.piece, xh.order)
         ctx.save_for_backward(xh.buf, xh.scale, w)
         return mm_nt(xh, split(w.t().contiguous() if kp else w, 1))
 
@@ -186,7 +210,7 @@ class _Matmul(torch.autograd.Function):
         dx = mm_nt(dh, split(w if kp else w.t().contiguous(), 1)) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = tn(Halves(buf, scale, *ctx.meta, 0), dh)               # [K, P]
+            dw = tn(Halves(buf, scale, *ctx.meta), dh)               # [K, P]
             dw = dw if kp else dw.t().contiguous()
         return dx, dw, None
 
@@ -200,7 +224,7 @@ class _MergedLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, sizes):
         xh = take(x, 0)
-        ctx.sizes, ctx.meta = sizes, (xh.n, xh.F, xh.piece)
+        ctx.sizes, ctx.meta = sizes, (xh.n, xh.F, xh.piece, xh.order)
         ctx.save_for_backward(xh.buf, xh.scale, w)
         y = mm_nt(xh, split(w, 1))
         return tuple(torch.split(y, sizes, dim=1))
@@ -229,7 +253,7 @@ class _MergedLinear(torch.autograd.Function):
             off += wd
         dh = Halves(dbuf, dscale, n, P, piece, 0)
         dx = mm_nt(dh, split(w.t().contiguous(), 1)) if ctx.needs_input_grad[0] else None
-        dw = tn(Halves(buf, scale, *ctx.meta, 0), dh).t().contiguous() if ctx.needs_input_grad[1] else None
+        dw = tn(Halves(buf, scale, *ctx.meta), dh).t().contiguous() if ctx.needs_input_grad[1] else None
         return dx, dw, None
 
 

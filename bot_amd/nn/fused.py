@@ -181,12 +181,13 @@ def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed=True):
     if piece is not None:
         mean, invstd, total, sync, group, hscale = bn_batch_stats(x, bn, bn_training, halves_p=drop_p)
         if hscale is not None:
-            y, buf = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed, halves=(hscale, piece), want_y=y_needed)
+            order = gemm.left_order(piece)
+            y, buf = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed, halves=(hscale, piece, 2 if order == 2 else 3), want_y=y_needed)
             if y is None:
                 global HANDLES
                 HANDLES += 1
                 y = gemm.make_handle(x, x.shape[0], HD)
-            gemm.stash(y, gemm.Halves(buf, hscale, x.shape[0], HD, piece, 0))
+            gemm.stash(y, gemm.Halves(buf, hscale, x.shape[0], HD, piece, order))
             return y, mean, invstd, total, sync, group, seed
     else:
         mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
@@ -206,7 +207,7 @@ class _GATHidden(torch.autograd.Function):
             out = gemm.mm_nt(xh, gemm.split(Wcat.t().contiguous() if kp else Wcat, 1))
         else:
             out = torch.mm(h, Wcat) if kp else torch.mm(h, Wcat.t())    # [N, P] = [ft | res | el | er | pad]
-        ctx.halves = None if xh is None else (xh.n, xh.F, xh.piece)
+        ctx.halves = None if xh is None else (xh.n, xh.F, xh.piece, xh.order)
         B = block_width(HD)                                             # [ft (HD) pad -> B | res (HD) pad -> B | el | er | pad]
         c = 2 * B if has_res else B
         ext = None
@@ -381,7 +382,7 @@ class _GATHidden(torch.autograd.Function):
             dout[:, used:].zero_()
         dW = dh = None
         if ctx.halves is not None:
-            xh = gemm.Halves(h, ctx.xscale, *ctx.halves, 0)
+            xh = gemm.Halves(h, ctx.xscale, *ctx.halves)
             if slots is not None:                                        # + the few score columns no big producer covers
                 _C.absmax_into(dout[:, c:used], slots)
                 dh_ = gemm.split(dout, 0, scale=_C.halves_scale_from_slots(slots))

@@ -359,8 +359,9 @@ class _BNActDrop(torch.autograd.Function):
         else:
             mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
         if hscale is not None:       # the next projection's fp16 halves written by this pass (bot_amd.gemm.take picks them up)
-            y, buf = _C.bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=(hscale, piece))
-            gemm.stash(y, gemm.Halves(buf, hscale, x.shape[0], x.shape[1], piece, 0))
+            order = gemm.left_order(piece)
+            y, buf = _C.bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=(hscale, piece, 2 if order == 2 else 3))
+            gemm.stash(y, gemm.Halves(buf, hscale, x.shape[0], x.shape[1], piece, order))
         else:
             y = _C.bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed)
         ctx.save_for_backward(x, mean, invstd, weight, bias)

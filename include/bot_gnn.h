@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 14
+#define BOT_ABI_VERSION 15
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -349,7 +349,8 @@ int bot_bn_act_fwd_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const 
 /* The same two calls when the epilogue's output is the next layer's GEMM operand (fp16 halves, see bot_gemm_halves_f32 below):
  * bn_stats_halves also tracks the column extremes and derives hscale = (s, 1/s) from the bound
  * max_c (|weight_c| max(|max_c - mean_c|, |min_c - mean_c|) invstd_c + |bias_c|) / (1 - p) >= max |y| — no pass over y;
- * bn_act_fwd_halves writes y AND its halves [h1 | h1 | 2^11 h2] (pieces of `piece` = F rounded up to x64 columns, zero padded), so the
+ * bn_act_fwd_halves writes y AND its halves [h1 | h1 | 2^11 h2] (pieces of `piece` = F rounded up to x64 columns, zero padded; v15:
+ * `pieces` = 2 leaves the duplicate out, [h1 | 2^11 h2] with ldh >= 2 * piece — halves_split's order 2), so the
  * separate halves_scale / halves_split passes over y disappear.  Needs the 4-column form (even F, 8-byte aligned rows).
  * y == NULL (v12): ONLY the halves are written — for a hidden state whose one consumer is the next projection GEMM (the backward
  * of this pass reads x, never y), which saves the fp32 store of an [n, F] matrix nobody reads. */
@@ -359,7 +360,7 @@ int bot_bn_stats_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, f
 int bot_bn_act_fwd_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
                               const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
                               const uint64_t* seed_offset, float* y, int64_t ldy, const float* hscale, uint16_t* hout, int64_t ldh,
-                              int32_t piece, bot_stream_t stream);
+                              int32_t piece, int32_t pieces, bot_stream_t stream);   /* pieces: 3 = [h1 | h1 | 2^11 h2], 2 = [h1 | 2^11 h2] (v15) */
 int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
                               const float* mean, const float* invstd, const float* weight, const float* bias,
                               int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, float* sum_g, float* sum_gx,
@@ -424,8 +425,11 @@ int bot_random_keep_u8(int64_t n, int64_t n_keep, uint64_t seed, uint8_t* keep, 
  * concatenated reduction axis.  h1 + h2 carries 22-23 of the 24 significand bits; against fp64 the result is as close as
  * hipBLASLt's fp32 GEMM (tools/exp_split_gemm*.py), at ~3x its speed.
  *
- *   halves_split  out[r, :] = [h1 | h1 | 2^11 h2] (order 0: left operands) or [h1 | h2 | 2^-11 h1] (order 1: right operands), every
- *                 piece `piece` >= F columns wide (zero padded; use a multiple of 64), out fp16 with row pitch ldo >= 3 * piece.
+ *   halves_split  out[r, :] = [h1 | h1 | 2^11 h2] (order 0: left operands) or [h1 | h2 | 2^-11 h1] (order 1: right operands) or, v15,
+ *                 [h1 | 2^11 h2] (order 2: a left operand WITHOUT the duplicate h1 piece, row pitch >= 2 * piece — only the library's
+ *                 concatenated-axis GEMM reads the duplicate; bot_gemm_halves3_nt_f32 / _tn_f32 take the offset of the second half), every
+ *                 piece `piece` >= F columns wide (zero padded; use a multiple of 64), out fp16 with row pitch ldo >= 3 * piece
+ *                 (order 2: >= 2 * piece).
  *                 The 2^11 keeps a left operand's second half in fp16's normal range: ROWS down to 2^-28 of the matrix maximum keep
  *                 22 significant bits (one scale per matrix alone: 2^-17), and every entry is reproduced to 2^-38 of the matrix
  *                 maximum in absolute terms.  A product of two LEFT layouts (x^T d, the weight gradient) is formed from separate

@@ -221,8 +221,8 @@ def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=None, want_y
     _, o = _bn_gate(x, mean, invstd, weight, bias, relu, p)
     y = torch.relu(o) if relu else o
     if halves is not None:                      # bot_bn_act_fwd_halves_f32: the output also as fp16 halves (want_y False: only them)
-        hscale, piece = halves
-        return (y if want_y else None), halves_split(y, hscale, 0, piece)
+        hscale, piece = halves[:2]
+        return (y if want_y else None), halves_split(y, hscale, 2 if len(halves) > 2 and halves[2] == 2 else 0, piece)
     return y
 
 
@@ -286,11 +286,16 @@ def halves_split(x, scale, order, piece, out=None):
     z = x.float() * (float(scale[0]) if scale is not None else 1.0)
     h1 = z.half()
     r = z - h1.float()
-    buf = torch.zeros((n, 3 * piece), dtype=torch.float16) if out is None else out
+    pieces = 2 if order == 2 else 3
+    buf = torch.zeros((n, pieces * piece), dtype=torch.float16) if out is None else out
     if out is not None:
-        buf[:, :3 * piece] = 0
+        buf[:, :pieces * piece] = 0
     buf[:, :F] = h1
-    # left operands [h1 | h1 | 2^11 h2], right operands [h1 | h2 | 2^-11 h1] (csrc/halves.hip "Dynamic range")
+    # left operands [h1 | h1 | 2^11 h2] (order 2: without the duplicate, [h1 | 2^11 h2]), right operands [h1 | h2 | 2^-11 h1]
+    # (csrc/halves.hip "Dynamic range")
+    if order == 2:
+        buf[:, piece:piece + F] = (r * 2048.0).half()
+        return buf
     buf[:, piece:piece + F] = h1 if order == 0 else r.half()
     buf[:, 2 * piece:2 * piece + F] = (r * 2048.0).half() if order == 0 else (h1.float() / 2048.0).half()
     return buf
@@ -324,9 +329,10 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     return out
 
 
-def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0):
+def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None):
     """include/bot_gnn.h bot_gemm_halves3_nt_f32: a1 b1^T + a1 b2^T + (2^11 a2) (2^-11 b1)^T from a LEFT and a RIGHT operand buffer."""
-    a1, a2 = a[:, :k].float(), a[:, 2 * piece_a:2 * piece_a + k].float()
+    a2_off = 2 * piece_a if a2_off is None else a2_off
+    a1, a2 = a[:, :k].float(), a[:, a2_off:a2_off + k].float()
     b1, b2 = b[:, :k].float(), b[:, piece_b:piece_b + k].float()
     b1s = (b[:, :k] * torch.tensor(2.0 ** -11, dtype=torch.float16)).float()          # the kernel's v_pk_mul_f16: exact or rounded into fp16 subnormals
     res = (a1 @ b1.t() + a1 @ b2.t() + a2 @ b1s.t()) * (scale_a[1] * scale_b[1])
@@ -336,11 +342,14 @@ def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=
     return out
 
 
-def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0):
-    """include/bot_gnn.h bot_gemm_halves3_tn_f32: x1^T d1 + x1^T d2 + x2^T d1 of two LEFT operand buffers ([h1 | h1 | 2^11 h2])."""
+def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0, x2_off=None, d2_off=None):
+    """include/bot_gnn.h bot_gemm_halves3_tn_f32: x1^T d1 + x1^T d2 + x2^T d1 of two LEFT operand buffers ([h1 | h1 | 2^11 h2], or
+    [h1 | 2^11 h2] with the second-half offset = the piece width)."""
     sh = torch.tensor(2.0 ** -11, dtype=torch.float16)
-    x1, x2s = x[:, :k], x[:, 2 * piece_x:2 * piece_x + k]
-    d1, d2s = d[:, :p], d[:, 2 * piece_d:2 * piece_d + p]
+    x2_off = 2 * piece_x if x2_off is None else x2_off
+    d2_off = 2 * piece_d if d2_off is None else d2_off
+    x1, x2s = x[:, :k], x[:, x2_off:x2_off + k]
+    d1, d2s = d[:, :p], d[:, d2_off:d2_off + p]
     res = x1.float().t() @ d1.float() + (x1 * sh).float().t() @ d2s.float() + x2s.float().t() @ (d1 * sh).float()
     return res * (scale_x[1] * scale_d[1])
 

@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 14
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 15
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
@@ -1199,8 +1199,11 @@ def test_gemm_halves_against_fp64():
         top = float(x.abs().max() * xs.scale[0])
         assert 2 ** 13 < top <= 2 ** 14
         # the halves reproduce the operand to fp32's own rounding
-        h1, h2 = xs.buf[:, :K].double(), xs.buf[:, 2 * xs.piece:2 * xs.piece + K].double() / gemm.SHIFT   # left layout: [h1 | h1 | 2^11 h2]
-        assert torch.equal(xs.buf[:, :K], xs.buf[:, xs.piece:xs.piece + K])
+        # left layouts: [h1 | h1 | 2^11 h2], or (wide operands, v15) [h1 | 2^11 h2] without the duplicate
+        h1, h2 = xs.buf[:, :K].double(), xs.buf[:, xs.h2_off:xs.h2_off + K].double() / gemm.SHIFT
+        assert xs.order == (2 if xs.piece >= gemm.NODUP_MIN_PIECE else 0) and xs.buf.shape[1] == (2 if xs.order == 2 else 3) * xs.piece
+        if xs.order == 0:
+            assert torch.equal(xs.buf[:, :K], xs.buf[:, xs.piece:xs.piece + K])
         assert ((h1 + h2) * float(xs.scale[1]) - x.double()).abs().max() <= 2.0 ** -22 * x.abs().max()
         assert not xs.buf[:, K:xs.piece].any()
         for name, got, ref, stock in (
@@ -1273,6 +1276,9 @@ def test_bn_epilogue_writes_halves():
         assert float(y.abs().max()) * s > 2.0 ** 5                     # the bound is not absurdly loose
         ref = _C.halves_split(y, hscale, 0, piece)
         assert torch.equal(buf, ref)
+        _, buf2 = _C.bn_act_fwd(x, mean, invstd, w, b, True, p, 1234, halves=(hscale, piece, 2), want_y=False)      # v15: without the duplicate
+        assert torch.equal(buf2, _C.halves_split(y, hscale, 2, piece)) and buf2.shape == (n, 2 * piece)
+        assert torch.equal(buf2[:, :piece], ref[:, :piece]) and torch.equal(buf2[:, piece:], ref[:, 2 * piece:])
 
 
 def test_skinny_gemm_against_fp64():
@@ -1519,13 +1525,19 @@ def test_gemm_halves3_nt_kernel():
     remainders, outputs narrower than a tile, odd output pitches incl. the [N, 750] input gradient's 8-byte rows and a strided `out`),
     bitwise run to run and bitwise equal to its own plain-loop build (same terms, same order), and refusing bad arguments."""
     from bot_amd import gemm
+
+    def left(x, order):                        # a left operand in a GIVEN layout (gemm.split chooses by piece width)
+        piece = (x.shape[1] + gemm.PIECE_ALIGN - 1) // gemm.PIECE_ALIGN * gemm.PIECE_ALIGN
+        scale = _C.halves_scale(x)
+        return gemm.Halves(_C.halves_split(x, scale, order, piece), scale, x.shape[0], x.shape[1], piece, order)
+
     gen = torch.Generator(device=DEV).manual_seed(11)
     for (m, K, P, ldc) in ((1000, 96, 300, None), (513, 750, 1536, None), (20000, 1536, 750, None), (4099, 64, 40, None), (777, 250, 257, 301),
                            (300, 33, 5, None), (9000, 750, 1536, 1540)):
         x = torch.randn(m, K, device=DEV, generator=gen) * 3
         x[:, ::5] = 0
         w = torch.randn(P, K, device=DEV, generator=gen) * 0.05
-        xs, ws = gemm.split(x, 0), gemm.split(w, 1)
+        xs, ws = left(x, 0), gemm.split(w, 1)
         ref = x.double() @ w.double().t()
         lib = _C.gemm_halves(xs.buf, ws.buf, gemm._alpha(xs, ws, P), trans_b=True)
         out = None
@@ -1542,6 +1554,16 @@ def test_gemm_halves3_nt_kernel():
         print(f"gemm_halves3_nt m={m} K={K} P={P}: err {e:.2e} (hipBLASLt, same operands: {el:.2e})")
         assert e <= max(4e-6, 1.5 * el), (m, K, P, e, el)
         assert torch.equal(got, again) and torch.equal(got, plain)
+        # the same left operand WITHOUT its duplicate piece (order 2, v15): the same halves at another offset -> the same bits; and
+        # gemm.split / gemm.mm_nt choose that layout by themselves for wide operands
+        x2 = left(x, 2)
+        assert x2.buf.shape == (m, 2 * xs.piece) and torch.equal(x2.buf[:, :xs.piece], xs.buf[:, :xs.piece])
+        assert torch.equal(x2.buf[:, xs.piece:], xs.buf[:, 2 * xs.piece:])
+        assert torch.equal(_C.gemm_halves3_nt(x2.buf, ws.buf, x2.scale, ws.scale, x2.piece, ws.piece, x2.piece, a2_off=x2.piece), got)
+        auto = gemm.split(x, 0)
+        assert auto.order == (2 if xs.piece >= gemm.NODUP_MIN_PIECE else 0) and gemm.LEFT_NODUP
+        if auto.order == 2 or P >= gemm.NT_MIN_COLS:
+            assert torch.equal(gemm.mm_nt(auto, ws), got)
     assert gemm.NT_KERNEL == "halves3"          # the default route of gemm.mm_nt (forward + input gradient of the merged projections)
     # --- TN: the weight gradient x^T d of two LEFT operands (192 x 192 tiles, transposing LDS reads, split-K, three LDS stages), against
     # fp64 next to the library formulation (batched chunk products + combine): ragged row counts (the last step of the last split is
@@ -1551,7 +1573,7 @@ def test_gemm_halves3_nt_kernel():
         x = torch.randn(n, K, device=DEV, generator=gen) * 3
         d = torch.randn(n, P, device=DEV, generator=gen) * 1e-3
         d[:, ::3] = 0
-        xs, ds = gemm.split(x, 0), gemm.split(d, 0)
+        xs, ds = left(x, 0), left(d, 0)
         ref = x.double().t() @ d.double()
         got = _C.gemm_halves3_tn(xs.buf, ds.buf, xs.scale, ds.scale, xs.piece, ds.piece, K, P)
         again = _C.gemm_halves3_tn(xs.buf, ds.buf, xs.scale, ds.scale, xs.piece, ds.piece, K, P)
@@ -1560,6 +1582,9 @@ def test_gemm_halves3_nt_kernel():
             lib = gemm.tn(xs, ds)
         finally:
             gemm.TN_KERNEL = "halves3"
+        x2, d2 = left(x, 2), left(d, 2)          # both, or either, without the duplicate piece: the same bits (either route of gemm.tn)
+        for (a, b) in ((x2, d2), (x2, ds), (xs, d2)):
+            assert torch.equal(gemm.tn(a, b), got if xs.piece * ds.piece >= gemm.TN_MIN_OUT else lib)
         sc = float(ref.abs().max())
         e, el = float((got.double() - ref).abs().max()) / sc, float((lib.double() - ref).abs().max()) / sc
         print(f"gemm_halves3_tn n={n} K={K} P={P}: err {e:.2e} (library formulation: {el:.2e})")

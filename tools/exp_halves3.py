@@ -27,14 +27,47 @@ def t_ms(fn, n=10):
 
 
 def h3(xs, ws, out=None, mode=0):
-    return _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, xs.piece, out=out, mode=mode)
+    return _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, xs.piece, out=out, mode=mode, a2_off=xs.h2_off)
+
+
+def left(x, order=0):
+    """a left operand in a GIVEN layout (0: [h1 | h1 | 2^11 h2], what the library form needs; 2: [h1 | 2^11 h2])"""
+    piece = (x.shape[1] + gemm.PIECE_ALIGN - 1) // gemm.PIECE_ALIGN * gemm.PIECE_ALIGN
+    scale = _C.halves_scale(x)
+    return gemm.Halves(_C.halves_split(x, scale, order, piece), scale, x.shape[0], x.shape[1], piece, order)
+
+
+if "--layouts" in sys.argv:  # both kernels on the config-2 shapes with the left operands in either layout (row pitch 3 or 2 pieces)
+    N = 169343
+    for name, (m, K, P) in (("fwd [N,750]x[1536,750]", (N, 750, 1536)), ("dx [N,1536]x[750,1536]", (N, 1536, 750)), ("out [N,750]x[240,750]", (N, 750, 240)),
+                            ("dx out [N,240]x[750,240]", (N, 240, 750))):
+        x = torch.randn(m, K, device=dev, generator=gen)
+        w = torch.randn(P, K, device=dev, generator=gen) * 0.05
+        ws = gemm.split(w, 1)
+        out = torch.empty(m, P, device=dev)
+        ops = {o: left(x, o) for o in (0, 2)}
+        fs = {o: (lambda o=o: h3(ops[o], ws, out)) for o in (0, 2)}
+        for f in fs.values():
+            f()
+        rounds = [tuple(t_ms(fs[o]) for o in (0, 2)) for _ in range(5)]
+        print(f"NT {name}: 3-piece left {sorted(r[0] for r in rounds)[2]:.3f} ms   2-piece left {sorted(r[1] for r in rounds)[2]:.3f} ms")
+    for name, (K, P) in (("[750,N]x[N,1536]", (750, 1536)), ("[1536,N]x[N,750]", (1536, 750)), ("[750,N]x[N,240]", (750, 240))):
+        x = torch.randn(N, K, device=dev, generator=gen)
+        d = torch.randn(N, P, device=dev, generator=gen) * 1e-3
+        combos = {(a, b): (left(x, a), left(d, b)) for a in (0, 2) for b in (0, 2)}
+        fs = {k: (lambda v=v: gemm.tn(*v)) for k, v in combos.items()}
+        for f in fs.values():
+            f()
+        rounds = [{k: t_ms(f) for k, f in fs.items()} for _ in range(5)]
+        print(f"TN {name}: " + "   ".join(f"x {3 if a == 0 else 2}-piece, d {3 if b == 0 else 2}-piece {sorted(r[(a, b)] for r in rounds)[2]:.3f} ms" for (a, b) in fs))
+    sys.exit(0)
 
 
 if "--pmc-tn" in sys.argv:   # a few launches of the TN kernel on the config-2 shape
     N = 169343
     x = torch.randn(N, 750, device=dev, generator=gen)
     d = torch.randn(N, 1536, device=dev, generator=gen) * 1e-3
-    xs, ds = gemm.split(x, 0), gemm.split(d, 0)
+    xs, ds = left(x), left(d)
     for _ in range(3):
         gemm.tn(xs, ds)
     torch.cuda.synchronize()
@@ -44,7 +77,7 @@ if "--pmc" in sys.argv:      # a few launches of each kernel on the forward shap
     m, K, P = 169343, 750, 1536
     x = torch.randn(m, K, device=dev, generator=gen)
     w = torch.randn(P, K, device=dev, generator=gen) * 0.05
-    xs, ws = gemm.split(x, 0), gemm.split(w, 1)
+    xs, ws = left(x), gemm.split(w, 1)
     out = torch.empty(m, P, device=dev)
     for _ in range(3):
         _C.gemm_halves(xs.buf, ws.buf, gemm._alpha(xs, ws, P), trans_b=True, out=out)
@@ -56,7 +89,7 @@ if "--pmc" in sys.argv:      # a few launches of each kernel on the forward shap
 for (m, K, P) in ((1000, 96, 300), (513, 750, 1536), (20000, 1536, 750), (4099, 64, 40)):
     x = torch.randn(m, K, device=dev, generator=gen) * 3
     w = torch.randn(P, K, device=dev, generator=gen) * 0.05
-    xs, ws = gemm.split(x, 0), gemm.split(w, 1)
+    xs, ws = left(x), gemm.split(w, 1)
     ref = x.double() @ w.double().t()
     lib = _C.gemm_halves(xs.buf, ws.buf, gemm._alpha(xs, ws, P), trans_b=True)
     mine = h3(xs, ws)
@@ -70,7 +103,7 @@ for (m, K, P) in ((1000, 96, 300), (513, 750, 1536), (20000, 1536, 750), (4099, 
 for (n, K, P) in ((1000, 96, 300), (4099, 750, 1536), (50001, 168, 250), (33, 64, 40), (20000, 1536, 750)):
     x = torch.randn(n, K, device=dev, generator=gen) * 3
     d = torch.randn(n, P, device=dev, generator=gen) * 1e-3
-    xs, ds = gemm.split(x, 0), gemm.split(d, 0)
+    xs, ds = left(x), left(d)
     ref = x.double().t() @ d.double()
     gemm.TN_KERNEL = "lib"
     lib = gemm.tn(xs, ds)
@@ -83,7 +116,7 @@ for (n, K, P) in ((1000, 96, 300), (4099, 750, 1536), (50001, 168, 250), (33, 64
 N = 169343
 x = torch.randn(N, 750, device=dev, generator=gen)
 d = torch.randn(N, 1536, device=dev, generator=gen) * 1e-3
-xs, ds = gemm.split(x, 0), gemm.split(d, 0)
+xs, ds = left(x), left(d)
 
 
 def tn_with(kind):
@@ -109,7 +142,7 @@ N = 169343
 for name, (m, K, P) in (("fwd x W^T [N,750]x[1536,750]", (N, 750, 1536)), ("dx d W [N,1536]x[750,1536]", (N, 1536, 750))):
     x = torch.randn(m, K, device=dev, generator=gen)
     w = torch.randn(P, K, device=dev, generator=gen) * 0.05
-    xs, ws = gemm.split(x, 0), gemm.split(w, 1)
+    xs, ws = left(x), gemm.split(w, 1)
     alpha = gemm._alpha(xs, ws, P)
     out1 = torch.empty(m, P, device=dev)
     out2 = torch.empty(m, P, device=dev)
