@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -43,6 +43,8 @@ _SIGS = {
                                         _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P, _P]),
     "bot_spmm_bcast_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, _P, _P, c_int32,
                                           c_int32, _P, c_int64, c_int64, _P, _P]),
+    "bot_spmm_bcast_halves_f16": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, _P, _P, c_int32, c_int32, _P, _P,
+                                                 c_int64, c_int64, c_int32, c_int32, _P, _P]),
     "bot_spmm_dot_bcast_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P,
                                               _P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     "bot_sddmm_dot_f32": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
@@ -79,6 +81,10 @@ _SIGS = {
     "bot_gemm_halves3_tn_workspace_floats": (c_int64, [c_int64, c_int64, c_int64]),
     "bot_gemm_halves3_tn_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P,
                                                c_int64, _P, c_int32, _P]),
+    "bot_gemm_halves3_nt_grouped_f32": (ctypes.c_int, [c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int32, _P,
+                                                       c_int32, c_int32, _P]),
+    "bot_gemm_halves3_tn_grouped_workspace_floats": (c_int64, [c_int64, c_int32]),
+    "bot_gemm_halves3_tn_grouped_f32": (ctypes.c_int, [c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int32, _P, _P, c_int32, _P]),
     "bot_label_split_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, _P, c_float, c_uint64, _P, c_int32, _P, _P, _P, _P, _P]),
     "bot_build_input_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_int32, _P, c_float, c_uint64, _P, _P, c_int64, _P]),
     "bot_node_loss_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P, c_int32, c_float, _P, c_int64, _P, c_int64, _P]),
@@ -357,6 +363,28 @@ def spmm_bcast(d, x, w, wperm=None, head_outer=True):
         _ptr(d.long_ptr), d.n_long, x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(_i32(wperm, "wperm")), H, D, out.data_ptr(),
         ldo, hso, _ptr(partial), _stream())), "spmm_bcast")
     return out
+
+
+def spmm_bcast_halves(d, x, w, wperm, hscale, hout, col0, hsh, h2_off, hpiece):
+    """spmm_bcast with the result written as fp16 halves [h1 | 2^11 h2] of hscale[0] * out into the operand buffer `hout` [n_rows, ld]:
+    head h's row block at columns col0 + h hsh .. + hpiece - 1 (zeros behind the D = x.shape[1] columns), the second half h2_off columns
+    behind the first — the aggregated slab of the aggregate-first GAT layer as a GEMM operand, no fp32 copy (bot_spmm_bcast_halves_f16)."""
+    _dev(x, w, d.indptr, hout, hscale)
+    _f32(x, "x")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    w = _f32(w, "w").contiguous()
+    H, D = w.shape[1], x.shape[1]
+    assert hout.dtype == torch.float16 and hout.dim() == 2 and hout.shape[0] == d.n_rows and hout.stride(1) == 1 and col0 % 4 == 0
+    assert col0 + h2_off + (H - 1) * hsh + hpiece <= hout.shape[1]
+    partial = None
+    if d.n_long:
+        partial = torch.empty(int(_lib.bot_spmm_workspace_floats(d.n_slots, H, D)), dtype=torch.float32, device=x.device)
+    _check(_timed("spmm_bcast", (H, D), lambda: _lib.bot_spmm_bcast_halves_f16(
+        d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
+        _ptr(d.long_ptr), d.n_long, x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(_i32(wperm, "wperm")), H, D, hscale.data_ptr(),
+        hout.data_ptr() + 2 * col0, hout.stride(0), hsh, h2_off, hpiece, _ptr(partial), _stream())), "spmm_bcast_halves")
+    return hout
 
 
 def spmm_dot_bcast(d, x, w, wperm, y, out=None):
@@ -652,11 +680,13 @@ def halves_split(x, scale, order, piece, out=None):
 
 def halves_split_cols(x, scale, order, buf, piece, col, width):
     """Split x [n,F] into columns [col, col + width) of the three pieces of the halves operand `buf` [n, 3 * piece] (zeros behind
-    the F columns of x): several matrices side by side as ONE operand under one scale — bot_halves_split_cols_f16."""
+    the F columns of x): several matrices side by side as ONE operand under one scale — bot_halves_split_cols_f16.  order 2: the two
+    pieces [h1 | 2^11 h2] of a buffer [n, >= 2 * piece], `piece` = the distance of the second half from the first."""
     _dev(x, scale, buf)
     x = _mat(x, "x")
     n, F = x.shape
-    assert buf.dtype == torch.float16 and buf.shape == (n, 3 * piece) and buf.stride(1) == 1 and col % 2 == 0 and col + width <= piece
+    assert buf.dtype == torch.float16 and buf.shape[0] == n and buf.shape[1] >= (2 if order == 2 else 3) * piece and buf.stride(1) == 1
+    assert col % 2 == 0 and col + width <= piece
     _check(_lib.bot_halves_split_cols_f16(x.data_ptr(), x.stride(0), n, F, _ptr(scale), order, buf.data_ptr() + 2 * col, buf.stride(0), piece,
                                           width, _stream()), "halves_split_cols")
     return buf
@@ -760,6 +790,47 @@ def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=
     _check(_timed("gemm_halves", (m, n, 3 * k, 1), lambda: _lib.bot_gemm_halves3_nt_f32(
         m, n, k, scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), 2 * piece_a if a2_off is None else a2_off, b.data_ptr(), _ld(b),
         piece_b, out.data_ptr(), _ld(out), int(mode), _stream())), "gemm_halves3_nt")
+    return out
+
+
+def _table(rows, width):
+    flat = [int(v) for r in rows for v in r]
+    assert len(flat) == width * len(rows)
+    return (ctypes.c_int64 * len(flat))(*flat)
+
+
+def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups, k_seg, mode=0):
+    """The grouped NT product (bot_gemm_halves3_nt_grouped_f32): for every group (b_row0, n_valid, a_col0, a_col1, k_steps, c_off)
+        out.flat[r * ld + c_off + j] = scale_a[1] scale_b[1] * sum_{t < k_steps} sum_{i < 32} A3[r, (a_col0 if t < k_seg else a_col1) + 32 t + i] . B3[b_row0 + j, 32 t + i]
+    for j < n_valid <= 256, over the rows of the left operand buffer a ([h1 at column c, 2^11 h2 at column c + a2_off]) and the right
+    operand buffer b ([h1 | h2 at + b2_off]); `out` is a row-major fp32 matrix view whose storage the offsets c_off address (ld = its
+    row pitch).  The per-head products of the aggregate-first GAT layer in one launch."""
+    _dev(a, b, out, scale_a, scale_b)
+    assert a.dtype == torch.float16 and b.dtype == torch.float16 and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    assert out.dtype == torch.float32 and out.stride(-1) == 1
+    tab = _table(groups, 6)
+    # (profile key: m, n, k, batch with 2 m n k batch = the fp16 MFMA flops of the valid output columns, three products each)
+    _check(_timed("gemm_halves", (a.shape[0], sum(int(g[1]) * 96 * int(g[4]) for g in groups), 1, 1), lambda: _lib.bot_gemm_halves3_nt_grouped_f32(
+        a.shape[0], b.shape[0], scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), a2_off, b.data_ptr(), _ld(b), b2_off, out.data_ptr(),
+        int(out.stride(-2)), len(groups), tab, int(k_seg), int(mode), _stream())), "gemm_halves3_nt_grouped")
+    return out
+
+
+def gemm_halves3_tn_grouped(x, d, scale_x, scale_d, x2_off, d2_off, out, tiles, mode=0):
+    """The grouped TN product (bot_gemm_halves3_tn_grouped_f32): for every tile (x_col0, k_valid, d_col0, p_valid, out_off, ldo, transposed)
+        out.flat[out_off + k * ldo + p] = scale_x[1] scale_d[1] * sum_n X3[n, x_col0 + k] . D3[n, d_col0 + p],  k < k_valid <= 192, p < p_valid <= 192
+    (transposed: out.flat[out_off + p * ldo + k])
+    over the rows of two LEFT operand buffers (h1 at column c, 2^11 h2 at c + x2_off / d2_off); `out` is one contiguous fp32 buffer that
+    the offsets address.  The weight gradients of the aggregate-first GAT layer (per head, and of its merged projection) in one launch."""
+    _dev(x, d, out, scale_x, scale_d)
+    assert x.dtype == torch.float16 and d.dtype == torch.float16 and x.stride(1) == 1 and d.stride(1) == 1 and x.shape[0] == d.shape[0]
+    assert out.dtype == torch.float32 and out.is_contiguous()
+    n = x.shape[0]
+    ws = torch.empty(int(_lib.bot_gemm_halves3_tn_grouped_workspace_floats(n, len(tiles))), dtype=torch.float32, device=x.device)
+    tab = _table(tiles, 7)
+    _check(_timed("gemm_halves", (n, sum(3 * int(t[1]) * int(t[3]) for t in tiles), 1, 1), lambda: _lib.bot_gemm_halves3_tn_grouped_f32(
+        n, scale_x.data_ptr(), scale_d.data_ptr(), x.data_ptr(), _ld(x), x2_off, d.data_ptr(), _ld(d), d2_off, out.data_ptr(), len(tiles), tab,
+        ws.data_ptr(), int(mode), _stream())), "gemm_halves3_tn_grouped")
     return out
 
 

@@ -48,6 +48,21 @@ struct H3Args {
                             // bit 7 no DMA inside the loop, bit 8 one A fragment pair per k-step
 };
 
+// Grouped form (bot_gemm_halves3_nt_grouped_f32): the column tiles of a launch are GROUPS, each with its own B rows, output block and
+// A columns - the per-head products of the aggregate-first GAT layer (fused.py:_GATHiddenAggFirst) as ONE launch:
+//   C[r, c_off + j] = alpha * sum_{t < k_steps} sum_{i < 32} A[r, (t < k_seg ? a_col0 : a_col1) + 32 t + i] . B[b_row0 + j, 32 t + i],  j < n_valid <= 256
+struct H3Group {
+    int b_row0, n_valid;    // first B row of the tile; output columns written (the tile computes 256)
+    int a_off0, a_off1;     // byte offsets added to A's k offset before / from k-step k_seg
+    int k_steps, pad;
+    int64_t c_off;          // offset (floats) of the group's first output column from C
+};
+constexpr int kMaxGroups = 12;
+struct H3Groups {
+    H3Group g[kMaxGroups];
+    int k_seg;
+};
+
 // LDS-DMA, 16 bytes per lane: buffer_load_dwordx4 ... lds with the tile's resource descriptor in SGPRs, a per-lane 32-bit byte offset and a
 // wave-uniform byte offset (SGPR).  (The buffer builtins exist in the device pass only: the host pass needs just the kernel's stub.)
 __device__ __forceinline__ void dma16(const void* tile_base, unsigned char* lptr, uint32_t voff, int soff) {
@@ -59,8 +74,8 @@ __device__ __forceinline__ void dma16(const void* tile_base, unsigned char* lptr
 
 // One BM x BN output tile per workgroup of WM x WN waves (wave tile MT x NT MFMA tiles of 16 x 16).  LDS: two stages of
 // [a1 | a2 | b1 | b2], each piece [rows][64 B] with the 16-byte chunk index XOR-swizzled by f(row quad) = (-(row >> 2)) & 3.
-template <int BM, int BN, int WM, int WN, bool PIPE>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p) {
+template <int BM, int BN, int WM, int WN, bool PIPE, bool GROUPED>
+__device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Groups* groups) {
     constexpr int kWaves = WM * WN;
     constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
     constexpr int kABytes = BM * BK * 2, kBBytes = BN * BK * 2;             // one piece of each operand
@@ -73,7 +88,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p)
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
     if (tm >= p.tiles_m) return;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM;
+    // the column tile: B rows n0 .., output columns c0 .. c0 + n_valid - 1 (offsets from C), T k-steps, A's k offset shifted by a_off0 /
+    // a_off1 bytes before / from k-step k_seg (all zero / the plain tiling unless GROUPED)
+    int n0 = tn * BN, n_valid = p.N - n0, T = p.K / BK, a_off0 = 0, a_off1 = 0, k_seg = 0;
+    int64_t c0 = n0;
+    if constexpr (GROUPED) {
+        const H3Group& G = groups->g[tn];
+        n0 = G.b_row0, n_valid = G.n_valid, T = G.k_steps, a_off0 = G.a_off0, a_off1 = G.a_off1, c0 = G.c_off, k_seg = groups->k_seg;
+    }
     const float alpha = p.scale_a[1] * p.scale_b[1];
 
     // LDS-DMA plan: lane i of a wave instruction lands at byte 16 i of its 1 KB row group: row i >> 2, stored chunk i & 3, which holds
@@ -104,7 +127,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p)
         unsigned char* base = lds + stage * kStageBytes + w * 1024;
         if (i < 2 * GA) {
             const int q = i / GA, h = i % GA;
-            dma16(tileA, base + q * kABytes + h * kWaves * 1024, offA[i], kt * stepA);
+            dma16(tileA, base + q * kABytes + h * kWaves * 1024, offA[i], GROUPED ? kt * stepA + (kt < k_seg ? a_off0 : a_off1) : kt * stepA);
         } else {
             const int k = i - 2 * GA, q = k / GB, h = k % GB;
             dma16(tileB, base + 2 * kABytes + q * kBBytes + h * kWaves * 1024, offB[k], kt * stepB);
@@ -127,7 +150,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int T = p.K / BK;
     auto mfma12 = [&](int mt, const half8& a1, const half8& a2, const half8 (&b1)[NT], const half8 (&b2)[NT], const half8 (&b1s)[NT]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -242,8 +264,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p)
         if (acc[0][0][0] == 1.2345e-33f) p.C[0] = acc[MT - 1][NT - 1][3] + acc[MT / 2][1][2];      // keeps the accumulators live
         return;
     }
-    const bool vec_ok = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
-    const bool vec2_ok = (p.ldc % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 7) == 0);
+    float* const Cb = p.C + c0;                     // the tile's first output column
+    const bool vec_ok = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
+    const bool vec2_ok = (p.ldc % 2 == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 7) == 0);
     // Through LDS, so that a store instruction writes 4 rows x 256 contiguous bytes (full 128-byte lines) instead of 16 rows x 64 bytes:
     // the accumulator layout gives a lane 4 consecutive columns of ONE row per tile, 16 rows per instruction (measured with the
     // full-line address pattern as an ablation: -0.06 ... -0.14 ms of 1.1).  All stages are free after the last barrier; every wave
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p)
     static_assert(32 * P * 4 <= 2 * kStageBytes / kWaves, "staging slab does not fit the wave's share of the LDS");
     float* stg = reinterpret_cast<float*>(lds + w * (2 * kStageBytes / kWaves));
     const int q4 = (lane >> 4) * 4, l15 = lane & 15;
-    const int col = n0 + wc * NT * 16 + l15 * 4;
+    const int col = wc * NT * 16 + l15 * 4;         // within the tile
 #pragma unroll
     for (int pass = 0; pass < MT / 2; ++pass) {
 #pragma unroll
@@ -269,20 +292,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p)
             const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * P + l15 * 4);
             const int row = m0 + wr * MT * 16 + pass * 32 + r;
             if (row < p.M) {
-                float* c = p.C + (int64_t)row * p.ldc + col;
-                if (vec_ok && col + 3 < p.N) {
+                float* c = Cb + (int64_t)row * p.ldc + col;
+                if (vec_ok && col + 3 < n_valid) {
                     *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-                } else if (vec2_ok && col + 3 < p.N) {          // rows on an 8-byte pitch (the [N, 750] input gradient)
+                } else if (vec2_ok && col + 3 < n_valid) {      // rows on an 8-byte pitch (the [N, 750] input gradient)
                     *reinterpret_cast<float2*>(c) = make_float2(v[0], v[1]);
                     *reinterpret_cast<float2*>(c + 2) = make_float2(v[2], v[3]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (col + e < p.N) c[e] = v[e];
+                        if (col + e < n_valid) c[e] = v[e];
                 }
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, bool PIPE>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p) {
+    gemm_halves3_nt_body<BM, BN, WM, WN, PIPE, false>(p, nullptr);
+}
+
+template <int BM, int BN, int WM, int WN, bool PIPE>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_grouped_kernel(H3Args p, H3Groups groups) {
+    gemm_halves3_nt_body<BM, BN, WM, WN, PIPE, true>(p, &groups);
 }
 
 // ============================================================================================================================
@@ -322,6 +355,20 @@ struct TnArgs3 {
     int x2_off, d2_off;
     int tiles_k, tiles_p, splits, rows_per_split;       // rows_per_split: a multiple of TBK
     int mode;               // 0 = the product; measurement switches (tools/exp_halves3.py): bit 0 no DMA in the loop, bit 1 no barrier / wait
+};
+
+// Grouped form (bot_gemm_halves3_tn_grouped_f32): the tiles of a split are a LIST, each with its own x / d columns and output block - the
+// per-head weight gradients of the aggregate-first GAT layer and the gradient of its merged projection as ONE launch:
+//   out[out_off + k ldo + p] = alpha * sum_n X[n, x_col0 + k] . D[n, d_col0 + p],   k < k_valid <= 192, p < p_valid <= 192
+// (transposed: out[out_off + p ldo + k])
+struct TnTile {
+    int x_col0, d_col0, k_valid, p_valid;
+    int64_t out_off, ldo;
+    int transposed, pad;
+};
+constexpr int kMaxTnTiles = 16;
+struct TnTiles {
+    TnTile t[kMaxTnTiles];
 };
 
 __device__ __forceinline__ int tn_key8(int n) { return (n & 3) | ((n >> 1) & 4); }
@@ -366,7 +413,8 @@ __device__ __forceinline__ half8 tr_pack(const v2i& lo, const v2i& hi) {
     return __builtin_bit_cast(half8, q);
 }
 
-__global__ __launch_bounds__(512) void gemm_halves3_tn_kernel(TnArgs3 p) {
+template <bool GROUPED>
+__device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnTiles* tiles) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[kTnStages * kTnStage];
     // (readfirstlane: the compiler must KNOW the wave index is uniform, or every DMA instruction - whose LDS address goes through M0 - is
     // wrapped in a waterfall loop and every LDS read behind it waits for vmcnt(0))
@@ -376,16 +424,18 @@ __global__ __launch_bounds__(512) void gemm_halves3_tn_kernel(TnArgs3 p) {
     const int tps = p.tiles_k * p.tiles_p;
     const int split = (j / tps) * 8 + xcd, tile = j % tps;
     if (split >= p.splits) return;
-    const int tk = tile / p.tiles_p, tp = tile % p.tiles_p;
+    // the tile's first x / d column and where its 192 x 192 partial goes (plain: the [KP, PP] slab of the split; grouped: tile after tile)
+    int xc = (tile / p.tiles_p) * TT, dc = (tile % p.tiles_p) * TT;
+    if constexpr (GROUPED) xc = tiles->t[tile].x_col0, dc = tiles->t[tile].d_col0;
     const int row0 = split * p.rows_per_split;
     const int rows = min(p.rows_per_split, p.N - row0);          // > 0 by construction of the splits
     const int T = (rows + TBK - 1) / TBK;
 
     // LDS-DMA plan: 48 instructions of 1 KB per step (12 per piece: 8 x [4 rows x 256 B], 4 x [8 rows x 128 B]), six per wave.  Rows past the operand's end (the last split's last step) are outside the descriptor and arrive as zeros.
-    const _Float16* tileX = p.X + (int64_t)row0 * p.ldx + tk * TT;
-    const _Float16* tileD = p.D + (int64_t)row0 * p.ldd + tp * TT;
+    const _Float16* tileX = p.X + (int64_t)row0 * p.ldx + xc;
+    const _Float16* tileD = p.D + (int64_t)row0 * p.ldd + dc;
     // (plain integer arithmetic: HIP's min<int64_t> goes through double, which makes the descriptor a VGPR value -> waterfall loops)
-    const int64_t bytesX = ((int64_t)rows * p.ldx - tk * TT) * 2, bytesD = ((int64_t)rows * p.ldd - tp * TT) * 2;
+    const int64_t bytesX = ((int64_t)rows * p.ldx - xc) * 2, bytesD = ((int64_t)rows * p.ldd - dc) * 2;
     const uint32_t limX = bytesX > 0x7fffffff ? 0x7fffffffu : (uint32_t)bytesX;
     const uint32_t limD = bytesD > 0x7fffffff ? 0x7fffffffu : (uint32_t)bytesD;
     // Instruction i of wave w:  i = 0 .. 3: rows 4 w .. 4 w + 3 of the 256-byte sub-image of piece i (x1, x2, d1, d2);  i = 4 / 5: rows
@@ -511,17 +561,69 @@ __global__ __launch_bounds__(512) void gemm_halves3_tn_kernel(TnArgs3 p) {
         }
         stage = stage == 2 ? 0 : stage + 1;
     }
-    // acc[mt][nt][r] = partial of dW[k = tk 192 + wc 48 + nt 16 + (lane & 15)][p = tp 192 + wr 96 + mt 16 + (lane >> 4) 4 + r]
-    float* out = p.part + (int64_t)split * p.KP * p.PP;
+    // acc[mt][nt][r] = partial of dW[k = xc + wc 48 + nt 16 + (lane & 15)][p = dc + wr 96 + mt 16 + (lane >> 4) 4 + r]
+    if constexpr (GROUPED) {
+        float* out = p.part + ((int64_t)split * tps + tile) * (TT * TT);       // the tile's own [192][192] block
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) {
-        const int k = tk * TT + wc * 48 + nt * 16 + (lane & 15);
-        if (k >= p.KP) continue;
+        for (int nt = 0; nt < 3; ++nt) {
+            const int k = wc * 48 + nt * 16 + (lane & 15);
 #pragma unroll
-        for (int mt = 0; mt < 6; ++mt) {
-            const int pc = tp * TT + wr * 96 + mt * 16 + (lane >> 4) * 4;
-            if (pc < p.PP) *reinterpret_cast<float4*>(out + (int64_t)k * p.PP + pc) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+            for (int mt = 0; mt < 6; ++mt) {
+                const int pc = wr * 96 + mt * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<float4*>(out + k * TT + pc) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+            }
         }
+    } else {
+        float* out = p.part + (int64_t)split * p.KP * p.PP;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int k = xc + wc * 48 + nt * 16 + (lane & 15);
+            if (k >= p.KP) continue;
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) {
+                const int pc = dc + wr * 96 + mt * 16 + (lane >> 4) * 4;
+                if (pc < p.PP) *reinterpret_cast<float4*>(out + (int64_t)k * p.PP + pc) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm_halves3_tn_kernel(TnArgs3 p) { gemm_halves3_tn_body<false>(p, nullptr); }
+__global__ __launch_bounds__(512) void gemm_halves3_tn_grouped_kernel(TnArgs3 p, TnTiles tiles) { gemm_halves3_tn_body<true>(p, &tiles); }
+
+// grouped: out[out_off + k ldo + p] = scale_x[1] scale_d[1] * sum_s part[s][tile][k][p]   (split order), k < k_valid, p < p_valid
+__global__ __launch_bounds__(256) void tn_reduce_h3_grouped_kernel(const float* part, int splits, int n_tiles, TnTiles tiles, const float* scale_x,
+                                                                   const float* scale_d, float* out) {
+    constexpr int P4 = TT / 4;
+    const int tile = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= TT * P4) return;
+    const TnTile& t = tiles.t[tile];
+    const int k = i / P4, pc = (i - k * P4) * 4;
+    if (k >= t.k_valid || pc >= t.p_valid) return;
+    const float alpha = scale_x[1] * scale_d[1];
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = part + (int64_t)tile * (TT * TT) + k * TT + pc;
+    const int64_t sstride = (int64_t)n_tiles * (TT * TT);
+    constexpr int U = 4;                                    // loads in flight; added in split order
+    for (int s0 = 0; s0 < splits; s0 += U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = s0 + u < splits ? *reinterpret_cast<const float4*>(src + (s0 + u) * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < U; ++u) s4.x += v[u].x, s4.y += v[u].y, s4.z += v[u].z, s4.w += v[u].w;
+    }
+    const float r[4] = {s4.x * alpha, s4.y * alpha, s4.z * alpha, s4.w * alpha};
+    if (t.transposed) {
+        float* o = out + t.out_off + (int64_t)pc * t.ldo + k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (pc + e < t.p_valid) o[e * t.ldo] = r[e];
+    } else {
+        float* o = out + t.out_off + (int64_t)k * t.ldo + pc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (pc + e < t.p_valid) o[e] = r[e];
     }
 }
 
@@ -585,12 +687,95 @@ extern "C" int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const fl
     return hip_status("gemm_halves3_nt");
 }
 
+extern "C" int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
+                                               int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t n_groups,
+                                               const int64_t* groups, int32_t k_seg, int32_t mode, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(m > 0 && b_rows > 0 && n_groups >= 1 && n_groups <= kMaxGroups && k_seg >= 0, -1, "gemm_halves3_nt_grouped: m, b_rows > 0, 1 .. %d groups (got %lld %lld %d)",
+                kMaxGroups, (long long)m, (long long)b_rows, n_groups);
+    BOT_REQUIRE(scale_a && scale_b && A && B && C && groups, -1, "gemm_halves3_nt_grouped: null pointer");
+    BOT_REQUIRE(aligned(A, 16) && aligned(B, 16) && lda % 8 == 0 && ldb % 8 == 0 && a2_off % 8 == 0 && b2_off % 8 == 0, -1,
+                "gemm_halves3_nt_grouped: operands, row pitches and piece offsets must be 16-byte aligned");
+    BOT_REQUIRE(m < (1ll << 31) - 256 && b_rows < (1ll << 31) - 256 && 256 * lda * 2 < (1ll << 31) && 256 * ldb * 2 < (1ll << 31), -1, "gemm_halves3_nt_grouped: bad sizes");
+    H3Args p;
+    p.A = reinterpret_cast<const _Float16*>(A), p.B = reinterpret_cast<const _Float16*>(B), p.scale_a = scale_a, p.scale_b = scale_b, p.C = C;
+    p.lda = lda, p.ldb = ldb, p.ldc = ldc, p.M = (int)m, p.N = (int)b_rows, p.K = 0, p.a2_off = (int)a2_off, p.b2_off = (int)b2_off;
+    p.mode = mode & ~32;
+    H3Groups g;
+    g.k_seg = k_seg;
+    for (int i = 0; i < n_groups; ++i) {
+        const int64_t* d = groups + 6 * i;       // b_row0, n_valid, a_col0, a_col1, k_steps, c_off
+        const int64_t k_steps = d[4], a_hi = std::max(k_seg > 0 ? d[2] + 32 * std::min<int64_t>(k_seg, k_steps) : 0, k_steps > k_seg ? d[3] + 32 * k_steps : 0);
+        BOT_REQUIRE(d[0] >= 0 && d[0] < b_rows && d[1] >= 1 && d[1] <= 256 && k_steps >= 1 && d[2] >= 0 && d[3] >= 0 && d[2] % 8 == 0 && d[3] % 8 == 0 && d[5] >= 0, -1,
+                    "gemm_halves3_nt_grouped: group %d: b_row0=%lld n_valid=%lld a_col0=%lld a_col1=%lld k_steps=%lld c_off=%lld", i, (long long)d[0],
+                    (long long)d[1], (long long)d[2], (long long)d[3], (long long)d[4], (long long)d[5]);
+        BOT_REQUIRE(a_hi + a2_off <= lda && 32 * k_steps + b2_off <= ldb && 32 * k_steps <= b2_off, -1,
+                    "gemm_halves3_nt_grouped: group %d reads past a row (A columns to %lld + %lld of %lld, B columns to %lld + %lld of %lld)", i, (long long)a_hi,
+                    (long long)a2_off, (long long)lda, (long long)(32 * k_steps), (long long)b2_off, (long long)ldb);
+        g.g[i] = H3Group{(int)d[0], (int)d[1], (int)d[2] * 2, (int)d[3] * 2, (int)k_steps, 0, d[5]};
+    }
+    p.tiles_m = (int)((m + 255) / 256), p.tiles_n = n_groups;
+    set_kernel("bot::gemm_halves3_nt_grouped_kernel<256,256,2,4,pipelined>");
+    hipLaunchKernelGGL((gemm_halves3_nt_grouped_kernel<256, 256, 2, 4, true>), dim3(((p.tiles_m + 7) / 8) * 8 * n_groups), dim3(512), 0, (hipStream_t)stream, p, g);
+    return hip_status("gemm_halves3_nt_grouped");
+}
+
 namespace bot {
 namespace {
 // splits: whole multiples of 8 (one per XCD at a time) while a split keeps >= 4096 rows; fewer for short operands
 int tn_splits(int64_t n_rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(8, n_rows / 4096)); }
 }  // namespace
 }  // namespace bot
+
+namespace bot {
+namespace {
+// grouped: as many whole rounds of 8 splits (one per XCD) as keep an XCD's workgroups (splits / 8 x tiles) within its 32 CUs, each
+// split >= 1024 rows
+int tn_grouped_splits(int64_t n_rows, int n_tiles) {
+    const int per_xcd = std::max(1, 32 / n_tiles);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(8 * per_xcd, n_rows / 1024));
+}
+}  // namespace
+}  // namespace bot
+
+extern "C" int64_t bot_gemm_halves3_tn_grouped_workspace_floats(int64_t n_rows, int32_t n_tiles) {
+    return (int64_t)bot::tn_grouped_splits(n_rows, n_tiles) * n_tiles * bot::TT * bot::TT;
+}
+
+extern "C" int bot_gemm_halves3_tn_grouped_f32(int64_t n_rows, const float* scale_x, const float* scale_d, const uint16_t* X, int64_t ldx, int64_t x2_off,
+                                               const uint16_t* D, int64_t ldd, int64_t d2_off, float* out, int32_t n_tiles, const int64_t* tiles,
+                                               float* workspace, int32_t mode, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n_rows > 0 && n_tiles >= 1 && n_tiles <= kMaxTnTiles, -1, "gemm_halves3_tn_grouped: need n > 0 and 1 .. %d tiles (got %lld, %d)", kMaxTnTiles,
+                (long long)n_rows, n_tiles);
+    BOT_REQUIRE(scale_x && scale_d && X && D && out && workspace && tiles, -1, "gemm_halves3_tn_grouped: null pointer");
+    BOT_REQUIRE(aligned(X, 16) && aligned(D, 16) && ldx % 8 == 0 && ldd % 8 == 0 && x2_off % 8 == 0 && d2_off % 8 == 0 && x2_off < ldx && d2_off < ldd &&
+                    n_rows < (1ll << 31) - 4096, -1, "gemm_halves3_tn_grouped: bad alignment or pitches");
+    TnArgs3 a;
+    TnTiles tl;
+    for (int i = 0; i < n_tiles; ++i) {
+        const int64_t* d = tiles + 7 * i;        // x_col0, k_valid, d_col0, p_valid, out_off, ldo, transposed
+        BOT_REQUIRE(d[0] >= 0 && d[0] % 8 == 0 && d[2] >= 0 && d[2] % 8 == 0 && d[1] >= 1 && d[1] <= TT && d[3] >= 1 && d[3] <= TT && d[4] >= 0 &&
+                        d[5] >= (d[6] ? d[1] : d[3]) && d[0] + d[1] + x2_off <= ldx && d[2] + d[3] + d2_off <= ldd, -1,
+                    "gemm_halves3_tn_grouped: tile %d: x_col0=%lld k_valid=%lld d_col0=%lld p_valid=%lld out_off=%lld ldo=%lld", i, (long long)d[0], (long long)d[1],
+                    (long long)d[2], (long long)d[3], (long long)d[4], (long long)d[5]);
+        tl.t[i] = TnTile{(int)d[0], (int)d[2], (int)d[1], (int)d[3], d[4], d[5], d[6] != 0, 0};
+    }
+    a.X = reinterpret_cast<const _Float16*>(X), a.D = reinterpret_cast<const _Float16*>(D), a.part = workspace, a.ldx = ldx, a.ldd = ldd;
+    a.N = (int)n_rows, a.K = a.P = a.KP = a.PP = 0, a.x2_off = (int)x2_off, a.d2_off = (int)d2_off;
+    a.tiles_k = n_tiles, a.tiles_p = 1;
+    int splits = tn_grouped_splits(n_rows, n_tiles);
+    const int rps = (int)(((n_rows + splits - 1) / splits + TBK - 1) / TBK * TBK);
+    splits = (int)((n_rows + rps - 1) / rps);             // no empty split (never more than tn_grouped_splits: the workspace holds them)
+    a.splits = splits, a.rows_per_split = rps;
+    a.mode = mode;
+    BOT_REQUIRE((int64_t)rps * std::max(ldx, ldd) * 2 < (1ll << 31), -1, "gemm_halves3_tn_grouped: a split of %d rows exceeds the 2 GiB a buffer descriptor spans", rps);
+    set_kernel("bot::gemm_halves3_tn_grouped_kernel");
+    hipLaunchKernelGGL(gemm_halves3_tn_grouped_kernel, dim3(((splits + 7) / 8) * 8 * n_tiles), dim3(512), 0, (hipStream_t)stream, a, tl);
+    hipLaunchKernelGGL(tn_reduce_h3_grouped_kernel, dim3((TT * (TT / 4) + 255) / 256, n_tiles), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits,
+                       (int)n_tiles, tl, scale_x, scale_d, out);
+    return hip_status("gemm_halves3_tn_grouped");
+}
 
 extern "C" int64_t bot_gemm_halves3_tn_workspace_floats(int64_t n_rows, int64_t kp, int64_t pp) { return (int64_t)bot::tn_splits(n_rows) * kp * pp; }
 

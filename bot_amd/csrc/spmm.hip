@@ -11,9 +11,12 @@
 // spmm_combine_kernel.  Work is ordered head-major (see common.h).
 //
 // HBM roofline: algorithmic bytes per launch = 4*[2*n*H*D + nnz + (n+1) + (w? nnz*H : 0)].
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 #include <stdlib.h>
+#include <algorithm>
 #include <string.h>
 
 namespace bot {
@@ -40,7 +43,34 @@ struct SpmmArgs {
     int64_t lda, hsa;
     // optional by-product of the fused backward: max|out| into kAbsmaxSlots words (common.h absmax_publish)
     uint32_t* absmax;
+    // spmm_bcast only: the result as fp16 halves [h1 | 2^11 h2] of hscale[0] * out (halves.hip), h1 at hout[r, h hsh + e] and the second
+    // half h2_off columns behind it, zeros in the columns D .. hpiece - 1 of a head's block; nothing is written to `out`
+    __half* hout;
+    int64_t ldh, hsh;
+    int32_t h2_off, hpiece;
+    const float* hscale;
 };
+
+// VEC consecutive entries of a halves operand: h1 at p, 2^11 h2 at p + h2_off (see halves.hip halves_split_kernel<2>)
+template <int VEC>
+__device__ __forceinline__ void store_halves(__half* p, int32_t h2_off, const float (&v)[VEC], float s) {
+    __half a[VEC], b[VEC];
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+        const float z = v[t] * s;
+        a[t] = __float2half_rn(z);
+        b[t] = __float2half_rn((z - __half2float(a[t])) * 2048.0f);
+    }
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(a);
+        *reinterpret_cast<uint2*>(p + h2_off) = *reinterpret_cast<const uint2*>(b);
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<uint32_t*>(p) = *reinterpret_cast<const uint32_t*>(a);
+        *reinterpret_cast<uint32_t*>(p + h2_off) = *reinterpret_cast<const uint32_t*>(b);
+    } else {
+        p[0] = a[0], p[h2_off] = b[0];
+    }
+}
 
 // Backward of u_mul_e_sum in ONE sweep over the out-edges (CSR direction) — each gathered row dx[v,h,:] is used twice:
 //   out[u,h,:]           = sum_k w[wperm[k],h] * x[indices[k],h,:]        (d ft: transposed SpMM)
@@ -609,6 +639,19 @@ __global__ __launch_bounds__(kBlock) void spmm_bcast_kernel(SpmmArgs a) {
                         for (int t = 0; t < VEC; ++t) acc[h][c][t] = fmaf(ww[u][h], v[u][c][t], acc[h][c][t]);
         }
     }
+    if (a.hout && slot < 0) {           // the row's result as fp16 halves (zeros behind the D columns of each head's block)
+        const float s = a.hscale[0];
+#pragma unroll
+        for (int h = 0; h < HB; ++h) {
+            __half* ob = a.hout + (int64_t)row * a.ldh + (int64_t)h * a.hsh;
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) {
+                const int e = (c * LANES + lane) * VEC;
+                if (e < a.hpiece) store_halves<VEC>(ob + e, a.h2_off, acc[h][c], act[c] ? s : 0.f);      // (lanes past D hold a copy of column 0)
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < HB; ++h) {
         float* ob = slot < 0 ? a.out + (int64_t)row * a.ldo + (int64_t)h * a.hso : a.partial + (int64_t)slot * a.ldp + (int64_t)h * a.D;
@@ -616,6 +659,25 @@ __global__ __launch_bounds__(kBlock) void spmm_bcast_kernel(SpmmArgs a) {
         for (int c = 0; c < NCHUNK; ++c)
             if (act[c]) vstore<VEC>(ob + off[c], acc[h][c]);
     }
+}
+
+// halves form of spmm_combine_kernel: hout[row, h hsh + e] = halves of hscale[0] * (partial[first slot] + ... + partial[last slot]), e < D;
+// zeros for D <= e < hpiece
+__global__ __launch_bounds__(kBlock) void spmm_combine_halves_kernel(const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, int32_t H,
+                                                                    int32_t D, const float* partial, int64_t ldp, __half* hout, int64_t ldh,
+                                                                    int64_t hsh, int32_t h2_off, int32_t hpiece, const float* hscale) {
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t hp = (int64_t)H * hpiece;
+    if (gid >= n_long * hp) return;
+    const int64_t i = gid / hp;
+    const int e2 = (int)(gid - i * hp);
+    const int h = e2 / hpiece, d = e2 - h * hpiece;
+    float v[1] = {0.f};
+    if (d < D) {
+        const int e = h * D + d;
+        for (int p = long_ptr[i]; p < long_ptr[i + 1]; ++p) v[0] += partial[(int64_t)p * ldp + e];      // slot order
+    }
+    store_halves<1>(hout + (int64_t)long_rows[i] * ldh + (int64_t)h * hsh + d, h2_off, v, hscale[0]);
 }
 
 template <int VEC, int LANES, int NCHUNK, int HB>
@@ -704,7 +766,7 @@ __global__ __launch_bounds__(kBlock) void spmm_dot_bcast_kernel(SpmmArgs a) {
 
 template <int VEC, int HB, bool DOT>
 static void dispatch_bcast(SpmmArgs& a, hipStream_t st) {
-    const int L = (a.D + VEC - 1) / VEC;
+    const int L = (std::max(a.D, a.hout ? a.hpiece : 0) + VEC - 1) / VEC;       // (the halves form also writes the zero padding of a head's block)
 #define BOT_BCAST(LN, NC)                                                                                                     \
     do {                                                                                                                      \
         const int64_t blocks = (a.n_items * LN + kBlock - 1) / kBlock;                                                        \
@@ -1038,6 +1100,38 @@ int bot_spmm_bcast_f32(const int32_t* indptr, const int32_t* indices, int64_t n_
         hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows,
                            long_ptr, n_long, H, D, partial, (int64_t)H * D, out, ldo, hso, (const float*)nullptr, (int64_t)0, (int64_t)0);
         if (int rc = hip_status("spmm_bcast combine launch")) return rc;
+    }
+    return 0;
+}
+
+int bot_spmm_bcast_halves_f16(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz, const int32_t* items, int64_t n_items,
+                              const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, const float* x, int64_t ldx, const float* w,
+                              const int32_t* wperm, int32_t H, int32_t D, const float* hscale, uint16_t* hout, int64_t ldh, int64_t hsh, int32_t h2_off,
+                              int32_t hpiece, float* partial, bot_stream_t stream) {
+    using namespace bot;
+    (void)indptr;
+    BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_items >= 0 && n_long >= 0 && nnz < INT32_MAX, BOT_E_RANGE, "spmm_bcast_halves: bad size");
+    BOT_REQUIRE(H >= 1 && H <= 4 && D >= 1 && D <= 1024, BOT_E_RANGE, "spmm_bcast_halves: H=%d (1..4) D=%d (1..1024)", H, D);
+    if (n_rows == 0) return 0;
+    BOT_REQUIRE(items && x && hout && hscale && (nnz == 0 || (indices && w)), BOT_E_NULL, "spmm_bcast_halves: NULL pointer");
+    BOT_REQUIRE(n_long == 0 || (long_rows && long_ptr && partial), BOT_E_NULL, "spmm_bcast_halves: long rows need long_rows/long_ptr/partial");
+    BOT_REQUIRE(ldx >= D && hpiece >= D && hpiece % 4 == 0 && (hsh >= hpiece || H == 1) && h2_off % 4 == 0 && hsh % 4 == 0 && ldh % 4 == 0 &&
+                    h2_off >= (int64_t)(H - 1) * hsh + hpiece && ldh >= h2_off + (int64_t)(H - 1) * hsh + hpiece && aligned(hout, 8),
+                BOT_E_RANGE, "spmm_bcast_halves: D=%d hpiece=%d hsh=%lld h2_off=%d ldh=%lld", D, hpiece, (long long)hsh, h2_off, (long long)ldh);
+    hipStream_t st = (hipStream_t)stream;
+    SpmmArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, 0, w, wperm, H, D, 1, nullptr, 0, 0, partial,
+               (int64_t)H * D, nullptr, 0, 0, nullptr, nullptr, 0, 0};
+    a.hout = reinterpret_cast<__half*>(hout), a.ldh = ldh, a.hsh = hsh, a.h2_off = h2_off, a.hpiece = hpiece, a.hscale = hscale;
+    const int vec = pick_vec(D, {ldx}, {x, partial});
+    BOT_REQUIRE(hpiece <= vec * 256, BOT_E_RANGE, "spmm_bcast_halves: hpiece=%d exceeds one launch tile", hpiece);
+    // (the lane layout must cover the padded block: dispatch on hpiece, the kernels mask the loads with D)
+    a.D = D;
+    if (int rc = run_bcast<false>(a, vec, H, st)) return rc;
+    if (n_long > 0) {
+        const int64_t n = n_long * H * hpiece;
+        hipLaunchKernelGGL(spmm_combine_halves_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows, long_ptr, n_long, H, D,
+                           (const float*)partial, (int64_t)H * D, a.hout, ldh, hsh, h2_off, hpiece, hscale);
+        if (int rc = hip_status("spmm_bcast_halves combine launch")) return rc;
     }
     return 0;
 }

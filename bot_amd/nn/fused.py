@@ -34,6 +34,7 @@ SKINNY = os.environ.get("BOT_SKINNY", "1") != "0"   # the small-K products of th
 FORCE = False  # tests set this to run the fused node over the emulated (CPU) backend
 CALLS = 0      # number of fused-layer invocations (tests assert the path was actually taken)
 AGG_CALLS = 0  # ... of which aggregate-before-project
+L0_CALLS = 0   # ... of which on the grouped-halves kernels (_l0_halves_ok)
 
 
 def can_fuse(conv, norm, activation, graph, training, stack_residual) -> bool:
@@ -431,6 +432,55 @@ def _kp(w):
 AGG_FIRST = True  # aggregate-before-project for layers whose input is narrower than one head (Fin <= D, H <= 4)
 
 
+# The aggregate-first layer's dense products on the grouped fp16-halves kernels (csrc/halves3.hip, ABI 16) instead of bot_skinny_gemm_f32 /
+# bot_tn_gemm_f32 / the stock fp32 GEMM: the aggregated slab is written by the SpMM as a halves operand next to the input's halves, one
+# launch computes  rst_h = [x | z_h] [Wres_h | W_h]^T  for all heads, one  d z_h = d rst_h W_h,  one all weight gradients.
+L0_HALVES = os.environ.get("BOT_L0_HALVES", "1") != "0"
+_L0_TABLES = {}
+
+
+def _l0_tables(H, D, Fin, P2, kp, N):
+    """Group / tile lists of the three grouped launches (host-side, cached per shape)."""
+    key = (H, D, Fin, P2, kp, N)
+    if key not in _L0_TABLES:
+        FP = (Fin + 63) // 64 * 64           # piece width of x and of every z_h
+        DP = (D + 63) // 64 * 64             # a head's block of the gradient operand
+        HD = H * D
+        # forward: group h = output columns h D .. h D + D - 1; reduction over x (A columns 0 ..) then z_h (A columns FP (1 + h) ..)
+        fwd = [(h * D, D, 0, h * FP, 2 * FP // 32, h * D) for h in range(H)]
+        # d z_h [N, Fin] = d rst_h [N, D] W_h [D, Fin]: A columns h DP .., B rows h Fin .. (W_h^T), output slab h
+        dz = [(h * Fin, Fin, 0, h * DP, DP // 32, h * N * Fin) for h in range(H)]
+        # weight gradients: x-role = the gradient operand's head blocks, d-role = [x | z_0 .. z_{H-1}]
+        tn = []
+        for h in range(H):
+            for j in range((D + 191) // 192):
+                kv = min(192, D - 192 * j)
+                col = h * D + 192 * j                                # row of d W / column of the merged gradient
+                tn.append((h * DP + 192 * j, kv, FP * (1 + h), Fin, col * Fin, Fin, 0))                 # d W_h = d rst_h^T z_h
+                if kp:
+                    tn.append((h * DP + 192 * j, kv, 0, Fin, HD * Fin + col, P2, 1))                       # d Wres^T [Fin, P2]: written transposed
+                else:
+                    tn.append((h * DP + 192 * j, kv, 0, Fin, HD * Fin + col * Fin, Fin, 0))               # d Wres [P2, Fin]
+        _L0_TABLES[key] = (FP, DP, fwd, dz, tn)
+    return _L0_TABLES[key]
+
+
+def _l0_halves_ok(h, H, D, Fin, has_res, sym, attn_p, graph) -> bool:
+    """The grouped-halves form of the aggregate-first layer: needs the residual branch (its columns are the launch's output), row sums of
+    the edge weights <= 1 / (1 - attn_p) < 4 (the slab shares x's scale: fp16 has two binades of headroom above it) and the hand-written
+    kernels as the halves path."""
+    return (L0_HALVES and (h.is_cuda or FORCE) and has_res and not sym and attn_p <= 0.7 and D <= 256 and Fin <= 256 and H * 2 * ((D + 191) // 192) <= 16
+            and gemm.MODE == "halves" and gemm.NT_KERNEL == "halves3" and gemm.TN_KERNEL == "halves3" and (h.shape[0] >= gemm.MIN_ROWS or gemm.FORCE or FORCE))
+
+
+def _small_mm(a, b, b_is_kn, out):
+    """out = a @ (b if b_is_kn else b^T) for a handful of output columns (the attention columns of the merged projection)."""
+    if a.is_cuda and SKINNY:
+        return _C.skinny_gemm(a, b, b_is_kn=b_is_kn, out=out)
+    out.copy_(a @ (b if b_is_kn else b.t()))
+    return out
+
+
 def use_agg_first(conv) -> bool:
     return AGG_FIRST and conv._in_src_feats <= conv._out_feats and conv._num_heads <= 4 and conv._in_src_feats <= 256
 
@@ -449,7 +499,14 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         ctx.kp = kp                                                     # Wr is [Fin, P2] (see WEIGHT_KP) instead of [P2, Fin]
         # small-K products (K = Fin <= 256) on bot_skinny_gemm_f32: fp32 operands split in registers into bf16 terms, MFMA products
         skinny = SKINNY and h.is_cuda and Fin <= 256 and N >= 4096
-        if skinny:
+        l0h = _l0_halves_ok(h, H, D, Fin, has_res, sym, attn_p, graph) and not ctx.needs_input_grad[0]
+        ctx.l0h = l0h
+        if l0h:
+            # only the attention columns now (el / er feed the aggregation); the residual columns come out of the grouped launch below
+            P2 = Wr.shape[1 if kp else 0]
+            out2 = torch.empty((N, P2), dtype=h.dtype, device=h.device)
+            _small_mm(h, Wr[:, HD:] if kp else Wr[HD:], kp, out2[:, HD:])
+        elif skinny:
             out2 = _C.skinny_gemm(h, Wr, b_is_kn=kp, out=torch.empty((N, Wr.shape[1 if kp else 0]), dtype=h.dtype, device=h.device))
         else:
             out2 = torch.mm(h, Wr) if kp else torch.mm(h, Wr.t())       # [N, P2] = [res | el | er | pad]
@@ -481,6 +538,38 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         a, a_d = _C.gat_attn_fwd(csc, el, er, None, None, None, slope, H, None, ctx.zs, drop=ctx.adrop or (0.0, 0))
         if sym:
             a_d = a_d * w_e
+        if l0h:
+            global L0_CALLS
+            L0_CALLS += 1
+            FP, DP, g_fwd, _, _ = _l0_tables(H, D, Fin, out2.shape[1], kp, N)
+            KA = (1 + H) * FP
+            # left operand [x | z_0 .. z_{H-1}] (first halves, then the second halves KA columns behind), ONE scale: the rows of a_d sum
+            # to <= 1 / (1 - attn_p), so max|z| <= max|x| / (1 - attn_p), inside fp16's range above x's scale (_l0_halves_ok)
+            xscale = _C.halves_scale(h)
+            A = torch.empty((N, 2 * KA), dtype=torch.float16, device=h.device)
+            _C.halves_split_cols(h, xscale, 2, A, KA, 0, FP)
+            _C.spmm_bcast_halves(csc, xsrc, a_d, None, xscale, A, FP, FP, KA, FP)
+            # right operand: row j = output column j = [Wres_j | W_j], one scale
+            Wres = (Wr.t()[:HD] if kp else Wr[:HD]).contiguous()
+            slots = _C.absmax_slots(h.device)
+            _C.absmax_into(Wres, slots)
+            _C.absmax_into(W, slots)
+            wscale = _C.halves_scale_from_slots(slots)
+            B = torch.empty((HD, 6 * FP), dtype=torch.float16, device=h.device)
+            _C.halves_split_cols(Wres, wscale, 1, B, 2 * FP, 0, FP)
+            _C.halves_split_cols(W, wscale, 1, B, 2 * FP, FP, FP)
+            _C.gemm_halves3_nt_grouped(A, B, xscale, wscale, KA, 2 * FP, out2, g_fwd, FP // 32)
+            x = out2[:, :HD]
+            ctx.graph = graph
+            keep = (h, W, Wr, A, ext if ext is not None else h, el, er, a, a_d, xscale)
+            if bn is None:
+                ctx.save_for_backward(*keep)
+                ctx.cfg = (H, D, has_res, has_er, slope, None)
+                return x
+            y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed)
+            ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
+            ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
+            return y
         z = _C.spmm_bcast(csc, xsrc, a_d, None, head_outer=True)        # [H, N, Fin]
         Wh = W.view(H, D, Fin)
         # per-head projection (plain 2-D GEMMs: each has its own tuned kernel selection, see bot_amd/tuning), accumulated in
@@ -519,15 +608,20 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         g = ctx.graph
         dy = dy.contiguous()
         d_bn_w = d_bn_b = None
+        l0h, xscale = ctx.l0h, None
+        saved = ctx.saved_tensors
+        if l0h:                                                          # z: the operand [x | z_0 .. z_{H-1}] as fp16 halves
+            xscale, saved = saved[9], saved[:9] + saved[10:]
         if epi is None:
-            h, W, Wr, z, table, el, er, a, a_d = ctx.saved_tensors
+            h, W, Wr, z, table, el, er, a, a_d = saved
         else:
-            h, W, Wr, z, table, el, er, a, a_d, x, mean, invstd, bn_w, bn_b = ctx.saved_tensors
+            h, W, Wr, z, table, el, er, a, a_d, x, mean, invstd, bn_w, bn_b = saved
             drop_p, seed, bn_training, sync, group, total = epi
         kp = ctx.kp
         N, Fin, HD, P2 = h.shape[0], h.shape[1], H * D, Wr.shape[1 if kp else 0]
         dout2 = torch.empty((N, P2), dtype=h.dtype, device=h.device)
         dx = dout2[:, :HD] if has_res else torch.empty((N, HD), dtype=h.dtype, device=h.device)
+        slots = _C.absmax_slots(dy.device) if l0h and ABSMAX_BYPRODUCT and epi is not None else None
         if epi is None:
             dx.copy_(dy)
         else:
@@ -538,15 +632,26 @@ class _GATHiddenAggFirst(torch.autograd.Function):
                 dist.all_reduce(both, group=group)
                 sg, sgx = both[0].contiguous(), both[1].contiguous()
             _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
-                                sgx if bn_training else None, total, out=dx)
+                                sgx if bn_training else None, total, out=dx, absmax=slots)
         Wh = W.view(H, D, Fin)
         dz = torch.empty((H, N, Fin), dtype=h.dtype, device=h.device)    # gradient of the aggregated slab
-        dW3 = torch.empty((H, D, Fin), dtype=h.dtype, device=h.device) if ctx.needs_input_grad[1] else None
-        if ctx.skinny and D <= 256:     # d z_i = d x_i W_i for the H heads in one launch (A = column slices of d x)
+        dW3 = torch.empty((H, D, Fin), dtype=h.dtype, device=h.device) if ctx.needs_input_grad[1] and not l0h else None
+        Dh = dscale = None
+        if l0h:
+            # the gradient of the layer's output as a LEFT halves operand, each head's D columns in a block of DP (zero padded): it is the
+            # A operand of d z_h = d rst_h W_h and the x-role of every weight gradient
+            FP, DP, _, g_dz, t_tn = _l0_tables(H, D, Fin, P2, kp, N)
+            dscale = _C.halves_scale_from_slots(slots) if slots is not None else _C.halves_scale(dx)
+            Dh = torch.empty((N, 2 * H * DP), dtype=torch.float16, device=h.device)
+            for i in range(H):
+                _C.halves_split_cols(dx[:, i * D:(i + 1) * D], dscale, 2, Dh, H * DP, i * DP, DP)
+            Wt = gemm.split(Wh.transpose(1, 2).reshape(H * Fin, D), 1)           # rows h Fin + f = W_h[:, f]: the right operand of d z_h
+            _C.gemm_halves3_nt_grouped(Dh, Wt.buf, dscale, Wt.scale, H * DP, Wt.piece, dz[0], g_dz, 0)
+        elif ctx.skinny and D <= 256:     # d z_i = d x_i W_i for the H heads in one launch (A = column slices of d x)
             _C.skinny_gemm(dx, Wh, b_is_kn=True, out=dz, batch=H, strides=(D, D * Fin, N * Fin), m=N, n=Fin, k=D)
         if ctx.skinny and dW3 is not None:   # d W_i = d x_i^T z_i, reductions over the N rows: fp32 MFMA, chunked, one launch for the H heads
             _C.tn_gemm(dx, z, out=dW3, batch=H, strides=(D, N * Fin, 0), n=N, kx=D, ky=Fin)
-        for i in range(H):
+        for i in range(H if not l0h else 0):
             dxi = dx[:, i * D:(i + 1) * D]                               # [N, D] column slice (row-strided)
             if not (ctx.skinny and D <= 256):
                 torch.mm(dxi, Wh[i], out=dz[i])
@@ -595,7 +700,25 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         if used < P2:
             dout2[:, used:].zero_()
         dWr = None
-        if ctx.needs_input_grad[2]:
+        if l0h:
+            # every weight gradient from ONE grouped launch over the head blocks: d W_h = d rst_h^T z_h and the residual rows / columns of
+            # the merged gradient d rst^T x (written in Wr's layout); the attention columns (a handful, their own magnitude) apart
+            flat = torch.empty(HD * Fin + P2 * Fin, dtype=h.dtype, device=h.device)
+            _C.gemm_halves3_tn_grouped(Dh, z, dscale, xscale, H * DP, (1 + H) * FP, flat, t_tn)
+            dW = flat[:HD * Fin].view(HD, Fin)
+            dWr = flat[HD * Fin:].view((Fin, P2) if kp else (P2, Fin))
+            tail = dout2[:, HD:]
+            if h.is_cuda and SKINNY:
+                _C.tn_gemm(tail, h, out=dWr[:, HD:] if kp else dWr[HD:], transpose_out=kp)
+            elif kp:
+                dWr[:, HD:] = h.t() @ tail
+            else:
+                dWr[HD:] = tail.t() @ h
+            if not ctx.needs_input_grad[1]:
+                dW = None
+            if not ctx.needs_input_grad[2]:
+                dWr = None
+        elif ctx.needs_input_grad[2]:
             dWr = torch.mm(h.t(), dout2) if kp else torch.mm(dout2.t(), h)
         dh = None
         if need_dh:

@@ -226,7 +226,12 @@ class CapturedTrainStep:
                 body()
         torch.cuda.current_stream(self.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # With a process group alive, RCCL's watchdog THREAD polls its work events at any time; under the default "global" capture mode
+        # that poll is an illegal call during capture and aborts the process (seen once in ~10 suite runs: "operation not permitted when
+        # stream is capturing" raised from ProcessGroupNCCL's watchdog).  "thread_local" checks only the capturing thread's calls.
+        import torch.distributed as dist
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss, self.pred = body()
 
     def __call__(self):

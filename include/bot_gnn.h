@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 15
+#define BOT_ABI_VERSION 16
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -168,6 +168,16 @@ int bot_spmm_bcast_f32(const int32_t* indptr, const int32_t* indices, int64_t n_
                        const float* x, int64_t ldx, const float* w, const int32_t* wperm,
                        int32_t H, int32_t D, float* out, int64_t ldo, int64_t hso,
                        float* partial, bot_stream_t stream);
+/* v16: bot_spmm_bcast_f32 with the result written as a halves GEMM operand instead of fp32 (the aggregated slab's only consumers are the
+ * per-head projection and its weight gradient, csrc/halves3.hip grouped forms): hout[r, h hsh + e] = h1, hout[r, h hsh + e + h2_off] =
+ * 2^11 h2 of hscale[0] * out[r,h,e]  (halves_split's order 2), e < D; zeros for D <= e < hpiece.  hpiece, hsh, h2_off, ldh multiples of 4;
+ * h2_off >= (H - 1) hsh + hpiece.  hscale: a device (s, 1/s) pair that bounds the result (sum_e w <= 1 per row: the scale of x does). */
+int bot_spmm_bcast_halves_f16(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
+                              const int32_t* items, int64_t n_items,
+                              const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long,
+                              const float* x, int64_t ldx, const float* w, const int32_t* wperm,
+                              int32_t H, int32_t D, const float* hscale, uint16_t* hout, int64_t ldh, int64_t hsh, int32_t h2_off,
+                              int32_t hpiece, float* partial, bot_stream_t stream);
 int bot_spmm_dot_bcast_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
                            const int32_t* items, int64_t n_items,
                            const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long,
@@ -498,6 +508,27 @@ int64_t bot_gemm_halves3_tn_workspace_floats(int64_t n_rows, int64_t kp, int64_t
 int bot_gemm_halves3_tn_f32(int64_t n_rows, int64_t k, int64_t p, int64_t kp, int64_t pp, const float* scale_x, const float* scale_d,
                             const uint16_t* X, int64_t ldx, int64_t x2_off, const uint16_t* D, int64_t ldd, int64_t d2_off, float* out,
                             int64_t ldo, float* workspace, int32_t mode, bot_stream_t stream);
+
+/* v16: GROUPED forms of the two products above — the column tiles (NT) / output tiles (TN) of ONE launch are a host-side list, each entry
+ * with its own operand columns and output block.  They carry the aggregate-first GAT layer (fused.py:_GATHiddenAggFirst; models.py:490-492,
+ * :547, :558-560 reordered by linearity): per head h  rst_h = [x | z_h] [Wres_h | W_h]^T  (one reduction over two column ranges of the
+ * left operand), d z_h = d rst_h W_h, and the weight gradients d W_h = d rst_h^T z_h, d Wres = d rst^T x as blocks of one launch.
+ *
+ *   nt_grouped  groups[g] = (b_row0, n_valid, a_col0, a_col1, k_steps, c_off):
+ *     C[r * ldc + c_off + j] = scale_a[1] scale_b[1] * sum_{t < k_steps} sum_{i < 32} A3[r, (t < k_seg ? a_col0 : a_col1) + 32 t + i] . B3[b_row0 + j, 32 t + i]
+ *     for r < m, j < n_valid <= 256 (A3 . B3: the three products a1 b1 + a1 b2 + a2 b1; a1 at the given column, 2^11 a2 a2_off behind it;
+ *     b1 at column 32 t + i of B's row, b2 b2_off behind it).  1 <= n_groups <= 12; a_col0, a_col1 multiples of 8; b_rows = rows of B.
+ *   tn_grouped  tiles[i] = (x_col0, k_valid, d_col0, p_valid, out_off, ldo, transposed):
+ *     out[out_off + k * ldo + p] = scale_x[1] scale_d[1] * sum_n X3[n, x_col0 + k] . D3[n, d_col0 + p]   for k < k_valid <= 192, p < p_valid <= 192
+ *     (transposed != 0: out[out_off + p * ldo + k]); 1 <= n_tiles <= 16; workspace: bot_gemm_halves3_tn_grouped_workspace_floats(n_rows, n_tiles) floats.
+ * `groups` / `tiles` are HOST arrays of 6 resp. 7 int64 per entry (copied into the kernel arguments). */
+int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
+                                    int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t n_groups,
+                                    const int64_t* groups, int32_t k_seg, int32_t mode, bot_stream_t stream);
+int64_t bot_gemm_halves3_tn_grouped_workspace_floats(int64_t n_rows, int32_t n_tiles);
+int bot_gemm_halves3_tn_grouped_f32(int64_t n_rows, const float* scale_x, const float* scale_d, const uint16_t* X, int64_t ldx, int64_t x2_off,
+                                    const uint16_t* D, int64_t ldd, int64_t d2_off, float* out, int32_t n_tiles, const int64_t* tiles,
+                                    float* workspace, int32_t mode, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * v14: the train step's glue (csrc/step.hip) — what src/no-sampling/run.py does around the model with a dozen small tensor ops per

@@ -62,6 +62,21 @@ def spmm_bcast(d, x, w, wperm=None, head_outer=True):
     return res.permute(1, 0, 2).contiguous() if head_outer else res
 
 
+def spmm_bcast_halves(d, x, w, wperm, hscale, hout, col0, hsh, h2_off, hpiece):
+    """include/bot_gnn.h bot_spmm_bcast_halves_f16: the aggregated slab as a halves operand ([h1 | 2^11 h2] of hscale[0] * out)."""
+    res = spmm_bcast(d, x, w, wperm, head_outer=True)           # [H, n, D]
+    D = x.shape[1]
+    for h in range(res.shape[0]):
+        z = res[h].float() * float(hscale[0])
+        h1 = z.half()
+        c = col0 + h * hsh
+        hout[:, c:c + hpiece] = 0
+        hout[:, c + h2_off:c + h2_off + hpiece] = 0
+        hout[:, c:c + D] = h1
+        hout[:, c + h2_off:c + h2_off + D] = ((z - h1.float()) * 2048.0).half()
+    return hout
+
+
 def spmm_dot_bcast(d, x, w, wperm, y, out=None):
     xs = x[:, d.indices.long(), :].permute(1, 0, 2)               # [nnz, H, D]
     ww = w[_perm(wperm, d.nnz)]
@@ -244,8 +259,8 @@ def halves_scale(x):
 
 def halves_split_cols(x, scale, order, buf, piece, col, width):
     n, F = x.shape
-    tmp = halves_split(torch.nn.functional.pad(x.float(), (0, width - F)), scale, order, width)      # [n, 3 * width]
-    for k in range(3):
+    tmp = halves_split(torch.nn.functional.pad(x.float(), (0, width - F)), scale, order, width)      # [n, 3 * width] (order 2: two pieces)
+    for k in range(2 if order == 2 else 3):
         buf[:, k * piece + col:k * piece + col + width] = tmp[:, k * width:(k + 1) * width]
     return buf
 
@@ -339,6 +354,47 @@ def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=
     if out is None:
         return res
     out.copy_(res)
+    return out
+
+
+def _three(a1, a2s, b1, b2s, right, acc=torch.float32):
+    """a1 b1^T-style three-term products of fp16 blocks as the kernels form them: left x right (b2 plain, the 2^-11 on b1) or left x left
+    (both second halves carry 2^11, the 2^-11 on each first half); `acc`: the accumulation type (the GPU suite checks against float64)."""
+    sh = torch.tensor(2.0 ** -11, dtype=torch.float16)
+    f = lambda t: t.to(acc)
+    if right:
+        return f(a1) @ f(b1).t() + f(a1) @ f(b2s).t() + f(a2s) @ f(b1 * sh).t()
+    return f(a1).t() @ f(b1) + f(a1 * sh).t() @ f(b2s) + f(a2s).t() @ f(b1 * sh)
+
+
+def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups, k_seg, mode=0):
+    """include/bot_gnn.h bot_gemm_halves3_nt_grouped_f32 (accumulated in out's dtype)"""
+    acc = out.dtype
+    flat = out.as_strided((out.untyped_storage().nbytes() // out.element_size() - out.storage_offset(),), (1,))
+    ld, m = out.stride(-2), a.shape[0]
+    alpha = scale_a[1] * scale_b[1]
+    for (b_row0, n_valid, a_col0, a_col1, k_steps, c_off) in groups:
+        k0 = 32 * min(k_seg, k_steps)
+        k1 = 32 * k_steps - k0
+        rows = slice(b_row0, b_row0 + n_valid)
+        res = torch.zeros(m, n_valid, dtype=acc)
+        if k0:
+            res += _three(a[:, a_col0:a_col0 + k0], a[:, a_col0 + a2_off:a_col0 + a2_off + k0], b[rows, :k0], b[rows, b2_off:b2_off + k0], True, acc)
+        if k1:
+            res += _three(a[:, a_col1 + k0:a_col1 + k0 + k1], a[:, a_col1 + a2_off + k0:a_col1 + a2_off + k0 + k1], b[rows, k0:k0 + k1],
+                          b[rows, b2_off + k0:b2_off + k0 + k1], True, acc)
+        flat.as_strided((m, n_valid), (ld, 1), c_off).copy_(res * alpha)
+    return out
+
+
+def gemm_halves3_tn_grouped(x, d, scale_x, scale_d, x2_off, d2_off, out, tiles, mode=0):
+    """include/bot_gnn.h bot_gemm_halves3_tn_grouped_f32 (accumulated in out's dtype)"""
+    flat = out.reshape(-1)
+    alpha = scale_x[1] * scale_d[1]
+    for (x_col0, k_valid, d_col0, p_valid, out_off, ldo, transposed) in tiles:
+        res = _three(x[:, x_col0:x_col0 + k_valid], x[:, x_col0 + x2_off:x_col0 + x2_off + k_valid], d[:, d_col0:d_col0 + p_valid],
+                     d[:, d_col0 + d2_off:d_col0 + d2_off + p_valid], False, out.dtype)
+        flat.as_strided((k_valid, p_valid), (1, ldo) if transposed else (ldo, 1), out_off).copy_(res * alpha)
     return out
 
 
@@ -462,7 +518,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["gemm_halves3_tn", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["gemm_halves3_tn", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -461,9 +461,24 @@ def check_train_step_golden(golden, device):
 
 
 # ---------------------------------------------------------------------------------------------- aggregate-before-project
-def check_agg_first_against_oracle(golden, device):
+def check_agg_first_against_oracle(golden, device, l0_halves=False):
     """A stack whose first layer is narrower than one head (9 -> 3 x 16, like 168 -> 3 x 250 at config 2) takes the
-    aggregate-before-project node; logits and every gradient must match the oracle's project-first definition."""
+    aggregate-before-project node; logits and every gradient must match the oracle's project-first definition.
+    l0_halves: the input is DATA (no gradient wanted) and the projections run on the fp16 halves: the node's dense products go to the
+    grouped halves kernels (fused._l0_halves_ok; v16 bot_spmm_bcast_halves_f16, bot_gemm_halves3_nt_grouped_f32, _tn_grouped_f32)."""
+    from bot_amd import gemm
+    from bot_amd.nn import fused
+    if l0_halves:
+        force = gemm.FORCE
+        gemm.FORCE = True
+        try:
+            return _check_agg_first(golden, device, True)
+        finally:
+            gemm.FORCE = force
+    return _check_agg_first(golden, device, False)
+
+
+def _check_agg_first(golden, device, l0_halves):
     from bot_amd.nn import fused
     s, d, n = golden.graph("g300")
     g = bot_amd.Graph(s, d, n, chunk=8).to(device)
@@ -482,10 +497,11 @@ def check_agg_first_against_oracle(golden, device):
         names = [k for k, v in p.items() if v.requires_grad]
         ref_grads = torch.autograd.grad((ref * gout).sum(), [p[k] for k in names])
         model = model.to(device)
-        a0 = fused.AGG_CALLS
-        x = leaf(feat, device)
+        a0, l0 = fused.AGG_CALLS, fused.L0_CALLS
+        x = feat.to(device) if l0_halves else leaf(feat, device)
         logits = model(g, x)
         assert fused.AGG_CALLS == a0 + 1  # layer 0 only (9 <= 16); layers 1, 2 have 48 inputs
+        assert fused.L0_CALLS == l0 + (1 if l0_halves and linear else 0)      # (the grouped launch writes the residual columns: needs them)
         (logits * gout.to(device)).sum().backward()
         fwd_close(logits, ref.detach().numpy())
         got = dict(model.named_parameters())

@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 15
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 16
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
@@ -492,8 +492,9 @@ def test_midsize_edge_gat_stack_against_oracle():
             assert eh <= max(PC.GRAD_RTOL, 2 * eo), (kind, k, eh, eo)
 
 
-def test_agg_first_against_oracle(golden):
-    PC.check_agg_first_against_oracle(golden, DEV)
+@pytest.mark.parametrize("l0_halves", [False, True])
+def test_agg_first_against_oracle(golden, l0_halves):
+    PC.check_agg_first_against_oracle(golden, DEV, l0_halves=l0_halves)
 
 
 def test_bcast_kernels_direct(golden):
@@ -1592,6 +1593,94 @@ def test_gemm_halves3_nt_kernel():
         assert torch.equal(got, again)
     with pytest.raises(_C.BotKernelError):
         _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, 40)       # k not a multiple of 32
+
+
+def test_grouped_halves_kernels(golden):
+    """v16, the aggregate-first layer's dense products (csrc/halves3.hip grouped forms, csrc/spmm.hip halves epilogue) each against the
+    definition in include/bot_gnn.h evaluated in fp64 from the SAME fp16 operands (tests/_oracle_backend.py's restatement, accumulating in float64):
+    (1) bot_spmm_bcast_halves_f16 == halves_split(order 2) of bot_spmm_bcast_f32's slab, bit for bit, zero padding included, long rows too;
+    (2) nt_grouped in the forward arrangement ([x | z_h] [Wres_h | W_h]^T, 250-column groups on an [N, 768] output, two A column ranges)
+        and the d z arrangement (per-head A columns, per-head B rows, per-head output slabs);
+    (3) tn_grouped: per-head and merged weight gradients, plain and transposed blocks, ragged k_valid / p_valid, many splits."""
+    from tests import _oracle_backend as OB
+    from bot_amd import gemm
+    from bot_amd.nn import fused
+    gen = torch.Generator(device=DEV).manual_seed(23)
+    # --- (1)
+    s_, d_, n = golden.graph("g300")
+    for chunk in (8, 4096):
+        g = bot_amd.Graph(s_, d_, n, chunk=chunk).to(DEV)
+        H, Fin, FP = 3, 22, 64
+        x = torch.randn(n, Fin, device=DEV, generator=gen)
+        w = torch.rand(g.number_of_edges(), H, device=DEV, generator=gen)
+        scale = _C.halves_scale(x * 40)
+        KA = (1 + H) * FP
+        A = torch.full((n, 2 * KA), 7.0, dtype=torch.float16, device=DEV)
+        _C.spmm_bcast_halves(g.csc, x, w, None, scale, A, FP, FP, KA, FP)
+        z = _C.spmm_bcast(g.csc, x, w, None, head_outer=True)
+        for h in range(H):
+            ref = _C.halves_split(z[h], scale, 2, FP)
+            assert torch.equal(A[:, FP * (1 + h):FP * (2 + h)], ref[:, :FP]) and torch.equal(A[:, KA + FP * (1 + h):KA + FP * (2 + h)], ref[:, FP:])
+        assert bool((A[:, :FP] == 7.0).all()) and bool((A[:, KA:KA + FP] == 7.0).all())       # x's columns are not the SpMM's
+    # --- (2) + (3) at a shape with every raggedness of config 2: H = 3, D = 250, Fin = 168, N not a multiple of anything
+    for (N, H, D, Fin, kp) in ((20011, 3, 250, 168, True), (5000, 2, 70, 40, False)):
+        P2 = (H * D + 2 * H + 127) // 128 * 128
+        FP, DP, g_fwd, g_dz, t_tn = fused._l0_tables(H, D, Fin, P2, kp, N)
+        HD, KA = H * D, (1 + H) * FP
+        A = (torch.randn(N, 2 * KA, device=DEV, generator=gen) * 50).half()
+        A[:, KA:] *= 0.01
+        B = torch.randn(HD, 6 * FP, device=DEV, generator=gen) * 30
+        B[:, 2 * FP:] /= 2048                                  # a right operand's second half is a rounding remainder (the product drops a2 b2)
+        B = B.half()
+        sa, sb = torch.tensor([4.0, 0.25], device=DEV), torch.tensor([8.0, 0.125], device=DEV)
+        out = torch.full((N, P2), 3.0, device=DEV)
+        _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, out, g_fwd, FP // 32)
+        assert bool((out[:, HD:] == 3.0).all()), "wrote outside the groups' columns"
+        ref = torch.zeros(N, P2, dtype=torch.float64)
+        OB.gemm_halves3_nt_grouped(A.cpu(), B.cpu(), sa.cpu(), sb.cpu(), KA, 2 * FP, ref, g_fwd, FP // 32)
+        e = float((out[:, :HD].cpu() - ref[:, :HD]).abs().max() / ref[:, :HD].abs().max())
+        print(f"nt_grouped forward N={N} H={H} D={D} Fin={Fin}: vs restatement {e:.2e}")
+        assert e < 2e-6
+        # fp64 from the same halves, head 1
+        a64 = lambda c0, k: A[:, c0:c0 + k].double() + A[:, KA + c0:KA + c0 + k].double() / 2048
+        b64 = lambda r, c0, k: B[r, c0:c0 + k].double() + B[r, 2 * FP + c0:2 * FP + c0 + k].double()
+        rows = slice(D, 2 * D)
+        r64 = (a64(0, FP) @ b64(rows, 0, FP).t() + a64(2 * FP, FP) @ b64(rows, FP, FP).t()) * (0.25 * 0.125)
+        assert float((out[:, D:2 * D].double() - r64).abs().max() / r64.abs().max()) < 3e-6       # (the dropped a2 b2 term: 2^-22)
+        again = torch.empty_like(out)
+        _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, again, g_fwd, FP // 32)
+        assert torch.equal(again[:, :HD], out[:, :HD])
+        # d z
+        Dh = (torch.randn(N, 2 * H * DP, device=DEV, generator=gen) * 20).half()
+        Wt = torch.randn(H * Fin, 3 * DP, device=DEV, generator=gen) * 10
+        Wt[:, DP:] /= 2048
+        Wt = Wt.half()
+        dz = torch.full((H, N, Fin), 5.0, device=DEV)
+        _C.gemm_halves3_nt_grouped(Dh, Wt, sa, sb, H * DP, DP, dz[0], g_dz, 0)
+        ref = torch.zeros(H, N, Fin, dtype=torch.float64)
+        OB.gemm_halves3_nt_grouped(Dh.cpu(), Wt.cpu(), sa.cpu(), sb.cpu(), H * DP, DP, ref[0], g_dz, 0)
+        e = float((dz.cpu() - ref).abs().max() / ref.abs().max())
+        print(f"nt_grouped d z: vs restatement {e:.2e}")
+        assert e < 2e-6
+        # weight gradients
+        flat = torch.full((HD * Fin + P2 * Fin,), 9.0, device=DEV)
+        _C.gemm_halves3_tn_grouped(Dh, A, sa, sb, H * DP, KA, flat, t_tn)
+        ref = torch.full((HD * Fin + P2 * Fin,), 9.0, dtype=torch.float64)
+        OB.gemm_halves3_tn_grouped(Dh.cpu(), A.cpu(), sa.cpu(), sb.cpu(), H * DP, KA, ref, t_tn)
+        dW, dWr = flat[:HD * Fin], flat[HD * Fin:].view((Fin, P2) if kp else (P2, Fin))
+        rW, rWr = ref[:HD * Fin], ref[HD * Fin:].view((Fin, P2) if kp else (P2, Fin))
+        e1 = float((dW.cpu() - rW).abs().max() / rW.abs().max())
+        res = (dWr[:, :HD] if kp else dWr[:HD]).cpu(), (rWr[:, :HD] if kp else rWr[:HD])
+        e2 = float((res[0] - res[1]).abs().max() / res[1].abs().max())
+        print(f"tn_grouped: d W {e1:.2e}  d Wres {e2:.2e} vs restatement")
+        assert e1 < 3e-6 and e2 < 3e-6
+        tail = (dWr[:, HD:] if kp else dWr[HD:])
+        assert bool((tail == 9.0).all()), "wrote outside the tiles' blocks"
+        flat2 = torch.empty_like(flat)
+        _C.gemm_halves3_tn_grouped(Dh, A, sa, sb, H * DP, KA, flat2, t_tn)
+        assert torch.equal(flat2[:HD * Fin], dW)
+    with pytest.raises(_C.BotKernelError):
+        _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, out, [(0, 300, 0, 0, 1, 0)], 0)        # a group wider than a tile
 
 
 def test_step_glue_kernels():

@@ -112,10 +112,11 @@ def test_train_step_golden(golden, cpu_backend, monkeypatch):
     assert fused.CALLS > c0
 
 
-def test_agg_first_against_oracle(golden, cpu_backend, monkeypatch):
+@pytest.mark.parametrize("l0_halves", [False, True])
+def test_agg_first_against_oracle(golden, cpu_backend, monkeypatch, l0_halves):
     from bot_amd.nn import fused
     monkeypatch.setattr(fused, "FORCE", True)
-    PC.check_agg_first_against_oracle(golden, "cpu")
+    PC.check_agg_first_against_oracle(golden, "cpu", l0_halves=l0_halves)
 
 
 def test_blocked_plan_streams_cover_every_edge_once():
