@@ -85,6 +85,8 @@ _SIGS = {
                                                        c_int32, c_int32, _P]),
     "bot_gemm_halves3_tn_grouped_workspace_floats": (c_int64, [c_int64, c_int32]),
     "bot_gemm_halves3_tn_grouped_f32": (ctypes.c_int, [c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int32, _P, _P, c_int32, _P]),
+    "bot_tn_narrow_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
+    "bot_tn_narrow_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int32, _P, _P]),
     "bot_label_split_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, _P, c_float, c_uint64, _P, c_int32, _P, _P, _P, _P, _P]),
     "bot_build_input_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_int32, _P, c_float, c_uint64, _P, _P, c_int64, _P]),
     "bot_node_loss_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P, c_int32, c_float, _P, c_int64, _P, c_int64, _P]),
@@ -945,6 +947,21 @@ def tn_gemm(x, y, *, out=None, batch=1, strides=(0, 0, 0), n=None, kx=None, ky=N
         x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), n, kx, ky, out.data_ptr(), _ld(out), int(transpose_out), batch, sx, sy, so,
         ws.data_ptr(),
         _stream())), "tn_gemm")
+    return out
+
+
+def tn_narrow(x, y, out, transpose_out=False):
+    """out[kx, ky] = x[n, kx]^T y[n, ky] for a handful of x columns (kx <= 32, ky <= 256), transpose_out: out[ky, kx] (include/bot_gnn.h
+    bot_tn_narrow_f32: fp32 FMAs, deterministic).  x, y, out: fp32 row-major views with unit column stride."""
+    _dev(x, y, out)
+    _f32(x, "x"), _f32(y, "y"), _f32(out, "out")
+    n, kx, ky = x.shape[0], x.shape[1], y.shape[1]
+    assert y.shape[0] == n and out.shape == ((ky, kx) if transpose_out else (kx, ky))
+    if x.stride(1) != 1 or y.stride(1) != 1 or (out.stride(1) != 1 and out.shape[1] != 1):
+        raise BotKernelError("tn_narrow: operands must have unit column stride")
+    ws = torch.empty(int(_lib.bot_tn_narrow_workspace_floats(n, kx, ky)), dtype=torch.float32, device=x.device)
+    _check(_timed("tn_narrow", (n, kx, ky), lambda: _lib.bot_tn_narrow_f32(
+        x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), n, kx, ky, out.data_ptr(), _ld(out), int(transpose_out), ws.data_ptr(), _stream())), "tn_narrow")
     return out
 
 

@@ -164,9 +164,116 @@ __global__ __launch_bounds__(kBlock) void tn_reduce_kernel(const float* part, in
     out[z * so + (transposed ? (int64_t)c * ldo + r : (int64_t)r * ldo + c)] = s;
 }
 
+// bot_tn_narrow_f32: the same product when X has only a handful of columns (kx <= 32: the attention columns d el / d er of the merged
+// gradient against the layer input, ky <= 256): a memory-bound reduction.  One thread per column of Y, X's row is a wave-uniform
+// (scalar) load, kx accumulators per thread; a workgroup takes a contiguous row range, the per-workgroup partials are added in
+// workgroup order by the second kernel (deterministic).  Plain fp32 FMAs: exact products, fp32 accumulation.
+constexpr int kNarrowMaxX = 32, kNarrowRows = 256;
+
+// KX4: kx rounded up to a multiple of 4 (compile time: the accumulators are registers).  X's rows of the workgroup's range are staged in
+// LDS once ([rows][KX4], zero padded; every thread then reads the same float4: a broadcast), Y is read eight rows at a time.
+template <int KX4>
+__global__ __launch_bounds__(256) void tn_narrow_kernel(const float* X, int64_t ldx, const float* Y, int64_t ldy, int64_t n, int kx, int ky,
+                                                        float* part) {
+    __shared__ float xs[kNarrowRows * KX4];
+    const int f = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * kNarrowRows;
+    const int rows = (int)(r0 + kNarrowRows < n ? kNarrowRows : n - r0);
+    for (int i = f; i < kNarrowRows * KX4; i += 256) {
+        const int r = i / KX4, j = i - r * KX4;
+        xs[i] = (r < rows && j < kx) ? X[(r0 + r) * ldx + j] : 0.f;
+    }
+    __syncthreads();
+    if (f >= ky) return;
+    float acc[KX4];
+#pragma unroll
+    for (int j = 0; j < KX4; ++j) acc[j] = 0.f;
+    const float* yp = Y + r0 * ldy + f;
+    constexpr int U = 8;
+    int r = 0;
+    for (; r + U <= rows; r += U) {
+        float y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) y[u] = yp[(int64_t)(r + u) * ldy];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < KX4; j += 4) {
+                const float4 x4 = *reinterpret_cast<const float4*>(&xs[(r + u) * KX4 + j]);
+                acc[j] = fmaf(x4.x, y[u], acc[j]), acc[j + 1] = fmaf(x4.y, y[u], acc[j + 1]);
+                acc[j + 2] = fmaf(x4.z, y[u], acc[j + 2]), acc[j + 3] = fmaf(x4.w, y[u], acc[j + 3]);
+            }
+    }
+    for (; r < rows; ++r) {
+        const float y = yp[(int64_t)r * ldy];
+#pragma unroll
+        for (int j = 0; j < KX4; ++j) acc[j] = fmaf(xs[r * KX4 + j], y, acc[j]);
+    }
+    float* o = part + ((int64_t)blockIdx.x * kx) * ky + f;
+#pragma unroll
+    for (int j = 0; j < KX4; ++j)
+        if (j < kx) o[(int64_t)j * ky] = acc[j];
+}
+
+// out[j, f] (transposed: out[f, j]) = sum_b part[b][j][f], in workgroup order: 32 outputs per workgroup, eight threads per output each
+// adding a contiguous eighth of the partials, the eight sums added in order by one of them
+__global__ __launch_bounds__(256) void tn_narrow_reduce_kernel(const float* part, int blocks, int kx, int ky, float* out, int64_t ldo, int transpose_out) {
+    __shared__ float sums[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
+    const int per = (blocks + 7) / 8, b0 = sl * per, b1 = b0 + per < blocks ? b0 + per : blocks;
+    float s = 0.f;
+    if (i < kx * ky) {
+        const float* src = part + i;
+        const int64_t stride = (int64_t)kx * ky;
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {           // four loads in flight, added in order
+            const float v0 = src[b * stride], v1 = src[(b + 1) * stride], v2 = src[(b + 2) * stride], v3 = src[(b + 3) * stride];
+            s += v0, s += v1, s += v2, s += v3;
+        }
+        for (; b < b1; ++b) s += src[b * stride];
+    }
+    sums[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < kx * ky) {
+        float t = sums[0][o];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sums[k][o];
+        const int j = i / ky, f = i - j * ky;
+        if (transpose_out) out[(int64_t)f * ldo + j] = t;
+        else out[(int64_t)j * ldo + f] = t;
+    }
+}
+
 }  // namespace bot
 
 extern "C" {
+
+int64_t bot_tn_narrow_workspace_floats(int64_t n, int32_t kx, int32_t ky) {
+    return ((n + bot::kNarrowRows - 1) / bot::kNarrowRows) * (int64_t)kx * ky;
+}
+
+int bot_tn_narrow_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int64_t n, int32_t kx, int32_t ky, float* out, int64_t ldo,
+                      int32_t transpose_out, float* workspace, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 1 && kx >= 1 && kx <= kNarrowMaxX && ky >= 1 && ky <= 256, BOT_E_RANGE, "tn_narrow: n=%lld kx=%d (1..%d) ky=%d (1..256)", (long long)n, kx,
+                kNarrowMaxX, ky);
+    BOT_REQUIRE(ldx >= kx && ldy >= ky && ldo >= (transpose_out ? kx : ky), BOT_E_RANGE, "tn_narrow: ldx=%lld ldy=%lld ldo=%lld", (long long)ldx, (long long)ldy,
+                (long long)ldo);
+    BOT_REQUIRE(X && Y && out && workspace, BOT_E_NULL, "tn_narrow: NULL pointer");
+    const int blocks = (int)((n + kNarrowRows - 1) / kNarrowRows);
+    hipStream_t st = (hipStream_t)stream;
+    set_kernel("bot::tn_narrow_kernel<%d>", (kx + 3) / 4 * 4);
+#define BOT_NARROW(K4) \
+    case K4: hipLaunchKernelGGL(tn_narrow_kernel<K4>, dim3(blocks), dim3(256), 0, st, X, ldx, Y, ldy, n, (int)kx, (int)ky, workspace); break;
+    switch ((kx + 3) / 4 * 4) {
+        BOT_NARROW(4) BOT_NARROW(8) BOT_NARROW(12) BOT_NARROW(16) BOT_NARROW(20) BOT_NARROW(24) BOT_NARROW(28) BOT_NARROW(32)
+    }
+#undef BOT_NARROW
+    hipLaunchKernelGGL(tn_narrow_reduce_kernel, dim3((kx * ky + 31) / 32), dim3(256), 0, st, (const float*)workspace, blocks, (int)kx, (int)ky, out, ldo,
+                       (int)transpose_out);
+    return hip_status("tn_narrow");
+}
 
 static void tn_shape(int64_t n, int32_t kx, int32_t ky, int32_t batch, int64_t* kxp, int64_t* kyp, int64_t* chunks) {
     using namespace bot;

@@ -708,7 +708,9 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             dW = flat[:HD * Fin].view(HD, Fin)
             dWr = flat[HD * Fin:].view((Fin, P2) if kp else (P2, Fin))
             tail = dout2[:, HD:]
-            if h.is_cuda and SKINNY:
+            if h.is_cuda and tail.shape[1] <= 32:
+                _C.tn_narrow(tail, h, dWr[:, HD:] if kp else dWr[HD:], transpose_out=kp)
+            elif h.is_cuda:
                 _C.tn_gemm(tail, h, out=dWr[:, HD:] if kp else dWr[HD:], transpose_out=kp)
             elif kp:
                 dWr[:, HD:] = h.t() @ tail

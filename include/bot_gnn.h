@@ -587,6 +587,12 @@ int bot_skinny_gemm_f32(const float* A, int64_t lda, const float* B, int64_t ldb
  * staged through LDS, transpose_out: out[ky, kx] instead (put the wider operand first: blocks are 256 of X by 192 of Y), per-chunk
  * partials in `workspace` (bot_tn_gemm_workspace_floats) added in chunk order: deterministic.  batch > 1: element strides.
  * ------------------------------------------------------------------------------------------- */
+/* v16: the same product for an X of a handful of columns (kx <= 32, ky <= 256: the attention columns of the merged gradient against the
+ * layer input): plain fp32 FMAs, one thread per column of Y, per-workgroup partials added in workgroup order.
+ * workspace: bot_tn_narrow_workspace_floats(n, kx, ky) floats. */
+int64_t bot_tn_narrow_workspace_floats(int64_t n, int32_t kx, int32_t ky);
+int bot_tn_narrow_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int64_t n, int32_t kx, int32_t ky, float* out, int64_t ldo,
+                      int32_t transpose_out, float* workspace, bot_stream_t stream);
 int64_t bot_tn_gemm_workspace_floats(int64_t n, int32_t kx, int32_t ky, int32_t batch);
 int bot_tn_gemm_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int64_t n, int32_t kx, int32_t ky, float* out, int64_t ldo,
                     int32_t transpose_out, int32_t batch, int64_t stride_x, int64_t stride_y, int64_t stride_out, float* workspace,

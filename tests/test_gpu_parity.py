@@ -1681,6 +1681,20 @@ def test_grouped_halves_kernels(golden):
         assert torch.equal(flat2[:HD * Fin], dW)
     with pytest.raises(_C.BotKernelError):
         _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, out, [(0, 300, 0, 0, 1, 0)], 0)        # a group wider than a tile
+    # --- bot_tn_narrow_f32: the attention columns of the merged gradient (a column slice of the gradient buffer) against the input
+    for (N, kx, ky, tr) in ((20011, 18, 168, True), (777, 1, 5, False), (5000, 32, 256, False)):
+        buf = torch.randn(N, kx + 7, device=DEV, generator=gen)
+        y = torch.randn(N, ky, device=DEV, generator=gen)
+        dst = torch.full((ky + 2, kx + 3) if tr else (kx + 2, ky + 3), 4.0, device=DEV)
+        view = dst[:ky, 3:] if tr else dst[:kx, :ky]
+        _C.tn_narrow(buf[:, 7:], y, view, transpose_out=tr)
+        ref = buf[:, 7:].double().t() @ y.double()
+        e = float((view.double() - (ref.t() if tr else ref)).abs().max() / ref.abs().max())
+        print(f"tn_narrow n={N} kx={kx} ky={ky}: err {e:.2e}")
+        assert e < 2e-6 and int((dst == 4.0).sum()) == dst.numel() - kx * ky
+        again = torch.empty_like(view)
+        _C.tn_narrow(buf[:, 7:], y, again, transpose_out=tr)
+        assert torch.equal(again, view)
 
 
 def test_step_glue_kernels():
