@@ -74,6 +74,7 @@ _SIGS = {
     "bot_halves_scale_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P]),
     "bot_halves_split_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int32, _P, c_int64, c_int32, _P]),
     "bot_halves_split_cols_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int32, _P, c_int64, c_int32, c_int32, _P]),
+    "bot_halves_split_heads_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_int32, _P, _P, c_int64, c_int32, c_int32, _P]),
     "bot_gemm_halves_f32": (ctypes.c_int, [c_int32, c_int32, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, c_int64, _P, c_int64,
                                            c_int32, c_int64, c_int64, c_int64, c_float, _P, c_int64, c_int32, c_int32, _P]),
     "bot_gemm_halves3_nt_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64,
@@ -692,6 +693,20 @@ def halves_split_cols(x, scale, order, buf, piece, col, width):
     _check(_lib.bot_halves_split_cols_f16(x.data_ptr(), x.stride(0), n, F, _ptr(scale), order, buf.data_ptr() + 2 * col, buf.stride(0), piece,
                                           width, _stream()), "halves_split_cols")
     return buf
+
+
+def halves_split_heads(x, scale, H, D, DP, out=None):
+    """x [n, H * D] (row-strided view allowed) -> the LEFT operand [n, 2 * H * DP] = [h1 | 2^11 h2] with every head's D columns in a block of
+    DP (zero padded) — bot_halves_split_heads_f16."""
+    _dev(x, scale)
+    _f32(x, "x")
+    n = x.shape[0]
+    assert x.shape[1] == H * D and x.stride(1) == 1
+    if out is None:
+        out = torch.empty((n, 2 * H * DP), dtype=torch.float16, device=x.device)
+    _check(_lib.bot_halves_split_heads_f16(x.data_ptr(), x.stride(0), n, H, D, _ptr(scale), out.data_ptr(), out.stride(0), H * DP, DP, _stream()),
+           "halves_split_heads")
+    return out
 
 
 _GEMM_WS = {}

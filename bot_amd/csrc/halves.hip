@@ -124,6 +124,35 @@ __global__ __launch_bounds__(128) void halves_split_kernel(const float* x, int64
     }
 }
 
+// x [n, H * D] -> a LEFT operand without the duplicate piece whose head blocks are DP >= D columns wide (zeros behind a head's D columns):
+// out[r, h DP + j] = h1, out[r, h2_off + h DP + j] = 2^11 h2 of scale[0] * x[r, h D + j].  One pass over the H heads (instead of H calls of
+// halves_split_cols on column slices): the gradient operand of the aggregate-first GAT layer (fused.py:_GATHiddenAggFirst.backward).
+__global__ __launch_bounds__(128) void halves_split_heads_kernel(const float* x, int64_t ldx, int32_t H, int32_t D, const float* scale, __half* out,
+                                                                 int64_t ldo, int32_t h2_off, int32_t DP, bool wide) {
+    const int64_t r = blockIdx.x;
+    const int c = (blockIdx.y * 128 + threadIdx.x) * 2;          // destination column pair
+    if (c >= H * DP) return;
+    const int h = c / DP, j = c - h * DP;
+    const float s = scale ? scale[0] : 1.f;
+    float v0 = 0.f, v1 = 0.f;
+    const float* xr = x + r * ldx + (int64_t)h * D + j;
+    if (j + 1 < D) {
+        if (wide) {
+            const float2 v = *reinterpret_cast<const float2*>(xr);
+            v0 = v.x * s, v1 = v.y * s;
+        } else {
+            v0 = xr[0] * s, v1 = xr[1] * s;
+        }
+    } else if (j < D) {
+        v0 = xr[0] * s;
+    }
+    const __half a0 = __float2half_rn(v0), a1 = __float2half_rn(v1);
+    const float r0 = v0 - __half2float(a0), r1 = v1 - __half2float(a1);        // exact in fp32
+    __half* o = out + r * ldo + c;
+    *reinterpret_cast<__half2*>(o) = __halves2half2(a0, a1);
+    *reinterpret_cast<__half2*>(o + h2_off) = __halves2half2(__float2half_rn(r0 * kHalvesShift), __float2half_rn(r1 * kHalvesShift));
+}
+
 void launch_halves_scale(const float* part, int n, float* scale, hipStream_t st) {
     hipLaunchKernelGGL(halves_scale_kernel, dim3(1), dim3(kWave), 0, st, part, n, scale);
 }
@@ -242,6 +271,21 @@ int bot_halves_tn_combine_f32(const float* a, const float* b, int32_t chunks, in
 
 static int halves_split_impl(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
                              int64_t ldo, int32_t piece, int32_t width, bot_stream_t stream);
+
+int bot_halves_split_heads_f16(const float* x, int64_t ldx, int64_t n, int32_t H, int32_t D, const float* scale, uint16_t* out, int64_t ldo,
+                               int32_t h2_off, int32_t DP, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 0 && H >= 1 && D >= 1 && DP >= D && DP % 2 == 0 && h2_off >= H * DP && h2_off % 2 == 0 && ldo >= h2_off + (int64_t)H * DP && ldo % 2 == 0 &&
+                    ldx >= (int64_t)H * D, BOT_E_RANGE, "halves_split_heads: n=%lld H=%d D=%d DP=%d h2_off=%d ldo=%lld ldx=%lld", (long long)n, H, D, DP, h2_off,
+                (long long)ldo, (long long)ldx);
+    BOT_REQUIRE(aligned(x, 4) && aligned(out, 4), BOT_E_ALIGN, "halves_split_heads: x and out must be 4-byte aligned");
+    BOT_REQUIRE((x && out) || n == 0, BOT_E_NULL, "halves_split_heads: NULL pointer");
+    if (n == 0) return 0;
+    const bool wide = ldx % 2 == 0 && D % 2 == 0 && aligned(x, 8);
+    hipLaunchKernelGGL(halves_split_heads_kernel, dim3((unsigned)n, (unsigned)((H * DP / 2 + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x, ldx, H, D, scale,
+                       (__half*)out, ldo, h2_off, DP, wide);
+    return hip_status("halves_split_heads launch");
+}
 
 int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
                          int64_t ldo, int32_t piece, bot_stream_t stream) {

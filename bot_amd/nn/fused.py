@@ -642,9 +642,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             # A operand of d z_h = d rst_h W_h and the x-role of every weight gradient
             FP, DP, _, g_dz, t_tn = _l0_tables(H, D, Fin, P2, kp, N)
             dscale = _C.halves_scale_from_slots(slots) if slots is not None else _C.halves_scale(dx)
-            Dh = torch.empty((N, 2 * H * DP), dtype=torch.float16, device=h.device)
-            for i in range(H):
-                _C.halves_split_cols(dx[:, i * D:(i + 1) * D], dscale, 2, Dh, H * DP, i * DP, DP)
+            Dh = _C.halves_split_heads(dx, dscale, H, D, DP)
             Wt = gemm.split(Wh.transpose(1, 2).reshape(H * Fin, D), 1)           # rows h Fin + f = W_h[:, f]: the right operand of d z_h
             _C.gemm_halves3_nt_grouped(Dh, Wt.buf, dscale, Wt.scale, H * DP, Wt.piece, dz[0], g_dz, 0)
         elif ctx.skinny and D <= 256:     # d z_i = d x_i W_i for the H heads in one launch (A = column slices of d x)

@@ -476,6 +476,11 @@ int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, cons
  * under ONE scale, without first copying them into one buffer. */
 int bot_halves_split_cols_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,
                               int64_t ldo, int32_t piece, int32_t width, bot_stream_t stream);
+/* v16: x [n, H * D] as a LEFT operand without the duplicate piece whose head blocks are DP >= D columns wide: out[r, h DP + j] = h1,
+ * out[r, h2_off + h DP + j] = 2^11 h2 of scale[0] * x[r, h D + j], zeros for D <= j < DP — H calls of bot_halves_split_cols_f16(order 2) on
+ * column slices in one pass (the gradient operand of the aggregate-first GAT layer: every head's block starts on a 128-byte boundary). */
+int bot_halves_split_heads_f16(const float* x, int64_t ldx, int64_t n, int32_t H, int32_t D, const float* scale, uint16_t* out, int64_t ldo,
+                               int32_t h2_off, int32_t DP, bot_stream_t stream);
 /* The weight gradient x^T d of two LEFT-layout operands, formed by the caller from row chunks (batched gemm_halves calls): a [chunks][K][2 PP]
  * = x1^T [d1 | 2^11 d2] and b [chunks][K][PP] = (2^11 x2)^T d1 per chunk, contiguous, plus optional remainder chunks rem_a [K][2 PP] / rem_b [K][PP]:
  *   out[k, p] = sum_c a[c][k][p] + (sum_c a[c][k][PP + p] + sum_c b[c][k][p]) * 2^-11      (chunk order, p < P <= PP)

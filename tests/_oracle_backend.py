@@ -265,6 +265,14 @@ def halves_split_cols(x, scale, order, buf, piece, col, width):
     return buf
 
 
+def halves_split_heads(x, scale, H, D, DP, out=None):
+    n = x.shape[0]
+    buf = torch.zeros((n, 2 * H * DP), dtype=torch.float16) if out is None else out
+    for h in range(H):
+        halves_split_cols(x[:, h * D:(h + 1) * D], scale, 2, buf, H * DP, h * DP, DP)
+    return buf
+
+
 def halves_tn_combine(a, b, P, rem_a=None, rem_b=None):
     if a.dim() == 2:
         a, b = a.unsqueeze(0), b.unsqueeze(0)
@@ -518,7 +526,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["gemm_halves3_tn", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["gemm_halves3_tn", "halves_split_heads", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -1681,6 +1681,15 @@ def test_grouped_halves_kernels(golden):
         assert torch.equal(flat2[:HD * Fin], dW)
     with pytest.raises(_C.BotKernelError):
         _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, out, [(0, 300, 0, 0, 1, 0)], 0)        # a group wider than a tile
+    # --- bot_halves_split_heads_f16 == H calls of halves_split_cols(order 2) on column slices (a row-strided source, odd D too)
+    for (N, H, D, DP, ld) in ((5003, 3, 250, 256, 768), (1000, 2, 7, 64, 20), (300, 4, 64, 64, 256)):
+        src = torch.randn(N, ld, device=DEV, generator=gen)[:, :H * D]
+        sc = _C.halves_scale(src)
+        got = _C.halves_split_heads(src, sc, H, D, DP)
+        ref = torch.full((N, 2 * H * DP), 1.0, dtype=torch.float16, device=DEV)
+        for h in range(H):
+            _C.halves_split_cols(src[:, h * D:(h + 1) * D], sc, 2, ref, H * DP, h * DP, DP)
+        assert torch.equal(got, ref)
     # --- bot_tn_narrow_f32: the attention columns of the merged gradient (a column slice of the gradient buffer) against the input
     for (N, kx, ky, tr) in ((20011, 18, 168, True), (777, 1, 5, False), (5000, 32, 256, False)):
         buf = torch.randn(N, kx + 7, device=DEV, generator=gen)
