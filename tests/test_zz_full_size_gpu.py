@@ -1,5 +1,6 @@
-"""GPU parity at FULL size for BASELINE configs 3, 5 and 4 — one whole train step each against the oracle's C kernels (minutes of host
-CPU time each: config 4 runs an fp32 and an fp64 oracle step).  In a file that sorts LAST so that under `pytest -x` and the driver's
+"""GPU parity at FULL size for BASELINE configs 3 and 5, and at half size for config 4 (full size with BOT_CONFIG4_TEST_SCALE=1: its fp32 +
+fp64 oracle steps take 300 s of host time at full size, VERDICT r3 #6b asked for < 180 s) — one whole train step each against the
+oracle's C kernels.  In a file that sorts LAST so that under `pytest -x` and the driver's
 wall-clock limit everything else has been tested before the long legs start (VERDICT r3 #6b).  Config 2's full-size tests are short
 and stay in test_gpu_parity.py."""
 import pytest
@@ -44,7 +45,9 @@ def test_full_size_config5_products_gat_against_c_oracle():
 
 
 def test_full_size_config4_proteins_gat_against_c_oracle():
-    """BASELINE config 4 at its full synthetic size — S-proteins, 132 534 nodes / 79 M edges with 8 edge features, GAT 6 layers x
+    """BASELINE config 4 — S-proteins at HALF its node count by default (66 267 nodes / 39 M edges, the same mean in-degree of 600 that
+    makes the stack badly conditioned; BOT_CONFIG4_TEST_SCALE=1 runs the full 132 534 nodes / 79 M edges, 300 s of oracle time — the
+    closing run of each round does, profiles/) with 8 edge features, GAT 6 layers x
     6 heads x 80 (src/ogbn-proteins/models.py, full-graph branch: node encoder, per-layer edge encoders, inter-layer residual)
     — one train step (drop rates 0, BCE-with-logits over 112 tasks, gat.py:203-207) on the HIP path against the oracle's C
     kernels, the oracle at the HIP run's gates.  Logits: within 1e-4 relative to their scale.  Gradients: this stack is badly
@@ -52,15 +55,16 @@ def test_full_size_config4_proteins_gat_against_c_oracle():
     gradients that cancel), so two fp32 runs differ by more than 1e-4 on some parameters no matter how they are written.
     The criterion is therefore against the SAME step in fp64 (liboracle_f64.so): every HIP gradient is within 1e-4 of the exact
     one, or at most twice as far from it as the reference-order fp32 CPU run is."""
-    from tests import full_size as FS
-    r, cpu = FS.workload_parity("proteins", DEV)
-    rank = r.pop("rank")
-    print("full-size parity S-proteins GAT", r, "fp32 oracle step %.1f s" % cpu["seconds"])
     import os
+    from tests import full_size as FS
+    scale = float(os.environ.get("BOT_CONFIG4_TEST_SCALE", "0.5"))
+    r, cpu = FS.workload_parity("proteins", DEV, scale=scale)
+    rank = r.pop("rank")
+    print("parity S-proteins GAT at scale %g" % scale, r, "fp32 oracle step %.1f s" % cpu["seconds"])
     if os.environ.get("BOT_PARITY_TABLE"):
         for k, (eh, eo) in rank.items():
             print("  %-28s HIP vs fp64 %.3e   fp32 oracle vs fp64 %.3e" % (k, eh, eo))
-    assert r["n"] == 132534 and r["edges"] > 70_000_000
+    assert abs(r["n"] - 132534 * scale) <= 1 and r["edges"] > 70_000_000 * scale
     # logits up to 125: not "within 1e-4 absolute of the fp32 oracle" (3.1e-4) — ranked against the fp64 step instead (FS.CRITERIA)
     assert r["criterion"] == "fp64-ranked" and r["logit_err_vs_fp64"] <= max(PC.FWD_ATOL, 2 * r["oracle_logit_err_vs_fp64"]), r
     for k, (eh, eo) in rank.items():
