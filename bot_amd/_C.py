@@ -88,6 +88,10 @@ _SIGS = {
     "bot_gemm_halves3_tn_grouped_f32": (ctypes.c_int, [c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int32, _P, _P, c_int32, _P]),
     "bot_tn_narrow_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "bot_tn_narrow_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int32, _P, _P]),
+    "bot_bn_act_bwd_reduce_max_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, _P, _P, _P, _P]),
+    "bot_bn_bwd_bound_f32": (ctypes.c_int, [c_int32, c_int64, _P, _P, _P, c_double, _P, _P, _P, _P]),
+    "bot_bn_act_bwd_apply_halves_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float, c_uint64, _P, _P, _P, c_double,
+                                                       _P, c_int64, _P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
     "bot_label_split_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, _P, c_float, c_uint64, _P, c_int32, _P, _P, _P, _P, _P]),
     "bot_build_input_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, c_int32, _P, c_float, c_uint64, _P, _P, c_int64, _P]),
     "bot_node_loss_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, c_int64, _P, _P, c_int32, c_float, _P, c_int64, _P, c_int64, _P]),
@@ -1053,18 +1057,45 @@ def bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=None, want_y
     return y
 
 
-def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed):
-    """Column sums (sum_g, sum_gx) of the masked upstream gradient and of g * xhat."""
+def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed, want_max=False):
+    """Column sums (sum_g, sum_gx) of the masked upstream gradient and of g * xhat.  want_max: also the column maxima of |g| and |xhat|,
+    left in the returned workspace for bn_bwd_bound -> (sum_g, sum_gx, workspace)."""
     _dev(dy, x)
     dy, x = _mat(dy, "dy"), _mat(x, "x")
     n, F = x.shape
     sg = torch.empty(F, dtype=torch.float32, device=x.device)
     sgx = torch.empty(F, dtype=torch.float32, device=x.device)
-    _check(_lib.bot_bn_act_bwd_reduce_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, F, mean.data_ptr(),
-                                          invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu), float(p), int(seed), _seed_off(p),
-                                          sg.data_ptr(), sgx.data_ptr(), _bn_ws(F, x.device).data_ptr(), _stream()),
-           "bn_act_bwd_reduce")
-    return sg, sgx
+    ws = _bn_ws(F, x.device)
+    fn = _lib.bot_bn_act_bwd_reduce_max_f32 if want_max else _lib.bot_bn_act_bwd_reduce_f32
+    _check(fn(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), invstd.data_ptr(), _ptr(weight), _ptr(bias), int(relu),
+              float(p), int(seed), _seed_off(p), sg.data_ptr(), sgx.data_ptr(), ws.data_ptr(), _stream()), "bn_act_bwd_reduce")
+    return (sg, sgx, ws) if want_max else (sg, sgx)
+
+
+def bn_bwd_bound(ws, n, sum_g, sum_gx, total_count, weight, invstd, slots):
+    """max |dx| of the BatchNorm backward bounded from the reduce pass's column maxima (`ws` of bn_act_bwd_reduce(want_max=True)) and the
+    FINAL column sums (None: eval statistics), folded into the by-product `slots` (bot_bn_bwd_bound_f32)."""
+    _dev(ws, invstd, slots)
+    F = invstd.shape[0]
+    _check(_lib.bot_bn_bwd_bound_f32(F, n, ws.data_ptr(), _ptr(sum_g), _ptr(sum_gx), float(total_count), _ptr(weight), invstd.data_ptr(), slots.data_ptr(),
+                                     _stream()), "bn_bwd_bound")
+    return slots
+
+
+def bn_act_bwd_apply_halves(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, hscale, hout, hD, hDP, out=None):
+    """bn_act_bwd_apply writing dx as the LEFT halves operand `hout` [n, 2 * (F / hD) * hDP] = [h1 | 2^11 h2] of hscale[0] * dx, the columns in
+    blocks of hD every hDP (padding columns untouched); `out`: optionally dx in fp32 as well (bot_bn_act_bwd_apply_halves_f32)."""
+    _dev(dy, x, hout, hscale)
+    dy, x = _mat(dy, "dy"), _mat(x, "x")
+    n, F = x.shape
+    h2_off = (F // hD) * hDP
+    assert hout.dtype == torch.float16 and hout.shape == (n, 2 * h2_off) and hout.stride(1) == 1
+    assert out is None or (out.stride(1) == 1 and out.dtype == torch.float32)
+    _check(_lib.bot_bn_act_bwd_apply_halves_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), invstd.data_ptr(), _ptr(weight),
+                                                _ptr(bias), int(relu), float(p), int(seed), _seed_off(p), _ptr(sum_g), _ptr(sum_gx), float(total_count),
+                                                _ptr(out), out.stride(0) if out is not None else 0, hscale.data_ptr(), hout.data_ptr(), hout.stride(0), h2_off,
+                                                hD, hDP, _stream()), "bn_act_bwd_apply_halves")
+    return hout
 
 
 def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, out=None, absmax=None):

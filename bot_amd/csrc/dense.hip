@@ -117,6 +117,9 @@ struct BnArgs {
     float* dx;
     int64_t lddx;
     float* part;  // [kRowBlocks][2][F]
+    float* pmax;  // optional (bwd reduce): [kRowBlocks][2][F] per-block column maxima of |g| and |xhat| (the operands of bn_bwd_bound_kernel)
+    int32_t hD, hDP, h2off;   // bwd apply with `hout`: dx as a LEFT halves operand [h1 | 2^11 h2] (second half h2off columns behind the first), the
+                              // columns in blocks of hD (a head) that start every hDP >= hD columns of the operand (halves.hip halves_split_heads_kernel)
     uint32_t* absmax;      // optional by-product of the backward apply pass: max|dx| (common.h absmax_publish)
     bool wx, wy, wdy, wdx;  // quad launches: which operands have 16-byte aligned rows (load_cols / store_cols)
 };
@@ -398,9 +401,9 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_reduce_kernel(BnArgs a) {
     __shared__ float lds[2][kTY][kTX * VEC];
     const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
     const int c = (blockIdx.x * kTX + tx) * VEC;
-    float s[VEC], q[VEC];
+    float s[VEC], q[VEC], gm[VEC], xm[VEC];
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) s[t] = q[t] = 0.f;
+    for (int t = 0; t < VEC; ++t) s[t] = q[t] = gm[t] = xm[t] = 0.f;
     const int nv = min(VEC, a.F - c);
     if (c < a.F) {
         float mu[VEC], is[VEC], sc[VEC], sh[VEC];
@@ -425,6 +428,7 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_reduce_kernel(BnArgs a) {
                 if (a.relu && !(fmaf(xh, sc[t], sh[t]) > 0.f)) gg = 0.f;
                 s[t] += gg;
                 q[t] = fmaf(gg, xh, q[t]);
+                if (t < nv) gm[t] = fmaxf(gm[t], fabsf(gg)), xm[t] = fmaxf(xm[t], fabsf(xh));
             }
         }
     }
@@ -442,6 +446,59 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_reduce_kernel(BnArgs a) {
             a.part[((int64_t)blockIdx.y * 2 + 1) * a.F + c + t] = w;
         }
     }
+    if (a.pmax) {                        // (uniform) the same two-stage shape for the column maxima
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) lds[0][ty][tx * VEC + t] = gm[t], lds[1][ty][tx * VEC + t] = xm[t];
+        __syncthreads();
+        if (ty == 0 && c < a.F) {
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                if (t >= nv) break;
+                float u = 0.f, w = 0.f;
+#pragma unroll
+                for (int j = 0; j < kTY; ++j) u = fmaxf(u, lds[0][j][tx * VEC + t]), w = fmaxf(w, lds[1][j][tx * VEC + t]);
+                a.pmax[((int64_t)blockIdx.y * 2 + 0) * a.F + c + t] = u;
+                a.pmax[((int64_t)blockIdx.y * 2 + 1) * a.F + c + t] = w;
+            }
+        }
+    }
+}
+
+// max_c |dx_c| bounded BEFORE dx exists:  dx = w invstd (g - mean g - xhat mean(g xhat))  =>
+//   |dx_{r,c}| <= |w_c| invstd_c (max_r |g| + |sum_g_c| / n + max_r |xhat| |sum_gx_c| / n)       (sum_g == NULL, eval statistics: |w_c| invstd_c max_r |g|)
+// with the column maxima of the reduce pass (pmax, nblk row blocks) and the FINAL column sums (after a cross-rank reduction, if any).
+// The maximum over the columns goes to the by-product slots: halves_scale_from_slots turns it into the scale under which
+// bn_act_bwd_apply writes dx directly as a halves operand (the format keeps 22 bits for entries down to 2^-28 of the scale: a bound that
+// is loose by a few binades costs nothing).
+__global__ __launch_bounds__(kBlock) void bn_bwd_bound_kernel(int32_t F, const float* pmax, int nblk, const float* sum_g, const float* sum_gx, float inv_count,
+                                                             const float* w, const float* invstd, uint32_t* slots) {
+    // 64 columns x 4 row-block groups per workgroup (the shape of pair_reduce), eight loads in flight per thread
+    __shared__ float lds[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float gm = 0.f, xm = 0.f;
+    if (c < F) {
+        int k = grp;
+        for (; k + 28 < nblk; k += 32) {
+            float vg[8], vx[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vg[j] = pmax[((int64_t)(k + 4 * j) * 2 + 0) * F + c], vx[j] = pmax[((int64_t)(k + 4 * j) * 2 + 1) * F + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gm = fmaxf(gm, vg[j]), xm = fmaxf(xm, vx[j]);
+        }
+        for (; k < nblk; k += 4) gm = fmaxf(gm, pmax[((int64_t)k * 2 + 0) * F + c]), xm = fmaxf(xm, pmax[((int64_t)k * 2 + 1) * F + c]);
+    }
+    lds[0][grp][threadIdx.x & 63] = gm, lds[1][grp][threadIdx.x & 63] = xm;
+    __syncthreads();
+    float b = 0.f;
+    if (grp == 0 && c < F) {
+#pragma unroll
+        for (int g = 1; g < 4; ++g) gm = fmaxf(gm, lds[0][g][threadIdx.x & 63]), xm = fmaxf(xm, lds[1][g][threadIdx.x & 63]);
+        float t = gm;
+        if (sum_g) t += fabsf(sum_g[c]) * inv_count + xm * fabsf(sum_gx[c]) * inv_count;
+        b = fabsf(w ? w[c] : 1.f) * invstd[c] * t * 1.0001f;          // (rounding of the three-term expression itself)
+    }
+    absmax_publish(wave_absmax(b), slots);
 }
 
 __global__ __launch_bounds__(kBlock) void pair_final_kernel(int32_t F, const float* part, int nblk, float* s0, float* s1) {
@@ -476,6 +533,19 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
         const uint64_t seed = eff_seed(a.seed, a.seed_offset);
         constexpr int UR = 4;
         const int64_t step = (int64_t)gridDim.y * kTY;
+        // halves output (a.hout): destination column of each column pair of this thread (fixed over the rows) and whether the thread's
+        // four columns lie in one head's block
+        int hdst[(VEC + 1) / 2] = {};
+        bool hquad = false;
+        const float hs = a.hout ? a.hscale[0] : 1.f;
+        if (a.hout) {
+#pragma unroll
+            for (int t = 0; t < VEC; t += 2) {
+                const int cc = c + t, hd = cc / a.hD;
+                hdst[t / 2] = hd * a.hDP + (cc - hd * a.hD);
+            }
+            if constexpr (VEC == 4) hquad = nv == 4 && c / a.hD == (c + 3) / a.hD;
+        }
         for (int64_t r0 = (int64_t)blockIdx.y * kTY + ty; r0 < a.n; r0 += step * UR) {
             float v[UR][VEC], g[UR][VEC];
 #pragma unroll
@@ -501,7 +571,34 @@ __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
                     v[u][t] = sc[t] * is[t] * (gg - mg[t] - xh * mgx[t]);
                     if (t < nv) amax = fmaxf(amax, fabsf(v[u][t]));
                 }
-                store_cols<VEC>(a.dx + r * a.lddx + c, v[u], a.wdx, nv);
+                if (a.dx) store_cols<VEC>(a.dx + r * a.lddx + c, v[u], a.wdx, nv);
+                if (a.hout) {            // dx as a halves operand, head blocks of hD columns every hDP (hD even: a column pair never straddles)
+                    __half* ho = a.hout + r * a.ldh;
+                    __half h1[VEC], h2[VEC];
+#pragma unroll
+                    for (int t = 0; t < VEC; ++t) {
+                        const float z = (t < nv ? v[u][t] : 0.f) * hs;
+                        h1[t] = __float2half_rn(z);
+                        h2[t] = __float2half_rn((z - __half2float(h1[t])) * kHalvesShift);
+                    }
+                    if constexpr (VEC == 4) {
+                        if (hquad) {         // the four columns are one head's: 8-byte stores (4-byte aligned)
+                            *reinterpret_cast<uint2*>(ho + hdst[0]) = *reinterpret_cast<const uint2*>(h1);
+                            *reinterpret_cast<uint2*>(ho + hdst[0] + a.h2off) = *reinterpret_cast<const uint2*>(h2);
+                            continue;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < VEC; t += 2) {
+                        if (t >= nv) break;
+                        if (VEC >= 2 && t + 1 < nv) {
+                            *reinterpret_cast<__half2*>(ho + hdst[t / 2]) = __halves2half2(h1[t], h1[t + 1]);
+                            *reinterpret_cast<__half2*>(ho + hdst[t / 2] + a.h2off) = __halves2half2(h2[t], h2[t + 1]);
+                        } else {
+                            ho[hdst[t / 2]] = h1[t], ho[hdst[t / 2] + a.h2off] = h2[t];
+                        }
+                    }
+                }
             }
         }
     }
@@ -666,16 +763,46 @@ int bot_bn_act_fwd_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F,
     return bn_act_fwd_impl(x, ldx, n, F, mean, invstd, weight, bias, relu, p, seed, seed_offset, y, ldy, hscale, hout, ldh, piece, pieces, stream);
 }
 
+static int bn_act_bwd_reduce_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
+                                  const float* weight, const float* bias, int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, float* sum_g,
+                                  float* sum_gx, float* workspace, bool want_max, bot_stream_t stream);
+
 int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
                               const float* mean, const float* invstd, const float* weight, const float* bias, int32_t relu,
                               float p, uint64_t seed, const uint64_t* seed_offset, float* sum_g, float* sum_gx, float* workspace,
                               bot_stream_t stream) {
+    return bn_act_bwd_reduce_impl(dy, lddy, x, ldx, n, F, mean, invstd, weight, bias, relu, p, seed, seed_offset, sum_g, sum_gx, workspace, false, stream);
+}
+
+int bot_bn_act_bwd_reduce_max_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
+                                  const float* mean, const float* invstd, const float* weight, const float* bias, int32_t relu,
+                                  float p, uint64_t seed, const uint64_t* seed_offset, float* sum_g, float* sum_gx, float* workspace,
+                                  bot_stream_t stream) {
+    return bn_act_bwd_reduce_impl(dy, lddy, x, ldx, n, F, mean, invstd, weight, bias, relu, p, seed, seed_offset, sum_g, sum_gx, workspace, true, stream);
+}
+
+int bot_bn_bwd_bound_f32(int32_t F, int64_t n, const float* workspace, const float* sum_g, const float* sum_gx, double total_count, const float* weight,
+                         const float* invstd, uint32_t* absmax_slots, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(F >= 1 && n >= 1 && workspace && invstd && absmax_slots, BOT_E_NULL, "bn_bwd_bound: F=%d n=%lld or a NULL pointer", F, (long long)n);
+    BOT_REQUIRE((sum_g == nullptr) == (sum_gx == nullptr) && (sum_g == nullptr || total_count >= 1.0), BOT_E_RANGE, "bn_bwd_bound: sums / total_count");
+    const int nblk = (int)bn_grid(F, 1, n).y;
+    static_assert(kBlock == 256, "bn_bwd_bound_kernel: 64 columns x 4 groups");
+    hipLaunchKernelGGL(bn_bwd_bound_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, (hipStream_t)stream, F, workspace + (int64_t)kRowBlocks * 2 * F, nblk,
+                       sum_g, sum_gx, sum_g ? (float)(1.0 / total_count) : 0.f, weight, invstd, absmax_slots);
+    return hip_status("bn_bwd_bound launch");
+}
+
+static int bn_act_bwd_reduce_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
+                                  const float* weight, const float* bias, int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, float* sum_g,
+                                  float* sum_gx, float* workspace, bool want_max, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(n >= 1 && F >= 1 && ldx >= F && lddy >= F, BOT_E_RANGE, "bn_act_bwd_reduce: n=%lld F=%d", (long long)n, F);
     BOT_REQUIRE(dy && x && mean && invstd && sum_g && sum_gx && workspace, BOT_E_NULL, "bn_act_bwd_reduce: NULL pointer");
     BnArgs a{};
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
     a.seed = seed, a.seed_offset = seed_offset, a.dy = dy, a.lddy = lddy, a.part = workspace;
+    a.pmax = want_max ? workspace + (int64_t)kRowBlocks * 2 * F : nullptr;        // (bot_bn_workspace_floats: 4 kRowBlocks F + F)
     bool quad;
     const int vec = bn_vec(F, {ldx, lddy}, {x, dy}, &quad);
     a.wx = !quad || rows16(x, ldx), a.wdy = !quad || rows16(dy, lddy);
@@ -689,20 +816,49 @@ int bot_bn_act_bwd_reduce_f32(const float* dy, int64_t lddy, const float* x, int
     return hip_status("bn_act_bwd_reduce launch");
 }
 
+static int bn_act_bwd_apply_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
+                                 const float* weight, const float* bias, int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, const float* sum_g,
+                                 const float* sum_gx, double total_count, float* dx, int64_t lddx, uint32_t* absmax_slots, const float* hscale, uint16_t* hout,
+                                 int64_t ldh, int32_t h2_off, int32_t hD, int32_t hDP, bot_stream_t stream);
+
 int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
                              const float* mean, const float* invstd, const float* weight, const float* bias, int32_t relu,
                              float p, uint64_t seed, const uint64_t* seed_offset, const float* sum_g, const float* sum_gx,
                              double total_count, float* dx, int64_t lddx, uint32_t* absmax_slots, bot_stream_t stream) {
+    BOT_REQUIRE(dx || n == 0, BOT_E_NULL, "bn_act_bwd_apply: NULL pointer");
+    return bn_act_bwd_apply_impl(dy, lddy, x, ldx, n, F, mean, invstd, weight, bias, relu, p, seed, seed_offset, sum_g, sum_gx, total_count, dx, lddx,
+                                 absmax_slots, nullptr, nullptr, 0, 0, 0, 0, stream);
+}
+
+int bot_bn_act_bwd_apply_halves_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
+                                    const float* weight, const float* bias, int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset,
+                                    const float* sum_g, const float* sum_gx, double total_count, float* dx, int64_t lddx, const float* hscale, uint16_t* hout,
+                                    int64_t ldh, int32_t h2_off, int32_t hD, int32_t hDP, bot_stream_t stream) {
     using namespace bot;
-    BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && lddy >= F && lddx >= F, BOT_E_RANGE, "bn_act_bwd_apply: n=%lld F=%d", (long long)n, F);
+    BOT_REQUIRE(hscale && hout, BOT_E_NULL, "bn_act_bwd_apply_halves: NULL pointer");
+    BOT_REQUIRE(hD >= 2 && hD % 2 == 0 && hDP >= hD && hDP % 2 == 0 && F % hD == 0 && h2_off % 2 == 0 && ldh % 2 == 0 && h2_off >= (int64_t)(F / hD) * hDP &&
+                    ldh >= h2_off + (int64_t)(F / hD) * hDP && aligned(hout, 4), BOT_E_RANGE, "bn_act_bwd_apply_halves: F=%d hD=%d hDP=%d h2_off=%d ldh=%lld", F, hD, hDP,
+                h2_off, (long long)ldh);
+    return bn_act_bwd_apply_impl(dy, lddy, x, ldx, n, F, mean, invstd, weight, bias, relu, p, seed, seed_offset, sum_g, sum_gx, total_count, dx, lddx, nullptr,
+                                 hscale, hout, ldh, h2_off, hD, hDP, stream);
+}
+
+static int bn_act_bwd_apply_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
+                                 const float* weight, const float* bias, int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, const float* sum_g,
+                                 const float* sum_gx, double total_count, float* dx, int64_t lddx, uint32_t* absmax_slots, const float* hscale, uint16_t* hout,
+                                 int64_t ldh, int32_t h2_off, int32_t hD, int32_t hDP, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 0 && F >= 1 && ldx >= F && lddy >= F && (dx == nullptr || lddx >= F), BOT_E_RANGE, "bn_act_bwd_apply: n=%lld F=%d", (long long)n, F);
     if (n == 0) return 0;
-    BOT_REQUIRE(dy && x && mean && invstd && dx, BOT_E_NULL, "bn_act_bwd_apply: NULL pointer");
+    BOT_REQUIRE(dy && x && mean && invstd && (dx || hout), BOT_E_NULL, "bn_act_bwd_apply: NULL pointer");
     BOT_REQUIRE((sum_g == nullptr) == (sum_gx == nullptr), BOT_E_NULL, "bn_act_bwd_apply: sum_g and sum_gx go together");
     BOT_REQUIRE(sum_g == nullptr || total_count >= 1.0, BOT_E_RANGE, "bn_act_bwd_apply: total_count=%f", total_count);
     BnArgs a{};
     a.x = x, a.ldx = ldx, a.n = n, a.F = F, a.mean = mean, a.invstd = invstd, a.w = weight, a.b = bias, a.relu = relu, a.p = p;
     a.seed = seed, a.seed_offset = seed_offset, a.dy = dy, a.lddy = lddy, a.sum_g = sum_g, a.sum_gx = sum_gx, a.inv_count = sum_g ? (float)(1.0 / total_count) : 0.f;
     a.dx = dx, a.lddx = lddx, a.absmax = absmax_slots;
+    a.hout = reinterpret_cast<__half*>(hout), a.hscale = hscale, a.ldh = ldh, a.h2off = h2_off, a.hD = hD, a.hDP = hDP;
+    if (!dx) lddx = ldx;        // (no fp32 output: its pitch must not narrow the launch width)
     bool quad;
     const int vec = bn_vec(F, {ldx, lddy, lddx}, {x, dy, dx}, &quad);
     a.wx = !quad || rows16(x, ldx), a.wdy = !quad || rows16(dy, lddy), a.wdx = !quad || rows16(dx, lddx);

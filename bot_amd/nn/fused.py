@@ -436,7 +436,21 @@ AGG_FIRST = True  # aggregate-before-project for layers whose input is narrower 
 # bot_tn_gemm_f32 / the stock fp32 GEMM: the aggregated slab is written by the SpMM as a halves operand next to the input's halves, one
 # launch computes  rst_h = [x | z_h] [Wres_h | W_h]^T  for all heads, one  d z_h = d rst_h W_h,  one all weight gradients.
 L0_HALVES = os.environ.get("BOT_L0_HALVES", "1") != "0"
+# ... and the layer's BatchNorm backward writes d rst directly as that launch's left operand, under a scale BOUNDED from the reduce pass
+# (bot_bn_bwd_bound_f32) instead of measured on a finished fp32 dx: no fp32 dx, no split pass
+L0_DIRECT = os.environ.get("BOT_L0_DIRECT", "1") != "0"
 _L0_TABLES = {}
+_L0_DH = {}
+
+
+def _l0_dh(device, N, H, DP):
+    """The gradient operand [N, 2 H DP] of the direct form: allocated once per shape with its padding columns zeroed (the apply pass writes
+    only the D columns of each head's block); it lives inside one backward call, so layers and steps can share it."""
+    key = (str(device), N, H, DP)
+    buf = _L0_DH.get(key)
+    if buf is None:
+        buf = _L0_DH[key] = torch.zeros((N, 2 * H * DP), dtype=torch.float16, device=device)
+    return buf
 
 
 def _l0_tables(H, D, Fin, P2, kp, N):
@@ -621,28 +635,41 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         N, Fin, HD, P2 = h.shape[0], h.shape[1], H * D, Wr.shape[1 if kp else 0]
         dout2 = torch.empty((N, P2), dtype=h.dtype, device=h.device)
         dx = dout2[:, :HD] if has_res else torch.empty((N, HD), dtype=h.dtype, device=h.device)
-        slots = _C.absmax_slots(dy.device) if l0h and ABSMAX_BYPRODUCT and epi is not None else None
+        direct = l0h and L0_DIRECT and epi is not None and D % 2 == 0
+        slots = _C.absmax_slots(dy.device) if l0h and (ABSMAX_BYPRODUCT or direct) and epi is not None else None
+        Dh = dscale = None
         if epi is None:
             dx.copy_(dy)
         else:
-            sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
+            if direct:
+                sg, sgx, ws = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, want_max=True)
+            else:
+                sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
             d_bn_w, d_bn_b = sgx, sg
             if bn_training and sync:
                 both = torch.stack([sg, sgx])
                 dist.all_reduce(both, group=group)
                 sg, sgx = both[0].contiguous(), both[1].contiguous()
-            _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
-                                sgx if bn_training else None, total, out=dx, absmax=slots)
+            if direct:
+                # a bound on max|dx| from the reduce pass's column maxima and the final sums -> the operand's scale -> dx written as halves
+                DP = (D + 63) // 64 * 64
+                _C.bn_bwd_bound(ws, N, sg if bn_training else None, sgx if bn_training else None, total, bn_w, invstd, slots)
+                dscale = _C.halves_scale_from_slots(slots)
+                Dh = _C.bn_act_bwd_apply_halves(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
+                                                sgx if bn_training else None, total, dscale, _l0_dh(dy.device, N, H, DP), D, DP)
+            else:
+                _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
+                                    sgx if bn_training else None, total, out=dx, absmax=slots)
         Wh = W.view(H, D, Fin)
         dz = torch.empty((H, N, Fin), dtype=h.dtype, device=h.device)    # gradient of the aggregated slab
         dW3 = torch.empty((H, D, Fin), dtype=h.dtype, device=h.device) if ctx.needs_input_grad[1] and not l0h else None
-        Dh = dscale = None
         if l0h:
             # the gradient of the layer's output as a LEFT halves operand, each head's D columns in a block of DP (zero padded): it is the
             # A operand of d z_h = d rst_h W_h and the x-role of every weight gradient
             FP, DP, _, g_dz, t_tn = _l0_tables(H, D, Fin, P2, kp, N)
-            dscale = _C.halves_scale_from_slots(slots) if slots is not None else _C.halves_scale(dx)
-            Dh = _C.halves_split_heads(dx, dscale, H, D, DP)
+            if Dh is None:
+                dscale = _C.halves_scale_from_slots(slots) if slots is not None else _C.halves_scale(dx)
+                Dh = _C.halves_split_heads(dx, dscale, H, D, DP)
             Wt = gemm.split(Wh.transpose(1, 2).reshape(H * Fin, D), 1)           # rows h Fin + f = W_h[:, f]: the right operand of d z_h
             _C.gemm_halves3_nt_grouped(Dh, Wt.buf, dscale, Wt.scale, H * DP, Wt.piece, dz[0], g_dz, 0)
         elif ctx.skinny and D <= 256:     # d z_i = d x_i W_i for the H heads in one launch (A = column slices of d x)

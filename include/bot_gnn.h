@@ -380,6 +380,26 @@ int bot_bn_act_bwd_apply_f32(const float* dy, int64_t lddy, const float* x, int6
                              int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, const float* sum_g,
                              const float* sum_gx, double total_count, float* dx, int64_t lddx, uint32_t* absmax_slots /* optional: max|dx|,
                              "Maxima as by-products" */, bot_stream_t stream);
+/* v16: the BatchNorm backward WITHOUT a split pass behind it, for a dx whose only consumers are halves GEMMs (the aggregate-first GAT layer):
+ *   bot_bn_act_bwd_reduce_max_f32   the reduce pass, which also leaves the column maxima of |g| and |xhat| in the workspace;
+ *   bot_bn_bwd_bound_f32            max_c |w_c| invstd_c (max|g_c| + |sum_g_c| / n + max|xhat_c| |sum_gx_c| / n) >= max |dx| into by-product slots
+ *                                   (sum_g / sum_gx: the FINAL sums, i.e. after a cross-rank reduction; NULL: eval statistics) — a scale
+ *                                   for dx BEFORE dx exists (bot_halves_scale_from_slots_f32); a bound that is loose by a few binades costs
+ *                                   nothing in this format (22 bits for entries down to 2^-28 of the scale);
+ *   bot_bn_act_bwd_apply_halves_f32 the apply pass writing dx as a LEFT operand [h1 | 2^11 h2] (second half h2_off columns behind the first),
+ *                                   columns in blocks of hD (a head; even, F % hD == 0) that start every hDP >= hD columns; the padding
+ *                                   columns are NOT written (the caller zeroes them once); dx (fp32) may be NULL. */
+int bot_bn_act_bwd_reduce_max_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
+                                  const float* mean, const float* invstd, const float* weight, const float* bias,
+                                  int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, float* sum_g, float* sum_gx,
+                                  float* workspace, bot_stream_t stream);
+int bot_bn_bwd_bound_f32(int32_t F, int64_t n, const float* workspace, const float* sum_g, const float* sum_gx, double total_count,
+                         const float* weight, const float* invstd, uint32_t* absmax_slots, bot_stream_t stream);
+int bot_bn_act_bwd_apply_halves_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F,
+                                    const float* mean, const float* invstd, const float* weight, const float* bias,
+                                    int32_t relu, float p, uint64_t seed, const uint64_t* seed_offset, const float* sum_g,
+                                    const float* sum_gx, double total_count, float* dx, int64_t lddx, const float* hscale, uint16_t* hout,
+                                    int64_t ldh, int32_t h2_off, int32_t hD, int32_t hDP, bot_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Merged projection weight of a GAT layer (host-side convenience of the fused layer node, not a DGL operator): the layer's

@@ -485,10 +485,27 @@ def bn_stats_halves(x, eps, momentum, running_mean, running_var, num_batches_tra
     return mean, invstd, _pow2_scale(float(bound.max()))
 
 
-def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed):
+def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed, want_max=False):
     xh, o = _bn_gate(x, mean, invstd, weight, bias, relu, p)
     g = torch.where(o > 0, dy, torch.zeros_like(dy)) if relu else dy
+    if want_max:        # the "workspace" of the restatement: the two column-maxima rows
+        return g.sum(0), (g * xh).sum(0), torch.stack([g.abs().max(0).values, xh.abs().max(0).values])
     return g.sum(0), (g * xh).sum(0)
+
+
+def bn_bwd_bound(ws, n, sum_g, sum_gx, total_count, weight, invstd, slots):
+    """include/bot_gnn.h bot_bn_bwd_bound_f32"""
+    t = ws[0].clone()
+    if sum_g is not None:
+        t = t + sum_g.abs() / total_count + ws[1] * sum_gx.abs() / total_count
+    _fold_absmax(slots, (weight.abs() if weight is not None else 1.0) * invstd * t * 1.0001)
+    return slots
+
+
+def bn_act_bwd_apply_halves(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, hscale, hout, hD, hDP, out=None):
+    res = bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, out=out)
+    halves_split_heads(res, hscale, x.shape[1] // hD, hD, hDP, out=hout)
+    return hout
 
 
 def bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, out=None, absmax=None):
@@ -526,7 +543,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["gemm_halves3_tn", "halves_split_heads", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["gemm_halves3_tn", "bn_bwd_bound", "bn_act_bwd_apply_halves", "halves_split_heads", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -1690,6 +1690,38 @@ def test_grouped_halves_kernels(golden):
         for h in range(H):
             _C.halves_split_cols(src[:, h * D:(h + 1) * D], sc, 2, ref, H * DP, h * DP, DP)
         assert torch.equal(got, ref)
+    # --- the BatchNorm backward that writes dx as the head-padded halves operand under a BOUNDED scale (reduce_max -> bound -> apply_halves):
+    # the bound holds (and is within 64x of max|dx|), the fp32 dx next to it is bit for bit bn_act_bwd_apply's, the halves are
+    # halves_split_heads of that dx at that scale, the padding columns stay as the caller left them; training and eval statistics
+    for (N, H, D, DP, p_drop, train) in ((20011, 3, 250, 256, 0.5, True), (5000, 2, 6, 64, 0.0, True), (3000, 3, 250, 256, 0.25, False)):
+        Fc = H * D
+        x = torch.randn(N, Fc, device=DEV, generator=gen) * 2 + 0.3
+        dy = torch.randn(N, Fc, device=DEV, generator=gen) * 1e-3
+        w, b = torch.randn(Fc, device=DEV, generator=gen), torch.randn(Fc, device=DEV, generator=gen)
+        mean, invstd = _C.bn_stats(x, 1e-5, 0.0)
+        sg, sgx, ws = _C.bn_act_bwd_reduce(dy, x, mean, invstd, w, b, True, p_drop, 77, want_max=True)
+        sg2, sgx2 = _C.bn_act_bwd_reduce(dy, x, mean, invstd, w, b, True, p_drop, 77)
+        assert torch.equal(sg, sg2) and torch.equal(sgx, sgx2)
+        slots = _C.absmax_slots(DEV)
+        _C.bn_bwd_bound(ws, N, sg if train else None, sgx if train else None, N, w, invstd, slots)
+        ref = _C.bn_act_bwd_apply(dy, x, mean, invstd, w, b, True, p_drop, 77, sg if train else None, sgx if train else None, N)
+        bound, true = float(slots.max().reshape(1).view(torch.float32)[0]), float(ref.abs().max())
+        print(f"bn_bwd_bound N={N} F={Fc} train={train}: bound {bound:.3e} max|dx| {true:.3e} (x{bound / true:.1f})")
+        assert true <= bound <= 64 * true
+        sc = _C.halves_scale_from_slots(slots)
+        hout = torch.full((N, 2 * H * DP), 3.0, dtype=torch.float16, device=DEV)
+        dx32 = torch.empty(N, Fc, device=DEV)
+        _C.bn_act_bwd_apply_halves(dy, x, mean, invstd, w, b, True, p_drop, 77, sg if train else None, sgx if train else None, N, sc, hout, D, DP, out=dx32)
+        assert torch.equal(dx32, ref)
+        want = _C.halves_split_heads(ref, sc, H, D, DP)
+        for h in range(H):
+            for off in (0, H * DP):
+                blk = slice(off + h * DP, off + h * DP + D)
+                assert torch.equal(hout[:, blk], want[:, blk])
+                assert bool((hout[:, off + h * DP + D:off + (h + 1) * DP] == 3.0).all())
+        only = torch.full_like(hout, 3.0)
+        _C.bn_act_bwd_apply_halves(dy, x, mean, invstd, w, b, True, p_drop, 77, sg if train else None, sgx if train else None, N, sc, only, D, DP)
+        assert torch.equal(only, hout)
     # --- bot_tn_narrow_f32: the attention columns of the merged gradient (a column slice of the gradient buffer) against the input
     for (N, kx, ky, tr) in ((20011, 18, 168, True), (777, 1, 5, False), (5000, 32, 256, False)):
         buf = torch.randn(N, kx + 7, device=DEV, generator=gen)

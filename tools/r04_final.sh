@@ -20,7 +20,7 @@ for W in arxiv reddit proteins products; do
 done
 cp gpurun_out/pmc/r04_* $O/ 2>/dev/null
 bash tools/pmc_halves3.sh > /dev/null 2>&1; cp gpurun_out/r04/pmc_halves3.csv $O/ 2>/dev/null
-bash tools/pmc_mfma.sh > $O/pmc_mfma.log 2>&1; cp gpurun_out/r03m/r03_pmc_mfma.csv $O/r04_pmc_mfma.csv 2>/dev/null
+bash tools/pmc_mfma.sh > $O/pmc_mfma.log 2>&1; cp gpurun_out/r04m/r04_pmc_mfma.csv gpurun_out/r04m/r04_pmc_mfma_summary.txt $O/ 2>/dev/null
 ls -la $O
 python tools/exp_halves3.py --ablate 2>&1 | grep -v amdgpu.ids > $O/halves3_kernel.txt
 bash tools/pmc_halves3_tn.sh > $O/pmc_halves3_tn.csv 2>/dev/null
