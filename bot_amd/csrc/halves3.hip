@@ -413,8 +413,13 @@ __device__ __forceinline__ half8 tr_pack(const v2i& lo, const v2i& hi) {
     return __builtin_bit_cast(half8, q);
 }
 
-template <bool GROUPED>
+// PT: columns of d per tile: 192, or 128 (grouped launches whose d blocks are a multiple of 128 wide: 4 instead of 6 tile rows per wave, the
+// 128-byte sub-image of d neither fetched nor read)
+template <bool GROUPED, int PT>
 __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnTiles* tiles) {
+    static_assert(PT == 192 || PT == 128, "tile widths of d");
+    constexpr int MTN = PT / 32;            // 16-column tile rows per wave (2 wave rows)
+    constexpr int kDma = PT == 192 ? 6 : 5; // DMA instructions per wave and step
     __shared__ __attribute__((aligned(1024))) unsigned char lds[kTnStages * kTnStage];
     // (readfirstlane: the compiler must KNOW the wave index is uniform, or every DMA instruction - whose LDS address goes through M0 - is
     // wrapped in a waterfall loop and every LDS read behind it waits for vmcnt(0))
@@ -445,7 +450,7 @@ __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnT
     uint32_t voff[6];       // per-lane source byte offset
     int loff[6];            // LDS byte offset inside a stage (wave-uniform)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < kDma; ++i) {
         const bool isx = i < 2 || i == 4;
         int q, row, col, lo;
         if (i < 4) {
@@ -481,7 +486,7 @@ __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnT
     };
     auto issue = [&](int stage, int kt) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) issue_one(i, stage, kt);
+        for (int i = 0; i < kDma; ++i) issue_one(i, stage, kt);
     };
 
     // fragment addressing: lane l = (t = l & 15, g = l >> 4) wants rows 8 g .. 8 g + 7 of column t of a 16-column chunk
@@ -492,23 +497,26 @@ __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnT
     L.a0 = rA * 256 + sub, L.a1 = rB * 256 + sub, L.b0 = rA * 128 + sub, L.b1 = rB * 128 + sub;
     L.k80 = tn_key8(rA), L.k81 = tn_key8(rB), L.k40 = tn_key4(rA), L.k41 = tn_key4(rB);
     // the swizzle makes a fragment's address lane-dependent in a way no immediate can carry: 18 per-lane offsets, computed once
-    int xo[3][2], dofs[6][2];
+    int xo[3][2], dofs[MTN][2];
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) xo[nt][0] = tr_off(L, wc * 3 + nt, 0), xo[nt][1] = tr_off(L, wc * 3 + nt, 1);
 #pragma unroll
-    for (int mt = 0; mt < 6; ++mt) dofs[mt][0] = tr_off(L, wr * 6 + mt, 0), dofs[mt][1] = tr_off(L, wr * 6 + mt, 1);
+    for (int mt = 0; mt < MTN; ++mt) dofs[mt][0] = tr_off(L, wr * MTN + mt, 0), dofs[mt][1] = tr_off(L, wr * MTN + mt, 1);
 
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    f32x4 acc[6][3];                                      // [mt: 16 p columns each][nt: 16 k columns each]
+    f32x4 acc[MTN][3];                                      // [mt: 16 p columns each][nt: 16 k columns each]
 #pragma unroll
-    for (int mt = 0; mt < 6; ++mt)
+    for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const _Float16 sh = (_Float16)(1.0f / kHalvesShift);
 
     issue(0, 0);
     if (T > 1) issue(1, 1);
-    if (T > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // step 0 landed, step 1 may still be in flight
+    if (T > 1) {                                                      // step 0 landed, step 1 may still be in flight
+        if constexpr (kDma == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int stage = 0;
@@ -535,15 +543,18 @@ __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnT
             x1s[nt] = x1[nt] * sh;
         }
 #pragma unroll
-        for (int mt = 0; mt < 6; ++mt) {
+        for (int mt = 0; mt < MTN; ++mt) {
             const half8 d1 = tr_pack(dl[mt & 1][0], dh[mt & 1][0]);
             const half8 d2 = tr_pack(dl[mt & 1][1], dh[mt & 1][1]);
             const half8 d1s = d1 * sh;
-            if (mt + 1 < 6) {                 // the next tile row's fragments, requested before this row's MFMAs
+            if (mt + 1 < MTN) {               // the next tile row's fragments, requested before this row's MFMAs
                 tr_issue<2 * kTnPiece>(dl[(mt + 1) & 1][0], dh[(mt + 1) & 1][0], sb + dofs[mt + 1][0], sb + dofs[mt + 1][1]);
                 tr_issue<3 * kTnPiece>(dl[(mt + 1) & 1][1], dh[(mt + 1) & 1][1], sb + dofs[mt + 1][0], sb + dofs[mt + 1][1]);
             }
-            if (ahead) issue_one(mt, s2, kt + 2);
+            if (ahead) {
+                issue_one(mt, s2, kt + 2);
+                if (kDma > MTN && mt == 0) issue_one(MTN, s2, kt + 2);      // (five instructions over four tile rows)
+            }
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
                 // D[i = p column][j = k column]: a lane holds 4 consecutive p of one k (float4 stores along p)
@@ -551,26 +562,30 @@ __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnT
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d2, x1s[nt], acc[mt][nt], 0, 0, 0);
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1s, x2[nt], acc[mt][nt], 0, 0, 0);
             }
-            if (mt + 1 < 6) tr_wait();
+            if (mt + 1 < MTN) tr_wait();
         }
         // step kt + 1 must have landed before anyone reads it; step kt + 2 (this wave's 6 youngest instructions) may stay in flight
         if (!(p.mode & 2)) {
-            if (ahead) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ahead) {
+                if constexpr (kDma == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
         }
         stage = stage == 2 ? 0 : stage + 1;
     }
     // acc[mt][nt][r] = partial of dW[k = xc + wc 48 + nt 16 + (lane & 15)][p = dc + wr 96 + mt 16 + (lane >> 4) 4 + r]
     if constexpr (GROUPED) {
-        float* out = p.part + ((int64_t)split * tps + tile) * (TT * TT);       // the tile's own [192][192] block
+        float* out = p.part + ((int64_t)split * tps + tile) * (TT * PT);       // the tile's own [192][PT] block
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             const int k = wc * 48 + nt * 16 + (lane & 15);
 #pragma unroll
-            for (int mt = 0; mt < 6; ++mt) {
-                const int pc = wr * 96 + mt * 16 + (lane >> 4) * 4;
-                *reinterpret_cast<float4*>(out + k * TT + pc) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+            for (int mt = 0; mt < MTN; ++mt) {
+                const int pc = wr * (PT / 2) + mt * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<float4*>(out + k * PT + pc) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
             }
         }
     } else {
@@ -580,7 +595,7 @@ __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnT
             const int k = xc + wc * 48 + nt * 16 + (lane & 15);
             if (k >= p.KP) continue;
 #pragma unroll
-            for (int mt = 0; mt < 6; ++mt) {
+            for (int mt = 0; mt < MTN; ++mt) {
                 const int pc = dc + wr * 96 + mt * 16 + (lane >> 4) * 4;
                 if (pc < p.PP) *reinterpret_cast<float4*>(out + (int64_t)k * p.PP + pc) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
             }
@@ -588,13 +603,14 @@ __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnT
     }
 }
 
-__global__ __launch_bounds__(512) void gemm_halves3_tn_kernel(TnArgs3 p) { gemm_halves3_tn_body<false>(p, nullptr); }
-__global__ __launch_bounds__(512) void gemm_halves3_tn_grouped_kernel(TnArgs3 p, TnTiles tiles) { gemm_halves3_tn_body<true>(p, &tiles); }
+__global__ __launch_bounds__(512) void gemm_halves3_tn_kernel(TnArgs3 p) { gemm_halves3_tn_body<false, 192>(p, nullptr); }
+template <int PT>
+__global__ __launch_bounds__(512) void gemm_halves3_tn_grouped_kernel(TnArgs3 p, TnTiles tiles) { gemm_halves3_tn_body<true, PT>(p, &tiles); }
 
 // grouped: out[out_off + k ldo + p] = scale_x[1] scale_d[1] * sum_s part[s][tile][k][p]   (split order), k < k_valid, p < p_valid
 __global__ __launch_bounds__(256) void tn_reduce_h3_grouped_kernel(const float* part, int splits, int n_tiles, TnTiles tiles, const float* scale_x,
-                                                                   const float* scale_d, float* out) {
-    constexpr int P4 = TT / 4;
+                                                                   const float* scale_d, float* out, int PT) {
+    const int P4 = PT / 4;
     const int tile = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= TT * P4) return;
@@ -603,8 +619,8 @@ __global__ __launch_bounds__(256) void tn_reduce_h3_grouped_kernel(const float* 
     if (k >= t.k_valid || pc >= t.p_valid) return;
     const float alpha = scale_x[1] * scale_d[1];
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* src = part + (int64_t)tile * (TT * TT) + k * TT + pc;
-    const int64_t sstride = (int64_t)n_tiles * (TT * TT);
+    const float* src = part + (int64_t)tile * (TT * PT) + k * PT + pc;
+    const int64_t sstride = (int64_t)n_tiles * (TT * PT);
     constexpr int U = 4;                                    // loads in flight; added in split order
     for (int s0 = 0; s0 < splits; s0 += U) {
         float4 v[U];
@@ -770,10 +786,14 @@ extern "C" int bot_gemm_halves3_tn_grouped_f32(int64_t n_rows, const float* scal
     a.splits = splits, a.rows_per_split = rps;
     a.mode = mode;
     BOT_REQUIRE((int64_t)rps * std::max(ldx, ldd) * 2 < (1ll << 31), -1, "gemm_halves3_tn_grouped: a split of %d rows exceeds the 2 GiB a buffer descriptor spans", rps);
-    set_kernel("bot::gemm_halves3_tn_grouped_kernel");
-    hipLaunchKernelGGL(gemm_halves3_tn_grouped_kernel, dim3(((splits + 7) / 8) * 8 * n_tiles), dim3(512), 0, (hipStream_t)stream, a, tl);
-    hipLaunchKernelGGL(tn_reduce_h3_grouped_kernel, dim3((TT * (TT / 4) + 255) / 256, n_tiles), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits,
-                       (int)n_tiles, tl, scale_x, scale_d, out);
+    int pmax = 0;
+    for (int i = 0; i < n_tiles; ++i) pmax = std::max(pmax, tl.t[i].p_valid);
+    const int PT = pmax <= 128 ? 128 : TT;      // narrow d blocks: 192 x 128 tiles
+    set_kernel("bot::gemm_halves3_tn_grouped_kernel<%d>", PT);
+    if (PT == 128) hipLaunchKernelGGL(gemm_halves3_tn_grouped_kernel<128>, dim3(((splits + 7) / 8) * 8 * n_tiles), dim3(512), 0, (hipStream_t)stream, a, tl);
+    else hipLaunchKernelGGL(gemm_halves3_tn_grouped_kernel<192>, dim3(((splits + 7) / 8) * 8 * n_tiles), dim3(512), 0, (hipStream_t)stream, a, tl);
+    hipLaunchKernelGGL(tn_reduce_h3_grouped_kernel, dim3((TT * (PT / 4) + 255) / 256, n_tiles), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits,
+                       (int)n_tiles, tl, scale_x, scale_d, out, PT);
     return hip_status("gemm_halves3_tn_grouped");
 }
 

@@ -464,17 +464,19 @@ def _l0_tables(H, D, Fin, P2, kp, N):
         fwd = [(h * D, D, 0, h * FP, 2 * FP // 32, h * D) for h in range(H)]
         # d z_h [N, Fin] = d rst_h [N, D] W_h [D, Fin]: A columns h DP .., B rows h Fin .. (W_h^T), output slab h
         dz = [(h * Fin, Fin, 0, h * DP, DP // 32, h * N * Fin) for h in range(H)]
-        # weight gradients: x-role = the gradient operand's head blocks, d-role = [x | z_0 .. z_{H-1}]
+        # weight gradients: x-role (192-column tiles) = [x | z_0 .. z_{H-1}] (Fin of FP columns used), d-role = the gradient operand's head
+        # blocks in 128-column tiles (DP = 256: two per head, 128 and D - 128 columns used): 192 x 128 tiles, 15 % padding (the other way
+        # round - 192-column tiles over a head's 250 columns - pads 43 %)
         tn = []
         for h in range(H):
-            for j in range((D + 191) // 192):
-                kv = min(192, D - 192 * j)
-                col = h * D + 192 * j                                # row of d W / column of the merged gradient
-                tn.append((h * DP + 192 * j, kv, FP * (1 + h), Fin, col * Fin, Fin, 0))                 # d W_h = d rst_h^T z_h
+            for j in range((D + 127) // 128):
+                pv = min(128, D - 128 * j)
+                col = h * D + 128 * j                                # row of d W / column of the merged gradient
+                tn.append((FP * (1 + h), Fin, h * DP + 128 * j, pv, col * Fin, Fin, 1))                  # d W_h [D, Fin] = (z_h^T d rst_h)^T
                 if kp:
-                    tn.append((h * DP + 192 * j, kv, 0, Fin, HD * Fin + col, P2, 1))                       # d Wres^T [Fin, P2]: written transposed
+                    tn.append((0, Fin, h * DP + 128 * j, pv, HD * Fin + col, P2, 0))                       # d Wres^T [Fin, P2] = x^T d rst
                 else:
-                    tn.append((h * DP + 192 * j, kv, 0, Fin, HD * Fin + col * Fin, Fin, 0))               # d Wres [P2, Fin]
+                    tn.append((0, Fin, h * DP + 128 * j, pv, HD * Fin + col * Fin, Fin, 1))               # d Wres [P2, Fin]
         _L0_TABLES[key] = (FP, DP, fwd, dz, tn)
     return _L0_TABLES[key]
 
@@ -483,7 +485,7 @@ def _l0_halves_ok(h, H, D, Fin, has_res, sym, attn_p, graph) -> bool:
     """The grouped-halves form of the aggregate-first layer: needs the residual branch (its columns are the launch's output), row sums of
     the edge weights <= 1 / (1 - attn_p) < 4 (the slab shares x's scale: fp16 has two binades of headroom above it) and the hand-written
     kernels as the halves path."""
-    return (L0_HALVES and (h.is_cuda or FORCE) and has_res and not sym and attn_p <= 0.7 and D <= 256 and Fin <= 256 and H * 2 * ((D + 191) // 192) <= 16
+    return (L0_HALVES and (h.is_cuda or FORCE) and has_res and not sym and attn_p <= 0.7 and D <= 256 and Fin <= 192 and H * 2 * ((D + 127) // 128) <= 16
             and gemm.MODE == "halves" and gemm.NT_KERNEL == "halves3" and gemm.TN_KERNEL == "halves3" and (h.shape[0] >= gemm.MIN_ROWS or gemm.FORCE or FORCE))
 
 
@@ -729,7 +731,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             # every weight gradient from ONE grouped launch over the head blocks: d W_h = d rst_h^T z_h and the residual rows / columns of
             # the merged gradient d rst^T x (written in Wr's layout); the attention columns (a handful, their own magnitude) apart
             flat = torch.empty(HD * Fin + P2 * Fin, dtype=h.dtype, device=h.device)
-            _C.gemm_halves3_tn_grouped(Dh, z, dscale, xscale, H * DP, (1 + H) * FP, flat, t_tn)
+            _C.gemm_halves3_tn_grouped(z, Dh, xscale, dscale, (1 + H) * FP, H * DP, flat, t_tn)
             dW = flat[:HD * Fin].view(HD, Fin)
             dWr = flat[HD * Fin:].view((Fin, P2) if kp else (P2, Fin))
             tail = dout2[:, HD:]

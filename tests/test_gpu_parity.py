@@ -1664,9 +1664,9 @@ def test_grouped_halves_kernels(golden):
         assert e < 2e-6
         # weight gradients
         flat = torch.full((HD * Fin + P2 * Fin,), 9.0, device=DEV)
-        _C.gemm_halves3_tn_grouped(Dh, A, sa, sb, H * DP, KA, flat, t_tn)
+        _C.gemm_halves3_tn_grouped(A, Dh, sb, sa, KA, H * DP, flat, t_tn)
         ref = torch.full((HD * Fin + P2 * Fin,), 9.0, dtype=torch.float64)
-        OB.gemm_halves3_tn_grouped(Dh.cpu(), A.cpu(), sa.cpu(), sb.cpu(), H * DP, KA, ref, t_tn)
+        OB.gemm_halves3_tn_grouped(A.cpu(), Dh.cpu(), sb.cpu(), sa.cpu(), KA, H * DP, ref, t_tn)
         dW, dWr = flat[:HD * Fin], flat[HD * Fin:].view((Fin, P2) if kp else (P2, Fin))
         rW, rWr = ref[:HD * Fin], ref[HD * Fin:].view((Fin, P2) if kp else (P2, Fin))
         e1 = float((dW.cpu() - rW).abs().max() / rW.abs().max())
@@ -1677,8 +1677,20 @@ def test_grouped_halves_kernels(golden):
         tail = (dWr[:, HD:] if kp else dWr[HD:])
         assert bool((tail == 9.0).all()), "wrote outside the tiles' blocks"
         flat2 = torch.empty_like(flat)
-        _C.gemm_halves3_tn_grouped(Dh, A, sa, sb, H * DP, KA, flat2, t_tn)
+        _C.gemm_halves3_tn_grouped(A, Dh, sb, sa, KA, H * DP, flat2, t_tn)
         assert torch.equal(flat2[:HD * Fin], dW)
+        # the 192 x 192 tile form of the same launch (a tile list with a d block wider than 128 columns selects it): x-role = the gradient
+        # operand's head blocks in 192-column tiles, d-role = [x | z_h]
+        t192 = []
+        for h in range(H):
+            for j in range((D + 191) // 192):
+                kv = min(192, D - 192 * j)
+                t192.append((h * DP + 192 * j, kv, FP * (1 + h), Fin, (h * D + 192 * j) * Fin, Fin, 0))
+        big = torch.full((HD * Fin,), 9.0, device=DEV)
+        _C.gemm_halves3_tn_grouped(Dh, A, sa, sb, H * DP, KA, big, t192)
+        e3 = float((big.cpu() - rW).abs().max() / rW.abs().max())
+        print(f"tn_grouped, 192 x 192 tiles: d W {e3:.2e}")
+        assert e3 < 3e-6
     with pytest.raises(_C.BotKernelError):
         _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, out, [(0, 300, 0, 0, 1, 0)], 0)        # a group wider than a tile
     # --- bot_halves_split_heads_f16 == H calls of halves_split_cols(order 2) on column slices (a row-strided source, odd D too)
