@@ -161,6 +161,21 @@ def mm_nt(a: Halves, b: Halves, out=None):
     return _C.gemm_halves(a.buf, b.buf, _alpha(a, b, b.n), trans_b=True, out=out)
 
 
+TN_NARROW = os.environ.get("BOT_GEMM_TN_NARROW", "1") != "0"
+_TN_TILES = {}
+
+
+def _tn_tiles(K: int, P: int):
+    """The regular tile grid of a [K, P] result as a tile list of bot_gemm_halves3_tn_grouped_f32 (None: more than its 16 tiles)."""
+    key = (K, P)
+    if key not in _TN_TILES:
+        pt = 128 if (P + 127) // 128 * ((K + 191) // 192) <= 16 else 192
+        tiles = [(192 * i, min(192, K - 192 * i), pt * j, min(pt, P - pt * j), 192 * i * P + pt * j, P, 0)
+                 for i in range((K + 191) // 192) for j in range((P + pt - 1) // pt)]
+        _TN_TILES[key] = tiles if len(tiles) <= 16 else None
+    return _TN_TILES[key]
+
+
 def tn(x: Halves, d: Halves):
     """x^T d for two LEFT-operand layouts x [N, K], d [N, P] (order 0 or 2 each): the weight gradient, a reduction over the N rows.
     Row chunks of CHUNK_ROWS are batch entries (x1^T [d1 | d2] and x2^T d1 per chunk), the partial products are added
@@ -169,6 +184,13 @@ def tn(x: Halves, d: Halves):
     N, K, P, KP, PP = x.n, x.F, d.F, x.piece, d.piece
     if TN_KERNEL == "halves3" and KP * PP >= TN_MIN_OUT:      # enough 192 x 192 output tiles x row splits to fill the chip
         return _C.gemm_halves3_tn(x.buf, d.buf, x.scale, d.scale, KP, PP, K, P, x2_off=x.h2_off, d2_off=d.h2_off)
+    if TN_KERNEL == "halves3" and TN_NARROW and N >= 8192:
+        # a narrow result (the 40-class output layer's [750, 240]): the grouped form of the kernel takes a tile LIST, so the same grid of
+        # tiles (192 x 128 when P allows) runs with as many row splits as fill the chip (8 tiles x 32 splits here, not x 8)
+        tiles = _tn_tiles(K, P)
+        if tiles is not None:
+            out = torch.empty((K, P), dtype=torch.float32, device=x.buf.device)
+            return _C.gemm_halves3_tn_grouped(x.buf, d.buf, x.scale, d.scale, x.h2_off, d.h2_off, out, tiles)
     alpha = _alpha(x, d, 2 * PP)                # one value per output column; the narrower products take a prefix
     S = max(1, N // CHUNK_ROWS)
     R = N // S

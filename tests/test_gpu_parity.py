@@ -1570,7 +1570,7 @@ def test_gemm_halves3_nt_kernel():
     # fp64 next to the library formulation (batched chunk products + combine): ragged row counts (the last step of the last split is
     # zero-filled by the buffer descriptor), piece widths that are not multiples of the tile, narrow and wide results, one and eight splits
     assert gemm.TN_KERNEL == "halves3"
-    for (n, K, P) in ((4099, 750, 1536), (20000, 1536, 750), (33, 64, 40), (50001, 168, 250), (40000, 100, 968), (169343 // 4, 750, 1536)):
+    for (n, K, P) in ((4099, 750, 1536), (20000, 1536, 750), (33, 64, 40), (50001, 168, 250), (40000, 100, 968), (169343 // 4, 750, 1536), (30011, 750, 240)):
         x = torch.randn(n, K, device=DEV, generator=gen) * 3
         d = torch.randn(n, P, device=DEV, generator=gen) * 1e-3
         d[:, ::3] = 0
@@ -1583,9 +1583,22 @@ def test_gemm_halves3_nt_kernel():
             lib = gemm.tn(xs, ds)
         finally:
             gemm.TN_KERNEL = "halves3"
-        x2, d2 = left(x, 2), left(d, 2)          # both, or either, without the duplicate piece: the same bits (either route of gemm.tn)
+        # gemm.tn's routes: wide results on the plain kernel, narrow ones of >= 8192 rows on its grouped form (the same tile grid as a
+        # list, 192 x 128 tiles, more row splits: other partial sums, so held to fp64 instead of bitwise), the rest on the library
+        # formulation; operands with or without the duplicate piece give the same bits on every route
+        big = xs.piece * ds.piece >= gemm.TN_MIN_OUT
+        routed = gemm.tn(xs, ds)
+        if big:
+            assert torch.equal(routed, got)
+        elif n >= 8192 and gemm._tn_tiles(K, P) is not None:
+            er = float((routed.double() - ref).abs().max() / ref.abs().max())
+            print(f"gemm.tn n={n} K={K} P={P} on the grouped kernel ({len(gemm._tn_tiles(K, P))} tiles): err {er:.2e}")
+            assert er <= 4e-6 and not torch.equal(routed, lib)
+        else:
+            assert torch.equal(routed, lib)
+        x2, d2 = left(x, 2), left(d, 2)
         for (a, b) in ((x2, d2), (x2, ds), (xs, d2)):
-            assert torch.equal(gemm.tn(a, b), got if xs.piece * ds.piece >= gemm.TN_MIN_OUT else lib)
+            assert torch.equal(gemm.tn(a, b), routed)
         sc = float(ref.abs().max())
         e, el = float((got.double() - ref).abs().max()) / sc, float((lib.double() - ref).abs().max()) / sc
         print(f"gemm_halves3_tn n={n} K={K} P={P}: err {e:.2e} (library formulation: {el:.2e})")
