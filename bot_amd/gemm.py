@@ -82,31 +82,42 @@ _STASH = {}
 STATS = {"stashed": 0, "taken": 0, "split": 0}   # how often an epilogue's halves were reused (tests, tools)
 
 
+_MAX_STASH = 4    # live entries kept (each holds an operand buffer): a second model or a recompute may interleave; older ones are dropped
+
+
 def stash(y, h: Halves):
     """The halves of `y` were produced together with it (fused BatchNorm epilogue): the next projection takes them from here
-    instead of splitting y again.  One entry at a time per tensor identity; consumed by `take`."""
-    _STASH.clear()
+    instead of splitting y again.  Keyed per tensor identity (a stash of another tensor no longer destroys this one), entries
+    of dead tensors are pruned, at most _MAX_STASH live ones are kept (a dropped entry costs a re-split, or - for a halves-only hidden
+    state - the loud error of `take`); consumed by `take`."""
+    for k in [k for k, (ref, _) in _STASH.items() if ref() is None]:
+        del _STASH[k]
+    while len(_STASH) >= _MAX_STASH:
+        del _STASH[next(iter(_STASH))]
     _STASH[(y.data_ptr(), y._version, tuple(y.shape))] = (weakref.ref(y), h)   # y itself must still be alive when the halves are taken
     STATS["stashed"] += 1
 
 
-_HANDLES = {}   # data_ptr of a handle's one-element base -> the base (held: its address cannot be recycled while it is listed)
-_MAX_HANDLES = 64  # a handle lives from one layer's epilogue to the next layer's projection; older bases are dropped
+# data_ptr of a handle's one-element base -> the base, WEAKLY: the entry lives exactly as long as the base does - i.e. as long as any
+# view of it (the handle, `._base`) is alive - so a live handle is never mistaken for data (ADVICE r3: the bounded FIFO that this replaces
+# could evict a live handle's base, after which `take` would have split the zeros placeholder into an all-zero operand), and an address
+# recycled after the base died is not mistaken for a handle
+_HANDLES = weakref.WeakValueDictionary()
 
 
 def make_handle(like, n: int, F: int):
     """The stand-in for a hidden state that exists as fp16 halves only (bot_amd.nn.fused._epilogue_forward): zeros of shape [n, F] on
     ONE element (strides 0, 0) — initialised memory, the autograd edge and the key of the stashed halves.  Registered by the address
-    of its base, so that `take` tells it from a caller's own broadcast tensor."""
-    while len(_HANDLES) >= _MAX_HANDLES:
-        del _HANDLES[next(iter(_HANDLES))]
+    of its base, so that `take` tells it from a caller's own broadcast tensor; the handle also carries the mark `_bot_handle`."""
     base = like.new_zeros(1)
     _HANDLES[base.data_ptr()] = base
-    return base.expand(n, F)
+    h = base.expand(n, F)
+    h._bot_handle = True
+    return h
 
 
 def is_handle(x) -> bool:
-    return x.dim() == 2 and x.stride(0) == 0 and x.stride(1) == 0 and x.data_ptr() in _HANDLES
+    return x.dim() == 2 and x.stride(0) == 0 and x.stride(1) == 0 and (getattr(x, "_bot_handle", False) or x.data_ptr() in _HANDLES)
 
 
 _SCALES = {}

@@ -437,6 +437,30 @@ def test_absmax_byproducts_emulated(golden, cpu_backend):
     PC.check_absmax_byproducts(golden, "cpu")
 
 
+def test_halves_handles_and_stash_bookkeeping(cpu_backend):
+    """(a) a LIVE halves-only handle is never mistaken for data — more live handles than the old 64-entry registry held,
+    re-wrapped ones (detach) included — and a dead handle's recycled address is not mistaken for a handle; (b) stashing the halves of
+    another tensor does not destroy an unconsumed stash; a handle whose halves are gone raises instead of becoming a zero operand."""
+    import gc
+    from bot_amd import gemm
+    like = torch.zeros(3)
+    hs = [gemm.make_handle(like, 4, 6) for _ in range(200)]
+    assert all(gemm.is_handle(h) and gemm.is_handle(h.detach()) for h in hs)
+    assert not gemm.is_handle(torch.zeros(1).expand(4, 6))                     # a caller's own broadcast tensor is data
+    n_live = len(gemm._HANDLES)
+    del hs
+    gc.collect()
+    assert len(gemm._HANDLES) <= n_live - 200
+    ya, yb = torch.randn(8, 64), torch.randn(8, 64)
+    ha, hb = gemm.split(ya, 0), gemm.split(yb, 0)
+    gemm.stash(ya, ha)
+    gemm.stash(yb, hb)                                                          # (used to clear ya's entry)
+    assert gemm.take(ya, 0) is ha and gemm.take(yb, 0) is hb
+    h = gemm.make_handle(like, 8, 64)
+    with pytest.raises(RuntimeError):
+        gemm.take(h, 0)
+
+
 def test_halves_only_hidden_states_emulated(golden, cpu_backend):
     PC.check_halves_only_hidden_states(golden, "cpu")
 
