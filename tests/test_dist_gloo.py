@@ -104,6 +104,9 @@ def _worker(rank, world, port, kind, tmp, fuse=False, halves=False, overlap=True
         loss, pred = bdist.forward_backward(model, part, use_labels=True, loss="loge", n_classes=C, mask=mask_full[tr_own])
         assert (fused.CALLS > calls0) == (fuse and kind == "gat_plain"), (fused.CALLS, calls0)
         assert (fused.AGG_CALLS > 0) == (fuse and kind == "gat_plain")
+        # ... and that node ran its grouped-halves form (v16: halo rows in the gather table, sync-BatchNorm sums reduced across ranks before
+        # the bound of its direct gradient operand)
+        assert (fused.L0_CALLS > 0) == (fuse and kind == "gat_plain")
         assert (fused.OVERLAP_CALLS > 0) == (fuse and kind == "gat_plain" and overlap), fused.OVERLAP_CALLS
         # the modular layers (GraphConv, GATConv outside the fused node) take bot_amd.halo's overlapped sums
         modular = kind in ("gat", "gcn") or not fuse
