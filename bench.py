@@ -451,9 +451,9 @@ def main():
         if gs:
             g_ms = sum(r[2].elapsed_time(r[3]) for r in gs)
             g_fl = sum(2.0 * r[1][0] * r[1][1] * r[1][2] * r[1][3] for r in gs)
-            roof["dense_projections"] = {"bound": "mfma", "what": "the halves-GEMM launches (bot_gemm_halves3_nt_f32 / _tn_f32 and their grouped forms: hand-written NT / TN products; bot_gemm_halves_f32: "
-                                                 "hipBLASLt fp16 -> fp32 for the output layer's weight gradient) of three more steps after the timed region (HIP events); flops = fp16 MFMA "
-                                                 "flops of the valid output columns, three products per fp32 product",
+            roof["dense_projections"] = {"bound": "mfma", "what": "the halves-GEMM launches (bot_gemm_halves3_nt_f32 / _tn_f32 and their grouped forms: hand-written NT / TN products; bot_gemm_halves_f32, "
+                                                 "hipBLASLt fp16 -> fp32, where a shape is left to it: none in config 2) of three more steps after the timed region (HIP events); flops = "
+                                                 "fp16 MFMA flops of the valid output columns, three products per fp32 product",
                                          "launches_per_step": len(gs) / gsteps, "ms_per_step": round(g_ms / gsteps, 3),
                                          "achieved": round(g_fl / g_ms / 1e9, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                          "frac": round(g_fl / g_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, 4),
