@@ -502,8 +502,9 @@ def main():
             "value_without_optimizer": None if opt_ms is None else wl.n_edges / ((ms - opt_ms) * 1e-3),
             "config": {"workload": wl.describe,
                        "gemm": ("fp32 operands as two fp16 halves each (h1 + h2 = 22-23 of the 24 significand bits, power-of-two scale found "
-                                "on the device), a1 b1 + a1 b2 + a2 b1 as one fp16 MFMA GEMM with fp32 accumulation; error against fp64 equal "
-                                "to the stock fp32 GEMM's (tests/test_gpu_parity.py::test_gemm_halves_against_fp64); --gemm f32 = stock fp32")
+                                "on the device), a1 b1 + a1 b2 + a2 b1 on the fp16 MFMAs with fp32 accumulation (hand-written gfx950 kernels, csrc/halves3.hip: each "
+                                "operand half staged once, three MFMAs per fragment pair); error against fp64 equal to the stock fp32 GEMM's "
+                                "(tests/test_gpu_parity.py::test_gemm_halves_against_fp64); --gemm f32 = stock fp32")
                        if gemm.MODE == "halves" else "stock fp32 GEMM (hipBLASLt / rocBLAS)",
                        "gemm_kernel_selection": "TunableOp file" if tuned else "library default",
                        "scale": args.scale, "launch": "one hipGraph replay per step" if wl.captured else "eager",
