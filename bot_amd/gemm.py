@@ -29,7 +29,7 @@ TN_KERNEL = os.environ.get("BOT_GEMM_TN", "halves3")   # weight gradients (reduc
 # that still go to the library.
 LEFT_NODUP = NT_KERNEL == "halves3" and TN_KERNEL == "halves3" and os.environ.get("BOT_HALVES_DUP", "0") != "1"
 NODUP_MIN_PIECE = 256
-TN_MIN_OUT = 512 * 1024                                # smaller results (the 40-class output layer: 768 x 128) stay on the library
+TN_MIN_OUT = 512 * 1024                                # smaller results (the 40-class output layer) go to the kernel's grouped form with more row splits (TN_NARROW), else the library
 NT_MIN_COLS = 192                                      # narrower outputs (the 40-class output layer) leave most of a 256-column tile empty: library
 LINEAR_BLOCKS = os.environ.get("BOT_LINEAR_BLOCKS", "1") != "0"   # merged projections hand their column blocks' gradients over without a `cat`
 FORCE = False              # tests set this to run the halves path over the emulated (CPU) backend at any row count
