@@ -449,7 +449,9 @@ def _l0_dh(device, N, H, DP):
     key = (str(device), N, H, DP)
     buf = _L0_DH.get(key)
     if buf is None:
-        buf = _L0_DH[key] = torch.zeros((N, 2 * H * DP), dtype=torch.float16, device=device)
+        buf = torch.zeros((N, 2 * H * DP), dtype=torch.float16, device=device)
+        if not (buf.is_cuda and torch.cuda.is_current_stream_capturing()):     # (a buffer born inside a capture belongs to that graph's pool)
+            _L0_DH[key] = buf
     return buf
 
 
