@@ -1621,9 +1621,8 @@ def test_grouped_halves_kernels(golden):
     gen = torch.Generator(device=DEV).manual_seed(23)
     # --- (1)
     s_, d_, n = golden.graph("g300")
-    for chunk in (8, 4096):
+    for chunk, (H, Fin, FP) in ((8, (3, 22, 64)), (4096, (3, 22, 64)), (8, (1, 7, 64)), (4096, (4, 64, 64)), (16, (2, 168, 192)), (4096, (3, 250, 256))):
         g = bot_amd.Graph(s_, d_, n, chunk=chunk).to(DEV)
-        H, Fin, FP = 3, 22, 64
         x = torch.randn(n, Fin, device=DEV, generator=gen)
         w = torch.rand(g.number_of_edges(), H, device=DEV, generator=gen)
         scale = _C.halves_scale(x * 40)
@@ -1633,7 +1632,7 @@ def test_grouped_halves_kernels(golden):
         z = _C.spmm_bcast(g.csc, x, w, None, head_outer=True)
         for h in range(H):
             ref = _C.halves_split(z[h], scale, 2, FP)
-            assert torch.equal(A[:, FP * (1 + h):FP * (2 + h)], ref[:, :FP]) and torch.equal(A[:, KA + FP * (1 + h):KA + FP * (2 + h)], ref[:, FP:])
+            assert torch.equal(A[:, FP * (1 + h):FP * (2 + h)], ref[:, :FP]) and torch.equal(A[:, KA + FP * (1 + h):KA + FP * (2 + h)], ref[:, FP:]), (chunk, H, Fin)
         assert bool((A[:, :FP] == 7.0).all()) and bool((A[:, KA:KA + FP] == 7.0).all())       # x's columns are not the SpMM's
     # --- (2) + (3) at a shape with every raggedness of config 2: H = 3, D = 250, Fin = 168, N not a multiple of anything
     for (N, H, D, Fin, kp) in ((20011, 3, 250, 168, True), (5000, 2, 70, 40, False)):
@@ -1761,6 +1760,73 @@ def test_grouped_halves_kernels(golden):
         again = torch.empty_like(view)
         _C.tn_narrow(buf[:, 7:], y, again, transpose_out=tr)
         assert torch.equal(again, view)
+
+
+def test_grouped_halves_kernels_random_lists():
+    """Random group / tile lists for the two grouped halves kernels (the layer only ever builds the regular ones of fused._l0_tables and
+    gemm._tn_tiles): ragged n_valid / k_valid / p_valid, odd output offsets (the float4 / float2 / scalar store paths), every k_seg
+    position, one to twelve groups, one to sixteen tiles of both tile widths, few and many rows (one split / many) — each against
+    tests/_oracle_backend.py's float64 restatement from the same fp16 operands, and untouched output around the blocks."""
+    import random
+    from tests import _oracle_backend as OB
+    rnd = random.Random(5)
+    gen = torch.Generator(device=DEV).manual_seed(29)
+    sa, sb = torch.tensor([2.0, 0.5], device=DEV), torch.tensor([0.25, 4.0], device=DEV)
+    for trial in range(24):
+        m = rnd.choice([1, 37, 256, 300, 1000, 4099])
+        ka, kb = rnd.choice([64, 192, 384]), rnd.choice([64, 128, 384])
+        a2, b2 = ka + rnd.choice([0, 64]), kb + rnd.choice([0, 32])
+        A = (torch.randn(m, a2 + ka, device=DEV, generator=gen) * 9).half()
+        nb = rnd.choice([5, 100, 256, 700])
+        B = torch.randn(nb, b2 + kb, device=DEV, generator=gen) * 5
+        B[:, b2:] /= 2048
+        B = B.half()
+        ld = rnd.choice([1030, 1031, 1032])
+        out = torch.full((m, ld), 6.0, device=DEV)
+        groups, col = [], rnd.choice([0, 1, 2, 3])
+        k_seg = rnd.choice([0, 1, 2])
+        for _ in range(rnd.randint(1, 12)):
+            steps = rnd.randint(1, min(ka, kb) // 32)
+            nv = rnd.choice([1, 3, 4, 60, 250, 256])
+            if col + nv > ld or len(groups) == 12:
+                break
+            a0 = 8 * rnd.randint(0, (ka - 32 * min(k_seg, steps)) // 8) if k_seg else 0
+            a1 = 8 * rnd.randint(0, (ka - 32 * steps) // 8)
+            groups.append((rnd.randint(0, nb - 1), nv, a0, a1, steps, col))
+            col += nv + rnd.choice([0, 1, 5])
+        if not groups:
+            continue
+        _C.gemm_halves3_nt_grouped(A, B, sa, sb, a2, b2, out, groups, k_seg)
+        ref = torch.full((m, ld), 6.0, dtype=torch.float64)
+        # the restatement reads B rows b_row0 .. b_row0 + n_valid - 1; rows past the end of B repeat its last row (the kernel clamps)
+        Bc = torch.cat([B.cpu(), B.cpu()[-1:].expand(256, -1)])
+        OB.gemm_halves3_nt_grouped(A.cpu(), Bc, sa.cpu(), sb.cpu(), a2, b2, ref, groups, k_seg)
+        err = float((out.cpu().double() - ref).abs().max() / max(1e-30, float(ref.abs().max())))
+        assert err < 3e-6, (trial, err, groups, k_seg)
+        # TN
+        n = rnd.choice([33, 1000, 5000, 20011])
+        kx, kd = rnd.choice([192, 448]), rnd.choice([128, 192, 320])
+        x2, d2 = kx + rnd.choice([0, 64]), kd + rnd.choice([0, 64])
+        X = (torch.randn(n, x2 + kx, device=DEV, generator=gen) * 7).half()
+        Dm = (torch.randn(n, d2 + kd, device=DEV, generator=gen) * 3).half()
+        pt = rnd.choice([128, 192])
+        tiles, off = [], rnd.choice([0, 1, 2])
+        for _ in range(rnd.randint(1, 16)):
+            kv, pv = rnd.choice([1, 58, 168, 192]), rnd.choice([1, 4, 122, 128] if pt == 128 else [5, 168, 192])
+            if kv > kx or pv > kd:
+                continue
+            tr = rnd.choice([0, 1])
+            ldo = (kv if tr else pv) + rnd.choice([0, 3])
+            tiles.append((8 * rnd.randint(0, (kx - kv) // 8), kv, 8 * rnd.randint(0, (kd - pv) // 8), pv, off, ldo, tr))
+            off += (pv if tr else kv) * ldo + rnd.choice([0, 7])
+        if not tiles:
+            continue
+        flat = torch.full((off + 8,), 2.0, device=DEV)
+        _C.gemm_halves3_tn_grouped(X, Dm, sa, sb, x2, d2, flat, tiles)
+        ref = torch.full((off + 8,), 2.0, dtype=torch.float64)
+        OB.gemm_halves3_tn_grouped(X.cpu(), Dm.cpu(), sa.cpu(), sb.cpu(), x2, d2, ref, tiles)
+        err = float((flat.cpu().double() - ref).abs().max() / max(1e-30, float(ref.abs().max())))
+        assert err < 3e-6, (trial, err, tiles)
 
 
 def test_step_glue_kernels():
