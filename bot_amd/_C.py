@@ -83,7 +83,7 @@ _SIGS = {
     "bot_gemm_halves3_tn_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P,
                                                c_int64, _P, c_int32, _P]),
     "bot_gemm_halves3_nt_grouped_f32": (ctypes.c_int, [c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int32, _P,
-                                                       c_int32, c_int32, _P]),
+                                                       c_int32, _P, _P, c_int32, _P, c_int32, _P]),
     "bot_gemm_halves3_tn_grouped_workspace_floats": (c_int64, [c_int64, c_int32]),
     "bot_gemm_halves3_tn_grouped_f32": (ctypes.c_int, [c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int32, _P, _P, c_int32, _P]),
     "bot_tn_narrow_workspace_floats": (c_int64, [c_int64, c_int32, c_int32]),
@@ -820,20 +820,22 @@ def _table(rows, width):
     return (ctypes.c_int64 * len(flat))(*flat)
 
 
-def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups, k_seg, mode=0):
+def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups, k_seg, mode=0, col_scale=None, col_shift=None, relu=False, absmax=None):
     """The grouped NT product (bot_gemm_halves3_nt_grouped_f32): for every group (b_row0, n_valid, a_col0, a_col1, k_steps, c_off)
         out.flat[r * ld + c_off + j] = scale_a[1] scale_b[1] * sum_{t < k_steps} sum_{i < 32} A3[r, (a_col0 if t < k_seg else a_col1) + 32 t + i] . B3[b_row0 + j, 32 t + i]
     for j < n_valid <= 256, over the rows of the left operand buffer a ([h1 at column c, 2^11 h2 at column c + a2_off]) and the right
     operand buffer b ([h1 | h2 at + b2_off]); `out` is a row-major fp32 matrix view whose storage the offsets c_off address (ld = its
-    row pitch).  The per-head products of the aggregate-first GAT layer in one launch."""
-    _dev(a, b, out, scale_a, scale_b)
+    row pitch).  The per-head products of the aggregate-first GAT layer in one launch.  Optional epilogue: out = relu?(out * col_scale[c] +
+    col_shift[c]) with c = c_off + j (the eval-mode BatchNorm / bias behind the layer) and max|out| into `absmax` slots."""
+    _dev(a, b, out, scale_a, scale_b, col_scale, col_shift, absmax)
     assert a.dtype == torch.float16 and b.dtype == torch.float16 and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     assert out.dtype == torch.float32 and out.stride(-1) == 1
     tab = _table(groups, 6)
     # (profile key: m, n, k, batch with 2 m n k batch = the fp16 MFMA flops of the valid output columns, three products each)
     _check(_timed("gemm_halves", (a.shape[0], sum(int(g[1]) * 96 * int(g[4]) for g in groups), 1, 1), lambda: _lib.bot_gemm_halves3_nt_grouped_f32(
         a.shape[0], b.shape[0], scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), a2_off, b.data_ptr(), _ld(b), b2_off, out.data_ptr(),
-        int(out.stride(-2)), len(groups), tab, int(k_seg), int(mode), _stream())), "gemm_halves3_nt_grouped")
+        int(out.stride(-2)), len(groups), tab, int(k_seg), _ptr(col_scale), _ptr(col_shift), int(bool(relu)), _ptr(absmax), int(mode), _stream())),
+        "gemm_halves3_nt_grouped")
     return out
 
 

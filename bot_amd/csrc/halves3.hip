@@ -43,6 +43,12 @@ struct H3Args {
     int M, N, K;            // K: columns per piece, a multiple of BK
     int a2_off, b2_off;
     int tiles_m, tiles_n;
+    // optional epilogue (grouped launches): C = act(C * col_scale[j] + col_shift[j]) per output column j = c_off + column (an eval-mode
+    // BatchNorm / bias behind the layer, models.py:726-734), ReLU, and max|C| into by-product slots (common.h absmax_publish)
+    const float* col_scale;
+    const float* col_shift;
+    int relu;
+    uint32_t* absmax;
     int mode;               // 0 = the product.  Measurement switches (tools/exp_halves3.py): bit 0 no output stores; bit 2 / 3 B / A never
                             // advance along k; bit 5 the plain loop (barrier at the end of a k-step) and, in it, bit 6 no barrier / wait,
                             // bit 7 no DMA inside the loop, bit 8 one A fragment pair per k-step
@@ -277,6 +283,18 @@ __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Gr
     float* stg = reinterpret_cast<float*>(lds + w * (2 * kStageBytes / kWaves));
     const int q4 = (lane >> 4) * 4, l15 = lane & 15;
     const int col = wc * NT * 16 + l15 * 4;         // within the tile
+    // optional per-column affine + ReLU + max|C| (this lane's four columns are the same in every pass)
+    float cs[4] = {1.f, 1.f, 1.f, 1.f}, ch[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool affine = p.col_scale != nullptr || p.col_shift != nullptr;
+    if (affine) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < n_valid) {
+                if (p.col_scale) cs[e] = p.col_scale[c0 + col + e];
+                if (p.col_shift) ch[e] = p.col_shift[c0 + col + e];
+            }
+    }
+    float amax = 0.f;
 #pragma unroll
     for (int pass = 0; pass < MT / 2; ++pass) {
 #pragma unroll
@@ -289,8 +307,20 @@ __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Gr
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = i * 4 + (lane >> 4);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * P + l15 * 4);
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * P + l15 * 4);
             const int row = m0 + wr * MT * 16 + pass * 32 + r;
+            if (affine || p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaf(v[e], cs[e], ch[e]);
+                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+            }
+            if (p.absmax && row < p.M) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < n_valid) amax = fmaxf(amax, fabsf(v[e]));
+            }
             if (row < p.M) {
                 float* c = Cb + (int64_t)row * p.ldc + col;
                 if (vec_ok && col + 3 < n_valid) {
@@ -306,6 +336,7 @@ __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Gr
             }
         }
     }
+    if (p.absmax) absmax_publish(wave_absmax(amax), p.absmax);      // (every lane of every wave arrives here)
 }
 
 template <int BM, int BN, int WM, int WN, bool PIPE>
@@ -692,6 +723,7 @@ extern "C" int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const fl
     p.A = reinterpret_cast<const _Float16*>(A), p.B = reinterpret_cast<const _Float16*>(B), p.scale_a = scale_a, p.scale_b = scale_b, p.C = C;
     p.lda = lda, p.ldb = ldb, p.ldc = ldc, p.M = (int)m, p.N = (int)n, p.K = (int)k, p.a2_off = (int)a2_off, p.b2_off = (int)b2_off;
     p.tiles_m = p.tiles_n = 0;
+    p.col_scale = p.col_shift = nullptr, p.relu = 0, p.absmax = nullptr;
     p.mode = mode;
     if (mode & 32) {        // measurement builds only: one barrier at the END of a k-step, with the ablation switches
         set_kernel("bot::gemm_halves3_nt_kernel<256,256,2,4,plain>");
@@ -705,7 +737,8 @@ extern "C" int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const fl
 
 extern "C" int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
                                                int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t n_groups,
-                                               const int64_t* groups, int32_t k_seg, int32_t mode, bot_stream_t stream) {
+                                               const int64_t* groups, int32_t k_seg, const float* col_scale, const float* col_shift, int32_t relu,
+                                               uint32_t* absmax_slots, int32_t mode, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE(m > 0 && b_rows > 0 && n_groups >= 1 && n_groups <= kMaxGroups && k_seg >= 0, -1, "gemm_halves3_nt_grouped: m, b_rows > 0, 1 .. %d groups (got %lld %lld %d)",
                 kMaxGroups, (long long)m, (long long)b_rows, n_groups);
@@ -717,6 +750,7 @@ extern "C" int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const 
     p.A = reinterpret_cast<const _Float16*>(A), p.B = reinterpret_cast<const _Float16*>(B), p.scale_a = scale_a, p.scale_b = scale_b, p.C = C;
     p.lda = lda, p.ldb = ldb, p.ldc = ldc, p.M = (int)m, p.N = (int)b_rows, p.K = 0, p.a2_off = (int)a2_off, p.b2_off = (int)b2_off;
     p.mode = mode & ~32;
+    p.col_scale = col_scale, p.col_shift = col_shift, p.relu = relu, p.absmax = absmax_slots;
     H3Groups g;
     g.k_seg = k_seg;
     for (int i = 0; i < n_groups; ++i) {

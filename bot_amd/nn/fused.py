@@ -933,6 +933,63 @@ def count_infer():
     INFER_CALLS += 1
 
 
+# The eval-mode forward of the aggregate-first layer on the training forward's kernels (round 4): attention columns -> softmax -> the SpMM
+# that writes the aggregated slab as a halves operand -> ONE grouped NT launch whose epilogue applies the eval-mode BatchNorm / bias and
+# the ReLU.  Instead of the [N, 168] x [168, 1536] projection + a sweep that gathers 3 000-byte rows: 672-byte rows and no [N, H D] slab.
+L0_INFER = os.environ.get("BOT_L0_INFER", "1") != "0"
+L0_INFER_CALLS = 0
+
+
+def _infer_l0_ok(conv, graph, h, label_reuse_cols) -> bool:
+    return (L0_INFER and L0_HALVES and use_agg_first(conv) and not label_reuse_cols and graph.halo is None and conv.res_fc is not None
+            and not conv._use_symmetric_norm and conv._out_feats <= 256 and h.shape[1] <= 192 and (h.is_cuda or FORCE)
+            and gemm.MODE == "halves" and gemm.NT_KERNEL == "halves3" and (h.shape[0] >= gemm.MIN_ROWS or gemm.FORCE or FORCE))
+
+
+def _infer_l0(conv, epi, graph, h, relu):
+    global L0_INFER_CALLS
+    L0_INFER_CALLS += 1
+    H, D = conv._num_heads, conv._out_feats
+    HD, N, Fin = H * D, h.shape[0], h.shape[1]
+    has_er = conv.attn_r is not None
+    csc = graph.csc
+    Wr = _cached(conv, "wcat_agg", _infer_key(conv), lambda: merged_weight(conv, with_fc=False).detach())   # [Fin, P2] / [P2, Fin]: [res | el | er | pad]
+    kp = WEIGHT_KP
+    P2 = Wr.shape[1 if kp else 0]
+    FP, _, g_fwd, _, _ = _l0_tables(H, D, Fin, P2, kp, N)
+    KA = (1 + H) * FP
+
+    def right_operand():        # row j = output column j = [Wres_j | W_j] as fp16 halves under one scale; lives with the weights' versions
+        Wres = (Wr.t()[:HD] if kp else Wr[:HD]).contiguous()
+        W = conv.fc.weight.detach()
+        slots = _C.absmax_slots(h.device)
+        _C.absmax_into(Wres, slots)
+        _C.absmax_into(W, slots)
+        wscale = _C.halves_scale_from_slots(slots)
+        B = torch.empty((HD, 6 * FP), dtype=torch.float16, device=h.device)
+        _C.halves_split_cols(Wres, wscale, 1, B, 2 * FP, 0, FP)
+        _C.halves_split_cols(W, wscale, 1, B, 2 * FP, FP, FP)
+        return B, wscale
+    B, wscale = _cached(conv, "infer_l0_halves", _infer_key(conv) + (str(h.device),), right_operand)
+    tail = torch.empty((N, P2 - HD), dtype=h.dtype, device=h.device)              # the attention columns (el | er | pad)
+    _small_mm(h, Wr[:, HD:] if kp else Wr[HD:], kp, tail)
+    el = tail[:, :H]
+    er = tail[:, H:2 * H] if has_er else None
+    a = _C.gat_attn_fwd(csc, el, er, None, None, None, conv.leaky_relu.negative_slope, H, None)
+    # [x | z_0 .. z_{H-1}] as one left operand (rows of `a` sum to 1: max|z| <= max|x|)
+    xscale = _C.halves_scale(h)
+    A = torch.empty((N, 2 * KA), dtype=torch.float16, device=h.device)
+    _C.halves_split_cols(h, xscale, 2, A, KA, 0, FP)
+    _C.spmm_bcast_halves(csc, h, a, None, xscale, A, FP, FP, KA, FP)
+    scale, shift = eval_affine(epi)
+    y = torch.empty((N, HD), dtype=h.dtype, device=h.device)
+    slots = _C.absmax_slots(h.device) if (relu and ABSMAX_BYPRODUCT and gemm.enabled(h)) else None
+    _C.gemm_halves3_nt_grouped(A, B, xscale, wscale, KA, 2 * FP, y, g_fwd, FP // 32, col_scale=scale, col_shift=shift, relu=relu, absmax=slots)
+    if slots is not None:
+        gemm.stash_scale(y, _C.halves_scale_from_slots(slots))
+    return y
+
+
 @torch.no_grad()
 def gat_infer_layer(conv, epi, graph, h, relu, first=False):
     """Eval-mode `act(epi(conv(graph, h).flatten(1)))` (models.py:716-731 with dropout off; for the output layer
@@ -948,6 +1005,8 @@ def gat_infer_layer(conv, epi, graph, h, relu, first=False):
     W = infer_weight(conv)                                              # [K, P] or [P, K]
     ctx = _LabelReuse.active
     F0 = ctx.static_cols if (ctx is not None and first and 0 < ctx.static_cols < h.shape[1]) else 0
+    if _infer_l0_ok(conv, graph, h, F0):
+        return _infer_l0(conv, epi, graph, h, relu)
     if F0:
         Wk = W if WEIGHT_KP else W.t()
         key = (id(conv), h.data_ptr(), tuple(h.shape)) + _versions(W)   # same layer, same input buffer, same weights

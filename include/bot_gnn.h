@@ -543,13 +543,17 @@ int bot_gemm_halves3_tn_f32(int64_t n_rows, int64_t k, int64_t p, int64_t kp, in
  *     C[r * ldc + c_off + j] = scale_a[1] scale_b[1] * sum_{t < k_steps} sum_{i < 32} A3[r, (t < k_seg ? a_col0 : a_col1) + 32 t + i] . B3[b_row0 + j, 32 t + i]
  *     for r < m, j < n_valid <= 256 (A3 . B3: the three products a1 b1 + a1 b2 + a2 b1; a1 at the given column, 2^11 a2 a2_off behind it;
  *     b1 at column 32 t + i of B's row, b2 b2_off behind it).  1 <= n_groups <= 12; a_col0, a_col1 multiples of 8; b_rows = rows of B.
+ *     Optional epilogue (the eval-mode layer, models.py:726-734): col_scale / col_shift (either may be NULL), indexed by c_off + j — groups
+ *     that write the columns of ONE [m, ldc] matrix —, then ReLU if `relu`, then max|C| into `absmax_slots` (NULL: none):
+ *     C = relu?(C * col_scale + col_shift).
  *   tn_grouped  tiles[i] = (x_col0, k_valid, d_col0, p_valid, out_off, ldo, transposed):
  *     out[out_off + k * ldo + p] = scale_x[1] scale_d[1] * sum_n X3[n, x_col0 + k] . D3[n, d_col0 + p]   for k < k_valid <= 192, p < p_valid <= 192
  *     (transposed != 0: out[out_off + p * ldo + k]); 1 <= n_tiles <= 16; workspace: bot_gemm_halves3_tn_grouped_workspace_floats(n_rows, n_tiles) floats.
  * `groups` / `tiles` are HOST arrays of 6 resp. 7 int64 per entry (copied into the kernel arguments). */
 int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
                                     int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t n_groups,
-                                    const int64_t* groups, int32_t k_seg, int32_t mode, bot_stream_t stream);
+                                    const int64_t* groups, int32_t k_seg, const float* col_scale, const float* col_shift, int32_t relu,
+                                    uint32_t* absmax_slots, int32_t mode, bot_stream_t stream);
 int64_t bot_gemm_halves3_tn_grouped_workspace_floats(int64_t n_rows, int32_t n_tiles);
 int bot_gemm_halves3_tn_grouped_f32(int64_t n_rows, const float* scale_x, const float* scale_d, const uint16_t* X, int64_t ldx, int64_t x2_off,
                                     const uint16_t* D, int64_t ldd, int64_t d2_off, float* out, int32_t n_tiles, const int64_t* tiles,

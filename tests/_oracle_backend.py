@@ -375,7 +375,7 @@ def _three(a1, a2s, b1, b2s, right, acc=torch.float32):
     return f(a1).t() @ f(b1) + f(a1 * sh).t() @ f(b2s) + f(a2s).t() @ f(b1 * sh)
 
 
-def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups, k_seg, mode=0):
+def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups, k_seg, mode=0, col_scale=None, col_shift=None, relu=False, absmax=None):
     """include/bot_gnn.h bot_gemm_halves3_nt_grouped_f32 (accumulated in out's dtype)"""
     acc = out.dtype
     flat = out.as_strided((out.untyped_storage().nbytes() // out.element_size() - out.storage_offset(),), (1,))
@@ -391,7 +391,15 @@ def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups,
         if k1:
             res += _three(a[:, a_col1 + k0:a_col1 + k0 + k1], a[:, a_col1 + a2_off + k0:a_col1 + a2_off + k0 + k1], b[rows, k0:k0 + k1],
                           b[rows, b2_off + k0:b2_off + k0 + k1], True, acc)
-        flat.as_strided((m, n_valid), (ld, 1), c_off).copy_(res * alpha)
+        res = res * alpha
+        if col_scale is not None:
+            res = res * col_scale[c_off:c_off + n_valid].to(acc)
+        if col_shift is not None:
+            res = res + col_shift[c_off:c_off + n_valid].to(acc)
+        if relu:
+            res = torch.relu(res)
+        _fold_absmax(absmax, res)
+        flat.as_strided((m, n_valid), (ld, 1), c_off).copy_(res)
     return out
 
 

@@ -507,6 +507,20 @@ def _check_agg_first(golden, device, l0_halves):
         got = dict(model.named_parameters())
         for k, rg in zip(names, ref_grads):
             grad_close(got[k].grad, rg.numpy())
+        # f3: the eval-mode forward of the same stack through the inference layers; with the halves on, its aggregate-first input layer
+        # runs on the training forward's kernels (fused._infer_l0: SpMM with the halves epilogue + ONE grouped NT launch whose epilogue is
+        # the eval-mode BatchNorm + ReLU) — against the oracle's eval-mode forward at the model's current running statistics
+        model.eval()
+        sd_eval = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        ref_eval = RM.gat_forward(RM.CooGraph(s, d, n), feat, sd_eval, n_classes=C, training=False, **cfg)
+        i0, li0 = fused.INFER_CALLS, fused.L0_INFER_CALLS
+        with torch.no_grad():
+            ev = model(g, feat.to(device))
+        if str(device) != "cpu" or fused.FORCE:
+            assert fused.INFER_CALLS == i0 + 3
+            # (taken when the halves path is on for this row count: forced by the halves variant of this check, or by fused.FORCE on the CPU backend)
+            assert fused.L0_INFER_CALLS == li0 + (1 if linear and (l0_halves or fused.FORCE) else 0)
+        fwd_close(ev, ref_eval.detach().numpy())
 
 
 def check_keep_mask_orders(golden, device):
