@@ -940,8 +940,14 @@ L0_INFER = os.environ.get("BOT_L0_INFER", "1") != "0"
 L0_INFER_CALLS = 0
 
 
+L0_INFER_OVER_LABEL_REUSE = os.environ.get("BOT_L0_INFER_LABEL_REUSE", "1") != "0"
+
+
 def _infer_l0_ok(conv, graph, h, label_reuse_cols) -> bool:
-    return (L0_INFER and L0_HALVES and use_agg_first(conv) and not label_reuse_cols and graph.halo is None and conv.res_fc is not None
+    # (label-reuse iterations: the static-column form saves the feature columns' share of a PROJECT-first layer 0 with stock fp32 GEMMs;
+    # this form has no such projection — the whole layer is cheaper than the remainder of that one, tools/r04_infer_ab.sh)
+    return (L0_INFER and L0_HALVES and use_agg_first(conv) and (not label_reuse_cols or L0_INFER_OVER_LABEL_REUSE) and graph.halo is None
+            and conv.res_fc is not None
             and not conv._use_symmetric_norm and conv._out_feats <= 256 and h.shape[1] <= 192 and (h.is_cuda or FORCE)
             and gemm.MODE == "halves" and gemm.NT_KERNEL == "halves3" and (h.shape[0] >= gemm.MIN_ROWS or gemm.FORCE or FORCE))
 
