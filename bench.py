@@ -63,8 +63,8 @@ def parse(argv=None):
     ap.add_argument("--capture", default="off", choices=["on", "off"],
                     help="on: replay the train step as ONE hipGraph (bot_amd.train.CapturedTrainStep) instead of ~300 eager launches "
                          "(configs 1-3; works partitioned too, RCCL collectives are captured).  Default off: the roofline object "
-                         "needs HIP events around individual launches inside the timed region, which a replay has none of; "
-                         "measured at config 2 on one GPU: 19.74 ms captured vs 19.80 ms eager (the step is GPU-bound)")
+                         "needs HIP events around individual launches inside the timed region, which a replay has none of, and "
+                         "the single-GPU step is GPU-bound (capture pays off where a rank's GPU work drops to a few ms)")
     ap.add_argument("--launch-timeout", type=float, default=3600.0,
                     help="N > 1 started without a launcher: seconds after which the self-started torch.distributed.run child is killed")
     ap.add_argument("--self-launch", action="store_true",

@@ -871,15 +871,36 @@ def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0, x2_o
     return out
 
 
+def _idx64(t, name):
+    if t.dtype != torch.int64 or not t.is_contiguous() or t.dim() != 1:
+        raise BotKernelError(f"{name} must be a contiguous 1-D int64 tensor (got {t.dtype}, stride {tuple(t.stride())})")
+
+
+def _labels64(labels):
+    """[N] or [N, 1..] int64 labels as a 2-D view with unit column stride (the kernels read column 0 at a row stride)."""
+    if labels.dtype != torch.int64:
+        raise BotKernelError(f"labels must be int64 (got {labels.dtype})")
+    lab = labels.reshape(labels.shape[0], -1)
+    if lab.shape[1] > 1 and lab.stride(1) != 1:
+        lab = lab.contiguous()
+    return lab
+
+
 def label_split(train_idx, labels, mask, mask_rate, seed, use_labels, code, wn):
     """include/bot_gnn.h bot_label_split_f32: writes code / wn at the training nodes, returns count (1-element float tensor on the device)."""
     _dev(train_idx, labels, wn)
+    _idx64(train_idx, "train_idx")
     count = torch.empty(1, dtype=torch.float32, device=wn.device)
     ws = torch.empty(128, dtype=torch.int32, device=wn.device)
-    lab = labels.reshape(labels.shape[0], -1)
+    lab = _labels64(labels)
+    if wn.dtype != torch.float32 or not wn.is_contiguous() or (code is not None and (code.dtype != torch.int32 or not code.is_contiguous())):
+        raise BotKernelError("label_split: wn must be contiguous float32, code contiguous int32")
     m = None
-    if mask is not None:
-        m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    if mask is not None:            # one byte per training node, nonzero = an input-label node (a float 0/1 mask is converted, not reinterpreted)
+        _dev(mask)
+        m = mask.to(torch.bool).contiguous().view(torch.uint8)
+        if m.numel() != train_idx.numel():
+            raise BotKernelError("label_split: mask must have one entry per training node")
     _check(_lib.bot_label_split_f32(train_idx.data_ptr(), train_idx.numel(), lab.data_ptr(), lab.stride(0), _ptr(m), float(mask_rate), int(seed),
                                     _seed_off(1.0), int(bool(use_labels)), _ptr(code), wn.data_ptr(), count.data_ptr(), ws.data_ptr(), _stream()), "label_split")
     return count
@@ -907,7 +928,9 @@ def node_loss(x, labels, wn, count, kind, eps, want_grad=True):
     n_pad = (n + 63) // 64 * 64
     y = torch.empty(n_pad, dtype=torch.float32, device=x.device)
     dx = torch.empty((n, C), dtype=torch.float32, device=x.device) if want_grad else None
-    lab = labels.reshape(labels.shape[0], -1)
+    lab = _labels64(labels)
+    if wn.dtype != torch.float32 or not wn.is_contiguous() or count.dtype != torch.float32:
+        raise BotKernelError("node_loss: wn / count must be contiguous float32")
     _check(_lib.bot_node_loss_f32(x.data_ptr(), _ld(x), n, C, lab.data_ptr(), lab.stride(0), wn.data_ptr(), count.data_ptr(), LOSS_KINDS[kind], float(eps),
                                   y.data_ptr(), n_pad, _ptr(dx), C, _stream()), "node_loss")
     return y, dx
@@ -925,6 +948,8 @@ def rmsprop_step(params, grads, square_avgs, lr, alpha, eps, weight_decay, lr_de
         G = (c_void_p * k)(*[t.data_ptr() for t in gs])
         S = (c_void_p * k)(*[t.data_ptr() for t in sq])
         Nn = (c_int64 * k)(*[t.numel() for t in ps])
+        if lr_dev is not None and (lr_dev.dtype != torch.float32 or lr_dev.device != ps[0].device):
+            raise BotKernelError("rmsprop_step: a tensor learning rate must be float32 on the parameters' device")
         _check(_lib.bot_rmsprop_step_f32(k, P, G, S, Nn, float(lr), _ptr(lr_dev), float(alpha), float(eps), float(weight_decay), _stream()), "rmsprop_step")
 
 

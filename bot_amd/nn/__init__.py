@@ -294,6 +294,7 @@ class GCN(nn.Module):
         self.activation = activation
 
     def forward(self, graph, feat):
+        from . import fused
         h = graph.to_internal(feat)  # identity unless the graph was renumbered (bot_amd.reorder_graph)
         if not fused.take_input_dropped():  # bot_amd.train assembles the input with the dropout applied (one pass) and says so
             h = self.input_drop(h)

@@ -443,10 +443,11 @@ _L0_TABLES = {}
 _L0_DH = {}
 
 
-def _l0_dh(device, N, H, DP):
+def _l0_dh(device, N, H, D, DP):
     """The gradient operand [N, 2 H DP] of the direct form: allocated once per shape with its padding columns zeroed (the apply pass writes
-    only the D columns of each head's block); it lives inside one backward call, so layers and steps can share it."""
-    key = (str(device), N, H, DP)
+    only the D columns of each head's block: the key carries D, a narrower layer must not inherit a wider one's columns); it lives inside
+    one backward call, so layers and steps can share it."""
+    key = (str(device), N, H, D, DP)
     buf = _L0_DH.get(key)
     if buf is None:
         buf = torch.zeros((N, 2 * H * DP), dtype=torch.float16, device=device)
@@ -563,7 +564,8 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             KA = (1 + H) * FP
             # left operand [x | z_0 .. z_{H-1}] (first halves, then the second halves KA columns behind), ONE scale: the rows of a_d sum
             # to <= 1 / (1 - attn_p), so max|z| <= max|x| / (1 - attn_p), inside fp16's range above x's scale (_l0_halves_ok)
-            xscale = _C.halves_scale(h)
+            # (partitioned mode: the sweep gathers halo rows too - the scale must cover every row of the extended table)
+            xscale = _C.halves_scale(h) if ext is None else _C.halves_scale_from_slots(_C.absmax_into(xsrc, _C.absmax_slots(h.device)))
             A = torch.empty((N, 2 * KA), dtype=torch.float16, device=h.device)
             _C.halves_split_cols(h, xscale, 2, A, KA, 0, FP)
             _C.spmm_bcast_halves(csc, xsrc, a_d, None, xscale, A, FP, FP, KA, FP)
@@ -660,7 +662,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
                 _C.bn_bwd_bound(ws, N, sg if bn_training else None, sgx if bn_training else None, total, bn_w, invstd, slots)
                 dscale = _C.halves_scale_from_slots(slots)
                 Dh = _C.bn_act_bwd_apply_halves(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
-                                                sgx if bn_training else None, total, dscale, _l0_dh(dy.device, N, H, DP), D, DP)
+                                                sgx if bn_training else None, total, dscale, _l0_dh(dy.device, N, H, D, DP), D, DP)
             else:
                 _C.bn_act_bwd_apply(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
                                     sgx if bn_training else None, total, out=dx, absmax=slots)

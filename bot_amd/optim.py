@@ -43,5 +43,9 @@ class RMSprop(torch.optim.Optimizer):
                 sq.append(st["square_avg"])
             lr = group["lr"]
             lr_dev = lr if isinstance(lr, torch.Tensor) else None      # a device scalar: read by the kernel (captured steps)
+            if lr_dev is not None and ps and (lr_dev.device != ps[0].device or lr_dev.dtype != torch.float32):
+                if lr_dev.is_cuda and torch.cuda.is_current_stream_capturing():
+                    raise ValueError("bot_amd.optim.RMSprop: a tensor lr must be float32 on the parameters' device to be captured")
+                lr, lr_dev = float(lr_dev), None                       # a CPU / non-fp32 tensor lr: its value, not its address
             _C.rmsprop_step(ps, gs, sq, 0.0 if lr_dev is not None else lr, group["alpha"], group["eps"], group["weight_decay"], lr_dev=lr_dev)
         return loss

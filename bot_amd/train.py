@@ -16,17 +16,22 @@ EPSILON = 1 - math.log(2)  # run.py:34
 # (bot_amd.optim.RMSprop) the optimizer update, instead of ~45 small tensor ops (include/bot_gnn.h "the train step's glue").
 # BOT_FUSED_STEP=0 restores the tensor-op form of the same step (kept: label reuse takes it, and the tests compare the two).
 FUSED_STEP = os.environ.get("BOT_FUSED_STEP", "1") != "0"
-_SPLIT = {}   # (device, N) -> (weakref to the train_idx tensor it was initialised for, code int32 [N], wn float32 [N])
+_SPLIT = {}   # (device, N, id(train_idx)) -> (weakref to train_idx, code int32 [N], wn float32 [N], train_idx._version)
 
 
 def _split_buffers(train_idx, n):
     """`code` (-1) and `wn` (0) arrays of bot_label_split_f32: entries of non-training nodes are never written, so they are
-    initialised once per train_idx TENSOR (identity, not address: a recycled address with other contents must not reuse them)."""
-    key = (train_idx.device, n)
+    initialised once per train_idx TENSOR (identity, not address: a recycled address with other contents must not reuse them).
+    One entry PER train_idx tensor, kept for as long as that tensor lives (a CapturedTrainStep bakes the buffers' addresses into its
+    hipGraph and its step function holds train_idx: another split of the same N - a second model, a k-fold split, a test helper -
+    must not evict them); the entry goes when the tensor is collected."""
+    key = (train_idx.device, n, id(train_idx))
     ent = _SPLIT.get(key)
     if ent is None or ent[0]() is not train_idx or ent[3] != train_idx._version:
         ent = (weakref.ref(train_idx), torch.full((n,), -1, dtype=torch.int32, device=train_idx.device),
                torch.zeros(n, dtype=torch.float32, device=train_idx.device), train_idx._version)
+        if key not in _SPLIT:
+            weakref.finalize(train_idx, _SPLIT.pop, key, None)
         _SPLIT[key] = ent
     return ent[1], ent[2]
 
@@ -75,7 +80,9 @@ def _fused_forward_backward(model, graph, feat, labels, train_idx, *, use_labels
         y = per_node_loss(pred, labels.clamp(0, pred.shape[1] - 1), loss)
         out = sum_all(torch.where(wn > 0, y, torch.zeros_like(y))) / count[0]
     out.backward()
-    return out, pred, wn
+    # (`wn` is the per-train_idx buffer the next step overwrites: callers get their own copy, except inside a hipGraph capture, where the
+    # replay rewrites the buffer in place and the alias is what a caller wants to read)
+    return out, pred, wn if (wn.is_cuda and torch.cuda.is_current_stream_capturing()) else wn.clone()
 
 
 def add_labels(feat, labels, idx, n_classes):

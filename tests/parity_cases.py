@@ -19,8 +19,7 @@ from oracle import ref_models as RM
 from oracle import ref_ops as R
 
 FWD_ATOL = 1e-4
-import os
-GRAD_RTOL = float(os.environ.get("BOT_TEST_GRAD_RTOL", "1e-4"))
+GRAD_RTOL = 1e-4          # of the reference gradient's largest entry; a constant of the suite - no environment override
 
 
 def fwd_close(a, b, atol=FWD_ATOL, rtol=0.0):

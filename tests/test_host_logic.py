@@ -472,3 +472,38 @@ def test_merged_linear_blocks_emulated(golden, cpu_backend):
 def test_halo_sums_emulated(golden, cpu_backend):
     """bot_amd.halo's overlapped aggregations (GraphConv / GATConv / edge-feature GATConv in partitioned mode) over the emulated backend."""
     PC.check_halo_sums(golden, "cpu")
+
+
+def test_gcn_forward_in_a_fresh_process():
+    """`from bot_amd.nn import GCN` with the user's own loop and nothing else imported (GCN.forward used `fused` without
+    importing it; every other test imports bot_amd.nn.fused first, which hid it).  The forward runs up to the first kernel call, which
+    refuses CPU tensors - a NameError would come first."""
+    import subprocess
+    import sys
+    code = (
+        "import torch, torch.nn.functional as F\n"
+        "import bot_amd, bot_amd.nn as bnn\n"
+        "from bot_amd._C import BotKernelError\n"
+        "g = bot_amd.Graph(torch.tensor([0, 1, 2, 0, 1, 2]), torch.tensor([1, 2, 0, 0, 1, 2]), 3)\n"
+        "m = bnn.GCN(4, 3, 8, 2, F.relu, 'batch', 'symm', 0.5, 0.1, False, True)\n"
+        "try:\n"
+        "    m(g, torch.randn(3, 4))\n"
+        "except BotKernelError:\n"
+        "    print('reached the kernels')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=_oracle_backend.__file__.rsplit("/tests/", 1)[0])
+    assert r.returncode == 0 and "reached the kernels" in r.stdout, r.stderr[-2000:]
+
+
+def test_split_buffers_are_per_train_idx_tensor(cpu_backend):
+    """One (code, wn) pair per live train_idx tensor: a second split of the same N must not evict the first (a captured step holds
+    the first's addresses); entries go with their tensor."""
+    import gc
+    from bot_amd import train as T
+    a, b = torch.arange(5), torch.arange(3)
+    ca, wa = T._split_buffers(a, 10)
+    cb, wb = T._split_buffers(b, 10)
+    assert T._split_buffers(a, 10)[0] is ca and T._split_buffers(b, 10)[0] is cb and ca is not cb
+    n0 = len(T._SPLIT)
+    del a, ca, wa
+    gc.collect()
+    assert len(T._SPLIT) == n0 - 1
