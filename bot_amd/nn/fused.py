@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _C, gemm, halo
+from .. import _C, gemm, halo, side
 from ..graph import take_rows
 from ..ops import bn_batch_stats, new_dropout_seed
 
@@ -98,6 +98,7 @@ class _MergeWeight(torch.autograd.Function):
         used = (blk if with_fc else 0) + (blk if Wres is not None else 0) + H + (H if attn_r is not None else 0)
         P = used + (-used) % 128
         ctx.save_for_backward(W, attn_l, attn_r)
+        ctx.wres_ref = Wres                     # (only its .grad is looked at, backward)
         ctx.cfg = (H, D, P, with_fc, Wres is not None, blk)
         return _C.merge_weight_fwd(W, Wres, attn_l.reshape(-1), None if attn_r is None else attn_r.reshape(-1), H, D, P, with_fc, block=blk)
 
@@ -105,8 +106,19 @@ class _MergeWeight(torch.autograd.Function):
     def backward(ctx, dm):
         W, attn_l, attn_r = ctx.saved_tensors
         H, D, P, with_fc, has_res, blk = ctx.cfg
-        dW, dWres, dal, dar = _C.merge_weight_bwd(W, attn_l.reshape(-1), None if attn_r is None else attn_r.reshape(-1), H, D, P,
-                                                  with_fc, has_res, dm, block=blk)
+
+        def body():
+            return _C.merge_weight_bwd(W, attn_l.reshape(-1), None if attn_r is None else attn_r.reshape(-1), H, D, P, with_fc, has_res, dm, block=blk)
+        if side.produced(dm):
+            # the merged gradient came from the side stream (bot_amd.side): its split runs there too when autograd will only STEAL the
+            # results (each parameter's one contribution, no .grad yet); otherwise the main stream joins first
+            if with_fc and side.MERGE_ON_SIDE and side.usable(dm) and all(p is None or p.grad is None for p in (W, ctx.wres_ref, attn_l, attn_r)):
+                dW, dWres, dal, dar = side.run(body, dm, W, attn_l, attn_r)
+            else:
+                side.join()
+                dW, dWres, dal, dar = body()
+        else:
+            dW, dWres, dal, dar = body()
         return dW, dWres, dal.view_as(attn_l), (None if dar is None else dar.view_as(attn_r)), None, None, None
 
 
@@ -389,11 +401,16 @@ class _GATHidden(torch.autograd.Function):
                 dh_ = gemm.split(dout, 0, scale=_C.halves_scale_from_slots(slots))
             else:
                 dh_ = gemm.split(dout, 0)
-            if ctx.needs_input_grad[1]:
-                dW = gemm.tn(xh, dh_)                                    # [K, P]
-                dW = dW if kp else dW.t().contiguous()
             if ctx.needs_input_grad[0]:
                 dh = gemm.mm_nt(dh_, gemm.split(Wcat if kp else Wcat.t().contiguous(), 1))
+            if ctx.needs_input_grad[1]:
+                def wgrad():
+                    dW = gemm.tn(xh, dh_)                                # [K, P]
+                    return dW if kp else dW.t().contiguous()
+                # only the optimizer needs it: on the side stream (bot_amd.side) it runs beside the previous layer's BatchNorm / sparse
+                # backward, which leave the matrix cores idle.  Issued BEHIND the input gradient's launch: two GEMM workgroups do not fit
+                # one CU's LDS, so the reduction starts when that product ends and the main stream has moved on to HBM-bound kernels
+                dW = side.run(wgrad, xh, dh_) if (side.usable(dout) and xh.piece * dh_.piece >= side.MIN_OUT) else wgrad()
         else:
             if ctx.needs_input_grad[1]:
                 dW = torch.mm(h.t(), dout) if kp else torch.mm(dout.t(), h)
@@ -678,6 +695,18 @@ class _GATHiddenAggFirst(torch.autograd.Function):
                 Dh = _C.halves_split_heads(dx, dscale, H, D, DP)
             Wt = gemm.split(Wh.transpose(1, 2).reshape(H * Fin, D), 1)           # rows h Fin + f = W_h[:, f]: the right operand of d z_h
             _C.gemm_halves3_nt_grouped(Dh, Wt.buf, dscale, Wt.scale, H * DP, Wt.piece, dz[0], g_dz, 0)
+            # every weight gradient from ONE grouped launch over the head blocks: d W_h = d rst_h^T z_h and the residual rows / columns of
+            # the merged gradient d rst^T x (written in Wr's layout).  Both operands exist from here on and only the optimizer needs the
+            # result: on the side stream (bot_amd.side) the launch runs beside the sparse sweep and the attention backward below
+            flat = torch.empty(HD * Fin + P2 * Fin, dtype=h.dtype, device=h.device)
+
+            def wgrad():
+                _C.gemm_halves3_tn_grouped(z, Dh, xscale, dscale, (1 + H) * FP, H * DP, flat, t_tn)
+                return flat
+            if side.usable(flat):
+                side.run(wgrad, z, Dh, xscale, dscale, flat)
+            else:
+                wgrad()
         elif ctx.skinny and D <= 256:     # d z_i = d x_i W_i for the H heads in one launch (A = column slices of d x)
             _C.skinny_gemm(dx, Wh, b_is_kn=True, out=dz, batch=H, strides=(D, D * Fin, N * Fin), m=N, n=Fin, k=D)
         if ctx.skinny and dW3 is not None:   # d W_i = d x_i^T z_i, reductions over the N rows: fp32 MFMA, chunked, one launch for the H heads
@@ -732,10 +761,10 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             dout2[:, used:].zero_()
         dWr = None
         if l0h:
-            # every weight gradient from ONE grouped launch over the head blocks: d W_h = d rst_h^T z_h and the residual rows / columns of
-            # the merged gradient d rst^T x (written in Wr's layout); the attention columns (a handful, their own magnitude) apart
-            flat = torch.empty(HD * Fin + P2 * Fin, dtype=h.dtype, device=h.device)
-            _C.gemm_halves3_tn_grouped(z, Dh, xscale, dscale, (1 + H) * FP, H * DP, flat, t_tn)
+            # the attention columns of the merged gradient (a handful, their own magnitude) apart.  fc.weight's gradient has a second
+            # contribution (through the merged weight's attention rows) that autograd ADDS on this stream: joined here - this layer is
+            # the end of the backward pass, nothing is left to run beside the side stream
+            side.join()
             dW = flat[:HD * Fin].view(HD, Fin)
             dWr = flat[HD * Fin:].view((Fin, P2) if kp else (P2, Fin))
             tail = dout2[:, HD:]

@@ -1489,6 +1489,57 @@ def test_captured_step_twelve_replays_bitwise(kind, request):
     _C.SEED_OFFSET = None
 
 
+@pytest.mark.parametrize("opt", ["bot", "torch"])
+def test_side_stream_bitwise(opt):
+    """bot_amd.side: the weight-gradient products on a second stream (event fork behind the input gradient's launch, joined when the
+    backward pass ends) - same kernels, same operands, separate outputs: loss, logits, every gradient and every parameter after the
+    optimizer step are bit for bit those of the serial order, over several steps (a race would show as a differing tensor: the steps
+    keep reusing the freed operand blocks), on the config-2 stack at its real width (layer 0 aggregate-first on the grouped kernels)."""
+    import copy
+    import torch.nn.functional as F
+    from bot_amd import nn as bnn, side, synth, train as T, optim as bopt
+    from bot_amd.nn import fused
+    ds = synth.make_dataset("arxiv", device=DEV, seed=0, scale=0.2)
+    g, C = ds.graph, ds.n_classes
+    g.create_formats_()
+
+    def make():
+        torch.manual_seed(0)
+        m = bnn.GAT(dim_node=ds.feat.shape[1] + C, dim_edge=0, dim_output=C, activation=F.relu, n_layers=3, n_heads=3, n_hidden=250,
+                    norm="batch", dropout=0.0, input_drop=0.0, attn_drop=0.0, linear=True).to(DEV)
+        return m, (bopt.RMSprop if opt == "bot" else torch.optim.RMSprop)(m.parameters(), lr=0.002)
+    m1, o1 = make()
+    m2, o2 = make()
+    m2.load_state_dict(copy.deepcopy(m1.state_dict()))
+    kw = dict(use_labels=True, loss="loge", n_classes=C)
+    was = side.ENABLED
+    try:
+        for it in range(6):
+            mask = torch.rand(ds.train_idx.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(it)) < 0.5
+            side.ENABLED = False
+            f0 = side.FORKS
+            l1, p1 = T.train_step(m1, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o1, mask=mask, **kw)
+            assert side.FORKS == f0
+            g1 = {k: v.grad.clone() for k, v in m1.named_parameters()}
+            side.ENABLED = True
+            l0c = fused.L0_CALLS
+            l2, p2 = T.train_step(m2, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o2, mask=mask, **kw)
+            assert side.FORKS >= f0 + 3, "the side stream was not used"
+            assert fused.L0_CALLS > l0c, "layer 0 did not take the grouped-halves form"
+            torch.cuda.synchronize()
+            assert torch.equal(l1, l2) and torch.equal(p1, p2), it
+            # the split of a side-produced merged gradient ran on the side stream and autograd STOLE its results (a clone would have
+            # been a main-stream kernel racing the side stream: what the first build of bot_amd.side did by holding a second reference)
+            stolen = [k for k, v in m2.named_parameters() if v.grad is not None and v.grad.untyped_storage().data_ptr() in side.LAST_MARKS]
+            assert any(k.startswith("convs.1.") for k in stolen), stolen
+            for k, v in m2.named_parameters():
+                assert torch.equal(g1[k], v.grad), (it, k, float((g1[k] - v.grad).abs().max()))
+        for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+            assert torch.equal(a, b), k
+    finally:
+        side.ENABLED = was
+
+
 @pytest.mark.parametrize("kind", ["arxiv", "cora", "reddit", "arxiv-1rank"])
 def test_no_multi_workgroup_torch_reduction_in_capturable_steps(kind, request, tmp_path):
     """The other half of the same ADVICE item: whatever the root cause of the wrong replayed sums is, no capturable step may contain
