@@ -800,9 +800,6 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     return out
 
 
-NT_MODE = int(os.environ.get("BOT_NT_MODE", "0"))   # OR-ed into the `mode` of the NT launches (512: the B-direct form, csrc/halves3.hip)
-
-
 def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None):
     """out[m, n] = scale_a[1] scale_b[1] (a1 b1^T + a1 b2^T + a2 b1^T) from a LEFT operand buffer a [m, 3 piece_a] (or [m, 2 piece_a]
     without the duplicate piece: a2_off = piece_a) and a RIGHT operand buffer b [n, 3 piece_b] (bot_amd.gemm.Halves.buf / .scale), k =
@@ -813,7 +810,7 @@ def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     _check(_timed("gemm_halves", (m, n, 3 * k, 1), lambda: _lib.bot_gemm_halves3_nt_f32(
         m, n, k, scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), 2 * piece_a if a2_off is None else a2_off, b.data_ptr(), _ld(b),
-        piece_b, out.data_ptr(), _ld(out), int(mode) | NT_MODE, _stream())), "gemm_halves3_nt")
+        piece_b, out.data_ptr(), _ld(out), int(mode), _stream())), "gemm_halves3_nt")
     return out
 
 
@@ -837,7 +834,7 @@ def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups,
     # (profile key: m, n, k, batch with 2 m n k batch = the fp16 MFMA flops of the valid output columns, three products each)
     _check(_timed("gemm_halves", (a.shape[0], sum(int(g[1]) * 96 * int(g[4]) for g in groups), 1, 1), lambda: _lib.bot_gemm_halves3_nt_grouped_f32(
         a.shape[0], b.shape[0], scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), a2_off, b.data_ptr(), _ld(b), b2_off, out.data_ptr(),
-        int(out.stride(-2)), len(groups), tab, int(k_seg), _ptr(col_scale), _ptr(col_shift), int(bool(relu)), _ptr(absmax), int(mode) | NT_MODE, _stream())),
+        int(out.stride(-2)), len(groups), tab, int(k_seg), _ptr(col_scale), _ptr(col_shift), int(bool(relu)), _ptr(absmax), int(mode), _stream())),
         "gemm_halves3_nt_grouped")
     return out
 

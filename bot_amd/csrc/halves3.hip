@@ -349,243 +349,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_grouped_kernel(H
     gemm_halves3_nt_body<BM, BN, WM, WN, PIPE, true>(p, &groups);
 }
 
-// ----------------------------------------------------------------------------------------------------------------------------
-// B-direct form (round 5).  The ablation of the kernel above put 0.18 of its 1.03 ms on the LDS-DMA (64 KB per k-step and
-// CU).  Here only the LEFT operand's two halves go through LDS: 8 waves as 1 (M) x 8 (N), a wave owns ALL 256 rows x 32 columns of the
-// tile (MT = 16, NT = 2: the same 96 MFMAs per k-step), so a weight row's fragment is needed by exactly one wave and comes straight from
-// global memory / L2 into its registers (buffer_load_dwordx4, one k-step ahead: the weights of config 2 are 4.7 MB, L2 / MALL resident).
-// Per k-step and wave: 4 LDS-DMA instructions (was 8) + 4 plain 1 KB loads; 32 ds_read_b128 (was 24).  LDS: THREE stages of
-// [a1 | a2] = 32 KB, the DMA two k-steps ahead behind a counted vmcnt (the B loads of step t + 1 are issued before the DMA of step
-// t + 2, so `vmcnt(4)` at the barrier leaves exactly that DMA in flight).  Barrier placement, fragment swizzle, XCD tile order and the
-// through-LDS epilogue are the kernel's above (the staging slab is 32 rows x 32 columns per wave: a store instruction writes 8 rows
-// x 128 contiguous bytes).  Same operands, same three products in the same order per accumulator: bit for bit the result of the form above.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ half8 load16(const void* tile_base, uint32_t voff, int soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tile_base), 0, 0x7fffffff, 0x00020000);
-    return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
-#else
-    return half8{};
-#endif
-}
-
-template <bool GROUPED, int ABL = 0>      // ABL: measurement builds (tools/exp_nt_bd.py): 1 no A DMA in the loop, 2 no B loads in the loop, 4 s_setprio 1 for waves 4-7
-__device__ __forceinline__ void gemm_halves3_nt_bd_body(const H3Args& p, const H3Groups* groups) {
-    constexpr int BM = 256, BN = 256, kWaves = 8, MT = BM / 16, NT = BN / kWaves / 16;
-    constexpr int kABytes = BM * BK * 2;                     // one piece of A per k-step: 16 KB
-    constexpr int kStageBytes = 2 * kABytes, kStages = 3;
-    constexpr int GA = BM / 16 / kWaves;                     // 16-row groups (one 1 KB DMA instruction) per wave and piece: 2
-    static_assert(NT == 2 && GA == 2, "wave tile 256 x 32");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[kStages * kStageBytes];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-    const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
-    if (tm >= p.tiles_m) return;
-    const int m0 = tm * BM;
-    int n0 = tn * BN, n_valid = p.N - n0, T = p.K / BK, a_off0 = 0, a_off1 = 0, k_seg = 0;
-    int64_t c0 = n0;
-    if constexpr (GROUPED) {
-        const H3Group& G = groups->g[tn];
-        n0 = G.b_row0, n_valid = G.n_valid, T = G.k_steps, a_off0 = G.a_off0, a_off1 = G.a_off1, c0 = G.c_off, k_seg = groups->k_seg;
-    }
-    const float alpha = p.scale_a[1] * p.scale_b[1];
-
-    // A: LDS-DMA plan as above (lane i of an instruction lands at byte 16 i of its 1 KB row group; the swizzle rides on the source address)
-    const int lr = lane >> 2, cq = (lane & 3) ^ ((-(lane >> 4)) & 3);
-    const _Float16* tileA = p.A + (int64_t)m0 * p.lda;
-    const _Float16* tileB = p.B + (int64_t)n0 * p.ldb;
-    uint32_t offA[2 * GA];
-#pragma unroll
-    for (int h = 0; h < GA; ++h) {
-        const uint32_t r = (uint32_t)(min(m0 + (w + kWaves * h) * 16 + lr, p.M - 1) - m0) * (uint32_t)p.lda + cq * 8;
-        offA[h] = r * 2, offA[GA + h] = (r + p.a2_off) * 2;
-    }
-    auto issue_a = [&](int i, int stage, int kt) {           // i = 0 .. 3: a1 group w, a1 group w + 8, a2 group w, a2 group w + 8
-        const int q = i / GA, h = i % GA;
-        dma16(tileA, lds + stage * kStageBytes + q * kABytes + (w + kWaves * h) * 1024, offA[i],
-              GROUPED ? kt * (BK * 2) + (kt < k_seg ? a_off0 : a_off1) : kt * (BK * 2));
-    };
-    // B: this wave's 32 weight rows; lane l holds row l & 15 of a 16-row tile, bytes 16 (l >> 4) .. + 15 of the k-step's 64
-    uint32_t offB[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-        offB[nt] = ((uint32_t)(min(n0 + w * (NT * 16) + nt * 16 + (lane & 15), p.N - 1) - n0) * (uint32_t)p.ldb) * 2 + (lane >> 4) * 16;
-    const uint32_t b2 = (uint32_t)p.b2_off * 2;
-    auto load_b = [&](half8 (&x1)[NT], half8 (&x2)[NT], int kt) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            x1[nt] = load16(tileB, offB[nt], kt * (BK * 2));
-            x2[nt] = load16(tileB, offB[nt] + b2, kt * (BK * 2));
-        }
-    };
-    // A fragments: lane l reads row l & 15 of a 16-row tile, chunk l >> 4, stored at chunk ^ f(row quad)
-    const int frow = lane & 15, fch = (lane >> 4) ^ ((-(frow >> 2)) & 3);
-    const int a_off = frow * 64 + fch * 16;                  // + mt * 1024 (+ kABytes for the second half)
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mfma6 = [&](int mt, const half8& a1, const half8& a2, const half8 (&b1)[NT], const half8 (&b2h)[NT], const half8 (&b1s)[NT]) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[nt], a1, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2h[nt], a1, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1s[nt], a2, acc[mt][nt], 0, 0, 0);
-        }
-    };
-    const _Float16 sh = (_Float16)(1.0f / kHalvesShift);
-
-    // prologue: A of steps 0 and 1 and B of step 0 in flight; in issue order A0 (4), B0 (4), A1 (4)
-    half8 b1[NT], b2h[NT], b1s[NT], bn1[NT], bn2[NT], a1, a2;
-#pragma unroll
-    for (int i = 0; i < 2 * GA; ++i) issue_a(i, 0, 0);
-    load_b(b1, b2h, 0);
-    if (T > 1) {
-#pragma unroll
-        for (int i = 0; i < 2 * GA; ++i) issue_a(i, 1, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    a1 = *reinterpret_cast<const half8*>(lds + a_off);
-    a2 = *reinterpret_cast<const half8*>(lds + a_off + kABytes);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        // (a use the compiler can see: its wait-count pass then knows every B register of step 0 has landed HERE - left pending into the
-        // loop it re-waits at the head of every k-step, behind the loads just issued for the next one: vmcnt(0), the whole latency exposed)
-        asm volatile("" : "+v"(b1[nt]), "+v"(b2h[nt]));
-        b1s[nt] = b1[nt] * sh;
-    }
-    int stage = 0;
-    if constexpr ((ABL & 4) != 0) {
-        if (w >= 4) __builtin_amdgcn_s_setprio(1);
-    }
-    // One k-step.  MORE / MORE2: steps t + 1 / t + 2 exist - compile-time, so that the steady-state loop has NO branch around its loads:
-    // the wait-count pass then sees exactly four DMA instructions behind the B loads and waits vmcnt(4) for them, not vmcnt(0).
-    auto kstep = [&](int t, auto more_tag, auto more2_tag) {
-        constexpr bool more = decltype(more_tag)::value, more2 = decltype(more2_tag)::value;
-        const int s1 = stage == 2 ? 0 : stage + 1, s2 = stage == 0 ? 2 : stage - 1;      // stages of steps t + 1, t + 2 (= t - 1: free since its barrier)
-        const unsigned char* st = lds + stage * kStageBytes;
-        const unsigned char* sn = lds + s1 * kStageBytes;
-        if constexpr (more && !(ABL & 2)) {
-            load_b(bn1, bn2, t + 1);
-            __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks these loads to the END of the step - into the registers of
-        }                                        // the fragments in use, to save VGPRs - and the next step waits for them at its head)
-#pragma unroll
-        for (int mt = 0; mt < MT - 1; ++mt) {
-            const half8 an1 = *reinterpret_cast<const half8*>(st + a_off + (mt + 1) * 1024);
-            const half8 an2 = *reinterpret_cast<const half8*>(st + a_off + kABytes + (mt + 1) * 1024);
-            if constexpr (more2 && !(ABL & 1)) {
-                if (mt < 2 * GA) issue_a(mt, s2, t + 2);
-            }
-            mfma6(mt, a1, a2, b1, b2h, b1s);
-            a1 = an1, a2 = an2;
-        }
-        // step t + 1 complete (A: issued during step t - 1; B: issued at the head of this step, before this step's DMA) and every read of
-        // this step's stage returned; the DMA of step t + 2 - this wave's four youngest - may stay in flight
-        if constexpr (more2 && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        half8 an1 = a1, an2 = a2;
-        if constexpr (more) {
-            an1 = *reinterpret_cast<const half8*>(sn + a_off);
-            an2 = *reinterpret_cast<const half8*>(sn + a_off + kABytes);
-        }
-        mfma6(MT - 1, a1, a2, b1, b2h, b1s);
-        if constexpr (more) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if constexpr (!(ABL & 2)) b1[nt] = bn1[nt], b2h[nt] = bn2[nt], b1s[nt] = bn1[nt] * sh;
-            }
-            a1 = an1, a2 = an2;
-        }
-        stage = s1;
-    };
-    int t = 0;
-    for (; t + 2 < T; ++t) kstep(t, std::true_type{}, std::true_type{});
-    if (t + 1 < T) kstep(t++, std::true_type{}, std::false_type{});
-    kstep(t, std::false_type{}, std::false_type{});
-    __builtin_amdgcn_s_barrier();       // the epilogue reuses the stages: every wave is past its last fragment read
-
-    // epilogue: acc[mt][nt][r] = C[m0 + mt 16 + (lane & 15)][c0 + w 32 + nt 16 + (lane >> 4) 4 + r], staged per wave in slabs of 32 rows x 32
-    // columns (pitch 36 floats) so that a store instruction writes 8 rows x 128 contiguous bytes
-    if (p.mode & 1) {
-        if (acc[0][0][0] == 1.2345e-33f) p.C[0] = acc[MT - 1][NT - 1][3] + acc[MT / 2][1][2];
-        return;
-    }
-    float* const Cb = p.C + c0;
-    const bool vec_ok = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
-    const bool vec2_ok = (p.ldc % 2 == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 7) == 0);
-    constexpr int P = NT * 16 + 4;
-    static_assert(32 * P * 4 <= kStages * kStageBytes / kWaves, "staging slab does not fit the wave's share of the LDS");
-    float* stg = reinterpret_cast<float*>(lds + w * (kStages * kStageBytes / kWaves));
-    const int q4 = (lane >> 4) * 4, l15 = lane & 15, l7 = lane & 7;
-    const int col = w * (NT * 16) + l7 * 4;         // within the tile: this lane's four columns, the same in every pass
-    float cs[4] = {1.f, 1.f, 1.f, 1.f}, ch[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool affine = p.col_scale != nullptr || p.col_shift != nullptr;
-    if (affine) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (col + e < n_valid) {
-                if (p.col_scale) cs[e] = p.col_scale[c0 + col + e];
-                if (p.col_shift) ch[e] = p.col_shift[c0 + col + e];
-            }
-    }
-    float amax = 0.f;
-#pragma unroll
-    for (int pass = 0; pass < MT / 2; ++pass) {
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const f32x4 v = acc[pass * 2 + mm][nt] * alpha;
-                *reinterpret_cast<f32x4*>(stg + (mm * 16 + l15) * P + nt * 16 + q4) = v;
-            }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = i * 8 + (lane >> 3);
-            f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * P + l7 * 4);
-            const int row = m0 + pass * 32 + r;
-            if (affine || p.relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = fmaf(v[e], cs[e], ch[e]);
-                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
-                }
-            }
-            if (p.absmax && row < p.M) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < n_valid) amax = fmaxf(amax, fabsf(v[e]));
-            }
-            if (row < p.M) {
-                float* c = Cb + (int64_t)row * p.ldc + col;
-                if (vec_ok && col + 3 < n_valid) {
-                    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-                } else if (vec2_ok && col + 3 < n_valid) {
-                    *reinterpret_cast<float2*>(c) = make_float2(v[0], v[1]);
-                    *reinterpret_cast<float2*>(c + 2) = make_float2(v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e < n_valid) c[e] = v[e];
-                }
-            }
-        }
-    }
-    if (p.absmax) absmax_publish(wave_absmax(amax), p.absmax);
-}
-
-__global__ __launch_bounds__(512) void gemm_halves3_nt_bd_kernel(H3Args p) { gemm_halves3_nt_bd_body<false>(p, nullptr); }
-template <int ABL>
-__global__ __launch_bounds__(512) void gemm_halves3_nt_bd_abl_kernel(H3Args p) { gemm_halves3_nt_bd_body<false, ABL>(p, nullptr); }
-__global__ __launch_bounds__(512) void gemm_halves3_nt_bd_grouped_kernel(H3Args p, H3Groups groups) { gemm_halves3_nt_bd_body<true>(p, &groups); }
-
 // ============================================================================================================================
 // TN: the weight gradient  dW[k, p] = sum_n x[n, k] d[n, p]  of two LEFT-layout operands (x: [N, 3 KP], d: [N, 3 PP]; h1 at piece 0,
 // 2^11 h2 at piece 2), a reduction over the N ~ 1.7e5 node rows with a small result:
@@ -962,18 +725,7 @@ extern "C" int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const fl
     p.tiles_m = p.tiles_n = 0;
     p.col_scale = p.col_shift = nullptr, p.relu = 0, p.absmax = nullptr;
     p.mode = mode;
-    if (mode & 512) {       // the B-direct form
-        p.tiles_m = (int)((m + 255) / 256), p.tiles_n = (int)((n + 255) / 256);
-        set_kernel("bot::gemm_halves3_nt_bd_kernel");
-        const dim3 grid(((p.tiles_m + 7) / 8) * 8 * p.tiles_n);
-        switch ((mode >> 10) & 7) {          // measurement builds
-            case 1: hipLaunchKernelGGL(gemm_halves3_nt_bd_abl_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p); break;
-            case 2: hipLaunchKernelGGL(gemm_halves3_nt_bd_abl_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, p); break;
-            case 3: hipLaunchKernelGGL(gemm_halves3_nt_bd_abl_kernel<3>, grid, dim3(512), 0, (hipStream_t)stream, p); break;
-            case 4: hipLaunchKernelGGL(gemm_halves3_nt_bd_abl_kernel<4>, grid, dim3(512), 0, (hipStream_t)stream, p); break;
-            default: hipLaunchKernelGGL(gemm_halves3_nt_bd_kernel, grid, dim3(512), 0, (hipStream_t)stream, p);
-        }
-    } else if (mode & 32) {        // measurement builds only: one barrier at the END of a k-step, with the ablation switches
+    if (mode & 32) {        // measurement builds only: one barrier at the END of a k-step, with the ablation switches
         set_kernel("bot::gemm_halves3_nt_kernel<256,256,2,4,plain>");
         launch_h3<256, 256, 2, 4, false>(p, m, n, (hipStream_t)stream);
     } else {
@@ -1013,11 +765,6 @@ extern "C" int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const 
         g.g[i] = H3Group{(int)d[0], (int)d[1], (int)d[2] * 2, (int)d[3] * 2, (int)k_steps, 0, d[5]};
     }
     p.tiles_m = (int)((m + 255) / 256), p.tiles_n = n_groups;
-    if (mode & 512) {
-        set_kernel("bot::gemm_halves3_nt_bd_grouped_kernel");
-        hipLaunchKernelGGL(gemm_halves3_nt_bd_grouped_kernel, dim3(((p.tiles_m + 7) / 8) * 8 * n_groups), dim3(512), 0, (hipStream_t)stream, p, g);
-        return hip_status("gemm_halves3_nt_grouped");
-    }
     set_kernel("bot::gemm_halves3_nt_grouped_kernel<256,256,2,4,pipelined>");
     hipLaunchKernelGGL((gemm_halves3_nt_grouped_kernel<256, 256, 2, 4, true>), dim3(((p.tiles_m + 7) / 8) * 8 * n_groups), dim3(512), 0, (hipStream_t)stream, p, g);
     return hip_status("gemm_halves3_nt_grouped");
