@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -116,6 +116,15 @@ _SIGS = {
     "bot_bn_act_bwd_apply_f32": (ctypes.c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_float,
                                                 c_uint64, _P, _P, _P, c_double, _P, c_int64, _P, _P]),
     "bot_halves_tn_combine_f32": (ctypes.c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P]),
+    "bot_halves_scale_from_slots2_f32": (ctypes.c_int, [_P, c_float, _P, c_float, _P, _P]),
+    "bot_halves_tail_f16": (ctypes.c_int, [c_int64, c_int32, _P, _P, _P, _P, _P, c_int64, c_int32, _P]),
+    "bot_spmm_dot_halves_fits": (ctypes.c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, c_int32]),
+    "bot_spmm_dot_halves_f16": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int64,
+                                               c_int32, c_int32, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P]),
+    "bot_gemm_halves3_nt2_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64,
+                                                c_int32, _P]),
+    "bot_gemm_halves3_tn2_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P,
+                                                c_int64, _P, c_int32, _P]),
     "bot_absmax_slots": (c_int32, []),
     "bot_absmax_slots_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P]),
     "bot_halves_scale_from_slots_f32": (ctypes.c_int, [_P, _P, _P]),
@@ -345,6 +354,37 @@ def spmm_dot(d, x, w, wperm, y, out=None, dot=None, absmax=None):
         _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, w.data_ptr(), _ptr(_i32(wperm, "wperm")), y.data_ptr(), ldy, hsy,
         H, D, out.data_ptr(), ldo, hso, dot.data_ptr(), _ptr(partial), _ptr(absmax), _stream())), "spmm_dot")
     return out, dot
+
+
+def spmm_dot_halves_fits(x, y, hout, hsh, h2_off) -> bool:
+    """Would `spmm_dot_halves` take these operands (x, y: [n, H, D] slabs; hout: the operand's [n, >= h2_off + H hsh] fp16 view)?"""
+    x, ldx, hsx = _slab(x, "x")
+    y, ldy, hsy = _slab(y, "y")
+    return bool(_lib.bot_spmm_dot_halves_fits(x.data_ptr(), ldx, hsx, y.data_ptr(), ldy, hsy, x.shape[1], x.shape[2], hout.data_ptr(), hout.stride(0),
+                                              int(hsh), int(h2_off)))
+
+
+def spmm_dot_halves(d, x, w, wperm, y, hscale, hout, hsh, h2_off, dot=None):
+    """`spmm_dot` whose first result leaves the kernel as a LEFT halves operand: hout[r, h * hsh + e] = h1, hout[r, h2_off + h * hsh + e] =
+    2^11 h2 of hscale[0] * out[r,h,e] (bot_spmm_dot_halves_f16; all-heads layout only: ask spmm_dot_halves_fits first).  Returns dot [nnz, H]."""
+    _dev(x, w, y, d.indptr, hout, hscale)
+    x, ldx, hsx = _slab(x, "x")
+    y, ldy, hsy = _slab(y, "y")
+    H, D = x.shape[1], x.shape[2]
+    w = _f32(w, "w").contiguous()
+    assert hout.dtype == torch.float16 and hout.stride(1) == 1 and hout.shape[0] == d.n_rows
+    if dot is None:
+        dot = torch.empty((d.nnz, H), dtype=torch.float32, device=x.device)
+    elif dot.dtype != torch.float32 or not dot.is_contiguous() or dot.dim() != 2 or dot.shape[1] != H:
+        raise BotKernelError(f"spmm_dot_halves: dot must be a contiguous float32 [E,{H}] array")
+    partial = None
+    if d.n_long:
+        partial = torch.empty(int(_lib.bot_spmm_workspace_floats(d.n_slots, H, D)), dtype=torch.float32, device=x.device)
+    _check(_timed("spmm_dot", (H, D), lambda: _lib.bot_spmm_dot_halves_f16(
+        d.indptr.data_ptr(), d.indices.data_ptr(), d.n_rows, d.nnz, d.items.data_ptr(), d.n_items, _ptr(d.long_rows),
+        _ptr(d.long_ptr), d.n_long, x.data_ptr(), ldx, hsx, w.data_ptr(), _ptr(_i32(wperm, "wperm")), y.data_ptr(), ldy, hsy,
+        H, D, hscale.data_ptr(), hout.data_ptr(), hout.stride(0), int(hsh), int(h2_off), dot.data_ptr(), _ptr(partial), _stream())), "spmm_dot_halves")
+    return dot
 
 
 def spmm_bcast(d, x, w, wperm=None, head_outer=True):
@@ -646,11 +686,41 @@ def absmax_into(x, slots):
     return slots
 
 
-def halves_scale_from_slots(slots):
-    """scale [2] = (s, 1/s) from the by-product slots: what halves_scale finds with a pass over the matrix."""
+def halves_scale_from_slots(slots, mult=None, cap=None, cap_ratio=1.0):
+    """scale [2] = (s, 1/s) from the by-product slots: what halves_scale finds with a pass over the matrix.  `mult`: the scale of mult x
+    the slots' maximum (a bound assembled by the caller); `cap`: another (s, 1/s) pair - the result is at most cap[0] * cap_ratio
+    (bot_halves_scale_from_slots2_f32)."""
     scale = torch.empty(2, dtype=torch.float32, device=slots.device)
-    _check(_lib.bot_halves_scale_from_slots_f32(slots.data_ptr(), scale.data_ptr(), _stream()), "halves_scale_from_slots")
+    if mult is None and cap is None:
+        _check(_lib.bot_halves_scale_from_slots_f32(slots.data_ptr(), scale.data_ptr(), _stream()), "halves_scale_from_slots")
+    else:
+        _dev(cap)
+        _check(_lib.bot_halves_scale_from_slots2_f32(slots.data_ptr(), float(1.0 if mult is None else mult), _ptr(cap), float(cap_ratio), scale.data_ptr(),
+                                                     _stream()), "halves_scale_from_slots2")
     return scale
+
+
+def halves_tail(segments, scale, out, h2_off):
+    """Column segments of the LEFT halves operand `out` [n, ld] (h1 at column c, 2^11 h2 at c + h2_off) from small fp32 sources, or zeroed:
+    segments = [(col, width, src [n, width] float32 (row-strided) or None), ...]  (bot_halves_tail_f16)."""
+    _dev(out, scale)
+    assert out.dtype == torch.float16 and out.stride(1) == 1 and 1 <= len(segments) <= 8
+    n = out.shape[0]
+    cols = (c_int64 * (2 * len(segments)))()
+    srcs = (c_void_p * len(segments))()
+    lds = (c_int64 * len(segments))()
+    for g, (col, width, src) in enumerate(segments):
+        cols[2 * g], cols[2 * g + 1] = int(col), int(width)
+        if src is not None:
+            _dev(src)
+            _f32(src, "segment source")
+            if src.shape != (n, width) or src.stride(1) != 1:
+                raise BotKernelError(f"halves_tail: segment {g}: source shape {tuple(src.shape)} / stride {tuple(src.stride())} for width {width}")
+            srcs[g], lds[g] = src.data_ptr(), src.stride(0)
+        else:
+            srcs[g], lds[g] = None, 0
+    _check(_lib.bot_halves_tail_f16(n, len(segments), cols, srcs, lds, scale.data_ptr(), out.data_ptr(), out.stride(0), int(h2_off), _stream()), "halves_tail")
+    return out
 
 
 def halves_tn_combine(a, b, P, rem_a=None, rem_b=None):
@@ -800,17 +870,18 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     return out
 
 
-def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None):
+def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0):
     """out[m, n] = scale_a[1] scale_b[1] (a1 b1^T + a1 b2^T + a2 b1^T) from a LEFT operand buffer a [m, 3 piece_a] (or [m, 2 piece_a]
     without the duplicate piece: a2_off = piece_a) and a RIGHT operand buffer b [n, 3 piece_b] (bot_amd.gemm.Halves.buf / .scale), k =
-    the common piece width used (bot_gemm_halves3_nt_f32)."""
-    _dev(a, b, scale_a, scale_b)
+    the common piece width used (bot_gemm_halves3_nt_f32).  scale_a2 / k_split: a's columns from k_split (a multiple of 32) on were
+    written under a second scale (bot_gemm_halves3_nt2_f32)."""
+    _dev(a, b, scale_a, scale_b, scale_a2)
     m, n = a.shape[0], b.shape[0]
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-    _check(_timed("gemm_halves", (m, n, 3 * k, 1), lambda: _lib.bot_gemm_halves3_nt_f32(
-        m, n, k, scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), 2 * piece_a if a2_off is None else a2_off, b.data_ptr(), _ld(b),
-        piece_b, out.data_ptr(), _ld(out), int(mode), _stream())), "gemm_halves3_nt")
+    _check(_timed("gemm_halves", (m, n, 3 * k, 1), lambda: _lib.bot_gemm_halves3_nt2_f32(
+        m, n, k, scale_a.data_ptr(), _ptr(scale_a2), int(k_split), scale_b.data_ptr(), a.data_ptr(), _ld(a), 2 * piece_a if a2_off is None else a2_off,
+        b.data_ptr(), _ld(b), piece_b, out.data_ptr(), _ld(out), int(mode), _stream())), "gemm_halves3_nt")
     return out
 
 
@@ -857,16 +928,17 @@ def gemm_halves3_tn_grouped(x, d, scale_x, scale_d, x2_off, d2_off, out, tiles, 
     return out
 
 
-def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0, x2_off=None, d2_off=None):
+def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0, x2_off=None, d2_off=None, scale_d2=None, p_split=0):
     """out[k, p] = scale_x[1] scale_d[1] (x1^T d1 + x1^T d2 + x2^T d1) from two LEFT operand buffers x [n, 3 piece_x], d [n, 3 piece_d]
-    (include/bot_gnn.h bot_gemm_halves3_tn_f32): the weight gradient of a projection, reduced over the n rows."""
-    _dev(x, d, scale_x, scale_d)
+    (include/bot_gnn.h bot_gemm_halves3_tn_f32): the weight gradient of a projection, reduced over the n rows.  scale_d2 / p_split: d's
+    columns from p_split (a multiple of 4) on were written under a second scale (bot_gemm_halves3_tn2_f32)."""
+    _dev(x, d, scale_x, scale_d, scale_d2)
     n = x.shape[0]
     out = torch.empty((k, p), dtype=torch.float32, device=x.device)
     ws = torch.empty(int(_lib.bot_gemm_halves3_tn_workspace_floats(n, piece_x, piece_d)), dtype=torch.float32, device=x.device)
-    _check(_timed("gemm_halves", (k, p, 3 * n, 1), lambda: _lib.bot_gemm_halves3_tn_f32(
-        n, k, p, piece_x, piece_d, scale_x.data_ptr(), scale_d.data_ptr(), x.data_ptr(), _ld(x), 2 * piece_x if x2_off is None else x2_off,
-        d.data_ptr(), _ld(d), 2 * piece_d if d2_off is None else d2_off,
+    _check(_timed("gemm_halves", (k, p, 3 * n, 1), lambda: _lib.bot_gemm_halves3_tn2_f32(
+        n, k, p, piece_x, piece_d, scale_x.data_ptr(), scale_d.data_ptr(), _ptr(scale_d2), int(p_split), x.data_ptr(), _ld(x),
+        2 * piece_x if x2_off is None else x2_off, d.data_ptr(), _ld(d), 2 * piece_d if d2_off is None else d2_off,
         out.data_ptr(), _ld(out), ws.data_ptr(), int(mode), _stream())), "gemm_halves3_tn")
     return out
 
@@ -1109,14 +1181,18 @@ def bn_bwd_bound(ws, n, sum_g, sum_gx, total_count, weight, invstd, slots):
     return slots
 
 
-def bn_act_bwd_apply_halves(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, hscale, hout, hD, hDP, out=None):
+def bn_act_bwd_apply_halves(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, hscale, hout, hD, hDP, out=None, h2_off=None):
     """bn_act_bwd_apply writing dx as the LEFT halves operand `hout` [n, 2 * (F / hD) * hDP] = [h1 | 2^11 h2] of hscale[0] * dx, the columns in
     blocks of hD every hDP (padding columns untouched); `out`: optionally dx in fp32 as well (bot_bn_act_bwd_apply_halves_f32)."""
     _dev(dy, x, hout, hscale)
     dy, x = _mat(dy, "dy"), _mat(x, "x")
     n, F = x.shape
-    h2_off = (F // hD) * hDP
-    assert hout.dtype == torch.float16 and hout.shape == (n, 2 * h2_off) and hout.stride(1) == 1
+    if h2_off is None:
+        h2_off = (F // hD) * hDP
+        assert hout.shape == (n, 2 * h2_off)
+    else:       # `hout`: a column range of a wider operand (its first column = the block's first), the second half h2_off columns behind
+        assert hout.shape[0] == n and hout.stride(0) >= h2_off + (F // hD) * hDP
+    assert hout.dtype == torch.float16 and hout.stride(1) == 1
     assert out is None or (out.stride(1) == 1 and out.dtype == torch.float32)
     _check(_lib.bot_bn_act_bwd_apply_halves_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, F, mean.data_ptr(), invstd.data_ptr(), _ptr(weight),
                                                 _ptr(bias), int(relu), float(p), int(seed), _seed_off(p), _ptr(sum_g), _ptr(sum_gx), float(total_count),

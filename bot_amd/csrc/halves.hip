@@ -153,6 +153,51 @@ __global__ __launch_bounds__(128) void halves_split_heads_kernel(const float* x,
     *reinterpret_cast<__half2*>(o + h2_off) = __halves2half2(__float2half_rn(r0 * kHalvesShift), __float2half_rn(r1 * kHalvesShift));
 }
 
+// halves_scale_kernel on `mult` x the maximum (a BOUND assembled on the host side of the maximum: max|dx| x the largest row sum of the edge
+// weights), optionally capped at cap[0] x cap_ratio (a second scale of one operand may be finer than the first only by a bounded factor:
+// the GEMM multiplies its accumulators by their ratio, csrc/halves3.hip `scale_a2`)
+__global__ __launch_bounds__(kWave) void halves_scale2_kernel(const float* part, int nblk, float mult, const float* cap, float cap_ratio, float* scale) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += kWave) m = fmaxf(m, part[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (threadIdx.x == 0) {
+        m *= mult;
+        float s = 1.f;
+        if (m > 0.f && m < INFINITY) {
+            int e;
+            const float f = frexpf(m, &e);
+            if (f == 0.5f) e -= 1;
+            s = ldexpf(1.f, min(60, 14 - e));
+        }
+        if (cap) s = fminf(s, cap[0] * cap_ratio);
+        scale[0] = s;
+        scale[1] = 1.f / s;
+    }
+}
+
+// Column segments of a LEFT halves operand written from small fp32 sources (or as zeros): the attention columns and the padding columns
+// of a layer's gradient operand, whose big column blocks their producers wrote (bot_halves_tail_f16).
+constexpr int kTailSegs = 8;
+struct TailArgs {
+    int col[kTailSegs], width[kTailSegs];
+    const float* src[kTailSegs];        // nullptr: zeros
+    int64_t ld[kTailSegs];
+    int n_seg, total;
+};
+__global__ __launch_bounds__(kBlock) void halves_tail_kernel(TailArgs t, int64_t n, const float* scale, __half* out, int64_t ldo, int32_t h2_off) {
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= n * t.total) return;
+    const int64_t r = gid / t.total;
+    int j = (int)(gid - r * t.total), g = 0;
+    while (j >= t.width[g]) j -= t.width[g], ++g;       // (g < n_seg: j < total)
+    const float v = t.src[g] ? t.src[g][r * t.ld[g] + j] * scale[0] : 0.f;
+    const __half a = __float2half_rn(v);
+    __half* o = out + r * ldo + t.col[g] + j;
+    o[0] = a;
+    o[h2_off] = __float2half_rn((v - __half2float(a)) * kHalvesShift);
+}
+
 void launch_halves_scale(const float* part, int n, float* scale, hipStream_t st) {
     hipLaunchKernelGGL(halves_scale_kernel, dim3(1), dim3(kWave), 0, st, part, n, scale);
 }
@@ -255,6 +300,36 @@ int bot_halves_scale_from_slots_f32(const uint32_t* slots, float* scale, bot_str
     // a non-negative float and its bit pattern are the same word: the slots ARE an array of partial maxima
     launch_halves_scale(reinterpret_cast<const float*>(slots), kAbsmaxSlots, scale, (hipStream_t)stream);
     return hip_status("halves_scale_from_slots launch");
+}
+
+int bot_halves_scale_from_slots2_f32(const uint32_t* slots, float mult, const float* cap_scale, float cap_ratio, float* scale, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(slots && scale, BOT_E_NULL, "halves_scale_from_slots2: NULL pointer");
+    BOT_REQUIRE(mult > 0.f && mult < INFINITY && (cap_scale == nullptr || cap_ratio > 0.f), BOT_E_RANGE, "halves_scale_from_slots2: mult=%g cap_ratio=%g", mult, cap_ratio);
+    hipLaunchKernelGGL(halves_scale2_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, reinterpret_cast<const float*>(slots), kAbsmaxSlots, mult, cap_scale,
+                       cap_ratio, scale);
+    return hip_status("halves_scale_from_slots2 launch");
+}
+
+int bot_halves_tail_f16(int64_t n, int32_t n_seg, const int64_t* seg_cols, const float* const* srcs, const int64_t* src_ld, const float* scale, uint16_t* out,
+                        int64_t ldo, int32_t h2_off, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 0 && n_seg >= 1 && n_seg <= kTailSegs && seg_cols && srcs && src_ld && scale && out, BOT_E_NULL, "halves_tail: 1 .. %d segments, no NULL pointer",
+                kTailSegs);
+    TailArgs t{};
+    t.n_seg = n_seg, t.total = 0;
+    for (int g = 0; g < n_seg; ++g) {
+        const int64_t col = seg_cols[2 * g], w = seg_cols[2 * g + 1];
+        BOT_REQUIRE(col >= 0 && w >= 1 && col + w <= h2_off && h2_off + col + w <= ldo && (srcs[g] == nullptr || src_ld[g] >= w), BOT_E_RANGE,
+                    "halves_tail: segment %d: col=%lld width=%lld (h2_off=%d ldo=%lld)", g, (long long)col, (long long)w, h2_off, (long long)ldo);
+        t.col[g] = (int)col, t.width[g] = (int)w, t.src[g] = srcs[g], t.ld[g] = src_ld[g];
+        t.total += (int)w;
+    }
+    if (n == 0) return 0;
+    const int64_t total = n * t.total;
+    hipLaunchKernelGGL(halves_tail_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, t, n, scale, (__half*)out, ldo,
+                       h2_off);
+    return hip_status("halves_tail launch");
 }
 
 int bot_halves_tn_combine_f32(const float* a, const float* b, int32_t chunks, int32_t K, int32_t PP, int32_t P, const float* rem_a,

@@ -49,6 +49,11 @@ struct H3Args {
     const float* col_shift;
     int relu;
     uint32_t* absmax;
+    // optional (bot_gemm_halves3_nt2_f32): A's columns from k-step k2 on are stored under a SECOND scale (scale_a2: the handful of attention
+    // columns of a layer's gradient buffer, whose magnitude is known only after the big column blocks have been written under a bound):
+    // the accumulators are multiplied by scale_a2[0] / scale_a[0] (a power of two: exact) in front of k-step k2, alpha = scale_a2[1] scale_b[1]
+    const float* scale_a2;
+    int k2;                 // -1: one scale
     int mode;               // 0 = the product.  Measurement switches (tools/exp_halves3.py): bit 0 no output stores; bit 2 / 3 B / A never
                             // advance along k; bit 5 the plain loop (barrier at the end of a k-step) and, in it, bit 6 no barrier / wait,
                             // bit 7 no DMA inside the loop, bit 8 one A fragment pair per k-step
@@ -80,7 +85,9 @@ __device__ __forceinline__ void dma16(const void* tile_base, unsigned char* lptr
 
 // One BM x BN output tile per workgroup of WM x WN waves (wave tile MT x NT MFMA tiles of 16 x 16).  LDS: two stages of
 // [a1 | a2 | b1 | b2], each piece [rows][64 B] with the 16-byte chunk index XOR-swizzled by f(row quad) = (-(row >> 2)) & 3.
-template <int BM, int BN, int WM, int WN, bool PIPE, bool GROUPED>
+// ABLATE: the measurement build (tools/exp_halves3.py --ablate): only there is `p.mode` read inside the kernel; the production
+// instantiations (ABLATE = false) carry no switch, no branch and no live register for it.
+template <int BM, int BN, int WM, int WN, bool PIPE, bool GROUPED, bool ABLATE>
 __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Groups* groups) {
     constexpr int kWaves = WM * WN;
     constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
@@ -103,7 +110,7 @@ __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Gr
         const H3Group& G = groups->g[tn];
         n0 = G.b_row0, n_valid = G.n_valid, T = G.k_steps, a_off0 = G.a_off0, a_off1 = G.a_off1, c0 = G.c_off, k_seg = groups->k_seg;
     }
-    const float alpha = p.scale_a[1] * p.scale_b[1];
+    const float alpha = (p.scale_a2 ? p.scale_a2[1] : p.scale_a[1]) * p.scale_b[1];
 
     // LDS-DMA plan: lane i of a wave instruction lands at byte 16 i of its 1 KB row group: row i >> 2, stored chunk i & 3, which holds
     // the row's chunk (i & 3) ^ f(row quad) - the swizzle is applied to the per-lane SOURCE address (the DMA writes lane-linear)
@@ -126,7 +133,7 @@ __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Gr
         const uint32_t r = (uint32_t)(min(n0 + (w + kWaves * h) * 16 + lr, p.N - 1) - n0) * (uint32_t)p.ldb + cq * 8;
         offB[h] = r * 2, offB[GB + h] = (r + p.b2_off) * 2;
     }
-    const int stepA = (p.mode & 8) ? 0 : BK * 2, stepB = (p.mode & 4) ? 0 : BK * 2;     // ablations: an operand re-read from its first k-step
+    const int stepA = (ABLATE && (p.mode & 8)) ? 0 : BK * 2, stepB = (ABLATE && (p.mode & 4)) ? 0 : BK * 2;     // ablations: an operand re-read from its first k-step
     // DMA instruction i of a k-step (0 .. kDma - 1): a1 groups, a2 groups, b1 groups, b2 groups; `kt` = the k-step being fetched
     constexpr int kDma = 2 * GA + 2 * GB;
     auto issue_one = [&](int i, int stage, int kt) {
@@ -156,6 +163,13 @@ __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Gr
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    auto rescale = [&]() {       // in front of k-step k2: what was accumulated under scale_a continues under scale_a2
+        const float r = p.scale_a2[0] * p.scale_a[1];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc[mt][nt] * r;
+    };
     auto mfma12 = [&](int mt, const half8& a1, const half8& a2, const half8 (&b1)[NT], const half8 (&b2)[NT], const half8 (&b1s)[NT]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -173,6 +187,7 @@ __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Gr
             constexpr bool more = decltype(more_tag)::value;     // the last k-step is peeled: no branch around the DMA inside the MFMA phase
             const int nstage = (t + 1) & 1;
             const unsigned char* st = lds + (t & 1) * kStageBytes;
+            if (t == p.k2) rescale();
             half8 b1[NT], b2[NT], b1s[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -182,17 +197,17 @@ __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Gr
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int am = (p.mode & 256) ? 0 : mt;                 // ablation: one A fragment pair per k-step instead of MT
+                const int am = (ABLATE && (p.mode & 256)) ? 0 : mt;     // ablation: one A fragment pair per k-step instead of MT
                 const half8 a1 = *reinterpret_cast<const half8*>(st + a_off + am * 1024);
                 const half8 a2 = *reinterpret_cast<const half8*>(st + a_off + kABytes + am * 1024);
                 // the DMA of the next stage is spread over the MFMA phase (one or two instructions per row of MFMA tiles)
-                if (more && !(p.mode & 128)) {                          // ablation: no LDS-DMA in the loop
+                if (more && !(ABLATE && (p.mode & 128))) {              // ablation: no LDS-DMA in the loop
 #pragma unroll
                     for (int i = mt * kDma / MT; i < (mt + 1) * kDma / MT; ++i) issue_one(i, nstage, t + 1);
                 }
                 mfma12(mt, a1, a2, b1, b2, b1s);
             }
-            if (!(p.mode & 64)) {                                       // ablation: no wait, no barrier
+            if (!(ABLATE && (p.mode & 64))) {                           // ablation: no wait, no barrier
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -228,6 +243,7 @@ __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Gr
             const bool more = t + 1 < T, more2 = t + 2 < T;
             const unsigned char* st = lds + (t & 1) * kStageBytes;
             const unsigned char* sn = lds + ((t + 1) & 1) * kStageBytes;
+            if (t == p.k2) rescale();        // (wave-uniform, once per tile; k2 = -1 without a second scale)
 #pragma unroll
             for (int mt = 0; mt < MT - 1; ++mt) {
                 const half8 an1 = *reinterpret_cast<const half8*>(st + a_off + (mt + 1) * 1024);
@@ -266,9 +282,11 @@ __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Gr
     }
 
     // epilogue: acc[mt][nt][r] = C[m0 + wr MT 16 + mt 16 + (lane & 15)][n0 + wc NT 16 + nt 16 + (lane >> 4) 4 + r]
-    if (p.mode & 1) {
-        if (acc[0][0][0] == 1.2345e-33f) p.C[0] = acc[MT - 1][NT - 1][3] + acc[MT / 2][1][2];      // keeps the accumulators live
-        return;
+    if constexpr (ABLATE) {
+        if (p.mode & 1) {
+            if (acc[0][0][0] == 1.2345e-33f) p.C[0] = acc[MT - 1][NT - 1][3] + acc[MT / 2][1][2];      // keeps the accumulators live
+            return;
+        }
     }
     float* const Cb = p.C + c0;                     // the tile's first output column
     const bool vec_ok = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
@@ -339,14 +357,14 @@ __device__ __forceinline__ void gemm_halves3_nt_body(const H3Args& p, const H3Gr
     if (p.absmax) absmax_publish(wave_absmax(amax), p.absmax);      // (every lane of every wave arrives here)
 }
 
-template <int BM, int BN, int WM, int WN, bool PIPE>
+template <int BM, int BN, int WM, int WN, bool PIPE, bool ABLATE>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p) {
-    gemm_halves3_nt_body<BM, BN, WM, WN, PIPE, false>(p, nullptr);
+    gemm_halves3_nt_body<BM, BN, WM, WN, PIPE, false, ABLATE>(p, nullptr);
 }
 
 template <int BM, int BN, int WM, int WN, bool PIPE>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_grouped_kernel(H3Args p, H3Groups groups) {
-    gemm_halves3_nt_body<BM, BN, WM, WN, PIPE, true>(p, &groups);
+    gemm_halves3_nt_body<BM, BN, WM, WN, PIPE, true, false>(p, &groups);
 }
 
 // ============================================================================================================================
@@ -387,6 +405,7 @@ struct TnArgs3 {
     int tiles_k, tiles_p, splits, rows_per_split;       // rows_per_split: a multiple of TBK
     int mode;               // 0 = the product; measurement switches (tools/exp_halves3.py): bit 0 no DMA in the loop, bit 1 no barrier / wait
 };
+
 
 // Grouped form (bot_gemm_halves3_tn_grouped_f32): the tiles of a split are a LIST, each with its own x / d columns and output block - the
 // per-head weight gradients of the aggregate-first GAT layer and the gradient of its merged projection as ONE launch:
@@ -446,7 +465,7 @@ __device__ __forceinline__ half8 tr_pack(const v2i& lo, const v2i& hi) {
 
 // PT: columns of d per tile: 192, or 128 (grouped launches whose d blocks are a multiple of 128 wide: 4 instead of 6 tile rows per wave, the
 // 128-byte sub-image of d neither fetched nor read)
-template <bool GROUPED, int PT>
+template <bool GROUPED, int PT, bool ABLATE = false>     // ABLATE: the measurement build, the only one that reads `p.mode` in the kernel
 __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnTiles* tiles) {
     static_assert(PT == 192 || PT == 128, "tile widths of d");
     constexpr int MTN = PT / 32;            // 16-column tile rows per wave (2 wave rows)
@@ -553,7 +572,7 @@ __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnT
     int stage = 0;
     for (int kt = 0; kt < T; ++kt) {
         const int s2 = stage >= 1 ? stage - 1 : 2;        // (stage + 2) % 3: free since the barrier that ended step kt - 1
-        const bool ahead = kt + 2 < T && !(p.mode & 1);      // this step issues the DMA of step kt + 2, one instruction per tile row: six
+        const bool ahead = kt + 2 < T && !(ABLATE && (p.mode & 1));      // this step issues the DMA of step kt + 2, one instruction per tile row: six
         // at once right behind the barrier cost every wave ~900 cycles of issue before its first MFMA (0.55 of 1.46 ms, ablation)
         // the k-column fragments (x: the MFMA's B operand after the swap) of this wave's 48 columns: x1, 2^11 x2, 2^-11 x1
         const unsigned sb = lds_base + stage * kTnStage;
@@ -596,7 +615,7 @@ __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnT
             if (mt + 1 < MTN) tr_wait();
         }
         // step kt + 1 must have landed before anyone reads it; step kt + 2 (this wave's 6 youngest instructions) may stay in flight
-        if (!(p.mode & 2)) {
+        if (!(ABLATE && (p.mode & 2))) {
             if (ahead) {
                 if constexpr (kDma == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -635,6 +654,7 @@ __device__ __forceinline__ void gemm_halves3_tn_body(const TnArgs3& p, const TnT
 }
 
 __global__ __launch_bounds__(512) void gemm_halves3_tn_kernel(TnArgs3 p) { gemm_halves3_tn_body<false, 192>(p, nullptr); }
+__global__ __launch_bounds__(512) void gemm_halves3_tn_ablate_kernel(TnArgs3 p) { gemm_halves3_tn_body<false, 192, true>(p, nullptr); }
 template <int PT>
 __global__ __launch_bounds__(512) void gemm_halves3_tn_grouped_kernel(TnArgs3 p, TnTiles tiles) { gemm_halves3_tn_body<true, PT>(p, &tiles); }
 
@@ -675,13 +695,14 @@ __global__ __launch_bounds__(256) void tn_reduce_h3_grouped_kernel(const float* 
 }
 
 // out[k, p] = scale_x[1] scale_d[1] * sum_s part[s][k][p]   (split order), k < K, p < P
+// (scale_d2: d's columns from p2 on - a multiple of 4 - were stored under a second scale, bot_gemm_halves3_tn2_f32)
 __global__ __launch_bounds__(256) void tn_reduce_h3_kernel(const float* part, int splits, int K, int P, int KP, int PP, const float* scale_x,
-                                                           const float* scale_d, float* out, int64_t ldo) {
+                                                           const float* scale_d, float* out, int64_t ldo, const float* scale_d2, int p2) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int p4 = (P + 3) >> 2;
     if (i >= (int64_t)K * p4) return;
     const int k = (int)(i / p4), pc = (int)(i - (int64_t)k * p4) * 4;
-    const float alpha = scale_x[1] * scale_d[1];
+    const float alpha = scale_x[1] * ((scale_d2 && pc >= p2) ? scale_d2[1] : scale_d[1]);
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* src = part + (int64_t)k * PP + pc;
     constexpr int U = 4;                                    // loads in flight; added in split order
@@ -699,11 +720,11 @@ __global__ __launch_bounds__(256) void tn_reduce_h3_kernel(const float* part, in
         if (pc + e < P) o[e] = r[e];
 }
 
-template <int BM, int BN, int WM, int WN, bool PIPE>
+template <int BM, int BN, int WM, int WN, bool PIPE, bool ABLATE>
 void launch_h3(H3Args p, int64_t m, int64_t n, hipStream_t st) {
     p.tiles_m = (int)((m + BM - 1) / BM), p.tiles_n = (int)((n + BN - 1) / BN);
     const int groups = (p.tiles_m + 7) / 8;
-    hipLaunchKernelGGL((gemm_halves3_nt_kernel<BM, BN, WM, WN, PIPE>), dim3(groups * 8 * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+    hipLaunchKernelGGL((gemm_halves3_nt_kernel<BM, BN, WM, WN, PIPE, ABLATE>), dim3(groups * 8 * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
 }
 
 }  // namespace
@@ -712,7 +733,16 @@ void launch_h3(H3Args p, int64_t m, int64_t n, hipStream_t st) {
 extern "C" int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
                                        int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t mode,
                                        bot_stream_t stream) {
+    return bot_gemm_halves3_nt2_f32(m, n, k, scale_a, nullptr, 0, scale_b, A, lda, a2_off, B, ldb, b2_off, C, ldc, mode, stream);
+}
+
+extern "C" int bot_gemm_halves3_nt2_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_a2, int64_t k_split, const float* scale_b,
+                                        const uint16_t* A, int64_t lda, int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc,
+                                        int32_t mode, bot_stream_t stream) {
     using namespace bot;
+    BOT_REQUIRE(scale_a2 == nullptr || (k_split > 0 && k_split < k && k_split % BK == 0), -1,
+                "gemm_halves3_nt2: the second scale starts at a column that is a positive multiple of %d below k (got %lld of %lld)", BK, (long long)k_split,
+                (long long)k);
     BOT_REQUIRE(m > 0 && n > 0 && k > 0 && k % BK == 0, -1, "gemm_halves3_nt: m, n > 0 and k a positive multiple of %d (got %lld %lld %lld)", BK,
                 (long long)m, (long long)n, (long long)k);
     BOT_REQUIRE(scale_a && scale_b && A && B && C, -1, "gemm_halves3_nt: null pointer");
@@ -724,13 +754,17 @@ extern "C" int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const fl
     p.lda = lda, p.ldb = ldb, p.ldc = ldc, p.M = (int)m, p.N = (int)n, p.K = (int)k, p.a2_off = (int)a2_off, p.b2_off = (int)b2_off;
     p.tiles_m = p.tiles_n = 0;
     p.col_scale = p.col_shift = nullptr, p.relu = 0, p.absmax = nullptr;
+    p.scale_a2 = scale_a2, p.k2 = scale_a2 ? (int)(k_split / BK) : -1;
     p.mode = mode;
     if (mode & 32) {        // measurement builds only: one barrier at the END of a k-step, with the ablation switches
         set_kernel("bot::gemm_halves3_nt_kernel<256,256,2,4,plain>");
-        launch_h3<256, 256, 2, 4, false>(p, m, n, (hipStream_t)stream);
-    } else {
+        launch_h3<256, 256, 2, 4, false, true>(p, m, n, (hipStream_t)stream);
+    } else if (mode) {      // the pipelined loop with `mode` read in the kernel (bit 0: no output stores; bits 2 / 3: an operand never advances)
+        set_kernel("bot::gemm_halves3_nt_kernel<256,256,2,4,pipelined,ablate>");
+        launch_h3<256, 256, 2, 4, true, true>(p, m, n, (hipStream_t)stream);
+    } else {                // the product: no switch inside the kernel
         set_kernel("bot::gemm_halves3_nt_kernel<256,256,2,4,pipelined>");
-        launch_h3<256, 256, 2, 4, true>(p, m, n, (hipStream_t)stream);
+        launch_h3<256, 256, 2, 4, true, false>(p, m, n, (hipStream_t)stream);
     }
     return hip_status("gemm_halves3_nt");
 }
@@ -749,7 +783,8 @@ extern "C" int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const 
     H3Args p;
     p.A = reinterpret_cast<const _Float16*>(A), p.B = reinterpret_cast<const _Float16*>(B), p.scale_a = scale_a, p.scale_b = scale_b, p.C = C;
     p.lda = lda, p.ldb = ldb, p.ldc = ldc, p.M = (int)m, p.N = (int)b_rows, p.K = 0, p.a2_off = (int)a2_off, p.b2_off = (int)b2_off;
-    p.mode = mode & ~32;
+    p.mode = 0;             // (the grouped kernel is a production instantiation: no measurement switch inside)
+    p.scale_a2 = nullptr, p.k2 = -1;
     p.col_scale = col_scale, p.col_shift = col_shift, p.relu = relu, p.absmax = absmax_slots;
     H3Groups g;
     g.k_seg = k_seg;
@@ -836,7 +871,15 @@ extern "C" int64_t bot_gemm_halves3_tn_workspace_floats(int64_t n_rows, int64_t 
 extern "C" int bot_gemm_halves3_tn_f32(int64_t n_rows, int64_t k, int64_t p, int64_t kp, int64_t pp, const float* scale_x, const float* scale_d,
                                        const uint16_t* X, int64_t ldx, int64_t x2_off, const uint16_t* D, int64_t ldd, int64_t d2_off, float* out,
                                        int64_t ldo, float* workspace, int32_t mode, bot_stream_t stream) {
+    return bot_gemm_halves3_tn2_f32(n_rows, k, p, kp, pp, scale_x, scale_d, nullptr, 0, X, ldx, x2_off, D, ldd, d2_off, out, ldo, workspace, mode, stream);
+}
+
+extern "C" int bot_gemm_halves3_tn2_f32(int64_t n_rows, int64_t k, int64_t p, int64_t kp, int64_t pp, const float* scale_x, const float* scale_d,
+                                        const float* scale_d2, int64_t p_split, const uint16_t* X, int64_t ldx, int64_t x2_off, const uint16_t* D, int64_t ldd,
+                                        int64_t d2_off, float* out, int64_t ldo, float* workspace, int32_t mode, bot_stream_t stream) {
     using namespace bot;
+    BOT_REQUIRE(scale_d2 == nullptr || (p_split > 0 && p_split < pp && p_split % 4 == 0), -1,
+                "gemm_halves3_tn2: the second scale starts at a column that is a positive multiple of 4 below pp (got %lld of %lld)", (long long)p_split, (long long)pp);
     BOT_REQUIRE(n_rows > 0 && k > 0 && p > 0 && kp >= k && pp >= p && kp % 64 == 0 && pp % 64 == 0, -1,
                 "gemm_halves3_tn: need n, k, p > 0 and piece widths >= k, p that are multiples of 64");
     BOT_REQUIRE(scale_x && scale_d && X && D && out && workspace, -1, "gemm_halves3_tn: null pointer");
@@ -853,9 +896,10 @@ extern "C" int bot_gemm_halves3_tn_f32(int64_t n_rows, int64_t k, int64_t p, int
     a.mode = mode;
     BOT_REQUIRE((int64_t)rps * std::max(ldx, ldd) * 2 < (1ll << 31), -1, "gemm_halves3_tn: a split of %d rows exceeds the 2 GiB a buffer descriptor spans", rps);
     set_kernel("bot::gemm_halves3_tn_kernel");
-    hipLaunchKernelGGL(gemm_halves3_tn_kernel, dim3(((splits + 7) / 8) * 8 * a.tiles_k * a.tiles_p), dim3(512), 0, (hipStream_t)stream, a);
+    if (mode) hipLaunchKernelGGL(gemm_halves3_tn_ablate_kernel, dim3(((splits + 7) / 8) * 8 * a.tiles_k * a.tiles_p), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gemm_halves3_tn_kernel, dim3(((splits + 7) / 8) * 8 * a.tiles_k * a.tiles_p), dim3(512), 0, (hipStream_t)stream, a);
     const int64_t n4 = k * ((p + 3) / 4);
     hipLaunchKernelGGL(tn_reduce_h3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits, (int)k, (int)p,
-                       (int)kp, (int)pp, scale_x, scale_d, out, ldo);
+                       (int)kp, (int)pp, scale_x, scale_d, out, ldo, scale_d2, (int)p_split);
     return hip_status("gemm_halves3_tn");
 }

@@ -242,6 +242,13 @@ __global__ __launch_bounds__(kBlock) void spmm_dot_rows_kernel(SpmmArgs a) {
             }
         }
     }
+    if (a.hout && slot < 0) {            // (bot_spmm_dot_halves_f16) the row's sums straight as a halves operand, no fp32 copy
+        const float hs = a.hscale[0];
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c)
+            if (act[c]) store_halves<VEC>(a.hout + (int64_t)row * a.ldh + (int64_t)hd[c] * a.hsh + el[c], a.h2_off, acc[c], hs);
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
         if (act[c]) {
@@ -1132,6 +1139,62 @@ int bot_spmm_bcast_halves_f16(const int32_t* indptr, const int32_t* indices, int
         hipLaunchKernelGGL(spmm_combine_halves_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows, long_ptr, n_long, H, D,
                            (const float*)partial, (int64_t)H * D, a.hout, ldh, hsh, h2_off, hpiece, hscale);
         if (int rc = hip_status("spmm_bcast_halves combine launch")) return rc;
+    }
+    return 0;
+}
+
+// Would bot_spmm_dot_halves_f16 take these operands (the all-heads layout covers the shape, the operand's columns are aligned to the
+// lanes' stores)?  1 / 0; no launch.
+int bot_spmm_dot_halves_fits(const float* x, int64_t ldx, int64_t hsx, const float* y, int64_t ldy, int64_t hsy, int32_t H, int32_t D, const uint16_t* hout,
+                             int64_t ldh, int64_t hsh, int32_t h2_off) {
+    using namespace bot;
+    if (H < 2 || D < 1 || !spmm_dot_rows_wanted()) return 0;
+    const int vec = pick_vec(D, {ldx, hsx, ldy, hsy}, {x, y});
+    if (!(hsh >= D && h2_off >= (int64_t)(H - 1) * hsh + D && ldh >= h2_off + (int64_t)(H - 1) * hsh + D && hsh % vec == 0 && h2_off % vec == 0 && ldh % vec == 0 &&
+          aligned(hout, 2 * vec) && D <= vec * 256))
+        return 0;
+    const int L = (D + vec - 1) / vec;
+    if (L <= 8) return 0;
+    if (L > 64) return (L <= 128 && vec != 4 && H <= 3) ? 1 : 0;
+    const int HL = L <= 16 ? 16 : (L <= 32 ? 32 : 64);
+    return (H * HL + 63) / 64 <= 4 ? 1 : 0;
+}
+
+// bot_spmm_dot_f32 with `out` written as a LEFT halves operand [h1 | 2^11 h2] of hscale[0] * out (halves.hip) instead of fp32: the
+// gradient of the projected features goes straight into the operand of the layer's two backward GEMMs (include/bot_gnn.h).  The all-heads
+// ("rows") layout only; BOT_E_RANGE for shapes it does not cover (the caller keeps the fp32 form + a split pass).
+int bot_spmm_dot_halves_f16(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz, const int32_t* items,
+                            int64_t n_items, const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, const float* x,
+                            int64_t ldx, int64_t hsx, const float* w, const int32_t* wperm, const float* y, int64_t ldy, int64_t hsy,
+                            int32_t H, int32_t D, const float* hscale, uint16_t* hout, int64_t ldh, int64_t hsh, int32_t h2_off, float* dot_out,
+                            float* partial, bot_stream_t stream) {
+    using namespace bot;
+    (void)indptr;
+    BOT_REQUIRE(n_rows >= 0 && nnz >= 0 && n_items >= 0 && n_long >= 0 && nnz < INT32_MAX && n_rows < INT32_MAX, BOT_E_RANGE, "spmm_dot_halves: bad size");
+    BOT_REQUIRE(H >= 2 && D >= 1, BOT_E_RANGE, "spmm_dot_halves: H=%d D=%d (the all-heads layout needs H >= 2)", H, D);
+    if (n_rows == 0) return 0;
+    BOT_REQUIRE(items && x && hout && hscale && y && (nnz == 0 || (indices && w && dot_out)), BOT_E_NULL, "spmm_dot_halves: NULL pointer");
+    BOT_REQUIRE(n_long == 0 || (long_rows && long_ptr && partial), BOT_E_NULL, "spmm_dot_halves: long rows need long_rows/long_ptr/partial");
+    BOT_REQUIRE(hsx >= D && hsy >= D && ldx >= (int64_t)(H - 1) * hsx + D && ldy >= (int64_t)(H - 1) * hsy + D, BOT_E_RANGE,
+                "spmm_dot_halves: strides smaller than the slab");
+    hipStream_t st = (hipStream_t)stream;
+    SpmmArgs a{indices, reinterpret_cast<const int4*>(items), n_items, x, ldx, hsx, w, wperm, H, D, 1, nullptr, 0, 0, partial,
+               (int64_t)H * D, y, ldy, hsy, dot_out, nullptr, 0, 0};
+    const int vec = pick_vec(D, {ldx, hsx, ldy, hsy}, {x, partial, y});
+    // a lane stores `vec` consecutive halves of each half with one 2 * vec-byte store: the operand's columns must be aligned to it
+    BOT_REQUIRE(hsh >= D && h2_off >= (int64_t)(H - 1) * hsh + D && ldh >= h2_off + (int64_t)(H - 1) * hsh + D && hsh % vec == 0 && h2_off % vec == 0 &&
+                    ldh % vec == 0 && aligned(hout, 2 * vec), BOT_E_RANGE, "spmm_dot_halves: D=%d hsh=%lld h2_off=%d ldh=%lld vec=%d", D, (long long)hsh, h2_off,
+                (long long)ldh, vec);
+    BOT_REQUIRE(D <= vec * 256, BOT_E_RANGE, "spmm_dot_halves: D=%d exceeds one launch tile", D);
+    a.hout = reinterpret_cast<__half*>(hout), a.ldh = ldh, a.hsh = hsh, a.h2_off = h2_off, a.hpiece = D, a.hscale = hscale;
+    const bool rows = vec == 4 ? dispatch_spmm_dot_rows<4>(a, st) : (vec == 2 ? dispatch_spmm_dot_rows<2>(a, st) : dispatch_spmm_dot_rows<1>(a, st));
+    BOT_REQUIRE(rows, BOT_E_RANGE, "spmm_dot_halves: H=%d D=%d does not fit the all-heads layout", H, D);
+    if (int rc = hip_status("spmm_dot_halves launch")) return rc;
+    if (n_long > 0) {
+        const int64_t n = n_long * H * D;
+        hipLaunchKernelGGL(spmm_combine_halves_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, long_rows, long_ptr, n_long, H, D,
+                           (const float*)partial, (int64_t)H * D, a.hout, ldh, hsh, h2_off, D, hscale);
+        if (int rc = hip_status("spmm_dot_halves combine launch")) return rc;
     }
     return 0;
 }

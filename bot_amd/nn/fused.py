@@ -207,6 +207,34 @@ def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed=True):
     return _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed), mean, invstd, total, sync, group, seed
 
 
+# A hidden layer's gradient operand without a split pass (ABI 17, include/bot_gnn.h "v17"): the BatchNorm backward and the transposed sweep
+# write their column blocks of [d ft | d res | d el | d er | 0] as halves under a BOUNDED scale, the attention columns follow under a
+# second scale; no fp32 [N, P] buffer, no halves_split pass (1 GB read + 1 GB written per hidden layer at config 2).
+DOUT_DIRECT = os.environ.get("BOT_DOUT_DIRECT", "1") != "0"
+DOUT_DIRECT_CALLS = 0
+TAIL_CAP = 2.0 ** 20     # the attention columns' scale may be at most this much finer than the big blocks' (the GEMM rescales its accumulators by the ratio)
+
+
+def rowsum_bound(graph, attn_p: float) -> float:
+    """max over the sources u of sum_{e out of u} a_d[e, h] is at most (largest out-degree) / (1 - attn_p): every attention weight is
+    <= 1 (a softmax over the in-edges of its destination) and attention dropout rescales the kept ones by 1 / (1 - p).  Static per graph
+    (one host read, cached like the zero-in-degree check)."""
+    from . import _graph_cache
+    c = _graph_cache(graph)
+    if "max_out_deg" not in c:
+        ip = graph.csr.indptr
+        c["max_out_deg"] = int((ip[1:] - ip[:-1]).max()) if ip.numel() > 1 else 0
+    return max(1.0, c["max_out_deg"] / (1.0 - attn_p))
+
+
+def _dout_direct_ok(ctx, g, h, H, D, P, B, has_res, epi) -> bool:
+    HD = H * D
+    c = 2 * B
+    return (DOUT_DIRECT and ctx.halves is not None and has_res and epi is not None and not ctx.overlap and g.halo is None and not ctx.sym
+            and HD % 2 == 0 and H >= 2 and c % 32 == 0 and P % 64 == 0 and gemm.left_order(P) == 2
+            and gemm.NT_KERNEL == "halves3" and gemm.TN_KERNEL == "halves3" and (ctx.halves[2] * P >= gemm.TN_MIN_OUT or gemm.FORCE or FORCE) and not epi[3])
+
+
 class _GATHidden(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, Wcat, bn_w, bn_b, graph, bn, H, D, has_res, has_er, slope, attn_p, drop_p, bn_training, kp, sym, y_needed=True):
@@ -315,6 +343,10 @@ class _GATHidden(torch.autograd.Function):
         kp = ctx.kp
         N, HD, P = h.shape[0], H * D, Wcat.shape[1 if kp else 0]
         B = block_width(HD)
+        if _dout_direct_ok(ctx, g, h, H, D, P, B, has_res, epi):
+            out = _GATHidden._backward_direct(ctx, dy, g, h, Wcat, table, el, er, a, a_d, x, mean, invstd, bn_w, bn_b, epi, H, D, P, B, has_er, slope, kp)
+            if out is not None:
+                return out
         dout = torch.empty((N, P), dtype=dy.dtype, device=h.device)
         dx = dout[:, B:B + HD] if has_res else torch.empty((N, HD), dtype=dy.dtype, device=h.device)
         slots = None
@@ -418,6 +450,62 @@ class _GATHidden(torch.autograd.Function):
                 dh = torch.mm(dout, Wcat.t()) if kp else torch.mm(dout, Wcat)
         return (dh, dW, d_bn_w if ctx.needs_input_grad[2] else None, d_bn_b if ctx.needs_input_grad[3] else None,
                 None, None, None, None, None, None, None, None, None, None, None, None, None)
+
+
+def _backward_direct(ctx, dy, g, h, Wcat, table, el, er, a, a_d, x, mean, invstd, bn_w, bn_b, epi, H, D, P, B, has_er, slope, kp):
+    """_GATHidden.backward with the gradient operand written by its producers (see DOUT_DIRECT).  None: the sweep's all-heads layout does
+    not cover this shape - the caller takes the fp32 form."""
+    global DOUT_DIRECT_CALLS
+    drop_p, seed, bn_training, sync, group, total = epi
+    N, HD = h.shape[0], H * D
+    c = 2 * B
+    used = c + (2 * H if has_er else H)
+    piece = P                                           # the operand [h1 | 2^11 h2]: second half `piece` columns behind the first
+    buf = torch.empty((N, 2 * piece), dtype=torch.float16, device=h.device)
+    dxb = torch.empty((N, B), dtype=dy.dtype, device=h.device)          # fp32 d res beside the halves: the sweep gathers its rows (16-byte aligned pitch)
+    dx = dxb[:, :HD]
+    ft = table[:, :HD].unflatten(1, (H, D))
+    if not _C.spmm_dot_halves_fits(dx.unflatten(1, (H, D)), ft, buf, D, piece):
+        return None
+    DOUT_DIRECT_CALLS += 1
+    sg, sgx, ws = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, want_max=True)
+    d_bn_w, d_bn_b = sgx, sg
+    slots = _C.absmax_slots(dy.device)
+    _C.bn_bwd_bound(ws, N, sg if bn_training else None, sgx if bn_training else None, total, bn_w, invstd, slots)
+    # one scale for both big blocks: |d res| <= the BatchNorm bound, |d ft[u]| <= (row sum of the edge weights out of u) x that bound
+    s1 = _C.halves_scale_from_slots(slots, mult=rowsum_bound(g, ctx.adrop[0] if ctx.adrop else 0.0))
+    _C.bn_act_bwd_apply_halves(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None, sgx if bn_training else None, total,
+                               s1, buf[:, B:], HD, HD, out=dx, h2_off=piece)
+    da = _C.spmm_dot_halves(g.csr, dx.unflatten(1, (H, D)), a_d, g.csr2csc, ft, s1, buf, D, piece)
+    dz, der = _C.gat_attn_bwd(g.csc, el, er, None, None, slope, H, a, da, None, None, has_er, ctx.zs, drop=ctx.adrop)
+    d_el = _C.segment_sum(g.csr, dz, g.csr2csc)
+    # the attention columns (known only now, of their own magnitude) under a second scale, and the zero padding of the operand
+    slots2 = _C.absmax_slots(dy.device)
+    _C.absmax_into(d_el, slots2)
+    if has_er:
+        _C.absmax_into(der, slots2)
+    s2 = _C.halves_scale_from_slots(slots2, cap=s1, cap_ratio=TAIL_CAP)
+    segs = [(c, H, d_el)] + ([(c + H, H, der)] if has_er else [])
+    if B != HD:
+        segs += [(HD, B - HD, None), (B + HD, B - HD, None)]
+    if used < P:
+        segs.append((used, P - used, None))
+    _C.halves_tail(segs, s2, buf, piece)
+    dW = dh = None
+    xh = gemm.Halves(h, ctx.xscale, *ctx.halves)
+    if ctx.needs_input_grad[0]:
+        Ws = gemm.split(Wcat if kp else Wcat.t().contiguous(), 1)
+        dh = _C.gemm_halves3_nt(buf, Ws.buf, s1, Ws.scale, piece, Ws.piece, piece, a2_off=piece, scale_a2=s2, k_split=c)
+    if ctx.needs_input_grad[1]:
+        def wgrad():
+            dWk = _C.gemm_halves3_tn(xh.buf, buf, xh.scale, s1, xh.piece, piece, xh.F, P, x2_off=xh.h2_off, d2_off=piece, scale_d2=s2, p_split=c)
+            return dWk if kp else dWk.t().contiguous()
+        dW = side.run(wgrad, xh, buf, s1, s2) if (side.usable(buf) and xh.piece * piece >= side.MIN_OUT) else wgrad()
+    return (dh, dW, d_bn_w if ctx.needs_input_grad[2] else None, d_bn_b if ctx.needs_input_grad[3] else None,
+            None, None, None, None, None, None, None, None, None, None, None, None, None)
+
+
+_GATHidden._backward_direct = staticmethod(_backward_direct)
 
 
 def cat_weight_aggfirst(conv):

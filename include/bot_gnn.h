@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 16
+#define BOT_ABI_VERSION 17
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -533,6 +533,40 @@ int64_t bot_gemm_halves3_tn_workspace_floats(int64_t n_rows, int64_t kp, int64_t
 int bot_gemm_halves3_tn_f32(int64_t n_rows, int64_t k, int64_t p, int64_t kp, int64_t pp, const float* scale_x, const float* scale_d,
                             const uint16_t* X, int64_t ldx, int64_t x2_off, const uint16_t* D, int64_t ldd, int64_t d2_off, float* out,
                             int64_t ldo, float* workspace, int32_t mode, bot_stream_t stream);
+
+/* v17: a hidden layer's gradient operand without a split pass (bot_amd/nn/fused.py:_GATHidden.backward; the backward of
+ * src/no-sampling/models.py:490-492, :547, :558-560, :726-731).  The [N, P] gradient of the merged projection's output, [d ft | d res | d el | d er | 0],
+ * used to be assembled in fp32 and split into halves by one more pass (1 GB read + 1 GB written at config 2).  Its two big column blocks
+ * now leave their producers as halves - d res: bot_bn_act_bwd_apply_halves_f32 (fp32 dx beside it: the sweep gathers those rows), d ft:
+ * bot_spmm_dot_halves_f16 - under a scale that must exist BEFORE they run, i.e. a BOUND:
+ *     |d res| <= bound of bot_bn_bwd_bound_f32,    |d ft[u,h,:]| <= (sum of the edge weights out of u) max|d res| <= rowsum_bound * max|d res|
+ * (bot_halves_scale_from_slots2_f32: the scale of `mult` x the slots' maximum; the format keeps 22 bits for entries down to 2^-28 of the
+ * scale, a loose bound costs range, not accuracy).  The handful of attention columns, known only after the sweep and of another magnitude,
+ * get a SECOND scale (bot_halves_tail_f16 writes them and the zero padding): the NT product multiplies its accumulators by the ratio of the
+ * two scales (powers of two: exact) in front of the k-step where the second range starts, the TN product applies it per output column.
+ *   bot_halves_scale_from_slots2_f32   scale = halves_scale(mult * max(slots)); cap_scale != NULL: at most cap_scale[0] * cap_ratio
+ *   bot_halves_tail_f16                segments g < n_seg <= 8 of (col, width) = seg_cols[2 g], seg_cols[2 g + 1]: out[r, col + j] = h1,
+ *                                      out[r, h2_off + col + j] = 2^11 h2 of scale[0] * srcs[g][r * src_ld[g] + j]  (srcs[g] == NULL: zeros)
+ *   bot_spmm_dot_halves_f16            bot_spmm_dot_f32 with `out` replaced by the operand: hout[r, h * hsh + e] (h1) and + h2_off (2^11 h2) of
+ *                                      hscale[0] * out[r,h,e]; all-heads layout only (bot_spmm_dot_halves_fits: 1 when the shape and the
+ *                                      alignments are covered, else the caller keeps the fp32 form + a split pass)
+ *   bot_gemm_halves3_nt2_f32 / _tn2_f32  the products above with the second scale: A's columns >= k_split (a multiple of 32) resp. D's
+ *                                      columns >= p_split (a multiple of 4) are stored under scale_a2 / scale_d2 (NULL: one scale). */
+int bot_halves_scale_from_slots2_f32(const uint32_t* slots, float mult, const float* cap_scale, float cap_ratio, float* scale, bot_stream_t stream);
+int bot_halves_tail_f16(int64_t n, int32_t n_seg, const int64_t* seg_cols, const float* const* srcs, const int64_t* src_ld, const float* scale, uint16_t* out,
+                        int64_t ldo, int32_t h2_off, bot_stream_t stream);
+int bot_spmm_dot_halves_fits(const float* x, int64_t ldx, int64_t hsx, const float* y, int64_t ldy, int64_t hsy, int32_t H, int32_t D, const uint16_t* hout,
+                             int64_t ldh, int64_t hsh, int32_t h2_off);
+int bot_spmm_dot_halves_f16(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz, const int32_t* items, int64_t n_items,
+                            const int32_t* long_rows, const int32_t* long_ptr, int64_t n_long, const float* x, int64_t ldx, int64_t hsx, const float* w,
+                            const int32_t* wperm, const float* y, int64_t ldy, int64_t hsy, int32_t H, int32_t D, const float* hscale, uint16_t* hout,
+                            int64_t ldh, int64_t hsh, int32_t h2_off, float* dot_out, float* partial, bot_stream_t stream);
+int bot_gemm_halves3_nt2_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_a2, int64_t k_split, const float* scale_b,
+                             const uint16_t* A, int64_t lda, int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc,
+                             int32_t mode, bot_stream_t stream);
+int bot_gemm_halves3_tn2_f32(int64_t n_rows, int64_t k, int64_t p, int64_t kp, int64_t pp, const float* scale_x, const float* scale_d, const float* scale_d2,
+                             int64_t p_split, const uint16_t* X, int64_t ldx, int64_t x2_off, const uint16_t* D, int64_t ldd, int64_t d2_off, float* out,
+                             int64_t ldo, float* workspace, int32_t mode, bot_stream_t stream);
 
 /* v16: GROUPED forms of the two products above — the column tiles (NT) / output tiles (TN) of ONE launch are a host-side list, each entry
  * with its own operand columns and output block.  They carry the aggregate-first GAT layer (fused.py:_GATHiddenAggFirst; models.py:490-492,

@@ -300,8 +300,43 @@ def absmax_into(x, slots):
     return slots
 
 
-def halves_scale_from_slots(slots):
-    return _pow2_scale(float(slots.max().reshape(1).view(torch.float32)[0]))
+def halves_scale_from_slots(slots, mult=None, cap=None, cap_ratio=1.0):
+    """include/bot_gnn.h bot_halves_scale_from_slots_f32 / _slots2_f32"""
+    sc = _pow2_scale(float(slots.max().reshape(1).view(torch.float32)[0]) * (1.0 if mult is None else float(mult)))
+    if cap is not None:
+        s = min(float(sc[0]), float(cap[0]) * cap_ratio)
+        sc = torch.tensor([s, 1.0 / s], dtype=torch.float32)
+    return sc
+
+
+def halves_tail(segments, scale, out, h2_off):
+    """include/bot_gnn.h bot_halves_tail_f16"""
+    for col, width, src in segments:
+        if src is None:
+            out[:, col:col + width] = 0
+            out[:, h2_off + col:h2_off + col + width] = 0
+        else:
+            z = src.float() * float(scale[0])
+            h1 = z.half()
+            out[:, col:col + width] = h1
+            out[:, h2_off + col:h2_off + col + width] = ((z - h1.float()) * 2048.0).half()
+    return out
+
+
+def spmm_dot_halves_fits(x, y, hout, hsh, h2_off):
+    return x.shape[1] >= 2
+
+
+def spmm_dot_halves(d, x, w, wperm, y, hscale, hout, hsh, h2_off, dot=None):
+    """include/bot_gnn.h bot_spmm_dot_halves_f16"""
+    res, dot = spmm_dot(d, x, w, wperm, y, dot=dot)
+    H, D = res.shape[1], res.shape[2]
+    for h in range(H):
+        z = res[:, h].float() * float(hscale[0])
+        h1 = z.half()
+        hout[:, h * hsh:h * hsh + D] = h1
+        hout[:, h2_off + h * hsh:h2_off + h * hsh + D] = ((z - h1.float()) * 2048.0).half()
+    return dot
 
 
 def halves_split(x, scale, order, piece, out=None):
@@ -352,13 +387,20 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     return out
 
 
-def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None):
-    """include/bot_gnn.h bot_gemm_halves3_nt_f32: a1 b1^T + a1 b2^T + (2^11 a2) (2^-11 b1)^T from a LEFT and a RIGHT operand buffer."""
+def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0):
+    """include/bot_gnn.h bot_gemm_halves3_nt_f32 / _nt2_f32: a1 b1^T + a1 b2^T + (2^11 a2) (2^-11 b1)^T from a LEFT and a RIGHT operand buffer;
+    scale_a2: a's columns from k_split on carry a second scale (the accumulators are rescaled by the ratio in front of them)."""
     a2_off = 2 * piece_a if a2_off is None else a2_off
-    a1, a2 = a[:, :k].float(), a[:, a2_off:a2_off + k].float()
-    b1, b2 = b[:, :k].float(), b[:, piece_b:piece_b + k].float()
-    b1s = (b[:, :k] * torch.tensor(2.0 ** -11, dtype=torch.float16)).float()          # the kernel's v_pk_mul_f16: exact or rounded into fp16 subnormals
-    res = (a1 @ b1.t() + a1 @ b2.t() + a2 @ b1s.t()) * (scale_a[1] * scale_b[1])
+
+    def part(lo, hi):
+        a1, a2 = a[:, lo:hi].float(), a[:, a2_off + lo:a2_off + hi].float()
+        b1, b2 = b[:, lo:hi].float(), b[:, piece_b + lo:piece_b + hi].float()
+        b1s = (b[:, lo:hi] * torch.tensor(2.0 ** -11, dtype=torch.float16)).float()   # the kernel's v_pk_mul_f16: exact or rounded into fp16 subnormals
+        return a1 @ b1.t() + a1 @ b2.t() + a2 @ b1s.t()
+    if scale_a2 is None:
+        res = part(0, k) * (scale_a[1] * scale_b[1])
+    else:
+        res = (part(0, k_split) * (scale_a2[0] * scale_a[1]) + part(k_split, k)) * (scale_a2[1] * scale_b[1])
     if out is None:
         return res
     out.copy_(res)
@@ -414,7 +456,7 @@ def gemm_halves3_tn_grouped(x, d, scale_x, scale_d, x2_off, d2_off, out, tiles, 
     return out
 
 
-def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0, x2_off=None, d2_off=None):
+def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0, x2_off=None, d2_off=None, scale_d2=None, p_split=0):
     """include/bot_gnn.h bot_gemm_halves3_tn_f32: x1^T d1 + x1^T d2 + x2^T d1 of two LEFT operand buffers ([h1 | h1 | 2^11 h2], or
     [h1 | 2^11 h2] with the second-half offset = the piece width)."""
     sh = torch.tensor(2.0 ** -11, dtype=torch.float16)
@@ -423,7 +465,11 @@ def gemm_halves3_tn(x, d, scale_x, scale_d, piece_x, piece_d, k, p, mode=0, x2_o
     x1, x2s = x[:, :k], x[:, x2_off:x2_off + k]
     d1, d2s = d[:, :p], d[:, d2_off:d2_off + p]
     res = x1.float().t() @ d1.float() + (x1 * sh).float().t() @ d2s.float() + x2s.float().t() @ (d1 * sh).float()
-    return res * (scale_x[1] * scale_d[1])
+    if scale_d2 is None:
+        return res * (scale_x[1] * scale_d[1])
+    alpha = torch.full((p,), float(scale_d[1]))
+    alpha[p_split:] = float(scale_d2[1])
+    return res * (scale_x[1] * alpha)
 
 
 # ---- the train step's glue (include/bot_gnn.h v14: label_split / build_input / node_loss / rmsprop_step), restated with torch CPU ops.
@@ -510,9 +556,16 @@ def bn_bwd_bound(ws, n, sum_g, sum_gx, total_count, weight, invstd, slots):
     return slots
 
 
-def bn_act_bwd_apply_halves(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, hscale, hout, hD, hDP, out=None):
+def bn_act_bwd_apply_halves(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, hscale, hout, hD, hDP, out=None, h2_off=None):
     res = bn_act_bwd_apply(dy, x, mean, invstd, weight, bias, relu, p, seed, sum_g, sum_gx, total_count, out=out)
-    halves_split_heads(res, hscale, x.shape[1] // hD, hD, hDP, out=hout)
+    if h2_off is None:
+        halves_split_heads(res, hscale, x.shape[1] // hD, hD, hDP, out=hout)
+    else:       # a column range of a wider operand: head blocks of hD columns every hDP, the second half h2_off columns behind
+        for h in range(x.shape[1] // hD):
+            z = res[:, h * hD:(h + 1) * hD].float() * float(hscale[0])
+            h1 = z.half()
+            hout[:, h * hDP:h * hDP + hD] = h1
+            hout[:, h2_off + h * hDP:h2_off + h * hDP + hD] = ((z - h1.float()) * 2048.0).half()
     return hout
 
 
@@ -551,7 +604,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["gemm_halves3_tn", "bn_bwd_bound", "bn_act_bwd_apply_halves", "halves_split_heads", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["halves_tail", "spmm_dot_halves", "spmm_dot_halves_fits", "gemm_halves3_tn", "bn_bwd_bound", "bn_act_bwd_apply_halves", "halves_split_heads", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -522,6 +522,53 @@ def _check_agg_first(golden, device, l0_halves):
         fwd_close(ev, ref_eval.detach().numpy())
 
 
+def check_dout_direct_against_oracle(golden, device):
+    """ABI 17: a hidden layer whose gradient operand [d ft | d res | d el | d er | 0] is written by its producers - the BatchNorm backward
+    (bot_bn_act_bwd_apply_halves_f32 into a column range) and the transposed sweep (bot_spmm_dot_halves_f16) under a BOUNDED scale, the
+    attention columns (bot_halves_tail_f16) under a second one, the two GEMMs with the second scale (bot_gemm_halves3_nt2_f32 / _tn2_f32) -
+    against the oracle's logits and every gradient, with and without attention dropout off / `attn_r`, and bit for bit run to run.  The
+    stack: 2 heads x 64 (merged projection 2 x 128 + 4 columns -> P = 384: the attention columns start at column 256 = k-step 8)."""
+    from bot_amd import gemm
+    from bot_amd.nn import fused
+    s, d, n = golden.graph("g300")
+    g = bot_amd.Graph(s, d, n, chunk=8).to(device)
+    fin, C = 24, 5
+    force, gforce = fused.FORCE, gemm.FORCE
+    gemm.FORCE = True
+    try:
+        for attn_r in (True, False):
+            cfg = dict(n_layers=3, n_heads=2, n_hidden=64, norm="batch", non_interactive_attn=not attn_r, use_symmetric_norm=False, linear=True,
+                       residual=False)
+            torch.manual_seed(21)
+            model = bnn.GAT(dim_node=fin, dim_edge=0, dim_output=C, activation=F.relu, **cfg).train()
+            gen = torch.Generator().manual_seed(22)
+            feat, gout = torch.randn(n, fin, generator=gen), torch.randn(n, C, generator=gen) * 37.0     # (the attention columns' magnitude differs from dx's)
+            sd = {k: v.clone() for k, v in model.state_dict().items()}
+            p = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+            ref = RM.gat_forward(RM.CooGraph(s, d, n), feat, p, n_classes=C, training=True, **cfg)
+            names = [k for k, v in p.items() if v.requires_grad]
+            ref_grads = torch.autograd.grad((ref * gout).sum(), [p[k] for k in names])
+            model = model.to(device)
+            runs = []
+            for on in (True, True, False):
+                fused.DOUT_DIRECT = on
+                c0 = fused.DOUT_DIRECT_CALLS
+                model.zero_grad(set_to_none=True)
+                logits = model(g, feat.to(device))
+                (logits * gout.to(device)).sum().backward()
+                assert (fused.DOUT_DIRECT_CALLS - c0 == 1) == on, "the hidden layer did not take / did take the direct form"
+                fwd_close(logits, ref.detach().numpy())
+                got = dict(model.named_parameters())
+                for k, rg in zip(names, ref_grads):
+                    grad_close(got[k].grad, rg.numpy())
+                runs.append({k: v.grad.detach().clone() for k, v in got.items()})
+            for k in runs[0]:
+                assert torch.equal(runs[0][k], runs[1][k]), k          # bitwise run to run
+    finally:
+        fused.DOUT_DIRECT = True
+        fused.FORCE, gemm.FORCE = force, gforce
+
+
 def check_keep_mask_orders(golden, device):
     """A keep mask given in CSC position order (what the layers do with their own random draw) equals the same mask given in
     edge-id order, with and without CSC-ordered edge logits."""

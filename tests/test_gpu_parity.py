@@ -497,6 +497,10 @@ def test_agg_first_against_oracle(golden, l0_halves):
     PC.check_agg_first_against_oracle(golden, DEV, l0_halves=l0_halves)
 
 
+def test_dout_direct_against_oracle(golden):
+    PC.check_dout_direct_against_oracle(golden, DEV)
+
+
 def test_bcast_kernels_direct(golden):
     """spmm_bcast / spmm_dot_bcast (aggregate-before-project forms) against plain torch indexing."""
     s, d, n = golden.graph("g300")
@@ -1811,6 +1815,88 @@ def test_grouped_halves_kernels(golden):
         again = torch.empty_like(view)
         _C.tn_narrow(buf[:, 7:], y, again, transpose_out=tr)
         assert torch.equal(again, view)
+
+
+def test_abi17_kernels(golden):
+    """ABI 17, each new entry point against its definition in include/bot_gnn.h (tests/_oracle_backend.py's restatement):
+    (1) bot_halves_scale_from_slots2_f32: multiplier and cap; (2) bot_halves_tail_f16: segments with sources and zeros, bit for bit;
+    (3) bot_spmm_dot_halves_f16 == halves_split(order 2) of bot_spmm_dot_f32's slab, bit for bit, and the same `dot`, long rows included;
+    (4) bot_gemm_halves3_nt2_f32 / _tn2_f32: equal to the one-scale products when both scales agree (bit for bit), and against fp64 from
+        the same fp16 operands when the tail's scale differs by 2^7 / 2^-9 (the accumulators rescaled by the exact ratio)."""
+    from tests import _oracle_backend as OB
+    from bot_amd import gemm
+    gen = torch.Generator(device=DEV).manual_seed(29)
+    # --- (1)
+    slots = _C.absmax_slots(DEV)
+    _C.absmax_into(torch.tensor([[0.3, -5.0, 1.0]], device=DEV), slots)
+    cap = torch.tensor([2.0 ** 3, 2.0 ** -3], device=DEV)
+    for mult, cp, ratio in ((None, None, 1.0), (700.0, None, 1.0), (1.0, cap, 4.0), (1e-6, cap, 2.0 ** 20), (3.0, cap, 2.0 ** 20)):
+        got = _C.halves_scale_from_slots(slots, mult=mult, cap=cp, cap_ratio=ratio).cpu()
+        ref = OB.halves_scale_from_slots(slots.cpu(), mult=mult, cap=None if cp is None else cp.cpu(), cap_ratio=ratio)
+        assert torch.equal(got, ref), (mult, ratio, got, ref)
+    # --- (2)
+    n, ld, h2 = 1237, 2 * 96, 96
+    out = torch.full((n, ld), 3.0, dtype=torch.float16, device=DEV)
+    a, b = torch.randn(n, 3, device=DEV, generator=gen) * 5, torch.randn(n, 8, device=DEV, generator=gen)[:, 1:4]
+    sc = torch.tensor([64.0, 1 / 64.0], device=DEV)
+    segs = [(64, 3, a), (67, 3, b), (30, 2, None), (70, 26, None)]
+    _C.halves_tail(segs, sc, out, h2)
+    ref = torch.full((n, ld), 3.0, dtype=torch.float16)
+    OB.halves_tail([(c, w, None if t is None else t.cpu()) for c, w, t in segs], sc.cpu(), ref, h2)
+    assert torch.equal(out.cpu(), ref)
+    # --- (3)
+    s_, d_, nn = golden.graph("g300")
+    for chunk, (H, D) in ((8, (3, 250)), (4096, (3, 250)), (8, (2, 64)), (4096, (4, 40)), (16, (3, 48))):
+        g = bot_amd.Graph(s_, d_, nn, chunk=chunk).to(DEV)
+        E = g.number_of_edges()
+        x = torch.randn(nn, H, D, device=DEV, generator=gen)
+        y = torch.randn(nn, H, D, device=DEV, generator=gen)
+        w = torch.rand(E, H, device=DEV, generator=gen)
+        piece = (H * D + 63) // 64 * 64
+        buf = torch.full((nn, 2 * piece), 7.0, dtype=torch.float16, device=DEV)
+        scale = _C.halves_scale(x.reshape(nn, -1) * 300)
+        assert _C.spmm_dot_halves_fits(x, y, buf, D, piece)
+        dot = _C.spmm_dot_halves(g.csr, x, w, g.csr2csc, y, scale, buf, D, piece)
+        o32, dot32 = _C.spmm_dot(g.csr, x, w, g.csr2csc, y)
+        ref = _C.halves_split(o32.reshape(nn, H * D), scale, 2, piece)
+        assert torch.equal(dot, dot32), (chunk, H, D)
+        assert torch.equal(buf[:, :H * D], ref[:, :H * D]) and torch.equal(buf[:, piece:piece + H * D], ref[:, piece:piece + H * D]), (chunk, H, D)
+        assert bool((buf[:, H * D:piece] == 7.0).all())
+    assert not _C.spmm_dot_halves_fits(x[:, :1], y[:, :1], buf, 16, piece)        # one head: the head-major kernel's shape
+    # --- (4)
+    for (N, K, P, split) in ((20011, 1536, 750, 1504), (5003, 384, 128, 256)):
+        A = (torch.randn(N, 2 * K, device=DEV, generator=gen) * 50).half()
+        A[:, K:] *= 0.01
+        Bm = torch.randn(P, 3 * K, device=DEV, generator=gen) * 30
+        Bm[:, K:2 * K] /= 2048
+        Bm = Bm.half()
+        X = (torch.randn(N, 2 * 192, device=DEV, generator=gen) * 20).half()
+        sa, sb, sx = (torch.tensor([v, 1 / v], device=DEV) for v in (4.0, 8.0, 2.0))
+        one = _C.gemm_halves3_nt(A, Bm, sa, sb, K, K, K, a2_off=K)
+        same = _C.gemm_halves3_nt(A, Bm, sa, sb, K, K, K, a2_off=K, scale_a2=sa, k_split=split)
+        assert torch.equal(one, same)
+        t_one = _C.gemm_halves3_tn(X, A, sx, sa, 192, K, 168, K - 3, x2_off=192, d2_off=K)
+        t_same = _C.gemm_halves3_tn(X, A, sx, sa, 192, K, 168, K - 3, x2_off=192, d2_off=K, scale_d2=sa, p_split=split)
+        assert torch.equal(t_one, t_same)
+        for v2 in (4.0 * 2 ** 7, 4.0 * 2 ** -9):
+            s2 = torch.tensor([v2, 1 / v2], device=DEV)
+            got = _C.gemm_halves3_nt(A, Bm, sa, sb, K, K, K, a2_off=K, scale_a2=s2, k_split=split)
+            a64 = (A[:, :K].double() + A[:, K:].double() / 2048)
+            a64[:, :split] /= 4.0
+            a64[:, split:] /= v2
+            b64 = (Bm[:, :K].double() + Bm[:, K:2 * K].double()) / 8.0
+            r64 = a64 @ b64.t()
+            e = float((got.double() - r64).abs().max() / r64.abs().max())
+            assert e < 3e-6, (N, v2, e)
+            assert torch.equal(got, _C.gemm_halves3_nt(A, Bm, sa, sb, K, K, K, a2_off=K, scale_a2=s2, k_split=split))
+            tg = _C.gemm_halves3_tn(X, A, sx, sa, 192, K, 168, K - 3, x2_off=192, d2_off=K, scale_d2=s2, p_split=split)
+            x64 = (X[:, :168].double() + X[:, 192:192 + 168].double() / 2048) / 2.0
+            t64 = x64.t() @ a64[:, :K - 3]
+            te = float((tg.double() - t64).abs().max() / t64.abs().max())
+            assert te < 3e-6, (N, v2, te)
+            # the restatement agrees (it is what the CPU suite runs the layer on)
+            ro = OB.gemm_halves3_nt(A.cpu(), Bm.cpu(), sa.cpu(), sb.cpu(), K, K, K, a2_off=K, scale_a2=s2.cpu(), k_split=split)
+            assert float((got.cpu() - ro).abs().max() / ro.abs().max()) < 3e-6
 
 
 def test_grouped_halves_kernels_random_lists():

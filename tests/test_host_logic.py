@@ -507,3 +507,9 @@ def test_split_buffers_are_per_train_idx_tensor(cpu_backend):
     del a, ca, wa
     gc.collect()
     assert len(T._SPLIT) == n0 - 1
+
+
+def test_dout_direct_emulated(golden, cpu_backend, monkeypatch):
+    from bot_amd.nn import fused
+    monkeypatch.setattr(fused, "FORCE", True)
+    PC.check_dout_direct_against_oracle(golden, "cpu")
