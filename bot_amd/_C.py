@@ -121,8 +121,9 @@ _SIGS = {
     "bot_spmm_dot_halves_fits": (ctypes.c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, c_int32]),
     "bot_spmm_dot_halves_f16": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int64,
                                                c_int32, c_int32, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P]),
-    "bot_gemm_halves3_nt2_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64,
+    "bot_gemm_halves3_nt2_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int32, _P, c_int64,
                                                 c_int32, _P]),
+    "bot_halves_split_frag_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, c_int32, _P]),
     "bot_gemm_halves3_tn2_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P,
                                                 c_int64, _P, c_int32, _P]),
     "bot_absmax_slots": (c_int32, []),
@@ -870,18 +871,33 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     return out
 
 
-def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0):
+def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0, b_frag=False, n=None):
     """out[m, n] = scale_a[1] scale_b[1] (a1 b1^T + a1 b2^T + a2 b1^T) from a LEFT operand buffer a [m, 3 piece_a] (or [m, 2 piece_a]
     without the duplicate piece: a2_off = piece_a) and a RIGHT operand buffer b [n, 3 piece_b] (bot_amd.gemm.Halves.buf / .scale), k =
     the common piece width used (bot_gemm_halves3_nt_f32).  scale_a2 / k_split: a's columns from k_split (a multiple of 32) on were
-    written under a second scale (bot_gemm_halves3_nt2_f32)."""
+    written under a second scale (bot_gemm_halves3_nt2_f32).  b_frag: b is a fragment-major right operand (halves_split_frag) of `n` rows."""
     _dev(a, b, scale_a, scale_b, scale_a2)
-    m, n = a.shape[0], b.shape[0]
+    m = a.shape[0]
+    if n is None:
+        assert not b_frag
+        n = b.shape[0]
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     _check(_timed("gemm_halves", (m, n, 3 * k, 1), lambda: _lib.bot_gemm_halves3_nt2_f32(
         m, n, k, scale_a.data_ptr(), _ptr(scale_a2), int(k_split), scale_b.data_ptr(), a.data_ptr(), _ld(a), 2 * piece_a if a2_off is None else a2_off,
-        b.data_ptr(), _ld(b), piece_b, out.data_ptr(), _ld(out), int(mode), _stream())), "gemm_halves3_nt")
+        b.data_ptr(), _ld(b), piece_b, int(bool(b_frag)), out.data_ptr(), _ld(out), int(mode), _stream())), "gemm_halves3_nt")
+    return out
+
+
+def halves_split_frag(x, scale, piece):
+    """x [n, F] scaled by scale[0] as a RIGHT operand in fragment-major layout (include/bot_gnn.h bot_halves_split_frag_f16): a fp16 buffer
+    [2 * ceil(n / 16) * piece / 32, 512] - one row per KB fragment block, h1 blocks first, h2 blocks behind them."""
+    _dev(x, scale)
+    x = _mat(x, "x")
+    n, F = x.shape
+    assert piece % 64 == 0 and piece >= F
+    out = torch.empty((2 * ((n + 15) // 16) * (piece // 32), 512), dtype=torch.float16, device=x.device)
+    _check(_lib.bot_halves_split_frag_f16(x.data_ptr(), x.stride(0), n, F, _ptr(scale), out.data_ptr(), piece, _stream()), "halves_split_frag")
     return out
 
 

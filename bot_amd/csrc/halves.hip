@@ -124,6 +124,30 @@ __global__ __launch_bounds__(128) void halves_split_kernel(const float* x, int64
     }
 }
 
+// A RIGHT operand in FRAGMENT-MAJOR layout (order 3, read by gemm_halves3_nt64_kernel only): the 16 bytes lane l of an MFMA operand fragment
+// holds - row 16 t + (l & 15), columns 32 s + 8 (l >> 4) .. + 7 of 16-row tile t and k-step s - stored at halves ((t T + s) 64 + l) 8 .. + 7
+// (T = piece / 32 k-steps), so that the 64 lanes of a fragment load read ONE contiguous KB; h1 in the first region, h2 in a second region
+// ceil(n / 16) T 512 halves behind it (the third piece, 2^-11 h1, is formed in registers).  Rows beyond n and columns beyond F are zeros.
+__global__ __launch_bounds__(128) void halves_split_frag_kernel(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, __half* out,
+                                                                int32_t piece, int64_t region) {
+    const int64_t r = blockIdx.x;
+    const int c = (blockIdx.y * 128 + threadIdx.x) * 2;
+    if (c >= piece) return;
+    const float s = scale ? scale[0] : 1.f;
+    float v0 = 0.f, v1 = 0.f;
+    if (r < n) {
+        const float* xr = x + r * ldx;
+        if (c < F) v0 = xr[c] * s;
+        if (c + 1 < F) v1 = xr[c + 1] * s;
+    }
+    const __half a0 = __float2half_rn(v0), a1 = __float2half_rn(v1);
+    const float r0 = v0 - __half2float(a0), r1 = v1 - __half2float(a1);
+    const int T = piece >> 5;
+    const int64_t o = ((((r >> 4) * T + (c >> 5)) * 64) + ((r & 15) + 16 * ((c & 31) >> 3))) * 8 + (c & 7);
+    *reinterpret_cast<__half2*>(out + o) = __halves2half2(a0, a1);
+    *reinterpret_cast<__half2*>(out + region + o) = __halves2half2(__float2half_rn(r0), __float2half_rn(r1));
+}
+
 // x [n, H * D] -> a LEFT operand without the duplicate piece whose head blocks are DP >= D columns wide (zeros behind a head's D columns):
 // out[r, h DP + j] = h1, out[r, h2_off + h DP + j] = 2^11 h2 of scale[0] * x[r, h D + j].  One pass over the H heads (instead of H calls of
 // halves_split_cols on column slices): the gradient operand of the aggregate-first GAT layer (fused.py:_GATHiddenAggFirst.backward).
@@ -360,6 +384,17 @@ int bot_halves_split_heads_f16(const float* x, int64_t ldx, int64_t n, int32_t H
     hipLaunchKernelGGL(halves_split_heads_kernel, dim3((unsigned)n, (unsigned)((H * DP / 2 + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x, ldx, H, D, scale,
                        (__half*)out, ldo, h2_off, DP, wide);
     return hip_status("halves_split_heads launch");
+}
+
+int bot_halves_split_frag_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, uint16_t* out, int32_t piece, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 1 && F >= 1 && ldx >= F && piece >= F && piece % 64 == 0, BOT_E_RANGE, "halves_split_frag: n=%lld F=%d ldx=%lld piece=%d (a multiple of 64)",
+                (long long)n, F, (long long)ldx, piece);
+    BOT_REQUIRE(x && out && aligned(out, 16), BOT_E_NULL, "halves_split_frag: NULL or misaligned pointer");
+    const int64_t tiles = (n + 15) / 16;
+    hipLaunchKernelGGL(halves_split_frag_kernel, dim3((unsigned)(tiles * 16), (unsigned)((piece / 2 + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x, ldx, n, F,
+                       scale, (__half*)out, piece, tiles * (piece / 32) * 512);
+    return hip_status("halves_split_frag launch");
 }
 
 int bot_halves_split_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, int32_t order, uint16_t* out,

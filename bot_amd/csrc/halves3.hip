@@ -20,6 +20,9 @@
 // Reference call sites: the projections of src/no-sampling/models.py:490-492 and :558-560 (fc / res_fc, merged) and their input gradients.
 #include <hip/hip_fp16.h>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -54,6 +57,7 @@ struct H3Args {
     // the accumulators are multiplied by scale_a2[0] / scale_a[0] (a power of two: exact) in front of k-step k2, alpha = scale_a2[1] scale_b[1]
     const float* scale_a2;
     int k2;                 // -1: one scale
+    int b_frag;             // B is a fragment-major RIGHT operand (halves.hip order 3; gemm_halves3_nt64_kernel only): rows of 16-row tiles = N rounded up
     int mode;               // 0 = the product.  Measurement switches (tools/exp_halves3.py): bit 0 no output stores; bit 2 / 3 B / A never
                             // advance along k; bit 5 the plain loop (barrier at the end of a k-step) and, in it, bit 6 no barrier / wait,
                             // bit 7 no DMA inside the loop, bit 8 one A fragment pair per k-step
@@ -365,6 +369,279 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_kernel(H3Args p)
 template <int BM, int BN, int WM, int WN, bool PIPE>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_grouped_kernel(H3Args p, H3Groups groups) {
     gemm_halves3_nt_body<BM, BN, WM, WN, PIPE, true, false>(p, &groups);
+}
+
+// ----------------------------------------------------------------------------------------------------------------------------
+// The 128-byte-line form (round 5).  Ablations of the kernel above and of a B-direct variant (profiles/r05_nt_bd.txt)
+// showed that what the k-loop pays besides the MFMAs is the operand traffic a CU pulls from its L2 - 64 KB per k-step - and that its price
+// is set by the ADDRESS PATTERN, not the mechanism: a wave instruction that fetches 16 rows x 64 bytes (half cache lines, BK = 32 halves)
+// costs about twice one that fetches 8 rows x 128 bytes (timing-only pattern switches on the B-direct kernel: 1.115 -> 1.021 ms forward,
+// 1.065 -> 0.973 ms input gradient).  This kernel stages TWO k-steps per iteration so that every fetch is a whole line:
+//   * 8 waves as 1 (M) x 8 (N): a wave owns all 256 rows x 32 columns of the tile (MT = 16, NT = 2; 96 MFMAs per k-step as before);
+//   * LEFT operand through LDS: per iteration and piece [256 rows][128 B] = 32 KB, two pieces, two stages = 128 KB; a DMA instruction
+//     writes 8 rows x 128 B; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7, which makes every 16-lane group of a
+//     ds_read_b128 (16 rows, two adjacent chunks) hit 64 different banks; the swizzle rides on the DMA's per-lane SOURCE address;
+//   * the wave's own 32 weight rows straight from global memory / L2 into registers (nobody else needs them): the two k-steps' fragments
+//     of a row are the two halves of ONE line, loaded back to back (the second hits the line the first brought in), one iteration ahead;
+//   * ONE barrier per iteration (two k-steps), placed in front of the last row of MFMA tiles as above.
+// Same operands, same three products in the same order per accumulator as the kernel above: bit for bit its result.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ half8 load16(const void* tile_base, uint32_t voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tile_base), 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+#else
+    return half8{};
+#endif
+}
+
+template <bool GROUPED, bool BFRAG>
+__device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3Groups* groups) {
+    constexpr int BM = 256, BN = 256, kWaves = 8, MT = BM / 16, NT = BN / kWaves / 16;
+    constexpr int kRow = 4 * BK;                             // bytes of a row per piece and iteration: two k-steps = one 128-byte line
+    constexpr int kABytes = BM * kRow;                       // one piece of A per iteration: 32 KB
+    constexpr int kStageBytes = 2 * kABytes, kStages = 2;
+    constexpr int GA = BM / 8 / kWaves;                      // 8-row groups (one 1 KB DMA instruction) per wave and piece: 4
+    static_assert(NT == 2 && GA == 4 && kRow == 128, "wave tile 256 x 32, 128-byte rows");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[kStages * kStageBytes];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
+    if (tm >= p.tiles_m) return;
+    const int m0 = tm * BM;
+    int n0 = tn * BN, n_valid = p.N - n0, T = p.K / BK, a_off0 = 0, a_off1 = 0, k_seg = 0;
+    int64_t c0 = n0;
+    if constexpr (GROUPED) {
+        const H3Group& G = groups->g[tn];
+        n0 = G.b_row0, n_valid = G.n_valid, T = G.k_steps, a_off0 = G.a_off0, a_off1 = G.a_off1, c0 = G.c_off, k_seg = groups->k_seg;
+    }
+    const int T2 = T >> 1;                                   // iterations (the launcher takes this form for an even number of k-steps only)
+    const float alpha = (p.scale_a2 ? p.scale_a2[1] : p.scale_a[1]) * p.scale_b[1];
+
+    // A: lane i of DMA instruction g (8-row group g = w + 8 h) lands at byte 16 i of the group's 1 KB: row 8 g + (i >> 3), stored chunk
+    // i & 7, which holds the row's chunk (i & 7) ^ ((row >> 1) & 7)
+    const _Float16* tileA = p.A + (int64_t)m0 * p.lda;
+    const _Float16* tileB = p.B + (int64_t)n0 * p.ldb;
+    // (per-lane offsets only where they differ per lane: the second half's column offset and the k offset ride in the scalar offset)
+    uint32_t offA[GA];
+#pragma unroll
+    for (int h = 0; h < GA; ++h) {
+        const int row = (w + kWaves * h) * 8 + (lane >> 3);
+        offA[h] = ((uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.lda + (((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2;
+    }
+    const int a2b = p.a2_off * 2;
+    auto issue_a = [&](int i, int stage, int it) {           // i = 0 .. 7: a1 groups w, w + 8, w + 16, w + 24, then a2 likewise
+        const int q = i / GA, h = i % GA;
+        dma16(tileA, lds + stage * kStageBytes + q * kABytes + (w + kWaves * h) * 1024, offA[h],
+              (GROUPED ? it * kRow + (2 * it < k_seg ? a_off0 : a_off1) : it * kRow) + q * a2b);
+    };
+    // B: lane l holds row l & 15 of a 16-row tile, bytes 16 (l >> 4) .. + 15 of a k-step's 64: k-step 2 it at byte 0, 2 it + 1 at byte 64 of the line
+    // BFRAG: the operand is stored fragment-major (halves.hip order 3): the fragment of 16-row tile t and k-step s is the KB at ((t T + s) KB),
+    // lane l at byte 16 l - one contiguous KB per load instruction; h2 one region behind
+    uint32_t offB[NT];
+    int tileoff[NT];
+    const int Tk = p.K / BK;                                 // (BFRAG: the plain launch only - the operand's k-steps per tile)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (BFRAG) {
+            offB[nt] = lane * 16;
+            tileoff[nt] = min((n0 + w * (NT * 16) + nt * 16) >> 4, ((p.N + 15) >> 4) - 1) * Tk * 1024;
+        } else {
+            offB[nt] = ((uint32_t)(min(n0 + w * (NT * 16) + nt * 16 + (lane & 15), p.N - 1) - n0) * (uint32_t)p.ldb) * 2 + (lane >> 4) * 16;
+            tileoff[nt] = 0;
+        }
+    }
+    const int b2 = BFRAG ? ((p.N + 15) >> 4) * Tk * 1024 : p.b2_off * 2;
+    const _Float16* baseB = BFRAG ? p.B : tileB;
+    auto load_b = [&](half8 (&x1)[NT], half8 (&x2)[NT], int it, int sub) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int so = BFRAG ? tileoff[nt] + (2 * it + sub) * 1024 : it * kRow + sub * 64;
+            x1[nt] = load16(baseB, offB[BFRAG ? 0 : nt], so);
+            x2[nt] = load16(baseB, offB[BFRAG ? 0 : nt], so + b2);
+        }
+    };
+    // A fragments: lane l reads row l & 15 of a 16-row tile, chunk 4 sub + (l >> 4), stored at chunk ^ ((row >> 1) & 7)
+    const int frow = lane & 15, fkey = (frow >> 1) & 7;
+    const int a_off_s0 = frow * kRow + (((lane >> 4) ^ fkey) * 16);              // + mt * 2048 (+ kABytes for the second half)
+    const int a_off_s1 = frow * kRow + (((4 + (lane >> 4)) ^ fkey) * 16);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto rescale = [&]() {
+        const float r = p.scale_a2[0] * p.scale_a[1];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc[mt][nt] * r;
+    };
+    auto mfma6 = [&](int mt, const half8& a1, const half8& a2, const half8 (&b1)[NT], const half8 (&b2h)[NT], const half8 (&b1s)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[nt], a1, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2h[nt], a1, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1s[nt], a2, acc[mt][nt], 0, 0, 0);
+        }
+    };
+    const _Float16 sh = (_Float16)(1.0f / kHalvesShift);
+
+    // prologue: A of iteration 0 and B of both its k-steps
+    half8 x1[NT], x2[NT], y1[NT], y2[NT], z1[NT], z2[NT], bs[NT], a1, a2;       // x: k-step 2 it, y: k-step 2 it + 1, z: the next iteration's second
+#pragma unroll
+    for (int i = 0; i < 2 * GA; ++i) issue_a(i, 0, 0);
+    load_b(x1, x2, 0, 0);
+    load_b(y1, y2, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    a1 = *reinterpret_cast<const half8*>(lds + a_off_s0);
+    a2 = *reinterpret_cast<const half8*>(lds + a_off_s0 + kABytes);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        // (uses the compiler can see: its wait-count pass then knows these registers have landed HERE; left pending into the loop it
+        // re-waits at the head of every iteration with vmcnt(0), behind the loads just issued for the next one)
+        asm volatile("" : "+v"(x1[nt]), "+v"(x2[nt]), "+v"(y1[nt]), "+v"(y2[nt]));
+    }
+    // One iteration = two k-steps.  MORE (iteration it + 1 exists) is compile-time: the steady-state loop has no branch around its loads.
+    auto iteration = [&](int it, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
+        const int stage = it & 1;
+        const unsigned char* st = lds + stage * kStageBytes;
+        const unsigned char* sn = lds + (stage ^ 1) * kStageBytes;
+        // ---- k-step 2 it: fragments x, the DMA of iteration it + 1 spread over the first tile rows (its stage is free since the
+        // barrier of iteration it - 1)
+        if (2 * it == p.k2) rescale();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bs[nt] = x1[nt] * sh;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int nx = mt + 1 < MT ? a_off_s0 + (mt + 1) * 2048 : a_off_s1;      // the last row prefetches the first fragments of k-step 2 it + 1
+            const half8 an1 = *reinterpret_cast<const half8*>(st + nx);
+            const half8 an2 = *reinterpret_cast<const half8*>(st + nx + kABytes);
+            if constexpr (more) {
+                if (mt < 2 * GA) issue_a(mt, stage ^ 1, it + 1);
+            }
+            mfma6(mt, a1, a2, x1, x2, bs);
+            a1 = an1, a2 = an2;
+        }
+        // ---- the next iteration's weight fragments: both k-steps of a row are the two halves of one line, loaded back to back (x is dead)
+        if constexpr (more) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(x1, x2, it + 1, 0);
+            load_b(z1, z2, it + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);       // (left alone, the scheduler sinks these loads to the end of the iteration)
+        }
+        // ---- k-step 2 it + 1: fragments y
+        if (2 * it + 1 == p.k2) rescale();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bs[nt] = y1[nt] * sh;
+#pragma unroll
+        for (int mt = 0; mt < MT - 1; ++mt) {
+            const half8 an1 = *reinterpret_cast<const half8*>(st + a_off_s1 + (mt + 1) * 2048);
+            const half8 an2 = *reinterpret_cast<const half8*>(st + a_off_s1 + kABytes + (mt + 1) * 2048);
+            mfma6(mt, a1, a2, y1, y2, bs);
+            a1 = an1, a2 = an2;
+        }
+        // the next iteration's operands have landed (they were issued a k-step or more ago) and every read of this stage has returned
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        half8 an1 = a1, an2 = a2;
+        if constexpr (more) {
+            an1 = *reinterpret_cast<const half8*>(sn + a_off_s0);
+            an2 = *reinterpret_cast<const half8*>(sn + a_off_s0 + kABytes);
+        }
+        mfma6(MT - 1, a1, a2, y1, y2, bs);
+        if constexpr (more) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) y1[nt] = z1[nt], y2[nt] = z2[nt];
+            a1 = an1, a2 = an2;
+        }
+    };
+    int it = 0;
+    for (; it + 1 < T2; ++it) iteration(it, std::true_type{});
+    iteration(it, std::false_type{});
+    __builtin_amdgcn_s_barrier();       // the epilogue reuses the stages: every wave is past its last fragment read
+
+    // epilogue: acc[mt][nt][r] = C[m0 + mt 16 + (lane & 15)][c0 + w 32 + nt 16 + (lane >> 4) 4 + r], staged per wave in slabs of 32 rows x 32
+    // columns (pitch 36 floats) so that a store instruction writes 8 rows x 128 contiguous bytes
+    float* const Cb = p.C + c0;
+    const bool vec_ok = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
+    const bool vec2_ok = (p.ldc % 2 == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 7) == 0);
+    constexpr int P = NT * 16 + 4;
+    static_assert(32 * P * 4 <= kStages * kStageBytes / kWaves, "staging slab does not fit the wave's share of the LDS");
+    float* stg = reinterpret_cast<float*>(lds + w * (kStages * kStageBytes / kWaves));
+    const int q4 = (lane >> 4) * 4, l15 = lane & 15, l7 = lane & 7;
+    const int col = w * (NT * 16) + l7 * 4;         // within the tile: this lane's four columns, the same in every pass
+    float cs[4] = {1.f, 1.f, 1.f, 1.f}, ch[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool affine = p.col_scale != nullptr || p.col_shift != nullptr;
+    if (affine) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < n_valid) {
+                if (p.col_scale) cs[e] = p.col_scale[c0 + col + e];
+                if (p.col_shift) ch[e] = p.col_shift[c0 + col + e];
+            }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < MT / 2; ++pass) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 v = acc[pass * 2 + mm][nt] * alpha;
+                *reinterpret_cast<f32x4*>(stg + (mm * 16 + l15) * P + nt * 16 + q4) = v;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 8 + (lane >> 3);
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * P + l7 * 4);
+            const int row = m0 + pass * 32 + r;
+            if (affine || p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaf(v[e], cs[e], ch[e]);
+                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+            }
+            if (p.absmax && row < p.M) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < n_valid) amax = fmaxf(amax, fabsf(v[e]));
+            }
+            if (row < p.M) {
+                float* c = Cb + (int64_t)row * p.ldc + col;
+                if (vec_ok && col + 3 < n_valid) {
+                    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (vec2_ok && col + 3 < n_valid) {
+                    *reinterpret_cast<float2*>(c) = make_float2(v[0], v[1]);
+                    *reinterpret_cast<float2*>(c + 2) = make_float2(v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < n_valid) c[e] = v[e];
+                }
+            }
+        }
+    }
+    if (p.absmax) absmax_publish(wave_absmax(amax), p.absmax);
+}
+
+__global__ __launch_bounds__(512) void gemm_halves3_nt64_kernel(H3Args p) { gemm_halves3_nt64_body<false, false>(p, nullptr); }
+__global__ __launch_bounds__(512) void gemm_halves3_nt64_frag_kernel(H3Args p) { gemm_halves3_nt64_body<false, true>(p, nullptr); }
+__global__ __launch_bounds__(512) void gemm_halves3_nt64_grouped_kernel(H3Args p, H3Groups groups) { gemm_halves3_nt64_body<true, false>(p, &groups); }
+
+// BOT_NT_KERNEL=256x32 (default) / 128x64: which of the two forms the NT launches take when both cover the shape; read once per process
+static bool nt64_wanted() {
+    static const bool wanted = [] {
+        const char* e = getenv("BOT_NT_KERNEL");
+        return !(e && !strcmp(e, "128x64"));
+    }();
+    return wanted;
 }
 
 // ============================================================================================================================
@@ -733,13 +1010,15 @@ void launch_h3(H3Args p, int64_t m, int64_t n, hipStream_t st) {
 extern "C" int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
                                        int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t mode,
                                        bot_stream_t stream) {
-    return bot_gemm_halves3_nt2_f32(m, n, k, scale_a, nullptr, 0, scale_b, A, lda, a2_off, B, ldb, b2_off, C, ldc, mode, stream);
+    return bot_gemm_halves3_nt2_f32(m, n, k, scale_a, nullptr, 0, scale_b, A, lda, a2_off, B, ldb, b2_off, 0, C, ldc, mode, stream);
 }
 
 extern "C" int bot_gemm_halves3_nt2_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_a2, int64_t k_split, const float* scale_b,
-                                        const uint16_t* A, int64_t lda, int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc,
-                                        int32_t mode, bot_stream_t stream) {
+                                        const uint16_t* A, int64_t lda, int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, int32_t b_layout,
+                                        float* C, int64_t ldc, int32_t mode, bot_stream_t stream) {
     using namespace bot;
+    BOT_REQUIRE(b_layout == 0 || (b_layout == 1 && mode == 0 && k % 64 == 0), -1,
+                "gemm_halves3_nt2: b_layout 1 (fragment-major B, bot_halves_split_frag_f16 with piece = k) needs mode 0 and k a multiple of 64");
     BOT_REQUIRE(scale_a2 == nullptr || (k_split > 0 && k_split < k && k_split % BK == 0), -1,
                 "gemm_halves3_nt2: the second scale starts at a column that is a positive multiple of %d below k (got %lld of %lld)", BK, (long long)k_split,
                 (long long)k);
@@ -748,15 +1027,27 @@ extern "C" int bot_gemm_halves3_nt2_f32(int64_t m, int64_t n, int64_t k, const f
     BOT_REQUIRE(scale_a && scale_b && A && B && C, -1, "gemm_halves3_nt: null pointer");
     BOT_REQUIRE(aligned(A, 16) && aligned(B, 16) && lda % 8 == 0 && ldb % 8 == 0 && a2_off % 8 == 0 && b2_off % 8 == 0, -1,
                 "gemm_halves3_nt: operands, row pitches and piece offsets must be 16-byte aligned");
-    BOT_REQUIRE(a2_off + k <= lda && b2_off + k <= ldb && ldc >= n && m < (1ll << 31) - 256 && n < (1ll << 31) - 256, -1, "gemm_halves3_nt: bad pitches");
+    BOT_REQUIRE(a2_off + k <= lda && (b_layout == 1 || b2_off + k <= ldb) && ldc >= n && m < (1ll << 31) - 256 && n < (1ll << 31) - 256, -1, "gemm_halves3_nt: bad pitches");
+    BOT_REQUIRE(b_layout == 0 || ((n + 15) / 16) * (k / 32) * 2048 < (1ll << 31), -1, "gemm_halves3_nt2: fragment-major B exceeds the 2 GiB a buffer descriptor spans");
     H3Args p;
     p.A = reinterpret_cast<const _Float16*>(A), p.B = reinterpret_cast<const _Float16*>(B), p.scale_a = scale_a, p.scale_b = scale_b, p.C = C;
     p.lda = lda, p.ldb = ldb, p.ldc = ldc, p.M = (int)m, p.N = (int)n, p.K = (int)k, p.a2_off = (int)a2_off, p.b2_off = (int)b2_off;
     p.tiles_m = p.tiles_n = 0;
     p.col_scale = p.col_shift = nullptr, p.relu = 0, p.absmax = nullptr;
     p.scale_a2 = scale_a2, p.k2 = scale_a2 ? (int)(k_split / BK) : -1;
+    p.b_frag = b_layout;
     p.mode = mode;
-    if (mode & 32) {        // measurement builds only: one barrier at the END of a k-step, with the ablation switches
+    const bool force_128x64 = (mode & 1024) != 0;            // (tools: both forms in one process)
+    mode &= ~1024;
+    p.mode = mode;
+    if (mode == 0 && !force_128x64 && nt64_wanted() && (k / BK) % 2 == 0) {      // the 128-byte-line form: an even number of k-steps
+        p.tiles_m = (int)((m + 255) / 256), p.tiles_n = (int)((n + 255) / 256);
+        set_kernel(b_layout ? "bot::gemm_halves3_nt64_frag_kernel" : "bot::gemm_halves3_nt64_kernel");
+        if (b_layout) hipLaunchKernelGGL(gemm_halves3_nt64_frag_kernel, dim3(((p.tiles_m + 7) / 8) * 8 * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(gemm_halves3_nt64_kernel, dim3(((p.tiles_m + 7) / 8) * 8 * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
+    } else if (b_layout) {
+        BOT_REQUIRE(false, -1, "gemm_halves3_nt2: a fragment-major B is read by the 256 x 32 form only (BOT_NT_KERNEL=128x64 / mode bit 1024 exclude it)");
+    } else if (mode & 32) {        // measurement builds only: one barrier at the END of a k-step, with the ablation switches
         set_kernel("bot::gemm_halves3_nt_kernel<256,256,2,4,plain>");
         launch_h3<256, 256, 2, 4, false, true>(p, m, n, (hipStream_t)stream);
     } else if (mode) {      // the pipelined loop with `mode` read in the kernel (bit 0: no output stores; bits 2 / 3: an operand never advances)
@@ -784,7 +1075,7 @@ extern "C" int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const 
     p.A = reinterpret_cast<const _Float16*>(A), p.B = reinterpret_cast<const _Float16*>(B), p.scale_a = scale_a, p.scale_b = scale_b, p.C = C;
     p.lda = lda, p.ldb = ldb, p.ldc = ldc, p.M = (int)m, p.N = (int)b_rows, p.K = 0, p.a2_off = (int)a2_off, p.b2_off = (int)b2_off;
     p.mode = 0;             // (the grouped kernel is a production instantiation: no measurement switch inside)
-    p.scale_a2 = nullptr, p.k2 = -1;
+    p.scale_a2 = nullptr, p.k2 = -1, p.b_frag = 0;
     p.col_scale = col_scale, p.col_shift = col_shift, p.relu = relu, p.absmax = absmax_slots;
     H3Groups g;
     g.k_seg = k_seg;
@@ -800,6 +1091,13 @@ extern "C" int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const 
         g.g[i] = H3Group{(int)d[0], (int)d[1], (int)d[2] * 2, (int)d[3] * 2, (int)k_steps, 0, d[5]};
     }
     p.tiles_m = (int)((m + 255) / 256), p.tiles_n = n_groups;
+    bool even = k_seg % 2 == 0;
+    for (int i = 0; i < n_groups; ++i) even = even && g.g[i].k_steps % 2 == 0;
+    if (!(mode & 1024) && even && nt64_wanted()) {
+        set_kernel("bot::gemm_halves3_nt64_grouped_kernel");
+        hipLaunchKernelGGL(gemm_halves3_nt64_grouped_kernel, dim3(((p.tiles_m + 7) / 8) * 8 * n_groups), dim3(512), 0, (hipStream_t)stream, p, g);
+        return hip_status("gemm_halves3_nt_grouped");
+    }
     set_kernel("bot::gemm_halves3_nt_grouped_kernel<256,256,2,4,pipelined>");
     hipLaunchKernelGGL((gemm_halves3_nt_grouped_kernel<256, 256, 2, 4, true>), dim3(((p.tiles_m + 7) / 8) * 8 * n_groups), dim3(512), 0, (hipStream_t)stream, p, g);
     return hip_status("gemm_halves3_nt_grouped");

@@ -45,7 +45,8 @@ def enabled(x) -> bool:
 
 class Halves:
     """fp16 halves of an fp32 matrix [n, F]: `buf` [n, 3 * piece] fp16 (order 2: [n, 2 * piece]), `scale` [2] = (s, 1/s) on the device.
-    order 0: left [h1 | h1 | 2^11 h2]; 1: right [h1 | h2 | 2^-11 h1]; 2: left without the duplicate, [h1 | 2^11 h2]."""
+    order 0: left [h1 | h1 | 2^11 h2]; 1: right [h1 | h2 | 2^-11 h1]; 2: left without the duplicate, [h1 | 2^11 h2]; 3: right, FRAGMENT-MAJOR
+    (bot_halves_split_frag_f16: `buf` is [2 ceil(n / 16) piece / 32, 512], read by the hand-written NT kernel only)."""
     __slots__ = ("buf", "scale", "n", "F", "piece", "order")
 
     def __init__(self, buf, scale, n, F, piece, order):
@@ -76,6 +77,21 @@ def split(x, order: int, scale=None) -> Halves:
     if scale is None:
         scale = _C.halves_scale(x)
     return Halves(_C.halves_split(x, scale, order, piece), scale, n, F, piece, order)
+
+
+RIGHT_FRAG = os.environ.get("BOT_RIGHT_FRAG", "1") != "0" and os.environ.get("BOT_NT_KERNEL", "") != "128x64"
+
+
+def split_right(w) -> Halves:
+    """The right operand of `mm_nt` for a weight w [p, F]: fragment-major (order 3) when the product will run on the hand-written NT kernel
+    (the same predicate `mm_nt` routes by, evaluated from w's shape: p >= NT_MIN_COLS or a left operand of this width has no duplicate
+    piece), else the row-major order 1 the library formulation reads."""
+    p, F = w.shape
+    piece = (F + PIECE_ALIGN - 1) // PIECE_ALIGN * PIECE_ALIGN
+    if RIGHT_FRAG and NT_KERNEL == "halves3" and (w.is_cuda or FORCE) and (p >= NT_MIN_COLS or left_order(piece) == 2):
+        scale = _C.halves_scale(w)
+        return Halves(_C.halves_split_frag(w, scale, piece), scale, p, F, piece, 3)
+    return split(w, 1)
 
 
 _STASH = {}
@@ -165,10 +181,10 @@ def _alpha(a: Halves, b: Halves, n=None):
 
 def mm_nt(a: Halves, b: Halves, out=None):
     """a [n, F] (order 0) times b [p, F]^T (order 1) -> fp32 [n, p]."""
-    assert a.left and b.order == 1 and a.F == b.F and a.piece == b.piece
-    if NT_KERNEL == "halves3" and (b.n >= NT_MIN_COLS or a.order == 2):      # (an operand without the duplicate piece has no library form)
-        return _C.gemm_halves3_nt(a.buf, b.buf, a.scale, b.scale, a.piece, b.piece, a.piece, out=out, a2_off=a.h2_off)
-    assert a.order == 0
+    assert a.left and b.order in (1, 3) and a.F == b.F and a.piece == b.piece
+    if NT_KERNEL == "halves3" and (b.order == 3 or b.n >= NT_MIN_COLS or a.order == 2):      # (an operand without the duplicate piece, or a fragment-major one, has no library form)
+        return _C.gemm_halves3_nt(a.buf, b.buf, a.scale, b.scale, a.piece, b.piece, a.piece, out=out, a2_off=a.h2_off, b_frag=b.order == 3, n=b.n)
+    assert a.order == 0 and b.order == 1
     return _C.gemm_halves(a.buf, b.buf, _alpha(a, b, b.n), trans_b=True, out=out)
 
 
@@ -233,14 +249,14 @@ class _Matmul(torch.autograd.Function):
         xh = take(x, 0)
         ctx.kp, ctx.meta = kp, (xh.n, xh.F, xh.piece, xh.order)
         ctx.save_for_backward(xh.buf, xh.scale, w)
-        return mm_nt(xh, split(w.t().contiguous() if kp else w, 1))
+        return mm_nt(xh, split_right(w.t().contiguous() if kp else w))
 
     @staticmethod
     def backward(ctx, dy):
         buf, scale, w = ctx.saved_tensors
         kp = ctx.kp
         dh = split(dy.contiguous(), 0)
-        dx = mm_nt(dh, split(w if kp else w.t().contiguous(), 1)) if ctx.needs_input_grad[0] else None
+        dx = mm_nt(dh, split_right(w if kp else w.t().contiguous())) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             dw = tn(Halves(buf, scale, *ctx.meta), dh)               # [K, P]
@@ -259,7 +275,7 @@ class _MergedLinear(torch.autograd.Function):
         xh = take(x, 0)
         ctx.sizes, ctx.meta = sizes, (xh.n, xh.F, xh.piece, xh.order)
         ctx.save_for_backward(xh.buf, xh.scale, w)
-        y = mm_nt(xh, split(w, 1))
+        y = mm_nt(xh, split_right(w))
         return tuple(torch.split(y, sizes, dim=1))
 
     @staticmethod
@@ -285,7 +301,7 @@ class _MergedLinear(torch.autograd.Function):
                 _C.halves_split_cols(g, dscale, 0, dbuf, piece, off, width)
             off += wd
         dh = Halves(dbuf, dscale, n, P, piece, 0)
-        dx = mm_nt(dh, split(w.t().contiguous(), 1)) if ctx.needs_input_grad[0] else None
+        dx = mm_nt(dh, split_right(w.t().contiguous())) if ctx.needs_input_grad[0] else None
         dw = tn(Halves(buf, scale, *ctx.meta), dh).t().contiguous() if ctx.needs_input_grad[1] else None
         return dx, dw, None
 

@@ -245,7 +245,7 @@ class _GATHidden(torch.autograd.Function):
         xh = None
         if gemm.enabled(h):                                             # fp32 GEMM on the fp16 matrix cores (bot_amd.gemm)
             xh = gemm.take(h, 0)                                        # written by the previous layer's epilogue, or split here
-            out = gemm.mm_nt(xh, gemm.split(Wcat.t().contiguous() if kp else Wcat, 1))
+            out = gemm.mm_nt(xh, gemm.split_right(Wcat.t().contiguous() if kp else Wcat))
         else:
             out = torch.mm(h, Wcat) if kp else torch.mm(h, Wcat.t())    # [N, P] = [ft | res | el | er | pad]
         ctx.halves = None if xh is None else (xh.n, xh.F, xh.piece, xh.order)
@@ -434,7 +434,7 @@ class _GATHidden(torch.autograd.Function):
             else:
                 dh_ = gemm.split(dout, 0)
             if ctx.needs_input_grad[0]:
-                dh = gemm.mm_nt(dh_, gemm.split(Wcat if kp else Wcat.t().contiguous(), 1))
+                dh = gemm.mm_nt(dh_, gemm.split_right(Wcat if kp else Wcat.t().contiguous()))
             if ctx.needs_input_grad[1]:
                 def wgrad():
                     dW = gemm.tn(xh, dh_)                                # [K, P]
@@ -494,8 +494,8 @@ def _backward_direct(ctx, dy, g, h, Wcat, table, el, er, a, a_d, x, mean, invstd
     dW = dh = None
     xh = gemm.Halves(h, ctx.xscale, *ctx.halves)
     if ctx.needs_input_grad[0]:
-        Ws = gemm.split(Wcat if kp else Wcat.t().contiguous(), 1)
-        dh = _C.gemm_halves3_nt(buf, Ws.buf, s1, Ws.scale, piece, Ws.piece, piece, a2_off=piece, scale_a2=s2, k_split=c)
+        Ws = gemm.split_right(Wcat if kp else Wcat.t().contiguous())
+        dh = _C.gemm_halves3_nt(buf, Ws.buf, s1, Ws.scale, piece, Ws.piece, piece, a2_off=piece, scale_a2=s2, k_split=c, b_frag=Ws.order == 3, n=Ws.n)
     if ctx.needs_input_grad[1]:
         def wgrad():
             dWk = _C.gemm_halves3_tn(xh.buf, buf, xh.scale, s1, xh.piece, piece, xh.F, P, x2_off=xh.h2_off, d2_off=piece, scale_d2=s2, p_split=c)
@@ -1141,7 +1141,7 @@ def gat_infer_layer(conv, epi, graph, h, relu, first=False):
     elif gemm.enabled(h):                                               # fp32 GEMM on the fp16 matrix cores (bot_amd.gemm)
         # the weight's halves live and die with the merged weight they were split from: same key (the parameters' versions)
         out = gemm.mm_nt(gemm.split_with_stash(h, 0), _cached(conv, "infer_halves", _infer_key(conv),
-                                                   lambda: gemm.split(W.t().contiguous() if WEIGHT_KP else W, 1)))
+                                                   lambda: gemm.split_right(W.t().contiguous() if WEIGHT_KP else W)))
     else:
         out = torch.mm(h, W) if WEIGHT_KP else torch.mm(h, W.t())       # [N, P] = [ft | res | el | er | pad]
     B = block_width(HD)

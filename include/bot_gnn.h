@@ -562,8 +562,14 @@ int bot_spmm_dot_halves_f16(const int32_t* indptr, const int32_t* indices, int64
                             const int32_t* wperm, const float* y, int64_t ldy, int64_t hsy, int32_t H, int32_t D, const float* hscale, uint16_t* hout,
                             int64_t ldh, int64_t hsh, int32_t h2_off, float* dot_out, float* partial, bot_stream_t stream);
 int bot_gemm_halves3_nt2_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_a2, int64_t k_split, const float* scale_b,
-                             const uint16_t* A, int64_t lda, int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc,
-                             int32_t mode, bot_stream_t stream);
+                             const uint16_t* A, int64_t lda, int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, int32_t b_layout, float* C,
+                             int64_t ldc, int32_t mode, bot_stream_t stream);
+/* v17: a RIGHT operand in FRAGMENT-MAJOR layout (b_layout = 1 of bot_gemm_halves3_nt2_f32; ldb / b2_off unused): the 16 bytes lane l of an
+ * MFMA fragment holds - row 16 t + (l & 15), columns 32 s + 8 (l >> 4) .. + 7 - at halves ((t T + s) 64 + l) 8, T = piece / 32, h1 in the
+ * first region, h2 ceil(n / 16) T 512 halves behind it: the 64 lanes of a fragment load read one contiguous KB (the NT kernel pays for the
+ * bytes a CU pulls from its L2 by their address pattern: profiles/r05_nt64.txt).  out: 2 * ceil(n / 16) * (piece / 32) * 512 halves, 16-byte
+ * aligned; piece a multiple of 64; rows beyond n and columns beyond F are zeros. */
+int bot_halves_split_frag_f16(const float* x, int64_t ldx, int64_t n, int32_t F, const float* scale, uint16_t* out, int32_t piece, bot_stream_t stream);
 int bot_gemm_halves3_tn2_f32(int64_t n_rows, int64_t k, int64_t p, int64_t kp, int64_t pp, const float* scale_x, const float* scale_d, const float* scale_d2,
                              int64_t p_split, const uint16_t* X, int64_t ldx, int64_t x2_off, const uint16_t* D, int64_t ldd, int64_t d2_off, float* out,
                              int64_t ldo, float* workspace, int32_t mode, bot_stream_t stream);

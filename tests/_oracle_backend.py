@@ -387,10 +387,35 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
     return out
 
 
-def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0):
+def halves_split_frag(x, scale, piece):
+    """include/bot_gnn.h bot_halves_split_frag_f16"""
+    n, F = x.shape
+    tiles, T = (n + 15) // 16, piece // 32
+    z = torch.zeros(tiles * 16, piece)
+    z[:n, :F] = x.float() * (float(scale[0]) if scale is not None else 1.0)
+    h1 = z.half()
+    h2 = (z - h1.float()).half()
+
+    def frag(h):       # [tiles, 16 rows, T, 4 groups, 8] -> [tiles, T, 4 groups, 16 rows, 8]: lane l = row + 16 group
+        return h.view(tiles, 16, T, 4, 8).permute(0, 2, 3, 1, 4).reshape(tiles * T, 512)
+    return torch.cat([frag(h1), frag(h2)])
+
+
+def _unfrag(buf, n, piece):
+    """the row-major [h1 | h2] of a fragment-major right operand"""
+    tiles, T = (n + 15) // 16, piece // 32
+
+    def rows(b):
+        return b.view(tiles, T, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(tiles * 16, piece)[:n]
+    return torch.cat([rows(buf[:tiles * T]), rows(buf[tiles * T:])], dim=1)
+
+
+def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0, b_frag=False, n=None):
     """include/bot_gnn.h bot_gemm_halves3_nt_f32 / _nt2_f32: a1 b1^T + a1 b2^T + (2^11 a2) (2^-11 b1)^T from a LEFT and a RIGHT operand buffer;
     scale_a2: a's columns from k_split on carry a second scale (the accumulators are rescaled by the ratio in front of them)."""
     a2_off = 2 * piece_a if a2_off is None else a2_off
+    if b_frag:
+        b = _unfrag(b, n, piece_b)
 
     def part(lo, hi):
         a1, a2 = a[:, lo:hi].float(), a[:, a2_off + lo:a2_off + hi].float()
@@ -604,7 +629,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["halves_tail", "spmm_dot_halves", "spmm_dot_halves_fits", "gemm_halves3_tn", "bn_bwd_bound", "bn_act_bwd_apply_halves", "halves_split_heads", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["halves_split_frag", "halves_tail", "spmm_dot_halves", "spmm_dot_halves_fits", "gemm_halves3_tn", "bn_bwd_bound", "bn_act_bwd_apply_halves", "halves_split_heads", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -1663,6 +1663,45 @@ def test_gemm_halves3_nt_kernel():
         _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, 40)       # k not a multiple of 32
 
 
+def test_nt64_kernel_and_fragment_major_operand():
+    """Round 5: the 128-byte-line form of the NT halves GEMM (csrc/halves3.hip gemm_halves3_nt64_kernel: two k-steps per iteration, wave tile
+    256 x 32, the wave's weight fragments straight into registers) is bit for bit the 128 x 64-wave-tile kernel (mode bit 1024 forces that one)
+    on ragged m / n / k, strided outputs, both left layouts and with the second scale; a fragment-major right operand
+    (bot_halves_split_frag_f16) gives bit for bit the result of the row-major one, and matches its restatement (tests/_oracle_backend.py)."""
+    from tests import _oracle_backend as OB
+    from bot_amd import gemm
+    gen = torch.Generator(device=DEV).manual_seed(31)
+    OLD = 1024
+    for (m, K, P) in ((1000, 96, 300), (513, 750, 1536), (20000, 1536, 750), (4099, 64, 40), (257, 128, 17), (3000, 250, 193)):
+        x = torch.randn(m, K, device=DEV, generator=gen) * 3
+        w = torch.randn(P, K, device=DEV, generator=gen) * 0.05
+        ws = gemm.split(w, 1)
+        frag = _C.halves_split_frag(w, ws.scale, ws.piece)
+        assert torch.equal(frag.cpu(), OB.halves_split_frag(w.cpu(), ws.scale.cpu(), ws.piece)), (m, K, P)
+        for order in (0, 2):
+            piece = ws.piece
+            sc = _C.halves_scale(x)
+            xb = _C.halves_split(x, sc, order, piece)
+            a2 = piece if order == 2 else 2 * piece
+            old = _C.gemm_halves3_nt(xb, ws.buf, sc, ws.scale, piece, piece, piece, a2_off=a2, mode=OLD)
+            new = _C.gemm_halves3_nt(xb, ws.buf, sc, ws.scale, piece, piece, piece, a2_off=a2)
+            fr = _C.gemm_halves3_nt(xb, frag, sc, ws.scale, piece, piece, piece, a2_off=a2, b_frag=True, n=P)
+            assert torch.equal(old, new) and torch.equal(old, fr), (m, K, P, order)
+            ref = x.double() @ w.double().t()
+            assert float((new.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+            if piece >= 64:
+                s2 = torch.tensor([float(sc[0]) * 128, float(sc[1]) / 128], device=DEV)
+                for split in (32, piece - 32):
+                    d1 = _C.gemm_halves3_nt(xb, ws.buf, sc, ws.scale, piece, piece, piece, a2_off=a2, mode=OLD, scale_a2=s2, k_split=split)
+                    d2 = _C.gemm_halves3_nt(xb, frag, sc, ws.scale, piece, piece, piece, a2_off=a2, scale_a2=s2, k_split=split, b_frag=True, n=P)
+                    assert torch.equal(d1, d2), (m, K, P, order, split)
+        big = torch.zeros(m, P + 6, device=DEV)
+        o = big[:, 2:2 + P]
+        _C.gemm_halves3_nt(xb, frag, sc, ws.scale, piece, piece, piece, a2_off=a2, out=o, b_frag=True, n=P)
+        assert torch.equal(o, old) and bool((big[:, :2] == 0).all()) and bool((big[:, 2 + P:] == 0).all())
+    assert gemm.split_right(torch.randn(1536, 750, device=DEV)).order == 3 and gemm.split_right(torch.randn(40, 100, device=DEV)).order == 1
+
+
 def test_grouped_halves_kernels(golden):
     """v16, the aggregate-first layer's dense products (csrc/halves3.hip grouped forms, csrc/spmm.hip halves epilogue) each against the
     definition in include/bot_gnn.h evaluated in fp64 from the SAME fp16 operands (tests/_oracle_backend.py's restatement, accumulating in float64):

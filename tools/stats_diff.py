@@ -14,7 +14,7 @@ args = ap.parse_args()
 def load(p):
     out = {}
     for r in csv.DictReader(open(p)):
-        name = re.sub(r"\(.*", "", r["Name"]).replace("void ", "").replace("bot::", "").replace("(anonymous namespace)::", "")[-70:]
+        name = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("bot::", "")[-70:]
         out[name] = (int(r["Calls"]), float(r["TotalDurationNs"]) / 1e3)
     return out
 
