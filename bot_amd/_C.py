@@ -126,6 +126,7 @@ _SIGS = {
     "bot_halves_split_frag_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, c_int32, _P]),
     "bot_gemm_halves3_tn2_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P,
                                                 c_int64, _P, c_int32, _P]),
+    "bot_stream_create": (ctypes.c_int, [c_int32, _P]),
     "bot_absmax_slots": (c_int32, []),
     "bot_absmax_slots_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P]),
     "bot_halves_scale_from_slots_f32": (ctypes.c_int, [_P, _P, _P]),
@@ -869,6 +870,15 @@ def gemm_halves(a, b, alpha, *, trans_a=False, trans_b=False, out=None, batch=1,
         _lib.bot_gemm_halves_last_algo(ctypes.byref(idx), ctypes.byref(ms))
         GEMM_SEEN[key] = (idx.value, ms.value)
     return out
+
+
+def stream_create(device, high_priority=False):
+    """A torch.cuda.ExternalStream over a HIP stream of the library's own (include/bot_gnn.h bot_stream_create): NOT one of torch's pooled
+    streams."""
+    h = c_void_p()
+    with torch.cuda.device(device):
+        _check(_lib.bot_stream_create(int(bool(high_priority)), ctypes.byref(h)), "stream_create")
+    return torch.cuda.ExternalStream(h.value, device=device)
 
 
 def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0, b_frag=False, n=None):

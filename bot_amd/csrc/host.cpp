@@ -29,6 +29,22 @@ int bot_abi_version(void) { return BOT_ABI_VERSION; }
 const char* bot_last_error(void) { return bot::g_err; }
 const char* bot_last_kernel(void) { return bot::g_kernel; }
 
+// A HIP stream of the library's OWN (v17): bot_amd.side runs the weight-gradient products on it.  PyTorch hands out its streams from a pool
+// of 32 per device round-robin: a pooled "second stream" held for the process lifetime is sooner or later the SAME stream a later
+// torch.cuda.Stream() / the graph-capture stream / the process group's collective stream gets - a fork that waits on itself, or captured
+// work interleaved with a collective's.  Non-blocking (no implicit synchronisation with the legacy default stream).
+int bot_stream_create(int32_t high_priority, bot_stream_t* out) {
+    using namespace bot;
+    BOT_REQUIRE(out != nullptr, BOT_E_NULL, "stream_create: NULL pointer");
+    int lo = 0, hi = 0;
+    hipStream_t s = nullptr;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);       // lo: the numerically largest = lowest priority
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? hi : lo);
+    BOT_REQUIRE(e == hipSuccess, (int)e, "stream_create: %s", hipGetErrorString(e));
+    *out = (bot_stream_t)s;
+    return 0;
+}
+
 int32_t bot_row_plan_default_chunk(int64_t nnz) {
     // cdna_hip_programming.md Appendix B "Scatter / gather": split lists longer than a quarter of one
     // wavefront's share of the rows; 256 CUs x 16 waves in flight.

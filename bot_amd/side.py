@@ -46,7 +46,10 @@ def _stream(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     s = _STREAMS.get(idx)
     if s is None:
-        s = _STREAMS[idx] = torch.cuda.Stream(device=device, priority=PRIORITY)
+        from . import _C
+        # a stream of the library's own, not one of torch's 32 pooled streams (round-robin: a pooled stream held for the process lifetime
+        # sooner or later IS the stream a later torch.cuda.Stream() / graph capture / process group gets)
+        s = _STREAMS[idx] = _C.stream_create(torch.device("cuda", idx), high_priority=PRIORITY < 0)
     return s
 
 

@@ -46,6 +46,10 @@ typedef void* bot_stream_t; /* hipStream_t */
 
 int bot_abi_version(void);
 const char* bot_last_error(void);
+/* v17: a HIP stream of the library's own (hipStreamNonBlocking; high_priority != 0: the device's highest priority), never destroyed -
+ * the second stream of bot_amd.side (weight-gradient products beside the sparse backward).  Not one of PyTorch's 32 pooled streams, which
+ * are handed out round-robin and would sooner or later alias a capture stream or a process group's collective stream. */
+int bot_stream_create(int32_t high_priority, bot_stream_t* out);
 /* Name (as a profiler prints it) of the main device kernel the calling thread's most recent SpMM-family launch function
  * dispatched — the template instance depends on H, D and the operands' alignment.  Diagnostic only (bench.py names the
  * kernel of its roofline line from it); thread-local like bot_last_error. */

@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 16
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 17
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
