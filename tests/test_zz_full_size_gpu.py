@@ -1,6 +1,5 @@
-"""GPU parity at FULL size for BASELINE configs 3 and 5, and at half size for config 4 (full size with BOT_CONFIG4_TEST_SCALE=1: its fp32 +
-fp64 oracle steps take 300 s of host time at full size, VERDICT r3 #6b asked for < 180 s) — one whole train step each against the
-oracle's C kernels.  In a file that sorts LAST so that under `pytest -x` and the driver's
+"""GPU parity at FULL size for BASELINE configs 3, 4 and 5 (config 4's fp32 + fp64 oracle steps take 300 s of host time, side by side;
+BOT_CONFIG4_TEST_SCALE=0.5 halves the graph for quick runs) — one whole train step each against the oracle's C kernels.  In a file that sorts LAST so that under `pytest -x` and the driver's
 wall-clock limit everything else has been tested before the long legs start (VERDICT r3 #6b).  Config 2's full-size tests are short
 and stay in test_gpu_parity.py."""
 import pytest
@@ -10,6 +9,13 @@ from tests import parity_cases as PC
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# config 4 at full size: the number of parameter gradients that are NOT within 1e-4 of the fp64 step and pass only because the HIP run is at
+# most twice as far from it as the fp32 oracle is (round 5, measured: profiles/r05_config4_full.log)
+# Round 5 at full size: 53 of 64 within 1e-4; 10 over 1e-4 but CLOSER to the fp64 step than the fp32 oracle is (5x .. 300x closer: the
+# attention / edge-encoder gradients, sums over 600 in-edges of cancelling terms); 1 (edge_encoder.0.bias, 3.9e-4 vs the oracle's 3.0e-4)
+# farther than the oracle, inside the factor 2.
+CONFIG4_RANKED_MAX = 11
+CONFIG4_WORSE_THAN_ORACLE_MAX = 1
 
 
 def test_full_size_config3_reddit_gcn_against_c_oracle():
@@ -45,9 +51,8 @@ def test_full_size_config5_products_gat_against_c_oracle():
 
 
 def test_full_size_config4_proteins_gat_against_c_oracle():
-    """BASELINE config 4 — S-proteins at HALF its node count by default (66 267 nodes / 39 M edges, the same mean in-degree of 600 that
-    makes the stack badly conditioned; BOT_CONFIG4_TEST_SCALE=1 runs the full 132 534 nodes / 79 M edges, 300 s of oracle time — the
-    closing run of each round does, profiles/) with 8 edge features, GAT 6 layers x
+    """BASELINE config 4 — S-proteins at FULL size (132 534 nodes / 79 M edges, mean in-degree 600: the stack is badly conditioned;
+    BOT_CONFIG4_TEST_SCALE=0.5 runs half the node count at the same mean degree) with 8 edge features, GAT 6 layers x
     6 heads x 80 (src/ogbn-proteins/models.py, full-graph branch: node encoder, per-layer edge encoders, inter-layer residual)
     — one train step (drop rates 0, BCE-with-logits over 112 tasks, gat.py:203-207) on the HIP path against the oracle's C
     kernels, the oracle at the HIP run's gates.  Logits: within 1e-4 relative to their scale.  Gradients: this stack is badly
@@ -57,7 +62,7 @@ def test_full_size_config4_proteins_gat_against_c_oracle():
     one, or at most twice as far from it as the reference-order fp32 CPU run is."""
     import os
     from tests import full_size as FS
-    scale = float(os.environ.get("BOT_CONFIG4_TEST_SCALE", "0.5"))
+    scale = float(os.environ.get("BOT_CONFIG4_TEST_SCALE", "1"))
     r, cpu = FS.workload_parity("proteins", DEV, scale=scale)
     rank = r.pop("rank")
     print("parity S-proteins GAT at scale %g" % scale, r, "fp32 oracle step %.1f s" % cpu["seconds"])
@@ -67,6 +72,15 @@ def test_full_size_config4_proteins_gat_against_c_oracle():
     assert abs(r["n"] - 132534 * scale) <= 1 and r["edges"] > 70_000_000 * scale
     # logits up to 125: not "within 1e-4 absolute of the fp32 oracle" (3.1e-4) — ranked against the fp64 step instead (FS.CRITERIA)
     assert r["criterion"] == "fp64-ranked" and r["logit_err_vs_fp64"] <= max(PC.FWD_ATOL, 2 * r["oracle_logit_err_vs_fp64"]), r
-    for k, (eh, eo) in rank.items():
-        assert eh <= max(PC.GRAD_RTOL, 2 * eo), (k, eh, eo)
+    by_abs = [k for k, (eh, eo) in rank.items() if eh <= PC.GRAD_RTOL]
+    by_rank = {k: (eh, eo) for k, (eh, eo) in rank.items() if PC.GRAD_RTOL < eh <= 2 * eo}
+    failed = {k: (eh, eo) for k, (eh, eo) in rank.items() if eh > max(PC.GRAD_RTOL, 2 * eo)}
+    worse = {k: v for k, v in by_rank.items() if v[0] > v[1]}        # over 1e-4 AND farther from the fp64 step than the fp32 oracle
+    msg = (f"{len(by_abs)} of {len(rank)} gradients within {PC.GRAD_RTOL:g} of the fp64 step; {len(by_rank)} only through the 2x clause, of which "
+           f"{len(by_rank) - len(worse)} are closer to fp64 than the fp32 oracle and {len(worse)} farther {sorted(worse)}: "
+           f"{ {k: ('%.2e' % a, '%.2e' % b) for k, (a, b) in by_rank.items()} }; {len(failed)} fail {failed}")
+    print(msg)
+    assert not failed, msg
+    # how many gradients need the second clause is part of the bar: neither count may grow (measured at full size, see the constants)
+    assert scale != 1.0 or (len(by_rank) <= CONFIG4_RANKED_MAX and len(worse) <= CONFIG4_WORSE_THAN_ORACLE_MAX), msg
     assert r["ok"], r
