@@ -315,6 +315,17 @@ def main():
         torch.cuda.tunable.set_filename(os.path.join(ROOT, "gpurun_out", f"tunableop_new_rank{rank}.csv"))
 
     capture = args.capture == "on"
+    # a coarse HBM budget BEFORE anything is allocated (every rank, stderr): a run that cannot fit says so here, rc 4, instead of dying in
+    # the allocator on the first multi-GPU box it sees
+    budget = workloads.hbm_budget(args.workload, world if partitioned else 1, args.scale)
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    print(f"[bench] rank {rank}: HBM budget (estimate) {budget['total'] / 2**30:.1f} GiB = whole-graph build {budget['whole_graph_build'] / 2**30:.1f} "
+          f"+ step {budget['step'] / 2**30:.1f}; free {free_b / 2**30:.1f} of {total_b / 2**30:.1f} GiB", file=sys.stderr, flush=True)
+    if budget["total"] > free_b:
+        print(f"[bench] rank {rank}: --workload {args.workload} at scale {args.scale} on {world} rank(s) needs ~{budget['total'] / 2**30:.0f} GiB per "
+              f"rank, {free_b / 2**30:.0f} GiB are free: not starting (lower --scale or raise --gpus)", file=sys.stderr, flush=True)
+        sys.exit(4)
+    torch.cuda.reset_peak_memory_stats(dev)
     wl = workloads.build(args.workload, dev, rank=rank, world=world, partitioned=partitioned, seed=0, scale=args.scale,
                          norm_adj=args.norm_adj, partitioner=args.partitioner, capture=capture)
     barrier = torch.distributed.barrier if partitioned else (lambda: None)
@@ -326,12 +337,15 @@ def main():
     prof = _C.PROFILE
     barrier()
     torch.cuda.synchronize()
+    from bot_amd import halo
+    halo_bytes0 = dict(halo.BYTES)              # (host counters of the halo all-to-alls: config.partition reports what the timed steps moved)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    halo_moved = {k: (halo.BYTES[k] - halo_bytes0[k]) // max(1, args.steps) for k in halo.BYTES}
     _C.PROFILE, _C.PROFILE_SKIP = None, ()
     gprof, gsteps = [], 3
     if gemm.MODE == "halves" and not wl.captured:      # the dense projections' launches, HIP events on the launch stream, 3 more steps
@@ -474,21 +488,22 @@ def main():
         # ships the narrow inputs, bot_amd/nn/fused.py)
         p = wl.dataset.part
         mine = torch.tensor([rank, int(p.n_owned), int(p.n_edges), int(p.graph.halo.n_halo), int(p.graph.halo.n_send),
-                             int(sum(1 for c in p.graph.halo.recv_splits if c)), int((p.graph.edges()[0] >= p.n_owned).sum())],
+                             int(sum(1 for c in p.graph.halo.recv_splits if c)), int((p.graph.edges()[0] >= p.n_owned).sum()),
+                             int(halo_moved["sent"]), int(halo_moved["received"]), int(halo_moved["calls"])],
                             dtype=torch.int64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(allr, mine)          # plain tensors: the same collective path as the step itself
         if rank == 0:
-            keys = ("rank", "owned_rows", "edges", "halo_rows", "send_rows", "peers_recv", "cut_edges")
+            keys = ("rank", "owned_rows", "edges", "halo_rows", "send_rows", "peers_recv", "cut_edges", "halo_bytes_sent_per_step",
+                    "halo_bytes_received_per_step", "halo_all_to_alls_per_step")
             gathered = [dict(zip(keys, t.tolist())) for t in allr]
-            H, D, _ = wl.dominant_shape
-            widths = wl.halo_widths if getattr(wl, "halo_widths", None) else [H * D]
-            per_rank_bytes = [4 * 2 * sum(w * (g["halo_rows"] + g["send_rows"]) for w in widths) for g in gathered]
             assert len(gathered) == world and [g["rank"] for g in gathered] == list(range(world))
-            part_info = {"n_ranks": len(gathered), "rccl_version": rccl, "ranks": gathered, "exchange_row_widths_per_layer": widths,
-                         "exchange_bytes_per_rank_per_step": per_rank_bytes,
-                         "note": "forward all-to-all of halo source rows + reverse all-to-all of their gradients per layer (RCCL); "
-                                 "bytes = 4 * 2 directions * sum over layers of width * (rows received + rows sent)"}
+            part_info = {"n_ranks": len(gathered), "rccl_version": rccl, "ranks": gathered,
+                         "exchange_bytes_per_rank_per_step": [g["halo_bytes_sent_per_step"] + g["halo_bytes_received_per_step"] for g in gathered],
+                         "note": "MEASURED: bytes this rank handed to + received from the halo all-to-alls of one timed step (bot_amd.halo.a2a counts "
+                                 "every one: forward rows other ranks need, reverse their gradients; layer 0 of the GAT ships its narrow inputs forward "
+                                 "and only the attention columns back) - tests/test_dist_gloo.py holds the counter to the bytes the collective saw and "
+                                 "to rows x widths of the partition plan"}
     if rank == 0:
         out = {
             "metric": "edges/sec full-batch GAT fwd+bwd on ogbn-arxiv; achieved HBM GB/s vs peak",
@@ -511,6 +526,8 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"1-D vertex partition x{world} ({args.partitioner} ranges)",
                        "partition": part_info},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "stock_fp32_gemm": stock,
+            "hbm": {"estimate_GiB_per_rank": round(budget["total"] / 2**30, 2), "peak_allocated_GiB_rank0": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
+                    "what": "bot_amd.workloads.hbm_budget printed before allocation (rc 4 if it exceeds the free memory) / torch's peak over build + all legs"},
         }
     if partitioned:
         torch.distributed.destroy_process_group()

@@ -28,7 +28,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import _C
+from . import _C, halo
 from . import train as T
 from .graph import Graph
 
@@ -62,7 +62,7 @@ class _HaloExchange(torch.autograd.Function):
         ext = torch.empty((n_own + plan.n_halo, F), dtype=x2.dtype, device=x2.device)
         ext[:n_own] = x2
         send = _C.gather_rows(x2, plan.send_rows) if plan.n_send else x2.new_empty((0, F))
-        dist.all_to_all_single(ext[n_own:], send, plan.recv_splits, plan.send_splits, group=plan.group)
+        halo.a2a(ext[n_own:], send, plan.recv_splits, plan.send_splits, plan.group)
         ctx.plan, ctx.shape = plan, x_own.shape
         return ext.view((n_own + plan.n_halo,) + tuple(x_own.shape[1:]))
 
@@ -73,7 +73,7 @@ class _HaloExchange(torch.autograd.Function):
         g2 = g_ext.reshape(g_ext.shape[0], -1)
         g_own = g2[:n_own].clone()
         back = torch.empty((plan.n_send, g2.shape[1]), dtype=g2.dtype, device=g2.device)
-        dist.all_to_all_single(back, g2[n_own:].contiguous(), plan.send_splits, plan.recv_splits, group=plan.group)
+        halo.a2a(back, g2[n_own:].contiguous(), plan.send_splits, plan.recv_splits, plan.group)
         off = 0
         for cnt in plan.send_splits:  # peer by peer, rank order: fixed summation order
             if cnt:

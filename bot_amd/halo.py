@@ -28,6 +28,21 @@ def enabled(graph) -> bool:
     return OVERLAP and graph.halo is not None
 
 
+# Every halo all-to-all of the product goes through `a2a`, which counts the bytes this rank sends and receives (host arithmetic on the
+# split sizes: no device read).  bench.py reports the counter's per-step delta as config.partition.exchange_bytes_per_rank_per_step;
+# tests/test_dist_gloo.py holds it to the bytes the collective actually saw and to the partition plan's row counts x the layers' widths.
+BYTES = {"sent": 0, "received": 0, "calls": 0}
+
+
+def a2a(out, inp, out_splits, in_splits, group, async_op=False):
+    """dist.all_to_all_single(out, inp, out_splits, in_splits) on rows of equal width, counted."""
+    import torch.distributed as dist
+    BYTES["sent"] += inp.numel() * inp.element_size()
+    BYTES["received"] += out.numel() * out.element_size()
+    BYTES["calls"] += 1
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
+
+
 def ship_rows(plan, own2d, async_op=False):
     """The rows of own2d [n_own, W] (row stride allowed) that other ranks need -> (halo [n_halo, W], work handle or None, send buffer:
     keep it referenced until the work is waited on)."""
@@ -35,7 +50,7 @@ def ship_rows(plan, own2d, async_op=False):
     W = own2d.shape[1]
     send = _C.gather_rows(own2d, plan.send_rows) if plan.n_send else own2d.new_empty((0, W))
     halo = torch.empty((plan.n_halo, W), dtype=own2d.dtype, device=own2d.device)
-    work = dist.all_to_all_single(halo, send, plan.recv_splits, plan.send_splits, group=plan.group, async_op=async_op)
+    work = a2a(halo, send, plan.recv_splits, plan.send_splits, plan.group, async_op=async_op)
     return halo, (work if async_op else None), send
 
 
@@ -43,7 +58,7 @@ def return_rows(plan, dhalo, async_op=False):
     """Reverse direction: gradients of the halo rows [n_halo, W] go back to their owners -> (back [n_send, W], work or None)."""
     import torch.distributed as dist
     back = torch.empty((plan.n_send, dhalo.shape[1]), dtype=dhalo.dtype, device=dhalo.device)
-    work = dist.all_to_all_single(back, dhalo, plan.send_splits, plan.recv_splits, group=plan.group, async_op=async_op)
+    work = a2a(back, dhalo, plan.send_splits, plan.recv_splits, plan.group, async_op=async_op)
     return back, (work if async_op else None)
 
 

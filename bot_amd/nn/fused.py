@@ -151,7 +151,7 @@ def _extend_forward(graph, out, HD, H, c):
     if W > HD + H:
         ext[:n_own, HD + H:].zero_()
     send = _C.gather_rows(ext[:n_own], plan.send_rows) if plan.n_send else ext.new_empty((0, W))
-    dist.all_to_all_single(ext[n_own:], send, plan.recv_splits, plan.send_splits, group=plan.group)
+    halo.a2a(ext[n_own:], send, plan.recv_splits, plan.send_splits, plan.group)
     return ext
 
 
@@ -161,7 +161,7 @@ def _extend_backward(graph, dext, n_own):
     import torch.distributed as dist
     plan = graph.halo
     back = torch.empty((plan.n_send, dext.shape[1]), dtype=dext.dtype, device=dext.device)
-    dist.all_to_all_single(back, dext[n_own:], plan.send_splits, plan.recv_splits, group=plan.group)
+    halo.a2a(back, dext[n_own:], plan.send_splits, plan.recv_splits, plan.group)
     own = dext[:n_own]
     off = 0
     for cnt in plan.send_splits:
@@ -647,7 +647,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             if Wd > Fin + H:
                 ext[:N, Fin + H:].zero_()
             send = _C.gather_rows(ext[:N], plan.send_rows) if plan.n_send else ext.new_empty((0, Wd))
-            dist.all_to_all_single(ext[N:], send, plan.recv_splits, plan.send_splits, group=plan.group)
+            halo.a2a(ext[N:], send, plan.recv_splits, plan.send_splits, plan.group)
             xsrc = ext[:, :Fin]
             el = ext[:, Fin:Fin + H].contiguous()
         else:

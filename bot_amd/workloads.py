@@ -82,6 +82,37 @@ def _edge_dataset(name, device, seed, scale):
     return ds
 
 
+MODEL_DIMS = {       # name: (layers, heads, head width, edge-feature GAT)
+    "cora": (2, 1, 16, False), "arxiv": (3, 3, 250, False), "reddit": (3, 1, 256, False), "proteins": (6, 6, 80, True), "products": (3, 4, 120, True)}
+
+
+def hbm_budget(name: str, world: int = 1, scale: float = 1.0) -> dict:
+    """A COARSE per-rank estimate (bytes) of what `build` + one step allocate, printed by bench.py before anything is allocated so that a
+    first multi-GPU run that cannot fit says so instead of dying in the allocator.  Every rank builds the whole seeded
+    dataset on its own device and cuts its block out of it (`build`), so the build term does not shrink with the world size; the step
+    term does.  Calibrated on the measured single-GPU peaks (tools/hbm_peak.py, profiles/r05_hbm_peak.txt: 0.18 / 7.1 / 23.8 / 39.4 /
+    75.2 GiB for configs 1-5; the estimate lands within +25 % of each):
+      build  80 B per edge (COO pairs, CSC, CSR, permutations, plans) + node features (+ 32 B per edge of edge features, config 4)
+      step   GAT family: 9 B per edge, head and layer (attention weights, their dropped copy / signs) + 7.5 fp32 [rows, H D] tensors per
+             wide layer (projection output, gradient operand, pre-BatchNorm state, halves, temporaries); GCN: 150 B per edge (the
+             L2-blocked sweep's streams) + the same node term; x 1.15.  Rows = owned + halo, the halo bounded by all other ranks' rows."""
+    n, e_raw, f, c = synth.SHAPES[name]
+    n, e_raw = max(8, int(n * scale)), max(8, int(e_raw * scale))
+    E = 2 * e_raw + n                                            # symmetrised + self-loops (an upper bound: duplicates merge)
+    layers, H, D, edge = MODEL_DIMS[name]
+    gcn = name in ("cora", "reddit")
+    n_own = -(-n // world)
+    n_ext = n if world > 1 else n_own                            # a power-law graph's halo is most of the other ranks' rows
+    e_loc = -(-E // world)
+    build = E * 80 + n * max(f, 8) * 4 + (E * 32 if name == "proteins" else 0)
+    if world > 1:
+        build += e_loc * 80 + n_ext * max(f, 8) * 4              # the rank's block beside the whole graph it was cut from
+    edge_part = e_loc * 150 if gcn else layers * e_loc * H * 9
+    node_part = max(1, layers - 1) * n_ext * H * D * 4 * 7.5
+    step = int(1.15 * (edge_part + node_part))
+    return {"whole_graph_build": int(build), "step": step, "total": int(build) + step + (1 << 28)}      # + 0.25 GiB of fixed costs
+
+
 def build(name: str, device, *, rank=0, world=1, partitioned=False, seed=0, scale=1.0, norm_adj="rw", partitioner="contiguous",
           group=None, drop=True, capture=False) -> Workload:
     """Dataset + model + optimizer + step of one configuration.  Every rank builds the same (seeded) whole dataset on its own
@@ -181,16 +212,4 @@ def build(name: str, device, *, rank=0, world=1, partitioned=False, seed=0, scal
     wl = Workload(name, describe, n, E, ds.raw_edges, step, model, ("spmm", shape), shape, n_local, e_local, ds, g)
     wl.captured = captured
     wl.optimizer = opt
-    # row widths (floats) of the halo tables one step exchanges, per layer: the GAT's aggregate-first layer 0 ships [x | el], the
-    # other layers [ft | el] (bot_amd/nn/fused.py:_ext_width); the GCN ships the narrower side of every GraphConv
-    if name == "arxiv":
-        fin = ds.feat.shape[1] + C
-        wl.halo_widths = [fin + 4, 3 * 250 + 4, 40 + 4]
-    elif name in ("cora", "reddit"):
-        dims = [ds.feat.shape[1]] + [hid] * (layers - 1) + [C]
-        wl.halo_widths = [min(dims[i], dims[i + 1]) for i in range(layers)]
-    elif name == "proteins":
-        wl.halo_widths = [6 * 80 + 6] * 6
-    else:
-        wl.halo_widths = [4 * 120 + 4] * 3
     return wl

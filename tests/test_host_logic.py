@@ -513,3 +513,16 @@ def test_dout_direct_emulated(golden, cpu_backend, monkeypatch):
     from bot_amd.nn import fused
     monkeypatch.setattr(fused, "FORCE", True)
     PC.check_dout_direct_against_oracle(golden, "cpu")
+
+
+def test_hbm_budget_estimates():
+    """bot_amd.workloads.hbm_budget (what bench.py prints, and refuses on, before allocating): at or above the measured single-GPU peaks
+    of profiles/r05_hbm_peak.txt and within 1.5x of them, every config fits one 288 GB GPU, the step term shrinks with the world size."""
+    from bot_amd import workloads
+    measured = {"arxiv": 7.08, "reddit": 23.83, "proteins": 39.44, "products": 75.22}
+    for name, gib in measured.items():
+        est = workloads.hbm_budget(name, 1)["total"] / 2 ** 30
+        assert gib <= est <= 1.5 * gib, (name, gib, est)
+        assert est < 268
+        assert workloads.hbm_budget(name, 8)["step"] < workloads.hbm_budget(name, 1)["step"]
+    assert workloads.hbm_budget("products", 1, scale=4.0)["total"] / 2 ** 30 > 288        # what bench.py would refuse with rc 4
