@@ -51,7 +51,8 @@ def main():
     res = []
 
     def report(name, ms, alg_bytes, gather_bytes):
-        r = {"kernel": name, "ms": round(ms, 4), "alg_GBs": round(alg_bytes / ms / 1e6, 1),
+        r = {"kernel": name, "device_kernel": _C._lib.bot_last_kernel().decode(), "ms": round(ms, 4), "alg_bytes": int(alg_bytes),
+             "alg_bytes_per_edge": round(alg_bytes / E, 1), "alg_GBs": round(alg_bytes / ms / 1e6, 1),
              "gather_model_GBs": round(gather_bytes / ms / 1e6, 1), "frac_of_8TBs_alg": round(alg_bytes / ms / 1e6 / 8000, 4)}
         res.append(r)
         print(json.dumps(r), flush=True)
@@ -80,6 +81,24 @@ def main():
         if not only or "sddmm" in only:
             ms, _ = timeit(lambda: _C.sddmm_dot(g.csc, x, y), args.iters)
             report(f"sddmm_dot H={H} D={D}", ms, 4 * (2 * n * F + E + E * H), 4 * (E * F + n * F + E + E * H))
+    if not only or "bcast" in only:      # the aggregate-first input layer of config 2: 168-float source rows broadcast over 3 heads
+        H, Fin = 3, 168
+        x = torch.randn(n, Fin, device=dev)
+        a = torch.rand(E, H, device=dev)
+        dz = torch.randn(H, n, Fin, device=dev)
+        ms, _ = timeit(lambda: _C.spmm_bcast(g.csc, x, a, None, head_outer=True), args.iters)
+        report(f"spmm_bcast fwd H={H} Fin={Fin}", ms, 4 * (n * Fin + H * n * Fin + E + n + 1 + E * H), 4 * (E * Fin + H * n * Fin + E + E * H))
+        ms, _ = timeit(lambda: _C.sddmm_dot_bcast(g.csc, x, dz), args.iters)
+        report(f"sddmm_dot_bcast H={H} Fin={Fin}", ms, 4 * (n * Fin + H * n * Fin + E + n + 1 + E * H), 4 * (E * Fin + H * n * Fin + E + E * H))
+    if not only or "halves" in only:     # ABI 17: the fused backward sweep with its first result written as a halves operand
+        H, D = 3, 250
+        x, y = torch.randn(n, H, D, device=dev), torch.randn(n, H, D, device=dev)
+        a = torch.rand(E, H, device=dev)
+        piece = 1536
+        buf = torch.empty(n, 2 * piece, dtype=torch.float16, device=dev)
+        scale = _C.halves_scale(x.reshape(n, -1) * 64)
+        ms, _ = timeit(lambda: _C.spmm_dot_halves(g.csr, x, a, g.csr2csc, y, scale, buf, D, piece), args.iters)
+        report(f"spmm_dot_halves fused bwd (CSR) H={H} D={D}", ms, 4 * (3 * n * H * D + E + n + 1 + 2 * E * H), 4 * (E * H * D + 2 * n * H * D + E + n + 1 + 2 * E * H))
     if not only or "attn" in only:
         for H in (3, 1):
             el, er = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
