@@ -127,6 +127,9 @@ _SIGS = {
     "bot_gemm_halves3_tn2_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P,
                                                 c_int64, _P, c_int32, _P]),
     "bot_stream_create": (ctypes.c_int, [c_int32, _P]),
+    "bot_gemm_halves3_nt_grouped2_f32": (ctypes.c_int, [c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int32, _P,
+                                                        c_int32, _P, _P, c_int32, _P, _P, _P, _P, c_int32, c_int32, _P]),
+    "bot_bn_stats_halves_partials_f32": (ctypes.c_int, [_P, _P, c_int32, _P, c_int64, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "bot_absmax_slots": (c_int32, []),
     "bot_absmax_slots_f32": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P]),
     "bot_halves_scale_from_slots_f32": (ctypes.c_int, [_P, _P, _P]),
@@ -917,7 +920,8 @@ def _table(rows, width):
     return (ctypes.c_int64 * len(flat))(*flat)
 
 
-def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups, k_seg, mode=0, col_scale=None, col_shift=None, relu=False, absmax=None):
+def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups, k_seg, mode=0, col_scale=None, col_shift=None, relu=False, absmax=None,
+                            stats=None):
     """The grouped NT product (bot_gemm_halves3_nt_grouped_f32): for every group (b_row0, n_valid, a_col0, a_col1, k_steps, c_off)
         out.flat[r * ld + c_off + j] = scale_a[1] scale_b[1] * sum_{t < k_steps} sum_{i < 32} A3[r, (a_col0 if t < k_seg else a_col1) + 32 t + i] . B3[b_row0 + j, 32 t + i]
     for j < n_valid <= 256, over the rows of the left operand buffer a ([h1 at column c, 2^11 h2 at column c + a2_off]) and the right
@@ -929,10 +933,21 @@ def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups,
     assert out.dtype == torch.float32 and out.stride(-1) == 1
     tab = _table(groups, 6)
     # (profile key: m, n, k, batch with 2 m n k batch = the fp16 MFMA flops of the valid output columns, three products each)
-    _check(_timed("gemm_halves", (a.shape[0], sum(int(g[1]) * 96 * int(g[4]) for g in groups), 1, 1), lambda: _lib.bot_gemm_halves3_nt_grouped_f32(
+    # stats = (part [tiles, 2, F], minmax [tiles, 2, F], pivot [F]): column statistics of the stored values as a by-product (tiles = ceil(m / 256)
+    # row blocks, F = the width the groups' output columns c_off + j index: bot_gemm_halves3_nt_grouped2_f32; finished by bn_stats_halves_partials)
+    sp = sm = sv = None
+    sF = 0
+    if stats is not None:
+        sp, sm, sv = stats
+        _dev(sp, sm, sv)
+        sF = sv.shape[0]
+        tiles = (a.shape[0] + 255) // 256
+        assert sp.shape == (tiles, 2, sF) and sm.shape == (tiles, 2, sF) and sp.is_contiguous() and sm.is_contiguous() and sv.is_contiguous()
+        assert sp.dtype == sm.dtype == sv.dtype == torch.float32
+    _check(_timed("gemm_halves", (a.shape[0], sum(int(g[1]) * 96 * int(g[4]) for g in groups), 1, 1), lambda: _lib.bot_gemm_halves3_nt_grouped2_f32(
         a.shape[0], b.shape[0], scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), a2_off, b.data_ptr(), _ld(b), b2_off, out.data_ptr(),
-        int(out.stride(-2)), len(groups), tab, int(k_seg), _ptr(col_scale), _ptr(col_shift), int(bool(relu)), _ptr(absmax), int(mode), _stream())),
-        "gemm_halves3_nt_grouped")
+        int(out.stride(-2)), len(groups), tab, int(k_seg), _ptr(col_scale), _ptr(col_shift), int(bool(relu)), _ptr(absmax), _ptr(sp), _ptr(sm), _ptr(sv),
+        int(sF), int(mode), _stream())), "gemm_halves3_nt_grouped")
     return out
 
 
@@ -1153,6 +1168,22 @@ def bn_stats_halves(x, eps, momentum, running_mean, running_var, num_batches_tra
     _check(_lib.bot_bn_stats_halves_f32(x.data_ptr(), x.stride(0), n, F, float(eps), float(momentum), mean.data_ptr(), invstd.data_ptr(),
                                         _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(weight), _ptr(bias),
                                         float(p), hscale.data_ptr(), _bn_ws(F, x.device).data_ptr(), _stream()), "bn_stats_halves")
+    _written(running_mean, running_var, num_batches_tracked)
+    return mean, invstd, hscale
+
+
+def bn_stats_halves_partials(part, minmax, pivot, n, eps, momentum, running_mean, running_var, num_batches_tracked, weight, bias, p):
+    """bn_stats_halves from column partials a producer of x delivered (gemm_halves3_nt_grouped `stats`) instead of a pass over x
+    (include/bot_gnn.h bot_bn_stats_halves_partials_f32): -> (mean, invstd, hscale)."""
+    _dev(part, minmax, pivot, running_mean, running_var, weight, bias)
+    nblk, _, F = part.shape
+    mean = torch.empty(F, dtype=torch.float32, device=part.device)
+    invstd = torch.empty(F, dtype=torch.float32, device=part.device)
+    hscale = torch.empty(2, dtype=torch.float32, device=part.device)
+    ws = torch.empty(F, dtype=torch.float32, device=part.device)
+    _check(_lib.bot_bn_stats_halves_partials_f32(part.data_ptr(), minmax.data_ptr(), int(nblk), pivot.data_ptr(), int(n), int(F), float(eps), float(momentum),
+                                                 mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked),
+                                                 _ptr(weight), _ptr(bias), float(p), hscale.data_ptr(), ws.data_ptr(), _stream()), "bn_stats_halves_partials")
     _written(running_mean, running_var, num_batches_tracked)
     return mean, invstd, hscale
 

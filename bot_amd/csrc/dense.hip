@@ -712,6 +712,27 @@ int bot_bn_stats_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, f
     return hip_status("bn_stats_halves launch");
 }
 
+// v17: bot_bn_stats_halves_f32 from column partials a PRODUCER of x delivered with it (the grouped NT GEMM's epilogue:
+// bot_gemm_halves3_nt_grouped2_f32 `stats_*`) instead of a pass over x:  part [nblk][2][F] = per row block the sums of (x - pivot) and
+// (x - pivot)^2, minmax [nblk][2][F] the column extremes, pivot [F] the shift the producer used (any value near the column mean; the
+// running mean serves - it is read here before this call updates it).  Same second stage as the pass form (partials added in block order).
+int bot_bn_stats_halves_partials_f32(const float* part, const float* minmax, int32_t nblk, const float* pivot, int64_t n, int32_t F, float eps, float momentum,
+                                     float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                     const float* weight, const float* bias, float p, float* hscale, float* bound_workspace, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(n >= 1 && F >= 1 && nblk >= 1, BOT_E_RANGE, "bn_stats_halves_partials: n=%lld F=%d nblk=%d", (long long)n, F, nblk);
+    BOT_REQUIRE(part && minmax && pivot && mean && invstd && hscale && bound_workspace, BOT_E_NULL, "bn_stats_halves_partials: NULL pointer");
+    BOT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), BOT_E_NULL, "bn_stats_halves_partials: running_mean and running_var go together");
+    BOT_REQUIRE(eps >= 0.f && momentum >= 0.f && momentum <= 1.f && p >= 0.f && p < 1.f, BOT_E_RANGE, "bn_stats_halves_partials: eps=%f momentum=%f p=%f",
+                (double)eps, (double)momentum, (double)p);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, pivot, n, F, part, (int)nblk, mean, (float*)nullptr, invstd, eps,
+                       momentum, running_mean, running_var, num_batches_tracked);
+    hipLaunchKernelGGL(bn_bound_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, F, minmax, (int)nblk, mean, invstd, weight, bias, p, bound_workspace);
+    launch_halves_scale(bound_workspace, F, hscale, st);
+    return hip_status("bn_stats_halves_partials launch");
+}
+
 static int bn_act_fwd_impl(const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,
                            const float* weight, const float* bias, int32_t relu, float p, uint64_t seed,
                            const uint64_t* seed_offset, float* y, int64_t ldy, const float* hscale, uint16_t* hout, int64_t ldh,

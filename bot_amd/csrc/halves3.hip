@@ -57,6 +57,13 @@ struct H3Args {
     // the accumulators are multiplied by scale_a2[0] / scale_a[0] (a power of two: exact) in front of k-step k2, alpha = scale_a2[1] scale_b[1]
     const float* scale_a2;
     int k2;                 // -1: one scale
+    // optional (grouped nt64 launches): column statistics of the stored values as a by-product - per 256-row tile t and output column c
+    // stats_part[(2 t + 0) F + c] = sum of (v - pivot[c]), [(2 t + 1) F + c] = sum of squares, stats_minmax likewise min / max (the
+    // partials of dense.hip colstats_partial_kernel, one row block per tile: bot_bn_stats_halves_partials_f32 finishes them)
+    float* stats_part;
+    float* stats_minmax;
+    const float* stats_pivot;
+    int stats_F;
     int b_frag;             // B is a fragment-major RIGHT operand (halves.hip order 3; gemm_halves3_nt64_kernel only): rows of 16-row tiles = N rounded up
     int mode;               // 0 = the product.  Measurement switches (tools/exp_halves3.py): bit 0 no output stores; bit 2 / 3 B / A never
                             // advance along k; bit 5 the plain loop (barrier at the end of a k-step) and, in it, bit 6 no barrier / wait,
@@ -587,6 +594,16 @@ __device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3
             }
     }
     float amax = 0.f;
+    // column statistics of what is stored (the wave owns ALL rows of its 32 columns: no cross-wave step)
+    const bool stats = p.stats_part != nullptr;
+    float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f}, st_mn[4], st_mx[4], piv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) st_mn[e] = INFINITY, st_mx[e] = -INFINITY;
+    if (stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < n_valid) piv[e] = p.stats_pivot[c0 + col + e];
+    }
 #pragma unroll
     for (int pass = 0; pass < MT / 2; ++pass) {
 #pragma unroll
@@ -606,6 +623,15 @@ __device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3
                 for (int e = 0; e < 4; ++e) {
                     v[e] = fmaf(v[e], cs[e], ch[e]);
                     if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+            }
+            if (stats && row < p.M) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[e] - piv[e];
+                    st_s[e] += d;
+                    st_q[e] = fmaf(d, d, st_q[e]);
+                    st_mn[e] = fminf(st_mn[e], v[e]), st_mx[e] = fmaxf(st_mx[e], v[e]);
                 }
             }
             if (p.absmax && row < p.M) {
@@ -629,6 +655,26 @@ __device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3
         }
     }
     if (p.absmax) absmax_publish(wave_absmax(amax), p.absmax);
+    if (stats) {        // fold the 8 row groups of the wave (lanes l, l + 8, ..., l + 56 hold the same four columns): fixed order, deterministic
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                st_s[e] += __shfl_xor(st_s[e], o);
+                st_q[e] += __shfl_xor(st_q[e], o);
+                st_mn[e] = fminf(st_mn[e], __shfl_xor(st_mn[e], o));
+                st_mx[e] = fmaxf(st_mx[e], __shfl_xor(st_mx[e], o));
+            }
+        }
+        if (lane < 8) {
+            const int64_t F = p.stats_F;
+            float* ps = p.stats_part + ((int64_t)tm * 2) * F + c0 + col;
+            float* pm = p.stats_minmax + ((int64_t)tm * 2) * F + c0 + col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < n_valid) ps[e] = st_s[e], ps[F + e] = st_q[e], pm[e] = st_mn[e], pm[F + e] = st_mx[e];
+        }
+    }
 }
 
 __global__ __launch_bounds__(512) void gemm_halves3_nt64_kernel(H3Args p) { gemm_halves3_nt64_body<false, false>(p, nullptr); }
@@ -1036,6 +1082,7 @@ extern "C" int bot_gemm_halves3_nt2_f32(int64_t m, int64_t n, int64_t k, const f
     p.col_scale = p.col_shift = nullptr, p.relu = 0, p.absmax = nullptr;
     p.scale_a2 = scale_a2, p.k2 = scale_a2 ? (int)(k_split / BK) : -1;
     p.b_frag = b_layout;
+    p.stats_part = p.stats_minmax = nullptr, p.stats_pivot = nullptr, p.stats_F = 0;
     p.mode = mode;
     const bool force_128x64 = (mode & 1024) != 0;            // (tools: both forms in one process)
     mode &= ~1024;
@@ -1064,7 +1111,18 @@ extern "C" int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const 
                                                int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t n_groups,
                                                const int64_t* groups, int32_t k_seg, const float* col_scale, const float* col_shift, int32_t relu,
                                                uint32_t* absmax_slots, int32_t mode, bot_stream_t stream) {
+    return bot_gemm_halves3_nt_grouped2_f32(m, b_rows, scale_a, scale_b, A, lda, a2_off, B, ldb, b2_off, C, ldc, n_groups, groups, k_seg, col_scale, col_shift,
+                                            relu, absmax_slots, nullptr, nullptr, nullptr, 0, mode, stream);
+}
+
+extern "C" int bot_gemm_halves3_nt_grouped2_f32(int64_t m, int64_t b_rows, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
+                                                int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t n_groups,
+                                                const int64_t* groups, int32_t k_seg, const float* col_scale, const float* col_shift, int32_t relu,
+                                                uint32_t* absmax_slots, float* stats_part, float* stats_minmax, const float* stats_pivot, int32_t stats_F,
+                                                int32_t mode, bot_stream_t stream) {
     using namespace bot;
+    BOT_REQUIRE((stats_part == nullptr) == (stats_minmax == nullptr) && (stats_part == nullptr) == (stats_pivot == nullptr) && (stats_part == nullptr || stats_F >= 1), -1,
+                "gemm_halves3_nt_grouped2: stats_part, stats_minmax and stats_pivot go together (stats_F = their row width)");
     BOT_REQUIRE(m > 0 && b_rows > 0 && n_groups >= 1 && n_groups <= kMaxGroups && k_seg >= 0, -1, "gemm_halves3_nt_grouped: m, b_rows > 0, 1 .. %d groups (got %lld %lld %d)",
                 kMaxGroups, (long long)m, (long long)b_rows, n_groups);
     BOT_REQUIRE(scale_a && scale_b && A && B && C && groups, -1, "gemm_halves3_nt_grouped: null pointer");
@@ -1076,6 +1134,7 @@ extern "C" int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const 
     p.lda = lda, p.ldb = ldb, p.ldc = ldc, p.M = (int)m, p.N = (int)b_rows, p.K = 0, p.a2_off = (int)a2_off, p.b2_off = (int)b2_off;
     p.mode = 0;             // (the grouped kernel is a production instantiation: no measurement switch inside)
     p.scale_a2 = nullptr, p.k2 = -1, p.b_frag = 0;
+    p.stats_part = stats_part, p.stats_minmax = stats_minmax, p.stats_pivot = stats_pivot, p.stats_F = stats_F;
     p.col_scale = col_scale, p.col_shift = col_shift, p.relu = relu, p.absmax = absmax_slots;
     H3Groups g;
     g.k_seg = k_seg;
@@ -1093,6 +1152,8 @@ extern "C" int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const 
     p.tiles_m = (int)((m + 255) / 256), p.tiles_n = n_groups;
     bool even = k_seg % 2 == 0;
     for (int i = 0; i < n_groups; ++i) even = even && g.g[i].k_steps % 2 == 0;
+    BOT_REQUIRE(stats_part == nullptr || (!(mode & 1024) && even && nt64_wanted()), -1,
+                "gemm_halves3_nt_grouped2: the statistics by-product exists in the 256 x 32 form only (even k-step counts, BOT_NT_KERNEL != 128x64)");
     if (!(mode & 1024) && even && nt64_wanted()) {
         set_kernel("bot::gemm_halves3_nt64_grouped_kernel");
         hipLaunchKernelGGL(gemm_halves3_nt64_grouped_kernel, dim3(((p.tiles_m + 7) / 8) * 8 * n_groups), dim3(512), 0, (hipStream_t)stream, p, g);

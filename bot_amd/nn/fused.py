@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from .. import _C, gemm, halo, side
 from ..graph import take_rows
-from ..ops import bn_batch_stats, new_dropout_seed
+from ..ops import bn_batch_stats, new_dropout_seed, stats_partials_for
 
 
 ABSMAX_BYPRODUCT = os.environ.get("BOT_ABSMAX_BYPRODUCT", "1") != "0"   # max|gradient| from its producers instead of a pass (_GATHidden.backward)
@@ -181,7 +181,7 @@ OVERLAP_CALLS = 0   # layer forwards that took the overlapped form (tests assert
 _ship_rows, _return_rows, _fold_back = halo.ship_rows, halo.return_rows, halo.fold_back
 
 
-def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed=True):
+def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed=True, partials=None):
     """BatchNorm statistics + the fused BatchNorm / ReLU / dropout pass.  When the next projection runs on fp16 halves
     (bot_amd.gemm) the pass writes them too and the scale comes from the statistics pass: y is not read again before its GEMM.
     y_needed=False (the caller KNOWS the one consumer of y is such a projection, `halves_only_consumer`): the fp32 y is not stored at
@@ -192,7 +192,8 @@ def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed=True):
     piece = gemm.epilogue_piece(HD, x) if bn_training else None
     seed = new_dropout_seed(drop_p)
     if piece is not None:
-        mean, invstd, total, sync, group, hscale = bn_batch_stats(x, bn, bn_training, halves_p=drop_p)
+        # `partials`: the kernel that wrote x delivered BatchNorm's column partials with it (no statistics pass over x)
+        mean, invstd, total, sync, group, hscale = bn_batch_stats(x, bn, bn_training, halves_p=drop_p, partials=partials)
         if hscale is not None:
             order = gemm.left_order(piece)
             y, buf = _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed, halves=(hscale, piece, 2 if order == 2 else 3), want_y=y_needed)
@@ -683,15 +684,20 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             B = torch.empty((HD, 6 * FP), dtype=torch.float16, device=h.device)
             _C.halves_split_cols(Wres, wscale, 1, B, 2 * FP, 0, FP)
             _C.halves_split_cols(W, wscale, 1, B, 2 * FP, FP, FP)
-            _C.gemm_halves3_nt_grouped(A, B, xscale, wscale, KA, 2 * FP, out2, g_fwd, FP // 32)
             x = out2[:, :HD]
+            # BatchNorm's batch statistics as a by-product of the launch that writes x (per 256-row tile and column: sum, sum of squares,
+            # extremes): the statistics pass over the [N, H D] output is gone (ops.stats_partials_for says when the epilogue takes them)
+            partials = None
+            if bn is not None and h.is_cuda | FORCE:
+                partials = stats_partials_for(bn, bn_training, N, HD, h.device, gemm.epilogue_piece(HD, x) is not None)
+            _C.gemm_halves3_nt_grouped(A, B, xscale, wscale, KA, 2 * FP, out2, g_fwd, FP // 32, stats=partials)
             ctx.graph = graph
             keep = (h, W, Wr, A, ext if ext is not None else h, el, er, a, a_d, xscale)
             if bn is None:
                 ctx.save_for_backward(*keep)
                 ctx.cfg = (H, D, has_res, has_er, slope, None)
                 return x
-            y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed)
+            y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed, partials=partials)
             ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
             ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
             return y

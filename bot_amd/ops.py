@@ -16,6 +16,8 @@ Backward formulas (hand-derived; checked against autograd of the oracle's forwar
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _C
@@ -282,7 +284,7 @@ def _dist_group(bn):
     return False, None
 
 
-def bn_batch_stats(x, bn, bn_training, halves_p=None):
+def bn_batch_stats(x, bn, bn_training, halves_p=None, partials=None):
     """Column statistics for the fused epilogue: (mean, invstd, total_count, sync, group); updates bn's running statistics
     exactly like nn.BatchNorm1d (momentum, unbiased running variance).  In partitioned mode the (count, mean, M2) triples of
     the ranks are merged with Chan et al.'s pairwise formula through two small all-reduces.
@@ -302,6 +304,11 @@ def bn_batch_stats(x, bn, bn_training, halves_p=None):
         args = (x, bn.eps, bn.momentum if track else 0.0, bn.running_mean if track else None, bn.running_var if track else None,
                 bn.num_batches_tracked if track else None)
         with torch.no_grad():
+            if halves_p is not None and partials is not None:
+                # the producer of x delivered the column partials with it (`stats_partials_for`): no pass over x
+                part, minmax, pivot = partials
+                mean, invstd, hscale = _C.bn_stats_halves_partials(part, minmax, pivot, n, *args[1:], bn.weight, bn.bias, halves_p)
+                return mean, invstd, total, sync, group, hscale
             if halves_p is not None:
                 mean, invstd, hscale = _C.bn_stats_halves(*args, bn.weight, bn.bias, halves_p)
                 return mean, invstd, total, sync, group, hscale
@@ -333,6 +340,27 @@ def bn_batch_stats(x, bn, bn_training, halves_p=None):
             bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
             bn.running_var.mul_(1 - mom).add_(m2 / max(total - 1.0, 1.0), alpha=mom)
     return (mean, invstd, total, sync, group) + extra
+
+
+STATS_BYPRODUCT = os.environ.get("BOT_STATS_BYPRODUCT", "1") != "0"
+_ZERO_PIVOT = {}
+
+
+def stats_partials_for(bn, bn_training, n_rows, F, device, halves_ok):
+    """Buffers for a producer that can deliver BatchNorm's column partials as a by-product (the grouped NT GEMM's epilogue), or None when
+    `bn_batch_stats` would not take them (eval mode, partitioned statistics, no halves epilogue): (part, minmax, pivot).  The pivot (the
+    shift of the sums, which must exist before the producer runs) is ZERO: a state-independent choice - the running mean would make the
+    batch statistics depend, at rounding level, on the module's history.  Sums of 256 rows in fp32, tiles added in double: against the
+    pass form's first-row pivot the variance loses (mean / std)^2 ulps, far inside the parity bounds for pre-BatchNorm activations."""
+    sync, _ = _dist_group(bn)
+    if not (STATS_BYPRODUCT and bn_training and halves_ok and not sync and (bn.momentum is not None or not bn.track_running_stats)):
+        return None
+    tiles = (n_rows + 255) // 256
+    key = (str(device), F)
+    if key not in _ZERO_PIVOT:
+        _ZERO_PIVOT[key] = torch.zeros(F, dtype=torch.float32, device=device)
+    pivot = _ZERO_PIVOT[key]
+    return (torch.empty((tiles, 2, F), dtype=torch.float32, device=device), torch.empty((tiles, 2, F), dtype=torch.float32, device=device), pivot)
 
 
 def random_edge_keep(graph, drop):

@@ -442,7 +442,8 @@ def _three(a1, a2s, b1, b2s, right, acc=torch.float32):
     return f(a1).t() @ f(b1) + f(a1 * sh).t() @ f(b2s) + f(a2s).t() @ f(b1 * sh)
 
 
-def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups, k_seg, mode=0, col_scale=None, col_shift=None, relu=False, absmax=None):
+def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups, k_seg, mode=0, col_scale=None, col_shift=None, relu=False, absmax=None,
+                            stats=None):
     """include/bot_gnn.h bot_gemm_halves3_nt_grouped_f32 (accumulated in out's dtype)"""
     acc = out.dtype
     flat = out.as_strided((out.untyped_storage().nbytes() // out.element_size() - out.storage_offset(),), (1,))
@@ -467,6 +468,13 @@ def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups,
             res = torch.relu(res)
         _fold_absmax(absmax, res)
         flat.as_strided((m, n_valid), (ld, 1), c_off).copy_(res)
+        if stats is not None:           # per 256-row tile: sums of (v - pivot), (v - pivot)^2, column extremes (bot_gemm_halves3_nt_grouped2_f32)
+            part, minmax, pivot = stats
+            for t in range((m + 255) // 256):
+                v = res[256 * t:256 * (t + 1)].float()
+                dlt = v - pivot[c_off:c_off + n_valid]
+                part[t, 0, c_off:c_off + n_valid], part[t, 1, c_off:c_off + n_valid] = dlt.sum(0), (dlt * dlt).sum(0)
+                minmax[t, 0, c_off:c_off + n_valid], minmax[t, 1, c_off:c_off + n_valid] = v.min(0).values, v.max(0).values
     return out
 
 
@@ -564,6 +572,23 @@ def bn_stats_halves(x, eps, momentum, running_mean, running_var, num_batches_tra
     return mean, invstd, _pow2_scale(float(bound.max()))
 
 
+def bn_stats_halves_partials(part, minmax, pivot, n, eps, momentum, running_mean, running_var, num_batches_tracked, weight, bias, p):
+    """include/bot_gnn.h bot_bn_stats_halves_partials_f32"""
+    S, Q = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    mean = (pivot.double() + S / n).float()
+    m2 = (Q - S * S / n).clamp(min=0).float()
+    invstd = torch.rsqrt(m2 / n + eps)
+    if running_mean is not None:
+        running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+        running_var.mul_(1 - momentum).add_(m2 / max(n - 1, 1), alpha=momentum)
+    if num_batches_tracked is not None:
+        num_batches_tracked += 1
+    mn, mx = minmax[:, 0].min(0).values, minmax[:, 1].max(0).values
+    dev = torch.maximum((mx - mean).abs(), (mn - mean).abs()) * invstd
+    bound = ((weight.abs() if weight is not None else 1.0) * dev + (bias.abs() if bias is not None else 0.0)) / (1.0 - p)
+    return mean, invstd, _pow2_scale(float(bound.max()))
+
+
 def bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed, want_max=False):
     xh, o = _bn_gate(x, mean, invstd, weight, bias, relu, p)
     g = torch.where(o > 0, dy, torch.zeros_like(dy)) if relu else dy
@@ -629,7 +654,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["halves_split_frag", "halves_tail", "spmm_dot_halves", "spmm_dot_halves_fits", "gemm_halves3_tn", "bn_bwd_bound", "bn_act_bwd_apply_halves", "halves_split_heads", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["bn_stats_halves_partials", "halves_split_frag", "halves_tail", "spmm_dot_halves", "spmm_dot_halves_fits", "gemm_halves3_tn", "bn_bwd_bound", "bn_act_bwd_apply_halves", "halves_split_heads", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

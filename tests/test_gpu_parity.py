@@ -1663,6 +1663,56 @@ def test_gemm_halves3_nt_kernel():
         _C.gemm_halves3_nt(xs.buf, ws.buf, xs.scale, ws.scale, xs.piece, ws.piece, 40)       # k not a multiple of 32
 
 
+def test_stats_byproduct_of_grouped_nt():
+    """ABI 17: BatchNorm's column partials as a by-product of the grouped NT launch that writes the layer output
+    (bot_gemm_halves3_nt_grouped2_f32 `stats_*`) + bot_bn_stats_halves_partials_f32, against the pass form on the same output
+    (bot_bn_stats_halves_f32): the output itself bit for bit the launch without statistics, partial sums / extremes against torch on it,
+    mean / invstd / running statistics / the halves scale against the pass form; a pivot far from zero too."""
+    from bot_amd.nn import fused
+    gen = torch.Generator(device=DEV).manual_seed(37)
+    for (N, H, D, Fin) in ((20011, 3, 250, 168), (700, 2, 70, 40)):
+        P2 = (H * D + 2 * H + 127) // 128 * 128
+        FP, DP, g_fwd, _, _ = fused._l0_tables(H, D, Fin, P2, True, N)
+        HD, KA = H * D, (1 + H) * FP
+        A = (torch.randn(N, 2 * KA, device=DEV, generator=gen) * 50).half()
+        A[:, KA:] *= 0.01
+        B = (torch.randn(HD, 6 * FP, device=DEV, generator=gen) * 30 + 3).half()
+        sa, sb = torch.tensor([4.0, 0.25], device=DEV), torch.tensor([8.0, 0.125], device=DEV)
+        ref = torch.zeros(N, P2, device=DEV)
+        _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, ref, g_fwd, FP // 32)
+        tiles = (N + 255) // 256
+        for pv in (0.0, 1e4):
+            part, minmax = torch.full((tiles, 2, HD), 7.0, device=DEV), torch.full((tiles, 2, HD), 7.0, device=DEV)
+            pivot = torch.full((HD,), pv, device=DEV)
+            out = torch.zeros(N, P2, device=DEV)
+            _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, out, g_fwd, FP // 32, stats=(part, minmax, pivot))
+            assert torch.equal(out, ref)
+            x = out[:, :HD]
+            pad = torch.cat([x, x.new_full((tiles * 256 - N, HD), float("nan"))]).view(tiles, 256, HD)
+            d64 = (pad.double() - pv)
+            s_ref, q_ref = torch.nansum(d64, 1), torch.nansum(d64 * d64, 1)
+            big = q_ref.sqrt().max() * 16                      # a tile's sum of 256 terms: errors relative to the tile's 2-norm
+            assert float((part[:, 0].double() - s_ref).abs().max() / big) < 1e-6
+            assert float(((part[:, 1].double() - q_ref).abs() / q_ref.abs().clamp(min=1e-30)).max()) < 1e-5
+            mn = torch.where(torch.isnan(pad), torch.full_like(pad, float("inf")), pad).min(1).values
+            mx = torch.where(torch.isnan(pad), torch.full_like(pad, float("-inf")), pad).max(1).values
+            assert torch.equal(minmax[:, 0], mn) and torch.equal(minmax[:, 1], mx)
+        # finished statistics against the pass form (zero pivot: the product's choice)
+        part, minmax, pivot = torch.empty((tiles, 2, HD), device=DEV), torch.empty((tiles, 2, HD), device=DEV), torch.zeros(HD, device=DEV)
+        out = torch.zeros(N, P2, device=DEV)
+        _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, out, g_fwd, FP // 32, stats=(part, minmax, pivot))
+        x = out[:, :HD]
+        w, b = torch.randn(HD, device=DEV, generator=gen), torch.randn(HD, device=DEV, generator=gen)
+        rm1, rv1, nb1 = torch.zeros(HD, device=DEV), torch.ones(HD, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        rm2, rv2, nb2 = rm1.clone(), rv1.clone(), nb1.clone()
+        m1, i1, h1 = _C.bn_stats_halves(x, 1e-5, 0.1, rm1, rv1, nb1, w, b, 0.25)
+        m2, i2, h2 = _C.bn_stats_halves_partials(part, minmax, pivot, N, 1e-5, 0.1, rm2, rv2, nb2, w, b, 0.25)
+        sd = (1.0 / i1).max()
+        assert float((m1 - m2).abs().max() / sd) < 2e-6 and float(((i1 - i2) / i1).abs().max()) < 2e-5, (float((m1 - m2).abs().max()), float(((i1 - i2) / i1).abs().max()))
+        assert float((rm1 - rm2).abs().max() / sd) < 2e-6 and float(((rv1 - rv2) / rv1).abs().max()) < 2e-5 and int(nb2) == 1
+        assert torch.equal(h1, h2)
+
+
 def test_nt64_kernel_and_fragment_major_operand():
     """Round 5: the 128-byte-line form of the NT halves GEMM (csrc/halves3.hip gemm_halves3_nt64_kernel: two k-steps per iteration, wave tile
     256 x 32, the wave's weight fragments straight into registers) is bit for bit the 128 x 64-wave-tile kernel (mode bit 1024 forces that one)
