@@ -38,8 +38,10 @@ _CB = [-1]          # id of the backward pass (graph task) an engine callback is
 
 
 def usable(t) -> bool:
-    """Fork only inside a backward pass run by the autograd engine (the join rides on its completion callback)."""
-    return ENABLED and t.is_cuda and torch._C._current_graph_task_id() != -1
+    """Fork only inside a backward pass run by the autograd engine (the join rides on its completion callback) - and not while the
+    stream is being captured into a hipGraph: a replayed multi-branch graph ran 3.7 ms SLOWER per config-2 step than the one-branch graph
+    (14.4 vs 10.7 ms, profiles/r05_prefetch_and_capture.txt), which already has what the fork buys in eager mode."""
+    return ENABLED and t.is_cuda and torch._C._current_graph_task_id() != -1 and not torch.cuda.is_current_stream_capturing()
 
 
 def _stream(device):
