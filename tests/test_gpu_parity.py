@@ -1752,6 +1752,47 @@ def test_nt64_kernel_and_fragment_major_operand():
     assert gemm.split_right(torch.randn(1536, 750, device=DEV)).order == 3 and gemm.split_right(torch.randn(40, 100, device=DEV)).order == 1
 
 
+def test_nt64_random_shapes():
+    """Randomised differential test of the NT halves GEMM family (round 5): for 24 random (m, K, P, left layout, output pitch, second scale,
+    right-operand layout) the 128-byte-line kernel - row-major and fragment-major weights - is bit for bit the 128 x 64 kernel and within
+    3e-6 of the fp64 product of the same fp32 operands; nothing outside the output's columns is touched."""
+    import random
+    from bot_amd import gemm
+    rng = random.Random(5)
+    gen = torch.Generator(device=DEV).manual_seed(41)
+    OLD = 1024
+    for case in range(24):
+        m = rng.choice([1, 15, 255, 256, 257, 1000, 4099, 9001])
+        K = rng.choice([1, 31, 64, 100, 250, 500, 750])
+        P = rng.choice([1, 17, 40, 191, 192, 256, 300, 750])
+        order = rng.choice([0, 2])
+        x = torch.randn(m, K, device=DEV, generator=gen) * 10 ** rng.uniform(-3, 3)
+        x[:, ::3] *= 1e-3
+        w = torch.randn(P, K, device=DEV, generator=gen) * 10 ** rng.uniform(-3, 1)
+        ws = gemm.split(w, 1)
+        piece = ws.piece
+        sc = _C.halves_scale(x)
+        xb = _C.halves_split(x, sc, order, piece)
+        a2 = piece if order == 2 else 2 * piece
+        frag = _C.halves_split_frag(w, ws.scale, piece)
+        pad = rng.choice([0, 1, 2, 6])
+        kw = {}
+        if piece >= 64 and rng.random() < 0.5:
+            f = 2.0 ** rng.randint(-12, 12)
+            kw = dict(scale_a2=torch.tensor([float(sc[0]) * f, float(sc[1]) / f], device=DEV), k_split=32 * rng.randint(1, piece // 32 - 1))
+        outs = []
+        for mode, b, bf in ((OLD, ws.buf, False), (0, ws.buf, False), (0, frag, True)):
+            big = torch.full((m, P + pad), 3.0, device=DEV)
+            o = big[:, pad // 2:pad // 2 + P]
+            _C.gemm_halves3_nt(xb, b, sc, ws.scale, piece, piece, piece, a2_off=a2, out=o, mode=mode, b_frag=bf, n=P, **kw)
+            assert bool((big[:, :pad // 2] == 3.0).all()) and bool((big[:, pad // 2 + P:] == 3.0).all()), (case, mode)
+            outs.append(o.clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (case, m, K, P, order, kw.get("k_split"))
+        if not kw:
+            ref = x.double() @ w.double().t()
+            assert float((outs[1].double() - ref).abs().max() / ref.abs().max().clamp(min=1e-300)) < 3e-6, (case, m, K, P)
+
+
 def test_grouped_halves_kernels(golden):
     """v16, the aggregate-first layer's dense products (csrc/halves3.hip grouped forms, csrc/spmm.hip halves epilogue) each against the
     definition in include/bot_gnn.h evaluated in fp64 from the SAME fp16 operands (tests/_oracle_backend.py's restatement, accumulating in float64):
