@@ -470,13 +470,29 @@ def main():
         if gs:
             g_ms = sum(r[2].elapsed_time(r[3]) for r in gs)
             g_fl = sum(2.0 * r[1][0] * r[1][1] * r[1][2] * r[1][3] for r in gs)
+            # The same launches against the COMBINED roofline: a projection with a short reduction axis (K = 100 .. 480 at configs 3-5: two to
+            # eight k-steps per tile) is bound by writing its fp32 output, not by the matrix cores.  Per launch t_roof = max(flops / MFMA peak,
+            # bytes / HBM peak) with bytes = 4 (m k + n k + m n) of the fp32-sized operands and result (plain launches: profile key (m, n, 3 k, 1);
+            # grouped launches carry only their flops and count as MFMA-bound)
+            t_roof = hbm_bound = g_by = 0.0
+            for r in gs:
+                m_, n_, k3, bt = r[1]
+                fl = 2.0 * m_ * n_ * k3 * bt
+                by = 4.0 * bt * (m_ * (k3 / 3.0) + n_ * (k3 / 3.0) + m_ * n_) if k3 > 1 else 0.0
+                tm, th = fl / (MFMA_F16_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)
+                t_roof += max(tm, th)
+                g_by += by
+                hbm_bound += 1 if th > tm else 0
             roof["dense_projections"] = {"bound": "mfma", "what": "the halves-GEMM launches (bot_gemm_halves3_nt_f32 / _tn_f32 and their grouped forms: hand-written NT / TN products; bot_gemm_halves_f32, "
                                                  "hipBLASLt fp16 -> fp32, where a shape is left to it: none in config 2) of three more steps after the timed region (HIP events; weight-gradient products inline for these steps, not on the side stream); flops = "
                                                  "fp16 MFMA flops of the valid output columns, three products per fp32 product",
                                          "launches_per_step": len(gs) / gsteps, "ms_per_step": round(g_ms / gsteps, 3),
                                          "achieved": round(g_fl / g_ms / 1e9, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                          "frac": round(g_fl / g_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, 4),
-                                         "fp32_equivalent_TFLOPs": round(g_fl / 3 / g_ms / 1e9, 1)}
+                                         "fp32_equivalent_TFLOPs": round(g_fl / 3 / g_ms / 1e9, 1),
+                                         "combined_roofline": {"frac": round(t_roof * 1e3 / g_ms, 4), "launches_bound_by_hbm": int(hbm_bound),
+                                                               "launches": len(gs), "bytes_per_step": int(g_by / gsteps),
+                                                               "what": "sum over the launches of max(flops / 2.5 PFLOP/s, 4 (m k + n k + m n) B / 8 TB/s) / measured time"}}
 
     cpu = parity = None
     if rank == 0 and world == 1 and args.cpu_baseline != "off" and args.workload == "arxiv" and args.norm_adj == "rw":

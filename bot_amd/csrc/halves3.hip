@@ -1166,8 +1166,22 @@ extern "C" int bot_gemm_halves3_nt_grouped2_f32(int64_t m, int64_t b_rows, const
 
 namespace bot {
 namespace {
-// splits: whole multiples of 8 (one per XCD at a time) while a split keeps >= 4096 rows; fewer for short operands
-int tn_splits(int64_t n_rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(8, n_rows / 4096)); }
+// splits: one per XCD (8) while a split keeps >= 4096 rows, fewer for short operands - and, round 5, q splits per XCD where the tile count
+// of a split does not fill an XCD's 32 CUs (config 2: 4 x 8 = 32 tiles, q = 1; S-products' [480, N] x [N, 968]: 3 x 6 = 18 tiles used
+// 144 of 256 CUs: q = 5 -> 90 workgroups per XCD in three rounds, 94 % of the slots; 11.4 -> ~7 ms): the q <= 8 with the best
+// (q tiles) / (32 ceil(q tiles / 32)), the smallest on ties, each split still >= 4096 rows
+int tn_splits(int64_t n_rows, int tiles) {
+    const int64_t by_rows = n_rows / 4096;
+    if (by_rows < 8) return (int)std::max<int64_t>(1, by_rows);
+    int best_q = 1;
+    double best = 0.0;
+    for (int q = 1; q <= 8 && 8 * q <= by_rows; ++q) {
+        const int wg = q * tiles, rounds = (wg + 31) / 32;
+        const double eff = (double)wg / (32.0 * rounds);
+        if (eff > best + 1e-9) best = eff, best_q = q;
+    }
+    return 8 * best_q;
+}
 }  // namespace
 }  // namespace bot
 
@@ -1225,7 +1239,10 @@ extern "C" int bot_gemm_halves3_tn_grouped_f32(int64_t n_rows, const float* scal
     return hip_status("gemm_halves3_tn_grouped");
 }
 
-extern "C" int64_t bot_gemm_halves3_tn_workspace_floats(int64_t n_rows, int64_t kp, int64_t pp) { return (int64_t)bot::tn_splits(n_rows) * kp * pp; }
+extern "C" int64_t bot_gemm_halves3_tn_workspace_floats(int64_t n_rows, int64_t kp, int64_t pp) {
+    const int tiles = (int)(((kp + bot::TT - 1) / bot::TT) * ((pp + bot::TT - 1) / bot::TT));
+    return (int64_t)bot::tn_splits(n_rows, tiles) * kp * pp;
+}
 
 extern "C" int bot_gemm_halves3_tn_f32(int64_t n_rows, int64_t k, int64_t p, int64_t kp, int64_t pp, const float* scale_x, const float* scale_d,
                                        const uint16_t* X, int64_t ldx, int64_t x2_off, const uint16_t* D, int64_t ldd, int64_t d2_off, float* out,
@@ -1248,7 +1265,7 @@ extern "C" int bot_gemm_halves3_tn2_f32(int64_t n_rows, int64_t k, int64_t p, in
     a.X = reinterpret_cast<const _Float16*>(X), a.D = reinterpret_cast<const _Float16*>(D), a.part = workspace, a.ldx = ldx, a.ldd = ldd;
     a.N = (int)n_rows, a.K = (int)k, a.P = (int)p, a.KP = (int)kp, a.PP = (int)pp, a.x2_off = (int)x2_off, a.d2_off = (int)d2_off;
     a.tiles_k = (int)((kp + TT - 1) / TT), a.tiles_p = (int)((pp + TT - 1) / TT);
-    int splits = tn_splits(n_rows);
+    int splits = tn_splits(n_rows, a.tiles_k * a.tiles_p);
     const int rps = (int)(((n_rows + splits - 1) / splits + TBK - 1) / TBK * TBK);
     splits = (int)((n_rows + rps - 1) / rps);             // no empty split (never more than tn_splits: the workspace holds them)
     a.splits = splits, a.rows_per_split = rps;

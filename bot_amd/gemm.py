@@ -25,10 +25,11 @@ TN_KERNEL = os.environ.get("BOT_GEMM_TN", "halves3")   # weight gradients (reduc
                                                        # kernel of csrc/halves3.hip, "lib" = batched hipBLASLt products over row chunks + combine
 # Left operands WITHOUT their duplicate h1 piece ([h1 | 2^11 h2], "order 2"): only the library's concatenated-axis NT GEMM reads the
 # duplicate, so with both hand-written kernels in place wide operands are written with two pieces (a third less to write and to hold:
-# 0.5 GB per split of the config-2 gradient buffer).  Narrow operands (piece < NODUP_MIN_PIECE) keep three: their products are the ones
-# that still go to the library.
+# 0.5 GB per split of the config-2 gradient buffer).  Narrow operands (piece < NODUP_MIN_PIECE) keep three.  (Round 5 tried 64 - with
+# fragment-major right operands no product is left that needs the duplicate: S-products 428-432 -> 434-440 ms, S-arxiv equal; no gain, kept
+# at 256: profiles/r05_nodup_ab.txt.  BOT_NODUP_MIN_PIECE overrides.)
 LEFT_NODUP = NT_KERNEL == "halves3" and TN_KERNEL == "halves3" and os.environ.get("BOT_HALVES_DUP", "0") != "1"
-NODUP_MIN_PIECE = 256
+NODUP_MIN_PIECE = int(os.environ.get("BOT_NODUP_MIN_PIECE", "256"))
 TN_MIN_OUT = 512 * 1024                                # smaller results (the 40-class output layer) go to the kernel's grouped form with more row splits (TN_NARROW), else the library
 NT_MIN_COLS = 192                                      # narrower outputs (the 40-class output layer) leave most of a 256-column tile empty: library
 LINEAR_BLOCKS = os.environ.get("BOT_LINEAR_BLOCKS", "1") != "0"   # merged projections hand their column blocks' gradients over without a `cat`
@@ -290,17 +291,19 @@ class _MergedLinear(torch.autograd.Function):
             if g is not None:
                 _C.absmax_into(g, slots)
         dscale = _C.halves_scale_from_slots(slots)
-        dbuf = torch.empty((n, 3 * piece), dtype=torch.float16, device=buf.device)
+        order = left_order(piece)
+        pieces = 2 if order == 2 else 3
+        dbuf = torch.empty((n, pieces * piece), dtype=torch.float16, device=buf.device)
         off = 0
         for i, (g, wd) in enumerate(zip(grads, sizes)):
             width = wd if i + 1 < len(sizes) else piece - off                        # the last block also zeroes the operand's padding
             if g is None:
-                for k in range(3):
+                for k in range(pieces):
                     dbuf[:, k * piece + off:k * piece + off + width].zero_()
             else:
-                _C.halves_split_cols(g, dscale, 0, dbuf, piece, off, width)
+                _C.halves_split_cols(g, dscale, order, dbuf, piece, off, width)
             off += wd
-        dh = Halves(dbuf, dscale, n, P, piece, 0)
+        dh = Halves(dbuf, dscale, n, P, piece, order)
         dx = mm_nt(dh, split_right(w.t().contiguous())) if ctx.needs_input_grad[0] else None
         dw = tn(Halves(buf, scale, *ctx.meta), dh).t().contiguous() if ctx.needs_input_grad[1] else None
         return dx, dw, None

@@ -966,12 +966,13 @@ def check_absmax_byproducts(golden, device):
                residual=False)
     feat, gout = torch.randn(n, fin, generator=gen).to(device), torch.randn(n, C, generator=gen).to(device)
     grads = {}
-    force0, by0, ff0 = gemm.FORCE, fused.ABSMAX_BYPRODUCT, fused.FORCE
+    force0, by0, ff0, dd0 = gemm.FORCE, fused.ABSMAX_BYPRODUCT, fused.FORCE, fused.DOUT_DIRECT
     calls = []
     orig = _C.halves_scale_from_slots
     try:
         gemm.FORCE = fused.FORCE = True                                             # (the fused nodes / halves path at this size and on the emulated backend)
-        _C.halves_scale_from_slots = lambda sl: (calls.append(1), orig(sl))[1]
+        fused.DOUT_DIRECT = False       # (the form this test is about: an fp32 gradient buffer whose maxima the producers deliver; the direct form has its own test)
+        _C.halves_scale_from_slots = lambda sl, **kw: (calls.append(1), orig(sl, **kw))[1]
         for by in (True, False):
             fused.ABSMAX_BYPRODUCT = by
             torch.manual_seed(11)
@@ -981,7 +982,7 @@ def check_absmax_byproducts(golden, device):
             assert (len(calls) > n0) == by
             grads[by] = {k: p.grad.clone() for k, p in model.named_parameters()}
     finally:
-        gemm.FORCE, fused.ABSMAX_BYPRODUCT, fused.FORCE, _C.halves_scale_from_slots = force0, by0, ff0, orig
+        gemm.FORCE, fused.ABSMAX_BYPRODUCT, fused.FORCE, _C.halves_scale_from_slots, fused.DOUT_DIRECT = force0, by0, ff0, orig, dd0
     for k in grads[True]:
         assert torch.equal(grads[True][k], grads[False][k]), k
     # evaluate(): the inference layers hand the next layer's split its scale — same logits bit for bit, and the scale was used

@@ -319,19 +319,22 @@ def test_stacks_unchanged_by_reordering(golden, cpu_backend, monkeypatch, method
                 assert torch.allclose(a, b, atol=1e-4 * max(1.0, float(a.abs().max())))
 
 
-def test_halves_gemm_host_logic(cpu_backend, monkeypatch):
-    """bot_amd.gemm over the emulated backend: operand layouts, the strided-batch weight gradient with a ragged row remainder,
+@pytest.mark.parametrize("nodup_min", [64, 256])
+def test_halves_gemm_host_logic(cpu_backend, monkeypatch, nodup_min):
+    """bot_amd.gemm over the emulated backend: operand layouts (round 5: every left operand without the duplicate piece; 256: the round-4
+    rule, narrow operands with it - the layout the library formulation reads), the strided-batch weight gradient with a ragged row remainder,
     the autograd wrapper in both weight layouts — against fp64 products."""
     from bot_amd import gemm
     monkeypatch.setattr(gemm, "FORCE", True)
     monkeypatch.setattr(gemm, "CHUNK_ROWS", 64)
+    monkeypatch.setattr(gemm, "NODUP_MIN_PIECE", nodup_min)
     gen = torch.Generator().manual_seed(0)
     n, K, P = 64 * 5 + 13, 160, 136
     x = torch.randn(n, K, generator=gen) * 3
     d = torch.randn(n, P, generator=gen) * 1e-6
     w = torch.randn(P, K, generator=gen) * 0.1
     xs, ds = gemm.split(x, 0), gemm.split(d, 0)
-    assert xs.buf.shape == (n, 3 * 192) and xs.piece == 192 and ds.piece == 192
+    assert xs.buf.shape == (n, (2 if nodup_min <= 192 else 3) * 192) and xs.piece == 192 and ds.piece == 192
     for got, ref in ((gemm.mm_nt(xs, gemm.split(w, 1)), x.double() @ w.double().t()),
                      (gemm.mm_nt(ds, gemm.split(w.t().contiguous(), 1)), d.double() @ w.double()),
                      (gemm.tn(xs, ds), x.double().t() @ d.double())):
