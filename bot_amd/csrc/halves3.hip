@@ -1168,7 +1168,7 @@ namespace bot {
 namespace {
 // splits: one per XCD (8) while a split keeps >= 4096 rows, fewer for short operands - and, round 5, q splits per XCD where the tile count
 // of a split does not fill an XCD's 32 CUs (config 2: 4 x 8 = 32 tiles, q = 1; S-products' [480, N] x [N, 968]: 3 x 6 = 18 tiles used
-// 144 of 256 CUs: q = 5 -> 90 workgroups per XCD in three rounds, 94 % of the slots; 11.4 -> ~7 ms): the q <= 8 with the best
+// 144 of 256 CUs: q = 7 -> 126 workgroups per XCD in four rounds, 98 % of the slots; 11.4 -> 8.4 ms): the q <= 8 with the best
 // (q tiles) / (32 ceil(q tiles / 32)), the smallest on ties, each split still >= 4096 rows
 int tn_splits(int64_t n_rows, int tiles) {
     const int64_t by_rows = n_rows / 4096;

@@ -81,3 +81,29 @@ def test_row_plan_rejects_bad_indptr():
     bad = torch.tensor([0, 5, 3], dtype=torch.int32)
     with pytest.raises(_C.BotKernelError):
         _C.row_plan(bad, 4)
+
+
+def test_tn_split_count_fills_the_xcds():
+    """bot_gemm_halves3_tn_workspace_floats = splits x kp x pp: one split per XCD when a split's 192 x 192 tiles are the XCD's 32 CUs (config 2:
+    4 x 8 tiles), q <= 8 per XCD where they are not - the q with the best (q tiles) / (32 ceil(q tiles / 32)), smallest on ties (S-products'
+    [480, N] x [N, 968]: 3 x 6 = 18 tiles -> q = 7: 126 workgroups per XCD, 98 % of four rounds) - never a split under 4096 rows.  Host
+    arithmetic only, against a restatement of the rule."""
+    from bot_amd import _C
+    f = _C._lib.bot_gemm_halves3_tn_workspace_floats
+
+    def rule(n, kp, pp):
+        tiles = -(-kp // 192) * -(-pp // 192)
+        by_rows = n // 4096
+        if by_rows < 8:
+            return max(1, by_rows)
+        best_q, best = 1, 0.0
+        for q in range(1, 9):
+            if 8 * q > by_rows:
+                break
+            eff = q * tiles / (32.0 * -(-(q * tiles) // 32))
+            if eff > best + 1e-9:
+                best, best_q = eff, q
+        return 8 * best_q
+    for n, kp, pp in ((169343, 768, 1536), (2449029, 512, 1024), (132534, 512, 1024), (232965, 640, 256), (20000, 768, 1536), (3000, 768, 1536)):
+        assert f(n, kp, pp) // (kp * pp) == rule(n, kp, pp), (n, kp, pp)
+    assert rule(169343, 768, 1536) == 8 and rule(2449029, 512, 1024) == 56 and rule(3000, 768, 1536) == 1
