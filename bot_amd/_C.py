@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -121,6 +121,11 @@ _SIGS = {
     "bot_spmm_dot_halves_fits": (ctypes.c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_int64, c_int32]),
     "bot_spmm_dot_halves_f16": (ctypes.c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_int64,
                                                c_int32, c_int32, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P]),
+    "bot_gemm_halves3_nt_bn_rows": (c_int32, [c_int64]),
+    "bot_gemm_halves3_nt3_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int32, _P, c_int64,
+                                                _P, c_int32, _P]),
+    "bot_bn_act_bwd_reduce_partials_f32": (ctypes.c_int, [_P, c_int32, c_int32, _P, _P, _P]),
+    "bot_bn_bwd_bound_partials_f32": (ctypes.c_int, [c_int32, _P, c_int32, _P, _P, c_double, _P, _P, _P, _P]),
     "bot_gemm_halves3_nt2_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int32, _P, c_int64,
                                                 c_int32, _P]),
     "bot_halves_split_frag_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, c_int32, _P]),
@@ -884,7 +889,56 @@ def stream_create(device, high_priority=False):
     return torch.cuda.ExternalStream(h.value, device=device)
 
 
-def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0, b_frag=False, n=None):
+class _BnBwdStats(ctypes.Structure):
+    """include/bot_gnn.h bot_bn_bwd_stats_t"""
+    _fields_ = [("x", c_void_p), ("ldx", c_int64), ("mean", c_void_p), ("invstd", c_void_p), ("weight", c_void_p), ("bias", c_void_p), ("relu", c_int32),
+                ("p", c_float), ("seed", c_uint64), ("seed_offset", c_void_p), ("part", c_void_p), ("pmax", c_void_p)]
+
+
+class BnBwdStats:
+    """The reduce pass of a fused BatchNorm / ReLU / dropout epilogue's backward as a by-product of the NT product that writes the epilogue's
+    incoming gradient (include/bot_gnn.h "v18"): x [m, F] the epilogue's input, the statistics / affine vectors, the dropout (p, seed) of its
+    forward.  `gemm_halves3_nt(..., bn=this)` fills part / pmax [ceil(m / 256), 2, F]; `sums()` / `bound()` finish them."""
+
+    def __init__(self, x, mean, invstd, weight, bias, relu, p, seed, want_max=True):
+        _dev(x, mean, invstd, weight, bias)
+        self.x = _mat(x, "x")
+        self.mean, self.invstd, self.weight, self.bias = _f32(mean, "mean"), _f32(invstd, "invstd"), weight, bias
+        self.relu, self.p, self.seed = bool(relu), float(p), int(seed)
+        n, F = self.x.shape
+        self.n, self.F, self.nblk = n, F, (n + 255) // 256
+        self.part = torch.empty((self.nblk, 2, F), dtype=torch.float32, device=x.device)
+        self.pmax = torch.empty((self.nblk, 2, F), dtype=torch.float32, device=x.device) if want_max else None
+
+    def fits(self, m, n, k) -> bool:
+        """The product [m, n] of piece width k can carry the by-product: the 256 x 32 form, n = F even, 8-byte aligned x rows."""
+        return (m == self.n and n == self.F and F_even(self.F) and self.x.stride(0) % 2 == 0 and self.x.data_ptr() % 8 == 0 and
+                _lib.bot_gemm_halves3_nt_bn_rows(int(k)) == 256)
+
+    def struct(self):
+        return _BnBwdStats(self.x.data_ptr(), self.x.stride(0), self.mean.data_ptr(), self.invstd.data_ptr(), _ptr(self.weight), _ptr(self.bias),
+                           int(self.relu), self.p, self.seed, _seed_off(self.p), self.part.data_ptr(), _ptr(self.pmax))
+
+    def sums(self):
+        sg = torch.empty(self.F, dtype=torch.float32, device=self.x.device)
+        sgx = torch.empty(self.F, dtype=torch.float32, device=self.x.device)
+        _check(_lib.bot_bn_act_bwd_reduce_partials_f32(self.part.data_ptr(), self.nblk, self.F, sg.data_ptr(), sgx.data_ptr(), _stream()),
+               "bn_act_bwd_reduce_partials")
+        return sg, sgx
+
+    def bound(self, sum_g, sum_gx, total_count, slots):
+        assert self.pmax is not None
+        _dev(slots)
+        _check(_lib.bot_bn_bwd_bound_partials_f32(self.F, self.pmax.data_ptr(), self.nblk, _ptr(sum_g), _ptr(sum_gx), float(total_count), _ptr(self.weight),
+                                                  self.invstd.data_ptr(), slots.data_ptr(), _stream()), "bn_bwd_bound_partials")
+        return slots
+
+
+def F_even(F) -> bool:
+    return F % 2 == 0
+
+
+def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0, b_frag=False, n=None, bn=None):
     """out[m, n] = scale_a[1] scale_b[1] (a1 b1^T + a1 b2^T + a2 b1^T) from a LEFT operand buffer a [m, 3 piece_a] (or [m, 2 piece_a]
     without the duplicate piece: a2_off = piece_a) and a RIGHT operand buffer b [n, 3 piece_b] (bot_amd.gemm.Halves.buf / .scale), k =
     the common piece width used (bot_gemm_halves3_nt_f32).  scale_a2 / k_split: a's columns from k_split (a multiple of 32) on were
@@ -896,9 +950,16 @@ def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=
         n = b.shape[0]
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-    _check(_timed("gemm_halves", (m, n, 3 * k, 1), lambda: _lib.bot_gemm_halves3_nt2_f32(
+    # bn (BnBwdStats): out is the gradient arriving at that epilogue - its reduce pass leaves with the tiles (bot_gemm_halves3_nt3_f32)
+    st = None
+    if bn is not None:
+        if not bn.fits(m, n, k):
+            raise BotKernelError("gemm_halves3_nt: this product cannot carry the BatchNorm-backward by-product (BnBwdStats.fits)")
+        st = bn.struct()
+    _check(_timed("gemm_halves", (m, n, 3 * k, 1), lambda: _lib.bot_gemm_halves3_nt3_f32(
         m, n, k, scale_a.data_ptr(), _ptr(scale_a2), int(k_split), scale_b.data_ptr(), a.data_ptr(), _ld(a), 2 * piece_a if a2_off is None else a2_off,
-        b.data_ptr(), _ld(b), piece_b, int(bool(b_frag)), out.data_ptr(), _ld(out), int(mode), _stream())), "gemm_halves3_nt")
+        b.data_ptr(), _ld(b), piece_b, int(bool(b_frag)), out.data_ptr(), _ld(out), ctypes.addressof(st) if st is not None else None, int(mode), _stream())),
+        "gemm_halves3_nt")
     return out
 
 

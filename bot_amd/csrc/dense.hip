@@ -512,6 +512,66 @@ __global__ __launch_bounds__(kBlock) void pair_final_kernel(int32_t F, const flo
     }
 }
 
+// v18: the second stage over MANY row blocks (one per 256-row GEMM tile: 662 at config 2, against <= 256 of the pass form) - 32 columns x
+// 16 block groups per workgroup; group g adds blocks g, g + 16, ... in order (eight pairs in flight), the groups are combined in order.
+// (8 KB of LDS: these launches run beside the side stream's weight-gradient product, whose workgroups leave 16 KB per CU)
+constexpr int kWideGroups = 16, kWideCols = 32;
+__global__ __launch_bounds__(kWideCols * kWideGroups) void pair_final_wide_kernel(int32_t F, const float* part, int nblk, float* s0, float* s1) {
+    __shared__ double lds[2][kWideGroups][kWideCols];
+    const int lc = threadIdx.x % kWideCols, c = blockIdx.x * kWideCols + lc, grp = threadIdx.x / kWideCols;
+    double s = 0.0, q = 0.0;
+    if (c < F) {
+        int b = grp;
+        for (; b + 7 * kWideGroups < nblk; b += 8 * kWideGroups) {
+            float vs[8], vq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                vs[j] = part[((int64_t)(b + kWideGroups * j) * 2 + 0) * F + c], vq[j] = part[((int64_t)(b + kWideGroups * j) * 2 + 1) * F + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (double)vs[j], q += (double)vq[j];
+        }
+        for (; b < nblk; b += kWideGroups) s += (double)part[((int64_t)b * 2 + 0) * F + c], q += (double)part[((int64_t)b * 2 + 1) * F + c];
+    }
+    lds[0][grp][lc] = s, lds[1][grp][lc] = q;
+    __syncthreads();
+    if (grp == 0 && c < F) {
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int g = 0; g < kWideGroups; ++g) S += lds[0][g][lc], Q += lds[1][g][lc];
+        s0[c] = (float)S, s1[c] = (float)Q;
+    }
+}
+
+__global__ __launch_bounds__(kWideCols * kWideGroups) void bn_bwd_bound_wide_kernel(int32_t F, const float* pmax, int nblk, const float* sum_g, const float* sum_gx,
+                                                                                   float inv_count, const float* w, const float* invstd, uint32_t* slots) {
+    __shared__ float lds[2][kWideGroups][kWideCols];
+    const int lc = threadIdx.x % kWideCols, c = blockIdx.x * kWideCols + lc, grp = threadIdx.x / kWideCols;
+    float gm = 0.f, xm = 0.f;
+    if (c < F) {
+        int k = grp;
+        for (; k + 7 * kWideGroups < nblk; k += 8 * kWideGroups) {
+            float vg[8], vx[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                vg[j] = pmax[((int64_t)(k + kWideGroups * j) * 2 + 0) * F + c], vx[j] = pmax[((int64_t)(k + kWideGroups * j) * 2 + 1) * F + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gm = fmaxf(gm, vg[j]), xm = fmaxf(xm, vx[j]);
+        }
+        for (; k < nblk; k += kWideGroups) gm = fmaxf(gm, pmax[((int64_t)k * 2 + 0) * F + c]), xm = fmaxf(xm, pmax[((int64_t)k * 2 + 1) * F + c]);
+    }
+    lds[0][grp][lc] = gm, lds[1][grp][lc] = xm;
+    __syncthreads();
+    float b = 0.f;
+    if (grp == 0 && c < F) {
+#pragma unroll
+        for (int g = 1; g < kWideGroups; ++g) gm = fmaxf(gm, lds[0][g][lc]), xm = fmaxf(xm, lds[1][g][lc]);
+        float t = gm;
+        if (sum_g) t += fabsf(sum_g[c]) * inv_count + xm * fabsf(sum_gx[c]) * inv_count;
+        b = fabsf(w ? w[c] : 1.f) * invstd[c] * t * 1.0001f;          // (bn_bwd_bound_kernel's expression)
+    }
+    if (threadIdx.x < 64) absmax_publish(wave_absmax(b), slots);       // (the first wave holds groups 0 and 1: b is 0 outside group 0)
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
     const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
@@ -812,6 +872,26 @@ int bot_bn_bwd_bound_f32(int32_t F, int64_t n, const float* workspace, const flo
     hipLaunchKernelGGL(bn_bwd_bound_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, (hipStream_t)stream, F, workspace + (int64_t)kRowBlocks * 2 * F, nblk,
                        sum_g, sum_gx, sum_g ? (float)(1.0 / total_count) : 0.f, weight, invstd, absmax_slots);
     return hip_status("bn_bwd_bound launch");
+}
+
+// v18: the two consumers of the reduce pass's partials, for partials a PRODUCER of dy delivered with it (bot_gemm_halves3_nt3_f32 `bn`):
+// part / pmax [nblk][2][F] as bn_act_bwd_reduce_kernel leaves them, one row block per 256-row GEMM tile
+int bot_bn_act_bwd_reduce_partials_f32(const float* part, int32_t nblk, int32_t F, float* sum_g, float* sum_gx, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(part && sum_g && sum_gx, BOT_E_NULL, "bn_act_bwd_reduce_partials: NULL pointer");
+    BOT_REQUIRE(nblk >= 1 && F >= 1, BOT_E_RANGE, "bn_act_bwd_reduce_partials: nblk=%d F=%d", nblk, F);
+    hipLaunchKernelGGL(pair_final_wide_kernel, dim3((F + kWideCols - 1) / kWideCols), dim3(kWideCols * kWideGroups), 0, (hipStream_t)stream, F, part, (int)nblk, sum_g, sum_gx);
+    return hip_status("bn_act_bwd_reduce_partials launch");
+}
+
+int bot_bn_bwd_bound_partials_f32(int32_t F, const float* pmax, int32_t nblk, const float* sum_g, const float* sum_gx, double total_count, const float* weight,
+                                  const float* invstd, uint32_t* absmax_slots, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(F >= 1 && nblk >= 1 && pmax && invstd && absmax_slots, BOT_E_NULL, "bn_bwd_bound_partials: F=%d nblk=%d or a NULL pointer", F, nblk);
+    BOT_REQUIRE((sum_g == nullptr) == (sum_gx == nullptr) && (sum_g == nullptr || total_count >= 1.0), BOT_E_RANGE, "bn_bwd_bound_partials: sums / total_count");
+    hipLaunchKernelGGL(bn_bwd_bound_wide_kernel, dim3((F + kWideCols - 1) / kWideCols), dim3(kWideCols * kWideGroups), 0, (hipStream_t)stream, F, pmax, (int)nblk, sum_g, sum_gx,
+                       sum_g ? (float)(1.0 / total_count) : 0.f, weight, invstd, absmax_slots);
+    return hip_status("bn_bwd_bound_partials launch");
 }
 
 static int bn_act_bwd_reduce_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t n, int32_t F, const float* mean, const float* invstd,

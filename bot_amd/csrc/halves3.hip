@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -64,6 +65,22 @@ struct H3Args {
     float* stats_minmax;
     const float* stats_pivot;
     int stats_F;
+    // optional (bot_gemm_halves3_nt3_f32, gemm_halves3_nt64_*_bnb_kernel): C is the gradient arriving at a fused BatchNorm / ReLU / dropout
+    // epilogue (dense.hip bn_act_bwd_*) whose input was bnb_x [M, N]: the column sums of that backward's reduce pass (masked gradient g,
+    // g * xhat) and the column maxima of |g|, |xhat| leave with the tile - per 256-row tile t: bnb_part[(2 t + 0) N + c] = sum g,
+    // [(2 t + 1) N + c] = sum g xhat, bnb_pmax likewise the maxima (the workspace layout of bn_act_bwd_reduce_kernel, one row block per tile)
+    const float* bnb_x;
+    int64_t bnb_ldx;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    const float* bnb_w;
+    const float* bnb_b;
+    int bnb_relu;
+    float bnb_p;
+    uint64_t bnb_seed;
+    const uint64_t* bnb_seed_offset;
+    float* bnb_part;
+    float* bnb_pmax;
     int b_frag;             // B is a fragment-major RIGHT operand (halves.hip order 3; gemm_halves3_nt64_kernel only): rows of 16-row tiles = N rounded up
     int mode;               // 0 = the product.  Measurement switches (tools/exp_halves3.py): bit 0 no output stores; bit 2 / 3 B / A never
                             // advance along k; bit 5 the plain loop (barrier at the end of a k-step) and, in it, bit 6 no barrier / wait,
@@ -394,6 +411,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_halves3_nt_grouped_kernel(H
 // Same operands, same three products in the same order per accumulator as the kernel above: bit for bit its result.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 __device__ __forceinline__ half8 load16(const void* tile_base, uint32_t voff, int soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tile_base), 0, 0x7fffffff, 0x00020000);
@@ -403,8 +429,9 @@ __device__ __forceinline__ half8 load16(const void* tile_base, uint32_t voff, in
 #endif
 }
 
-template <bool GROUPED, bool BFRAG>
+template <bool GROUPED, bool BFRAG, bool BNB = false>
 __device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3Groups* groups) {
+    static_assert(!(GROUPED && BNB), "the BatchNorm-backward by-product indexes the output columns of a plain launch");
     constexpr int BM = 256, BN = 256, kWaves = 8, MT = BM / 16, NT = BN / kWaves / 16;
     constexpr int kRow = 4 * BK;                             // bytes of a row per piece and iteration: two k-steps = one 128-byte line
     constexpr int kABytes = BM * kRow;                       // one piece of A per iteration: 32 KB
@@ -604,8 +631,62 @@ __device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3
         for (int e = 0; e < 4; ++e)
             if (col + e < n_valid) piv[e] = p.stats_pivot[c0 + col + e];
     }
+    // BatchNorm-backward by-product (BNB): this lane's quad of columns is a Philox quad of the epilogue's dropout mask (c0 + col is a multiple
+    // of 4), the x rows are read 8 rows x 128 bytes per instruction like the stores
+    float b_s[4] = {0.f, 0.f, 0.f, 0.f}, b_q[4] = {0.f, 0.f, 0.f, 0.f}, b_gm[4] = {0.f, 0.f, 0.f, 0.f}, b_xm[4] = {0.f, 0.f, 0.f, 0.f};
+    float b_mu[4] = {0.f, 0.f, 0.f, 0.f}, b_is[4] = {0.f, 0.f, 0.f, 0.f}, b_sc[4] = {1.f, 1.f, 1.f, 1.f}, b_sh[4] = {0.f, 0.f, 0.f, 0.f};
+    int b_nv = 0;
+    bool b_wide = false;
+    uint64_t b_seed = 0;
+    int64_t b_nquad = 0;
+    float b_keep = 1.f;
+    if constexpr (BNB) {
+        b_nv = max(0, min(4, n_valid - col));
 #pragma unroll
-    for (int pass = 0; pass < MT / 2; ++pass) {
+        for (int e = 0; e < 4; ++e)
+            if (e < b_nv) {
+                b_mu[e] = p.bnb_mean[c0 + col + e], b_is[e] = p.bnb_invstd[c0 + col + e];
+                if (p.bnb_w) b_sc[e] = p.bnb_w[c0 + col + e];
+                if (p.bnb_b) b_sh[e] = p.bnb_b[c0 + col + e];
+            }
+        b_wide = (p.bnb_ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.bnb_x) & 15) == 0);
+        b_seed = p.bnb_seed_offset ? p.bnb_seed + p.bnb_seed_offset[0] * 0x9E3779B97F4A7C15ull : p.bnb_seed;      // dense.hip eff_seed
+        b_nquad = (p.N + 3) / 4;
+        b_keep = p.bnb_p > 0.f ? 1.f / (1.f - p.bnb_p) : 1.f;
+    }
+    // the x quads of a pass are requested two passes ahead (a ring of three): a pass is short, an HBM round trip is not
+    f32x4 b_ring[3][4];
+    auto load_x = [&](auto pass_c) __attribute__((always_inline)) {
+        constexpr int pass = decltype(pass_c)::value;
+        if constexpr (BNB && pass < MT / 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + pass * 32 + i * 8 + (lane >> 3);
+                f32x4& q = b_ring[pass % 3][i];
+                q = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < p.M && b_nv > 0) {
+                    const float* xp = p.bnb_x + (int64_t)row * p.bnb_ldx + c0 + col;
+                    if (b_wide && b_nv == 4) {
+                        q = *reinterpret_cast<const f32x4*>(xp);
+                    } else {
+                        const float2 lo = *reinterpret_cast<const float2*>(xp);
+                        q[0] = lo.x, q[1] = lo.y;
+                        if (b_nv == 4) {
+                            const float2 hi = *reinterpret_cast<const float2*>(xp + 2);
+                            q[2] = hi.x, q[3] = hi.y;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    load_x(std::integral_constant<int, 0>{});
+    load_x(std::integral_constant<int, 1>{});
+    // (a compile-time pass index: the accumulator tiles must be addressed by constants whatever the unroller decides about a body this size)
+    auto do_pass = [&](auto pass_c) __attribute__((always_inline)) {
+        constexpr int pass = decltype(pass_c)::value;
+        load_x(std::integral_constant<int, pass + 2>{});
+        const f32x4 (&b_x)[4] = b_ring[pass % 3];
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
@@ -634,6 +715,28 @@ __device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3
                     st_mn[e] = fminf(st_mn[e], v[e]), st_mx[e] = fmaxf(st_mx[e], v[e]);
                 }
             }
+            if constexpr (BNB) {
+                if (row < p.M && b_nv > 0) {
+                    float f[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (p.bnb_p > 0.f) {        // dense.hip drop_factors: element (r, c) = word c % 4 of the block with counter r * ceil(F / 4) + c / 4
+                        uint32_t wd[4];
+                        Philox::gen(b_seed, (uint64_t)((int64_t)row * b_nquad + ((c0 + col) >> 2)), wd);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = ((wd[e] >> 8) * (1.0f / 16777216.0f)) >= p.bnb_p ? b_keep : 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (b_x[i][e] - b_mu[e]) * b_is[e];
+                        float gg = v[e] * f[e];
+                        if (p.bnb_relu && !(fmaf(xh, b_sc[e], b_sh[e]) > 0.f)) gg = 0.f;
+                        if (e < b_nv) {
+                            b_s[e] += gg;
+                            b_q[e] = fmaf(gg, xh, b_q[e]);
+                            b_gm[e] = fmaxf(b_gm[e], fabsf(gg)), b_xm[e] = fmaxf(b_xm[e], fabsf(xh));
+                        }
+                    }
+                }
+            }
             if (p.absmax && row < p.M) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -653,7 +756,8 @@ __device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3
                 }
             }
         }
-    }
+    };
+    static_for<MT / 2>(do_pass);
     if (p.absmax) absmax_publish(wave_absmax(amax), p.absmax);
     if (stats) {        // fold the 8 row groups of the wave (lanes l, l + 8, ..., l + 56 hold the same four columns): fixed order, deterministic
 #pragma unroll
@@ -675,11 +779,38 @@ __device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3
                 if (col + e < n_valid) ps[e] = st_s[e], ps[F + e] = st_q[e], pm[e] = st_mn[e], pm[F + e] = st_mx[e];
         }
     }
+    if constexpr (BNB) {       // the same fold: 8 row groups per wave, fixed order
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                b_s[e] += __shfl_xor(b_s[e], o);
+                b_q[e] += __shfl_xor(b_q[e], o);
+                b_gm[e] = fmaxf(b_gm[e], __shfl_xor(b_gm[e], o));
+                b_xm[e] = fmaxf(b_xm[e], __shfl_xor(b_xm[e], o));
+            }
+        }
+        if (lane < 8) {
+            const int64_t F = p.N;
+            float* ps = p.bnb_part + ((int64_t)tm * 2) * F + c0 + col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < b_nv) ps[e] = b_s[e], ps[F + e] = b_q[e];
+            if (p.bnb_pmax) {
+                float* pm = p.bnb_pmax + ((int64_t)tm * 2) * F + c0 + col;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < b_nv) pm[e] = b_gm[e], pm[F + e] = b_xm[e];
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(512) void gemm_halves3_nt64_kernel(H3Args p) { gemm_halves3_nt64_body<false, false>(p, nullptr); }
 __global__ __launch_bounds__(512) void gemm_halves3_nt64_frag_kernel(H3Args p) { gemm_halves3_nt64_body<false, true>(p, nullptr); }
 __global__ __launch_bounds__(512) void gemm_halves3_nt64_grouped_kernel(H3Args p, H3Groups groups) { gemm_halves3_nt64_body<true, false>(p, &groups); }
+__global__ __launch_bounds__(512) void gemm_halves3_nt64_bnb_kernel(H3Args p) { gemm_halves3_nt64_body<false, false, true>(p, nullptr); }
+__global__ __launch_bounds__(512) void gemm_halves3_nt64_frag_bnb_kernel(H3Args p) { gemm_halves3_nt64_body<false, true, true>(p, nullptr); }
 
 // BOT_NT_KERNEL=256x32 (default) / 128x64: which of the two forms the NT launches take when both cover the shape; read once per process
 static bool nt64_wanted() {
@@ -1062,7 +1193,23 @@ extern "C" int bot_gemm_halves3_nt_f32(int64_t m, int64_t n, int64_t k, const fl
 extern "C" int bot_gemm_halves3_nt2_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_a2, int64_t k_split, const float* scale_b,
                                         const uint16_t* A, int64_t lda, int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, int32_t b_layout,
                                         float* C, int64_t ldc, int32_t mode, bot_stream_t stream) {
+    return bot_gemm_halves3_nt3_f32(m, n, k, scale_a, scale_a2, k_split, scale_b, A, lda, a2_off, B, ldb, b2_off, b_layout, C, ldc, nullptr, mode, stream);
+}
+
+extern "C" int32_t bot_gemm_halves3_nt_bn_rows(int64_t k) {
     using namespace bot;
+    return (k > 0 && k % (2 * BK) == 0 && nt64_wanted()) ? 256 : 0;
+}
+
+extern "C" int bot_gemm_halves3_nt3_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_a2, int64_t k_split, const float* scale_b,
+                                        const uint16_t* A, int64_t lda, int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, int32_t b_layout,
+                                        float* C, int64_t ldc, const bot_bn_bwd_stats_t* bn, int32_t mode, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(bn == nullptr || (mode == 0 && bot_gemm_halves3_nt_bn_rows(k) == 256), -1,
+                "gemm_halves3_nt3: the BatchNorm-backward by-product rides on the 256 x 32 form (mode 0, k a multiple of 64, BOT_NT_KERNEL not 128x64)");
+    BOT_REQUIRE(bn == nullptr || (bn->x && bn->mean && bn->invstd && bn->part), -1, "gemm_halves3_nt3: bn->x, mean, invstd and part must be set");
+    BOT_REQUIRE(bn == nullptr || (n % 2 == 0 && bn->ldx >= n && bn->ldx % 2 == 0 && aligned(bn->x, 8) && bn->p >= 0.f && bn->p < 1.f), -1,
+                "gemm_halves3_nt3: the by-product needs an even n (= the BatchNorm width), 8-byte aligned x rows of pitch >= n and p in [0, 1)");
     BOT_REQUIRE(b_layout == 0 || (b_layout == 1 && mode == 0 && k % 64 == 0), -1,
                 "gemm_halves3_nt2: b_layout 1 (fragment-major B, bot_halves_split_frag_f16 with piece = k) needs mode 0 and k a multiple of 64");
     BOT_REQUIRE(scale_a2 == nullptr || (k_split > 0 && k_split < k && k_split % BK == 0), -1,
@@ -1083,11 +1230,20 @@ extern "C" int bot_gemm_halves3_nt2_f32(int64_t m, int64_t n, int64_t k, const f
     p.scale_a2 = scale_a2, p.k2 = scale_a2 ? (int)(k_split / BK) : -1;
     p.b_frag = b_layout;
     p.stats_part = p.stats_minmax = nullptr, p.stats_pivot = nullptr, p.stats_F = 0;
+    p.bnb_x = nullptr, p.bnb_ldx = 0, p.bnb_mean = p.bnb_invstd = p.bnb_w = p.bnb_b = nullptr, p.bnb_relu = 0, p.bnb_p = 0.f, p.bnb_seed = 0;
+    p.bnb_seed_offset = nullptr, p.bnb_part = p.bnb_pmax = nullptr;
     p.mode = mode;
     const bool force_128x64 = (mode & 1024) != 0;            // (tools: both forms in one process)
     mode &= ~1024;
     p.mode = mode;
-    if (mode == 0 && !force_128x64 && nt64_wanted() && (k / BK) % 2 == 0) {      // the 128-byte-line form: an even number of k-steps
+    if (bn) {
+        p.bnb_x = bn->x, p.bnb_ldx = bn->ldx, p.bnb_mean = bn->mean, p.bnb_invstd = bn->invstd, p.bnb_w = bn->weight, p.bnb_b = bn->bias;
+        p.bnb_relu = bn->relu, p.bnb_p = bn->p, p.bnb_seed = bn->seed, p.bnb_seed_offset = bn->seed_offset, p.bnb_part = bn->part, p.bnb_pmax = bn->pmax;
+        p.tiles_m = (int)((m + 255) / 256), p.tiles_n = (int)((n + 255) / 256);
+        set_kernel(b_layout ? "bot::gemm_halves3_nt64_frag_bnb_kernel" : "bot::gemm_halves3_nt64_bnb_kernel");
+        if (b_layout) hipLaunchKernelGGL(gemm_halves3_nt64_frag_bnb_kernel, dim3(((p.tiles_m + 7) / 8) * 8 * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(gemm_halves3_nt64_bnb_kernel, dim3(((p.tiles_m + 7) / 8) * 8 * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
+    } else if (mode == 0 && !force_128x64 && nt64_wanted() && (k / BK) % 2 == 0) {      // the 128-byte-line form: an even number of k-steps
         p.tiles_m = (int)((m + 255) / 256), p.tiles_n = (int)((n + 255) / 256);
         set_kernel(b_layout ? "bot::gemm_halves3_nt64_frag_kernel" : "bot::gemm_halves3_nt64_kernel");
         if (b_layout) hipLaunchKernelGGL(gemm_halves3_nt64_frag_kernel, dim3(((p.tiles_m + 7) / 8) * 8 * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);

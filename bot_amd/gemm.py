@@ -48,10 +48,11 @@ class Halves:
     """fp16 halves of an fp32 matrix [n, F]: `buf` [n, 3 * piece] fp16 (order 2: [n, 2 * piece]), `scale` [2] = (s, 1/s) on the device.
     order 0: left [h1 | h1 | 2^11 h2]; 1: right [h1 | h2 | 2^-11 h1]; 2: left without the duplicate, [h1 | 2^11 h2]; 3: right, FRAGMENT-MAJOR
     (bot_halves_split_frag_f16: `buf` is [2 ceil(n / 16) piece / 32, 512], read by the hand-written NT kernel only)."""
-    __slots__ = ("buf", "scale", "n", "F", "piece", "order")
+    __slots__ = ("buf", "scale", "n", "F", "piece", "order", "bn_link")
 
     def __init__(self, buf, scale, n, F, piece, order):
         self.buf, self.scale, self.n, self.F, self.piece, self.order = buf, scale, n, F, piece, order
+        self.bn_link = None      # BnLink: the halves were written by a fused BatchNorm epilogue whose backward wants its reduce pass as a by-product
 
     @property
     def left(self):
@@ -61,6 +62,46 @@ class Halves:
     def h2_off(self):
         """column of the second half (2^11 h2) of a left operand"""
         return self.piece if self.order == 2 else 2 * self.piece
+
+
+# The reduce pass of a fused BatchNorm / ReLU / dropout epilogue's backward (1 GB read per hidden layer at config 2) as a by-product of the
+# product that WRITES that backward's incoming gradient - the consumer layer's `d h = d out . W^T` (include/bot_gnn.h "v18").  The epilogue
+# hangs a BnLink on the halves it writes; the consumer keeps it with its context, passes it to `mm_nt` in its backward, and the epilogue's
+# backward claims the partials if the gradient it receives IS that product's output (same storage, same version, same shape: a gradient
+# autograd accumulated from several consumers is another tensor, or a bumped version, and takes the pass).
+BN_BYPRODUCT = os.environ.get("BOT_BN_BWD_BYPRODUCT", "1") != "0"
+BN_BYPRODUCT_CALLS = 0
+
+
+class BnLink:
+    __slots__ = ("x", "mean", "invstd", "w", "b", "p", "seed", "stats", "key")
+
+    def __init__(self, x, mean, invstd, w, b, p, seed):
+        self.x, self.mean, self.invstd, self.w, self.b, self.p, self.seed = x, mean, invstd, w, b, p, seed
+        self.stats = self.key = None
+
+    def stats_for(self, m, n, k):
+        """A by-product request for the product [m, n] of piece width k, None when it cannot carry one."""
+        if not BN_BYPRODUCT or self.x is None:
+            return None
+        st = _C.BnBwdStats(self.x, self.mean, self.invstd, self.w, self.b, True, self.p, self.seed)
+        return st if st.fits(m, n, k) else None
+
+    def deliver(self, st, dh):
+        self.stats, self.key = st, (dh.data_ptr(), dh._version, tuple(dh.shape), tuple(dh.stride()))
+
+    def claim(self, dy):
+        """The delivered partials if `dy` is the tensor they were computed from (one use), else None."""
+        st, key = self.stats, self.key
+        self.stats = self.key = None
+        if st is not None and key == (dy.data_ptr(), dy._version, tuple(dy.shape), tuple(dy.stride())):
+            global BN_BYPRODUCT_CALLS
+            BN_BYPRODUCT_CALLS += 1
+            return st
+        return None
+
+    def drop(self):
+        self.x = self.mean = self.invstd = self.w = self.b = self.stats = self.key = None
 
 
 def left_order(piece: int) -> int:
@@ -180,11 +221,15 @@ def _alpha(a: Halves, b: Halves, n=None):
     return torch.mul(a.scale[1:].expand(n), b.scale[1:].expand(n))
 
 
-def mm_nt(a: Halves, b: Halves, out=None):
-    """a [n, F] (order 0) times b [p, F]^T (order 1) -> fp32 [n, p]."""
+def mm_nt(a: Halves, b: Halves, out=None, link: BnLink | None = None):
+    """a [n, F] (order 0) times b [p, F]^T (order 1) -> fp32 [n, p].  link: the result is the gradient arriving at that epilogue (BnLink)."""
     assert a.left and b.order in (1, 3) and a.F == b.F and a.piece == b.piece
     if NT_KERNEL == "halves3" and (b.order == 3 or b.n >= NT_MIN_COLS or a.order == 2):      # (an operand without the duplicate piece, or a fragment-major one, has no library form)
-        return _C.gemm_halves3_nt(a.buf, b.buf, a.scale, b.scale, a.piece, b.piece, a.piece, out=out, a2_off=a.h2_off, b_frag=b.order == 3, n=b.n)
+        st = link.stats_for(a.n, b.n, a.piece) if (link is not None and out is None) else None
+        res = _C.gemm_halves3_nt(a.buf, b.buf, a.scale, b.scale, a.piece, b.piece, a.piece, out=out, a2_off=a.h2_off, b_frag=b.order == 3, n=b.n, bn=st)
+        if st is not None:
+            link.deliver(st, res)
+        return res
     assert a.order == 0 and b.order == 1
     return _C.gemm_halves(a.buf, b.buf, _alpha(a, b, b.n), trans_b=True, out=out)
 
@@ -248,7 +293,7 @@ class _Matmul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, kp):
         xh = take(x, 0)
-        ctx.kp, ctx.meta = kp, (xh.n, xh.F, xh.piece, xh.order)
+        ctx.kp, ctx.meta, ctx.bn_link = kp, (xh.n, xh.F, xh.piece, xh.order), xh.bn_link
         ctx.save_for_backward(xh.buf, xh.scale, w)
         return mm_nt(xh, split_right(w.t().contiguous() if kp else w))
 
@@ -257,7 +302,7 @@ class _Matmul(torch.autograd.Function):
         buf, scale, w = ctx.saved_tensors
         kp = ctx.kp
         dh = split(dy.contiguous(), 0)
-        dx = mm_nt(dh, split_right(w if kp else w.t().contiguous())) if ctx.needs_input_grad[0] else None
+        dx = mm_nt(dh, split_right(w if kp else w.t().contiguous()), link=ctx.bn_link) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             dw = tn(Halves(buf, scale, *ctx.meta), dh)               # [K, P]
@@ -274,7 +319,7 @@ class _MergedLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, sizes):
         xh = take(x, 0)
-        ctx.sizes, ctx.meta = sizes, (xh.n, xh.F, xh.piece, xh.order)
+        ctx.sizes, ctx.meta, ctx.bn_link = sizes, (xh.n, xh.F, xh.piece, xh.order), xh.bn_link
         ctx.save_for_backward(xh.buf, xh.scale, w)
         y = mm_nt(xh, split_right(w))
         return tuple(torch.split(y, sizes, dim=1))
@@ -304,7 +349,7 @@ class _MergedLinear(torch.autograd.Function):
                 _C.halves_split_cols(g, dscale, order, dbuf, piece, off, width)
             off += wd
         dh = Halves(dbuf, dscale, n, P, piece, order)
-        dx = mm_nt(dh, split_right(w.t().contiguous())) if ctx.needs_input_grad[0] else None
+        dx = mm_nt(dh, split_right(w.t().contiguous()), link=ctx.bn_link) if ctx.needs_input_grad[0] else None
         dw = tn(Halves(buf, scale, *ctx.meta), dh).t().contiguous() if ctx.needs_input_grad[1] else None
         return dx, dw, None
 

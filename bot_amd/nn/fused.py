@@ -201,11 +201,35 @@ def _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed=True, par
                 global HANDLES
                 HANDLES += 1
                 y = gemm.make_handle(x, x.shape[0], HD)
-            gemm.stash(y, gemm.Halves(buf, hscale, x.shape[0], HD, piece, order))
-            return y, mean, invstd, total, sync, group, seed
+            hv = gemm.Halves(buf, hscale, x.shape[0], HD, piece, order)
+            # the consumer's backward can deliver this epilogue's reduce pass with the gradient it sends back (gemm.BnLink)
+            hv.bn_link = link = gemm.BnLink(x, mean, invstd, bn_w, bn_b, drop_p, seed) if gemm.BN_BYPRODUCT else None
+            gemm.stash(y, hv)
+            return y, mean, invstd, total, sync, group, seed, link
     else:
         mean, invstd, total, sync, group = bn_batch_stats(x, bn, bn_training)
-    return _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed), mean, invstd, total, sync, group, seed
+    return _C.bn_act_fwd(x, mean, invstd, bn_w, bn_b, True, drop_p, seed), mean, invstd, total, sync, group, seed, None
+
+
+def _bwd_reduce(ctx, dy, x, mean, invstd, bn_w, bn_b, drop_p, seed, want_max=False):
+    """(sum_g, sum_gx, maxima) of the epilogue's backward: from the partials the consumer layer's `d h` product delivered with `dy`
+    (gemm.BnLink, include/bot_gnn.h "v18") when there are any for exactly this tensor, else by the reduce pass.  maxima: what `_bwd_bound`
+    reads (None unless want_max or delivered)."""
+    link = getattr(ctx, "out_link", None)
+    st = link.claim(dy) if link is not None else None
+    if st is not None:
+        sg, sgx = st.sums()
+        return sg, sgx, st
+    if want_max:
+        return _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, want_max=True)
+    sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
+    return sg, sgx, None
+
+
+def _bwd_bound(mx, n, sg, sgx, total, bn_w, invstd, slots):
+    if isinstance(mx, _C.BnBwdStats):
+        return mx.bound(sg, sgx, total, slots)
+    return _C.bn_bwd_bound(mx, n, sg, sgx, total, bn_w, invstd, slots)
 
 
 # A hidden layer's gradient operand without a split pass (ABI 17, include/bot_gnn.h "v17"): the BatchNorm backward and the transposed sweep
@@ -250,6 +274,8 @@ class _GATHidden(torch.autograd.Function):
         else:
             out = torch.mm(h, Wcat) if kp else torch.mm(h, Wcat.t())    # [N, P] = [ft | res | el | er | pad]
         ctx.halves = None if xh is None else (xh.n, xh.F, xh.piece, xh.order)
+        ctx.bn_link = None if xh is None else xh.bn_link                # the epilogue that wrote h (its backward's reduce pass rides on `d h`)
+        ctx.out_link = None
         B = block_width(HD)                                             # [ft (HD) pad -> B | res (HD) pad -> B | el | er | pad]
         c = 2 * B if has_res else B
         ext = None
@@ -281,7 +307,7 @@ class _GATHidden(torch.autograd.Function):
                 ctx.save_for_backward(*keep)
                 ctx.cfg = (H, D, has_res, has_er, slope, None)
                 return x
-            y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed)
+            y, mean, invstd, total, sync, group, seed, ctx.out_link = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed)
             ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
             ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
             return y
@@ -320,7 +346,7 @@ class _GATHidden(torch.autograd.Function):
             ctx.save_for_backward(*keep)
             ctx.cfg = (H, D, has_res, has_er, slope, None)
             return x
-        y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed)
+        y, mean, invstd, total, sync, group, seed, ctx.out_link = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed)
         ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
         ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
         return y
@@ -358,7 +384,7 @@ class _GATHidden(torch.autograd.Function):
         if epi is None:
             dx.copy_(dy)
         else:
-            sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
+            sg, sgx, _ = _bwd_reduce(ctx, dy, x, mean, invstd, bn_w, bn_b, drop_p, seed)
             d_bn_w, d_bn_b = sgx, sg                                     # local sums (ranks' parameter grads are summed later)
             if bn_training and sync:
                 both = torch.stack([sg, sgx])
@@ -435,7 +461,7 @@ class _GATHidden(torch.autograd.Function):
             else:
                 dh_ = gemm.split(dout, 0)
             if ctx.needs_input_grad[0]:
-                dh = gemm.mm_nt(dh_, gemm.split_right(Wcat if kp else Wcat.t().contiguous()))
+                dh = gemm.mm_nt(dh_, gemm.split_right(Wcat if kp else Wcat.t().contiguous()), link=ctx.bn_link)
             if ctx.needs_input_grad[1]:
                 def wgrad():
                     dW = gemm.tn(xh, dh_)                                # [K, P]
@@ -469,10 +495,10 @@ def _backward_direct(ctx, dy, g, h, Wcat, table, el, er, a, a_d, x, mean, invstd
     if not _C.spmm_dot_halves_fits(dx.unflatten(1, (H, D)), ft, buf, D, piece):
         return None
     DOUT_DIRECT_CALLS += 1
-    sg, sgx, ws = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, want_max=True)
+    sg, sgx, ws = _bwd_reduce(ctx, dy, x, mean, invstd, bn_w, bn_b, drop_p, seed, want_max=True)
     d_bn_w, d_bn_b = sgx, sg
     slots = _C.absmax_slots(dy.device)
-    _C.bn_bwd_bound(ws, N, sg if bn_training else None, sgx if bn_training else None, total, bn_w, invstd, slots)
+    _bwd_bound(ws, N, sg if bn_training else None, sgx if bn_training else None, total, bn_w, invstd, slots)
     # one scale for both big blocks: |d res| <= the BatchNorm bound, |d ft[u]| <= (row sum of the edge weights out of u) x that bound
     s1 = _C.halves_scale_from_slots(slots, mult=rowsum_bound(g, ctx.adrop[0] if ctx.adrop else 0.0))
     _C.bn_act_bwd_apply_halves(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None, sgx if bn_training else None, total,
@@ -496,7 +522,11 @@ def _backward_direct(ctx, dy, g, h, Wcat, table, el, er, a, a_d, x, mean, invstd
     xh = gemm.Halves(h, ctx.xscale, *ctx.halves)
     if ctx.needs_input_grad[0]:
         Ws = gemm.split_right(Wcat if kp else Wcat.t().contiguous())
-        dh = _C.gemm_halves3_nt(buf, Ws.buf, s1, Ws.scale, piece, Ws.piece, piece, a2_off=piece, scale_a2=s2, k_split=c, b_frag=Ws.order == 3, n=Ws.n)
+        link = ctx.bn_link
+        st = link.stats_for(N, Ws.n, piece) if link is not None else None
+        dh = _C.gemm_halves3_nt(buf, Ws.buf, s1, Ws.scale, piece, Ws.piece, piece, a2_off=piece, scale_a2=s2, k_split=c, b_frag=Ws.order == 3, n=Ws.n, bn=st)
+        if st is not None:
+            link.deliver(st, dh)
     if ctx.needs_input_grad[1]:
         def wgrad():
             dWk = _C.gemm_halves3_tn(xh.buf, buf, xh.scale, s1, xh.piece, piece, xh.F, P, x2_off=xh.h2_off, d2_off=piece, scale_d2=s2, p_split=c)
@@ -697,7 +727,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
                 ctx.save_for_backward(*keep)
                 ctx.cfg = (H, D, has_res, has_er, slope, None)
                 return x
-            y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed, partials=partials)
+            y, mean, invstd, total, sync, group, seed, ctx.out_link = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed, partials=partials)
             ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
             ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
             return y
@@ -727,7 +757,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             ctx.save_for_backward(*keep)
             ctx.cfg = (H, D, has_res, has_er, slope, None)
             return x
-        y, mean, invstd, total, sync, group, seed = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed)
+        y, mean, invstd, total, sync, group, seed, ctx.out_link = _epilogue_forward(x, bn, bn_w, bn_b, bn_training, drop_p, y_needed)
         ctx.save_for_backward(*keep, x, mean, invstd, bn_w, bn_b)
         ctx.cfg = (H, D, has_res, has_er, slope, (drop_p, seed, bn_training, sync, group, total))
         return y
@@ -758,10 +788,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         if epi is None:
             dx.copy_(dy)
         else:
-            if direct:
-                sg, sgx, ws = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, want_max=True)
-            else:
-                sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed)
+            sg, sgx, ws = _bwd_reduce(ctx, dy, x, mean, invstd, bn_w, bn_b, drop_p, seed, want_max=direct)
             d_bn_w, d_bn_b = sgx, sg
             if bn_training and sync:
                 both = torch.stack([sg, sgx])
@@ -770,7 +797,7 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             if direct:
                 # a bound on max|dx| from the reduce pass's column maxima and the final sums -> the operand's scale -> dx written as halves
                 DP = (D + 63) // 64 * 64
-                _C.bn_bwd_bound(ws, N, sg if bn_training else None, sgx if bn_training else None, total, bn_w, invstd, slots)
+                _bwd_bound(ws, N, sg if bn_training else None, sgx if bn_training else None, total, bn_w, invstd, slots)
                 dscale = _C.halves_scale_from_slots(slots)
                 Dh = _C.bn_act_bwd_apply_halves(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
                                                 sgx if bn_training else None, total, dscale, _l0_dh(dy.device, N, H, D, DP), D, DP)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 17
+#define BOT_ABI_VERSION 18
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -568,6 +568,40 @@ int bot_spmm_dot_halves_f16(const int32_t* indptr, const int32_t* indices, int64
 int bot_gemm_halves3_nt2_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_a2, int64_t k_split, const float* scale_b,
                              const uint16_t* A, int64_t lda, int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, int32_t b_layout, float* C,
                              int64_t ldc, int32_t mode, bot_stream_t stream);
+/* v18: the reduce pass of a fused BatchNorm / ReLU / dropout epilogue's backward (bot_bn_act_bwd_reduce_f32: 1 GB read per hidden layer at
+ * config 2) as a BY-PRODUCT of the NT product that writes that epilogue's incoming gradient (bot_amd/nn/fused.py: the next layer's
+ * `d h = d out . W^T`, backward of src/no-sampling/models.py:490-492 feeding the backward of :726-731).  With C = dy [m, n] and the
+ * epilogue's input x [m, n] (n = the BatchNorm width F), the tile epilogue of bot_gemm_halves3_nt3_f32 forms, per stored element,
+ *     g = dy * dropout_factor(seed, r, c) * [relu: weight_c xhat + bias_c > 0],   xhat = (x - mean_c) invstd_c
+ * and leaves per 256-row tile t the partials  part[(2 t + 0) n + c] = sum_r g,  part[(2 t + 1) n + c] = sum_r g xhat  and (pmax != NULL)
+ * pmax[(2 t + 0) n + c] = max_r |g|,  pmax[(2 t + 1) n + c] = max_r |xhat|  - the workspace layout of the reduce pass with one row block per
+ * tile: ceil(m / 256) blocks (bot_gemm_halves3_nt_bn_rows(k): 256 when the product of piece width k takes this form - k a multiple of 64,
+ * BOT_NT_KERNEL not 128x64 - else 0: the caller keeps the pass).  Finished by
+ *   bot_bn_act_bwd_reduce_partials_f32  sum_g / sum_gx [F] from `part` (blocks added in order, in double: deterministic)
+ *   bot_bn_bwd_bound_partials_f32       bot_bn_bwd_bound_f32 from `pmax`
+ * The mask is the Philox function of (seed, r, c) the forward used (a quad of output columns = a quad of the mask).  x rows: 8-byte aligned,
+ * pitch ldx >= n even; n even.  bn == NULL: bot_gemm_halves3_nt2_f32. */
+typedef struct bot_bn_bwd_stats {
+    const float* x;              /* [m, n] the epilogue's input (pre-BatchNorm), row pitch ldx */
+    int64_t ldx;
+    const float* mean;           /* [n] */
+    const float* invstd;         /* [n] */
+    const float* weight;         /* [n] or NULL (1) */
+    const float* bias;           /* [n] or NULL (0) */
+    int32_t relu;
+    float p;                     /* dropout probability of the epilogue, 0: none */
+    uint64_t seed;
+    const uint64_t* seed_offset; /* optional device word mixed into the seed (hipGraph replays), as in bot_bn_act_fwd_f32 */
+    float* part;                 /* [ceil(m / 256)][2][n] */
+    float* pmax;                 /* [ceil(m / 256)][2][n] or NULL */
+} bot_bn_bwd_stats_t;
+int32_t bot_gemm_halves3_nt_bn_rows(int64_t k);
+int bot_gemm_halves3_nt3_f32(int64_t m, int64_t n, int64_t k, const float* scale_a, const float* scale_a2, int64_t k_split, const float* scale_b,
+                             const uint16_t* A, int64_t lda, int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, int32_t b_layout, float* C,
+                             int64_t ldc, const bot_bn_bwd_stats_t* bn, int32_t mode, bot_stream_t stream);
+int bot_bn_act_bwd_reduce_partials_f32(const float* part, int32_t nblk, int32_t F, float* sum_g, float* sum_gx, bot_stream_t stream);
+int bot_bn_bwd_bound_partials_f32(int32_t F, const float* pmax, int32_t nblk, const float* sum_g, const float* sum_gx, double total_count,
+                                  const float* weight, const float* invstd, uint32_t* absmax_slots, bot_stream_t stream);
 /* v17: a RIGHT operand in FRAGMENT-MAJOR layout (b_layout = 1 of bot_gemm_halves3_nt2_f32; ldb / b2_off unused): the 16 bytes lane l of an
  * MFMA fragment holds - row 16 t + (l & 15), columns 32 s + 8 (l >> 4) .. + 7 - at halves ((t T + s) 64 + l) 8, T = piece / 32, h1 in the
  * first region, h2 ceil(n / 16) T 512 halves behind it: the 64 lanes of a fragment load read one contiguous KB (the NT kernel pays for the

@@ -410,7 +410,38 @@ def _unfrag(buf, n, piece):
     return torch.cat([rows(buf[:tiles * T]), rows(buf[tiles * T:])], dim=1)
 
 
-def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0, b_frag=False, n=None):
+class BnBwdStats:
+    """bot_amd._C.BnBwdStats / include/bot_gnn.h bot_bn_bwd_stats_t: the reduce pass of an epilogue's backward as a by-product of the NT product
+    that writes its incoming gradient - partials per 256-row tile, finished in tile order."""
+
+    def __init__(self, x, mean, invstd, weight, bias, relu, p, seed, want_max=True):
+        self.x, self.mean, self.invstd, self.weight, self.bias, self.relu, self.p, self.seed = x, mean, invstd, weight, bias, relu, p, seed
+        self.n, self.F = x.shape
+        self.nblk = (self.n + 255) // 256
+        self.part = torch.zeros((self.nblk, 2, self.F))
+        self.pmax = torch.zeros((self.nblk, 2, self.F)) if want_max else None
+
+    def fits(self, m, n, k):
+        return m == self.n and n == self.F and self.F % 2 == 0 and k % 64 == 0
+
+    def fill(self, dy):
+        xh, o = _bn_gate(self.x, self.mean, self.invstd, self.weight, self.bias, self.relu, self.p)
+        g = torch.where(o > 0, dy, torch.zeros_like(dy)) if self.relu else dy
+        for t in range(self.nblk):
+            r = slice(256 * t, min(256 * (t + 1), self.n))
+            self.part[t, 0], self.part[t, 1] = g[r].sum(0), (g[r] * xh[r]).sum(0)
+            if self.pmax is not None:
+                self.pmax[t, 0], self.pmax[t, 1] = g[r].abs().max(0).values, xh[r].abs().max(0).values
+
+    def sums(self):
+        s = self.part.double().sum(0)
+        return s[0].float(), s[1].float()
+
+    def bound(self, sum_g, sum_gx, total_count, slots):
+        return bn_bwd_bound(self.pmax.max(0).values, self.n, sum_g, sum_gx, total_count, self.weight, self.invstd, slots)
+
+
+def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0, b_frag=False, n=None, bn=None):
     """include/bot_gnn.h bot_gemm_halves3_nt_f32 / _nt2_f32: a1 b1^T + a1 b2^T + (2^11 a2) (2^-11 b1)^T from a LEFT and a RIGHT operand buffer;
     scale_a2: a's columns from k_split on carry a second scale (the accumulators are rescaled by the ratio in front of them)."""
     a2_off = 2 * piece_a if a2_off is None else a2_off
@@ -426,6 +457,9 @@ def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=
         res = part(0, k) * (scale_a[1] * scale_b[1])
     else:
         res = (part(0, k_split) * (scale_a2[0] * scale_a[1]) + part(k_split, k)) * (scale_a2[1] * scale_b[1])
+    if bn is not None:
+        assert bn.fits(res.shape[0], res.shape[1], k)
+        bn.fill(res)
     if out is None:
         return res
     out.copy_(res)
@@ -654,7 +688,7 @@ def random_keep(n, n_keep, seed, device):
     return keep.to(device)
 
 
-NAMES = ["bn_stats_halves_partials", "halves_split_frag", "halves_tail", "spmm_dot_halves", "spmm_dot_halves_fits", "gemm_halves3_tn", "bn_bwd_bound", "bn_act_bwd_apply_halves", "halves_split_heads", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
+NAMES = ["BnBwdStats", "bn_stats_halves_partials", "halves_split_frag", "halves_tail", "spmm_dot_halves", "spmm_dot_halves_fits", "gemm_halves3_tn", "bn_bwd_bound", "bn_act_bwd_apply_halves", "halves_split_heads", "gemm_halves3_nt_grouped", "gemm_halves3_tn_grouped", "spmm_bcast_halves", "label_split", "build_input", "node_loss", "rmsprop_step", "gemm_halves3_nt", "halves_split_cols", "halves_tn_combine", "absmax_slots", "absmax_into", "halves_scale_from_slots", "halves_scale", "halves_split", "gemm_halves", "bn_stats_halves", "colsum", "bn_stats", "sddmm_dot_bcast", "gat_infer", "random_keep", "spmm_bcast", "spmm_dot_bcast", "edge_mlp_supported", "edge_mlp_fwd", "edge_mlp_bwd", "spmm_dot", "spmm_dot_max_d", "colstats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply", "degrees", "spmm", "sddmm_dot", "u_add_v", "gat_attn_fwd", "gat_attn_bwd", "segment_sum", "gather_rows",
          "scatter_add_rows"]
 
 

@@ -569,6 +569,55 @@ def check_dout_direct_against_oracle(golden, device):
         fused.FORCE, gemm.FORCE = force, gforce
 
 
+def check_bn_bwd_byproduct_against_oracle(golden, device, drop=0.0):
+    """ABI 18: the reduce pass of a hidden layer's BatchNorm / ReLU / dropout backward delivered by the NEXT layer's `d h` product
+    (bot_gemm_halves3_nt3_f32, bot_amd.gemm.BnLink) - every gradient against the oracle with the by-product on and off, the on runs bit
+    for bit, both hidden layers of the 3-layer stack claim their partials (3 heads x 64: 192 output columns, the hand-written NT form).
+    drop > 0 (GPU only: the CPU emulation has no Philox stream): on vs off under the same seeds, i.e. the same masks."""
+    from bot_amd import gemm
+    from bot_amd.nn import fused
+    s, d, n = golden.graph("g300")
+    g = bot_amd.Graph(s, d, n, chunk=8).to(device)
+    fin, C = 24, 5
+    force, gforce, on0 = fused.FORCE, gemm.FORCE, gemm.BN_BYPRODUCT
+    gemm.FORCE = True
+    try:
+        cfg = dict(n_layers=3, n_heads=3, n_hidden=64, norm="batch", non_interactive_attn=False, use_symmetric_norm=False, linear=True, residual=False)
+        torch.manual_seed(23)
+        model = bnn.GAT(dim_node=fin, dim_edge=0, dim_output=C, activation=F.relu, dropout=drop, **cfg).train()
+        gen = torch.Generator().manual_seed(24)
+        feat, gout = torch.randn(n, fin, generator=gen), torch.randn(n, C, generator=gen) * 11.0
+        names = ref_grads = ref = None
+        if drop == 0.0:
+            sd = {k: v.clone() for k, v in model.state_dict().items()}
+            p = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+            ref = RM.gat_forward(RM.CooGraph(s, d, n), feat, p, n_classes=C, training=True, **cfg)
+            names = [k for k, v in p.items() if v.requires_grad]
+            ref_grads = torch.autograd.grad((ref * gout).sum(), [p[k] for k in names])
+        model = model.to(device)
+        runs = []
+        for on in (True, True, False):
+            gemm.BN_BYPRODUCT = on
+            c0 = gemm.BN_BYPRODUCT_CALLS
+            model.zero_grad(set_to_none=True)
+            torch.manual_seed(99)                                   # the dropout seeds of the step
+            logits = model(g, feat.to(device))
+            (logits * gout.to(device)).sum().backward()
+            assert gemm.BN_BYPRODUCT_CALLS - c0 == (2 if on else 0), "both hidden layers' reduce passes ride on the next layer's product, or none"
+            got = dict(model.named_parameters())
+            if ref is not None:
+                fwd_close(logits, ref.detach().numpy())
+                for k, rg in zip(names, ref_grads):
+                    grad_close(got[k].grad, rg.numpy())
+            runs.append({k: v.grad.detach().clone() for k, v in got.items()})
+        for k in runs[0]:
+            assert torch.equal(runs[0][k], runs[1][k]), k              # bitwise run to run
+            grad_close(runs[0][k], runs[2][k].cpu().numpy())           # by-product vs pass: the same sums in another order
+    finally:
+        gemm.BN_BYPRODUCT = on0
+        fused.FORCE, gemm.FORCE = force, gforce
+
+
 def check_keep_mask_orders(golden, device):
     """A keep mask given in CSC position order (what the layers do with their own random draw) equals the same mask given in
     edge-id order, with and without CSC-ordered edge logits."""

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in bot_gnn.h but not exported"
     assert set(syms) == set(_C.EXPORTED)  # the binding covers the whole header
-    assert lib.bot_abi_version() == 17
+    assert lib.bot_abi_version() == 18
 
 
 def test_argument_validation_without_gpu():

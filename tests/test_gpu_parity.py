@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 17
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 18
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
@@ -499,6 +499,68 @@ def test_agg_first_against_oracle(golden, l0_halves):
 
 def test_dout_direct_against_oracle(golden):
     PC.check_dout_direct_against_oracle(golden, DEV)
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.5])
+def test_bn_bwd_byproduct_against_oracle(golden, drop):
+    PC.check_bn_bwd_byproduct_against_oracle(golden, DEV, drop=drop)
+
+
+def test_abi18_bn_bwd_partials_from_the_nt_product():
+    """bot_gemm_halves3_nt3_f32: the BatchNorm-backward reduce pass as a by-product of the product that writes dy.  Against the pass over the
+    same dy (bot_bn_act_bwd_reduce_max_f32): the column maxima of |g| and |xhat| (through the bound) exactly, the sums to fp32 summation
+    noise; dy itself bit for bit the product without the by-product; with and without dropout (the forward's Philox mask of (seed, r, c)) /
+    ReLU / affine, rows of 750 floats at pitch 750 (8-byte quads) and 752, ragged m, row-major and fragment-major weights, two scales."""
+    from bot_amd import gemm
+    gen = torch.Generator(device=DEV).manual_seed(51)
+    for (m, K, F, ldx, p, relu, affine) in ((1000, 96, 300, 300, 0.0, True, True), (5000, 1536, 750, 752, 0.75, True, True),
+                                            (4099, 128, 750, 750, 0.5, True, False), (257, 64, 192, 192, 0.0, False, True),
+                                            (20000, 1536, 750, 752, 0.75, True, True)):
+        d = torch.randn(m, K, device=DEV, generator=gen) * 2
+        w = torch.randn(F, K, device=DEV, generator=gen) * 0.1
+        xbuf = torch.randn(m, ldx, device=DEV, generator=gen)
+        x = xbuf[:, :F]
+        mean, var = x.mean(0), x.var(0, unbiased=False)
+        invstd = (var + 1e-5).rsqrt()
+        bw = torch.randn(F, device=DEV, generator=gen) if affine else None
+        bb = torch.randn(F, device=DEV, generator=gen) * 0.3 if affine else None
+        seed = 123456789
+        ws = gemm.split(w, 1)
+        piece = ws.piece
+        frag = _C.halves_split_frag(w, ws.scale, piece)
+        sc = _C.halves_scale(d)
+        db = _C.halves_split(d, sc, 2, piece)
+        for b_frag in (False, True):
+            for two in (False, True):
+                kw = dict(a2_off=piece, b_frag=b_frag, n=F)
+                if two:
+                    if piece < 128:
+                        continue
+                    kw.update(scale_a2=torch.tensor([float(sc[0]) * 64, float(sc[1]) / 64], device=DEV), k_split=64)
+                B = frag if b_frag else ws.buf
+                plain = _C.gemm_halves3_nt(db, B, sc, ws.scale, piece, piece, piece, **kw)
+                st = _C.BnBwdStats(x, mean, invstd, bw, bb, relu, p, seed)
+                assert st.fits(m, F, piece)
+                dy = _C.gemm_halves3_nt(db, B, sc, ws.scale, piece, piece, piece, bn=st, **kw)
+                assert torch.equal(dy, plain), (m, K, F, b_frag, two)
+                sg, sgx = st.sums()
+                rg, rgx, rws = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bw, bb, relu, p, seed, want_max=True)
+                # (scale: a column's sum of |g| - the two forms add the same terms in different orders)
+                for a, b in ((sg, rg), (sgx, rgx)):
+                    tol = 2e-6 * float(dy.abs().sum(0).max()) * max(1.0, float(((x - mean) * invstd).abs().max()))
+                    assert float((a - b).abs().max()) <= tol, (m, K, F, float((a - b).abs().max()), tol)
+                s1, s2 = _C.absmax_slots(DEV), _C.absmax_slots(DEV)
+                st.bound(sg, sgx, m, s1)
+                _C.bn_bwd_bound(rws, m, sg, sgx, m, bw, invstd, s2)
+                assert torch.equal(s1, s2) or float(_C.halves_scale_from_slots(s1)[0]) == float(_C.halves_scale_from_slots(s2)[0]), (m, K, F)
+                if p > 0:        # the mask really is applied: the sums differ from the unmasked ones
+                    st0 = _C.BnBwdStats(x, mean, invstd, bw, bb, relu, 0.0, seed)
+                    _C.gemm_halves3_nt(db, B, sc, ws.scale, piece, piece, piece, bn=st0, **kw)
+                    assert float((st0.sums()[0] - sg).abs().max()) > 1e-3 * float(sg.abs().max())
+    # a product that cannot carry it is refused loudly (odd width), and the switch-off shape query
+    st = _C.BnBwdStats(torch.randn(300, 33, device=DEV), torch.zeros(33, device=DEV), torch.ones(33, device=DEV), None, None, True, 0.0, 0)
+    assert not st.fits(300, 33, 64)
+    assert _C._lib.bot_gemm_halves3_nt_bn_rows(96) == 0 and _C._lib.bot_gemm_halves3_nt_bn_rows(128) == 256
 
 
 def test_bcast_kernels_direct(golden):

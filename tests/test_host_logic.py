@@ -518,6 +518,12 @@ def test_dout_direct_emulated(golden, cpu_backend, monkeypatch):
     PC.check_dout_direct_against_oracle(golden, "cpu")
 
 
+def test_bn_bwd_byproduct_emulated(golden, cpu_backend, monkeypatch):
+    from bot_amd.nn import fused
+    monkeypatch.setattr(fused, "FORCE", True)
+    PC.check_bn_bwd_byproduct_against_oracle(golden, "cpu")
+
+
 def test_hbm_budget_estimates():
     """bot_amd.workloads.hbm_budget (what bench.py prints, and refuses on, before allocating): at or above the measured single-GPU peaks
     of profiles/r05_hbm_peak.txt and within 1.5x of them, every config fits one 288 GB GPU, the step term shrinks with the world size."""
