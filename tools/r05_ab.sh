@@ -1,0 +1,18 @@
+#!/bin/bash
+# Alternating step A/B of one environment switch on one box:  gpurun -- 'bash tools/r05_ab.sh BOT_GRAD_PITCH [a b [rounds]]'  -> gpurun_out/r05ab/<switch>.txt
+cd "$GRAFT_REPO_ROOT" || exit 1
+V=$1; A=${2:-0}; B=${3:-1}; R=${4:-3}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r05ab
+mkdir -p $OUT
+echo "# $V A/B, one box, alternating; bench.py --steps 30 --warmup 5 --cpu-baseline off; ms per step" > $OUT/$V.txt
+for r in $(seq $R); do
+  for k in $A $B; do
+    env $V=$k python bench.py --steps 30 --warmup 5 --cpu-baseline off > /tmp/b.log 2>&1
+    python - "$V" "$k" >> $OUT/$V.txt <<'P'
+import json, sys
+d = json.loads(open('/tmp/b.log').read().strip().splitlines()[-1])
+print(f"{sys.argv[1]}={sys.argv[2]} {d['ms_per_step']:.3f} ms/step")
+P
+  done
+done
+cat $OUT/$V.txt
