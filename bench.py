@@ -353,12 +353,14 @@ def main():
         # pair around one measures the shared interval, not the kernel - the timed region above keeps the side stream)
         from bot_amd import side
         side_was, side.ENABLED = side.ENABLED, False
+        # (and without the BatchNorm-backward by-product, ABI 18: with it two of the launches also do a reduce pass's work in their epilogue)
+        bnb_was, gemm.BN_BYPRODUCT = gemm.BN_BYPRODUCT, False
         _C.PROFILE = gprof
         for _ in range(gsteps):
             wl.step()
         torch.cuda.synchronize()
         _C.PROFILE = None
-        side.ENABLED = side_was
+        side.ENABLED, gemm.BN_BYPRODUCT = side_was, bnb_was
         gprof = [r for r in gprof if r[0] == "gemm_halves"]
     # "t_step ... optimizer excluded and reported separately".  `value` keeps the optimizer INSIDE (the conservative
     # number); three more steps with HIP events around optimizer.step() on its stream (torch's current stream) give its share
@@ -484,7 +486,7 @@ def main():
                 g_by += by
                 hbm_bound += 1 if th > tm else 0
             roof["dense_projections"] = {"bound": "mfma", "what": "the halves-GEMM launches (bot_gemm_halves3_nt_f32 / _tn_f32 and their grouped forms: hand-written NT / TN products; bot_gemm_halves_f32, "
-                                                 "hipBLASLt fp16 -> fp32, where a shape is left to it: none in config 2) of three more steps after the timed region (HIP events; weight-gradient products inline for these steps, not on the side stream); flops = "
+                                                 "hipBLASLt fp16 -> fp32, where a shape is left to it: none in config 2) of three more steps after the timed region (HIP events; weight-gradient products inline for these steps, not on the side stream, and the input-gradient products without the BatchNorm-backward by-product in their epilogue); flops = "
                                                  "fp16 MFMA flops of the valid output columns, three products per fp32 product",
                                          "launches_per_step": len(gs) / gsteps, "ms_per_step": round(g_ms / gsteps, 3),
                                          "achieved": round(g_fl / g_ms / 1e9, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
