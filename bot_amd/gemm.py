@@ -124,16 +124,18 @@ def split(x, order: int, scale=None) -> Halves:
 RIGHT_FRAG = os.environ.get("BOT_RIGHT_FRAG", "1") != "0" and os.environ.get("BOT_NT_KERNEL", "") != "128x64"
 
 
-def split_right(w) -> Halves:
+def split_right(w, scale=None) -> Halves:
     """The right operand of `mm_nt` for a weight w [p, F]: fragment-major (order 3) when the product will run on the hand-written NT kernel
     (the same predicate `mm_nt` routes by, evaluated from w's shape: p >= NT_MIN_COLS or a left operand of this width has no duplicate
     piece), else the row-major order 1 the library formulation reads."""
     p, F = w.shape
     piece = (F + PIECE_ALIGN - 1) // PIECE_ALIGN * PIECE_ALIGN
+    # scale: the (s, 1/s) pair of a matrix with the same entries (the forward split this weight's transpose: its maximum is this one's)
     if RIGHT_FRAG and NT_KERNEL == "halves3" and (w.is_cuda or FORCE) and (p >= NT_MIN_COLS or left_order(piece) == 2):
-        scale = _C.halves_scale(w)
+        if scale is None:
+            scale = _C.halves_scale(w)
         return Halves(_C.halves_split_frag(w, scale, piece), scale, p, F, piece, 3)
-    return split(w, 1)
+    return split(w, 1, scale=scale)
 
 
 _STASH = {}
@@ -295,14 +297,16 @@ class _Matmul(torch.autograd.Function):
         xh = take(x, 0)
         ctx.kp, ctx.meta, ctx.bn_link = kp, (xh.n, xh.F, xh.piece, xh.order), xh.bn_link
         ctx.save_for_backward(xh.buf, xh.scale, w)
-        return mm_nt(xh, split_right(w.t().contiguous() if kp else w))
+        ws = split_right(w.t().contiguous() if kp else w)
+        ctx.wscale = ws.scale
+        return mm_nt(xh, ws)
 
     @staticmethod
     def backward(ctx, dy):
         buf, scale, w = ctx.saved_tensors
         kp = ctx.kp
         dh = split(dy.contiguous(), 0)
-        dx = mm_nt(dh, split_right(w if kp else w.t().contiguous()), link=ctx.bn_link) if ctx.needs_input_grad[0] else None
+        dx = mm_nt(dh, split_right(w if kp else w.t().contiguous(), scale=ctx.wscale), link=ctx.bn_link) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             dw = tn(Halves(buf, scale, *ctx.meta), dh)               # [K, P]
@@ -321,7 +325,9 @@ class _MergedLinear(torch.autograd.Function):
         xh = take(x, 0)
         ctx.sizes, ctx.meta, ctx.bn_link = sizes, (xh.n, xh.F, xh.piece, xh.order), xh.bn_link
         ctx.save_for_backward(xh.buf, xh.scale, w)
-        y = mm_nt(xh, split_right(w))
+        ws = split_right(w)
+        ctx.wscale = ws.scale
+        y = mm_nt(xh, ws)
         return tuple(torch.split(y, sizes, dim=1))
 
     @staticmethod
@@ -349,7 +355,7 @@ class _MergedLinear(torch.autograd.Function):
                 _C.halves_split_cols(g, dscale, order, dbuf, piece, off, width)
             off += wd
         dh = Halves(dbuf, dscale, n, P, piece, order)
-        dx = mm_nt(dh, split_right(w.t().contiguous()), link=ctx.bn_link) if ctx.needs_input_grad[0] else None
+        dx = mm_nt(dh, split_right(w.t().contiguous(), scale=ctx.wscale), link=ctx.bn_link) if ctx.needs_input_grad[0] else None
         dw = tn(Halves(buf, scale, *ctx.meta), dh).t().contiguous() if ctx.needs_input_grad[1] else None
         return dx, dw, None
 

@@ -385,4 +385,5 @@ class GAT(nn.Module):
                     h = _epilogue(h, self.norms[i], self.activation, self.dropout, self.training)
                 else:
                     h = self.dropout(self.activation(self.biases[i](h)))
-        return graph.to_original(self.biases[-1](h.mean(1)))
+        # (one output head: the mean over it is the head itself, bit for bit - a view, not a reduction launch and its backward)
+        return graph.to_original(self.biases[-1](h.view(h.shape[0], -1) if h.shape[1] == 1 else h.mean(1)))

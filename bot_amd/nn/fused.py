@@ -270,7 +270,9 @@ class _GATHidden(torch.autograd.Function):
         xh = None
         if gemm.enabled(h):                                             # fp32 GEMM on the fp16 matrix cores (bot_amd.gemm)
             xh = gemm.take(h, 0)                                        # written by the previous layer's epilogue, or split here
-            out = gemm.mm_nt(xh, gemm.split_right(Wcat.t().contiguous() if kp else Wcat))
+            ws = gemm.split_right(Wcat.t().contiguous() if kp else Wcat)
+            ctx.wscale = ws.scale                                       # the backward splits the transpose: same entries, same scale
+            out = gemm.mm_nt(xh, ws)
         else:
             out = torch.mm(h, Wcat) if kp else torch.mm(h, Wcat.t())    # [N, P] = [ft | res | el | er | pad]
         ctx.halves = None if xh is None else (xh.n, xh.F, xh.piece, xh.order)
@@ -461,7 +463,7 @@ class _GATHidden(torch.autograd.Function):
             else:
                 dh_ = gemm.split(dout, 0)
             if ctx.needs_input_grad[0]:
-                dh = gemm.mm_nt(dh_, gemm.split_right(Wcat if kp else Wcat.t().contiguous()), link=ctx.bn_link)
+                dh = gemm.mm_nt(dh_, gemm.split_right(Wcat if kp else Wcat.t().contiguous(), scale=ctx.wscale), link=ctx.bn_link)
             if ctx.needs_input_grad[1]:
                 def wgrad():
                     dW = gemm.tn(xh, dh_)                                # [K, P]
@@ -521,7 +523,7 @@ def _backward_direct(ctx, dy, g, h, Wcat, table, el, er, a, a_d, x, mean, invstd
     dW = dh = None
     xh = gemm.Halves(h, ctx.xscale, *ctx.halves)
     if ctx.needs_input_grad[0]:
-        Ws = gemm.split_right(Wcat if kp else Wcat.t().contiguous())
+        Ws = gemm.split_right(Wcat if kp else Wcat.t().contiguous(), scale=ctx.wscale)
         link = ctx.bn_link
         st = link.stats_for(N, Ws.n, piece) if link is not None else None
         dh = _C.gemm_halves3_nt(buf, Ws.buf, s1, Ws.scale, piece, Ws.piece, piece, a2_off=piece, scale_a2=s2, k_split=c, b_frag=Ws.order == 3, n=Ws.n, bn=st)
@@ -882,10 +884,8 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             dout2[:, used:].zero_()
         dWr = None
         if l0h:
-            # the attention columns of the merged gradient (a handful, their own magnitude) apart.  fc.weight's gradient has a second
-            # contribution (through the merged weight's attention rows) that autograd ADDS on this stream: joined here - this layer is
-            # the end of the backward pass, nothing is left to run beside the side stream
-            side.join()
+            # the attention columns of the merged gradient (a handful, their own magnitude) apart: other rows / columns of `flat` than the
+            # grouped launch on the side stream writes, so this narrow product runs while that one finishes
             dW = flat[:HD * Fin].view(HD, Fin)
             dWr = flat[HD * Fin:].view((Fin, P2) if kp else (P2, Fin))
             tail = dout2[:, HD:]
@@ -897,6 +897,9 @@ class _GATHiddenAggFirst(torch.autograd.Function):
                 dWr[:, HD:] = h.t() @ tail
             else:
                 dWr[HD:] = tail.t() @ h
+            # fc.weight's gradient has a second contribution (through the merged weight's attention rows) that autograd ADDS on this
+            # stream: joined here - this layer is the end of the backward pass, nothing else is left to run beside the side stream
+            side.join()
             if not ctx.needs_input_grad[1]:
                 dW = None
             if not ctx.needs_input_grad[2]:
