@@ -683,9 +683,25 @@ def halves_scale(x):
     return scale
 
 
+_SLOT_POOL = {}          # device -> [zeroed block [_SLOT_SETS, slots], next free set]
+_SLOT_SETS = 512
+
+
 def absmax_slots(device):
-    """Zeroed words for the producers' max|value| by-products (include/bot_gnn.h "Maxima as by-products")."""
-    return torch.zeros(int(_lib.bot_absmax_slots()), dtype=torch.int32, device=device)
+    """Zeroed words for the producers' max|value| by-products (include/bot_gnn.h "Maxima as by-products").  Handed out from a block zeroed
+    by ONE fill per _SLOT_SETS requests (a set is used once: a fill launch per request was 5.7 us of the step each, seven times a step);
+    a block lives until its last set is dropped.  Inside a hipGraph capture every request is its own captured fill (a replay must find
+    zeros again)."""
+    n = int(_lib.bot_absmax_slots())
+    dev = torch.device(device)
+    if dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        return torch.zeros(n, dtype=torch.int32, device=dev)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ent = _SLOT_POOL.get(key)
+    if ent is None or ent[1] >= _SLOT_SETS:
+        ent = _SLOT_POOL[key] = [torch.zeros((_SLOT_SETS, n), dtype=torch.int32, device=dev), 0]
+    ent[1] += 1
+    return ent[0][ent[1] - 1]
 
 
 def absmax_into(x, slots):
