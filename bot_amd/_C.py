@@ -126,6 +126,7 @@ _SIGS = {
                                                 _P, c_int32, _P]),
     "bot_bn_act_bwd_reduce_partials_f32": (ctypes.c_int, [_P, c_int32, c_int32, _P, _P, _P]),
     "bot_bn_bwd_bound_partials_f32": (ctypes.c_int, [c_int32, _P, c_int32, _P, _P, c_double, _P, _P, _P, _P]),
+    "bot_bn_bwd_partials_finish_f32": (ctypes.c_int, [_P, _P, c_int32, c_int32, _P, _P, c_int32, c_double, _P, _P, _P, _P]),
     "bot_gemm_halves3_nt2_f32": (ctypes.c_int, [c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, c_int32, _P, c_int64,
                                                 c_int32, _P]),
     "bot_halves_split_frag_f16": (ctypes.c_int, [_P, c_int64, c_int64, c_int32, _P, _P, c_int32, _P]),
@@ -940,6 +941,17 @@ class BnBwdStats:
         sgx = torch.empty(self.F, dtype=torch.float32, device=self.x.device)
         _check(_lib.bot_bn_act_bwd_reduce_partials_f32(self.part.data_ptr(), self.nblk, self.F, sg.data_ptr(), sgx.data_ptr(), _stream()),
                "bn_act_bwd_reduce_partials")
+        return sg, sgx
+
+    def finish(self, batch_stats, total_count, slots):
+        """sums() and bound() in one launch (one rank: the local sums are the final ones) -> (sum_g, sum_gx)"""
+        assert self.pmax is not None
+        _dev(slots)
+        sg = torch.empty(self.F, dtype=torch.float32, device=self.x.device)
+        sgx = torch.empty(self.F, dtype=torch.float32, device=self.x.device)
+        _check(_lib.bot_bn_bwd_partials_finish_f32(self.part.data_ptr(), self.pmax.data_ptr(), self.nblk, self.F, sg.data_ptr(), sgx.data_ptr(),
+                                                   int(bool(batch_stats)), float(total_count), _ptr(self.weight), self.invstd.data_ptr(), slots.data_ptr(),
+                                                   _stream()), "bn_bwd_partials_finish")
         return sg, sgx
 
     def bound(self, sum_g, sum_gx, total_count, slots):

@@ -234,11 +234,24 @@ __device__ __forceinline__ void pair_reduce(const float* part, int nblk, int32_t
 // mean[c] = pivot + S/n ; m2[c] = Q - S^2/n.  With `invstd` given this is the whole training-mode statistics step of
 // nn.BatchNorm1d in one launch (it replaced nine elementwise launches per layer): invstd = rsqrt(m2/n + eps), and the running
 // statistics move by `momentum` towards the batch mean / the UNBIASED batch variance; the step counter is bumped by one.
+// `bound` (with minmax [nblk][2][F] = the column extremes per row block): bn_bound_kernel's stage in the same launch (round 5: the statistics'
+// second stage was three launches in a row of ~14 us each).
 __global__ __launch_bounds__(kBlock) void colstats_final_kernel(const float* x, int64_t n, int32_t F, const float* part, int nblk,
                                                                float* mean, float* m2, float* invstd, float eps, float momentum,
-                                                               float* running_mean, float* running_var, int64_t* num_batches) {
+                                                               float* running_mean, float* running_var, int64_t* num_batches,
+                                                               const float* minmax = nullptr, const float* bw = nullptr, const float* bb = nullptr,
+                                                               float bp = 0.f, float* bound = nullptr) {
     __shared__ double lds[2][4][64];
+    __shared__ float ldm[2][4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    if (bound) {                         // (uniform) group g folds the extremes of blocks g, g + 4, ...
+        float mn = INFINITY, mx = -INFINITY;
+        if (c < F) {
+#pragma unroll 8
+            for (int k = grp; k < nblk; k += 4) mn = fminf(mn, minmax[((int64_t)k * 2 + 0) * F + c]), mx = fmaxf(mx, minmax[((int64_t)k * 2 + 1) * F + c]);
+        }
+        ldm[0][grp][threadIdx.x & 63] = mn, ldm[1][grp][threadIdx.x & 63] = mx;
+    }
     double S, Q;
     pair_reduce(part, nblk, F, c, grp, lds, S, Q);
     if (grp == 0 && c < F) {
@@ -246,6 +259,14 @@ __global__ __launch_bounds__(kBlock) void colstats_final_kernel(const float* x, 
         const float q = (float)fmax(Q - S * S / (double)n, 0.0);
         mean[c] = mu;
         if (m2) m2[c] = q;
+        if (bound) {                     // (pair_reduce's barrier made ldm visible) bn_bound_kernel's expression on this column's statistics
+            float mn = ldm[0][0][threadIdx.x], mx = ldm[1][0][threadIdx.x];
+#pragma unroll
+            for (int g = 1; g < 4; ++g) mn = fminf(mn, ldm[0][g][threadIdx.x]), mx = fmaxf(mx, ldm[1][g][threadIdx.x]);
+            const float is = rsqrtf(q / (float)n + eps);
+            const float dev = fmaxf(fabsf(mx - mu), fabsf(mn - mu)) * is;
+            bound[c] = (fabsf(bw ? bw[c] : 1.f) * dev + fabsf(bb ? bb[c] : 0.f)) / (1.f - bp);
+        }
         if (invstd) {
             invstd[c] = rsqrtf(q / (float)n + eps);
             if (running_mean) {
@@ -572,6 +593,50 @@ __global__ __launch_bounds__(kWideCols * kWideGroups) void bn_bwd_bound_wide_ker
     if (threadIdx.x < 64) absmax_publish(wave_absmax(b), slots);       // (the first wave holds groups 0 and 1: b is 0 outside group 0)
 }
 
+// pair_final_wide_kernel + bn_bwd_bound_wide_kernel for one rank (the bound uses the sums this launch has just formed)
+__global__ __launch_bounds__(kWideCols * kWideGroups) void bn_bwd_finish_wide_kernel(int32_t F, const float* part, const float* pmax, int nblk, float* s0, float* s1,
+                                                                                    float inv_count, bool batch_stats, const float* w, const float* invstd,
+                                                                                    uint32_t* slots) {
+    __shared__ double lds[2][kWideGroups][kWideCols];
+    __shared__ float ldm[2][kWideGroups][kWideCols];
+    const int lc = threadIdx.x % kWideCols, c = blockIdx.x * kWideCols + lc, grp = threadIdx.x / kWideCols;
+    double s = 0.0, q = 0.0;
+    float gm = 0.f, xm = 0.f;
+    if (c < F) {
+        int b = grp;
+        for (; b + 3 * kWideGroups < nblk; b += 4 * kWideGroups) {
+            float vs[4], vq[4], vg[4], vx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t o = ((int64_t)(b + kWideGroups * j) * 2) * F + c;
+                vs[j] = part[o], vq[j] = part[o + F], vg[j] = pmax[o], vx[j] = pmax[o + F];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += (double)vs[j], q += (double)vq[j], gm = fmaxf(gm, vg[j]), xm = fmaxf(xm, vx[j]);
+        }
+        for (; b < nblk; b += kWideGroups) {
+            const int64_t o = ((int64_t)b * 2) * F + c;
+            s += (double)part[o], q += (double)part[o + F], gm = fmaxf(gm, pmax[o]), xm = fmaxf(xm, pmax[o + F]);
+        }
+    }
+    lds[0][grp][lc] = s, lds[1][grp][lc] = q, ldm[0][grp][lc] = gm, ldm[1][grp][lc] = xm;
+    __syncthreads();
+    float bnd = 0.f;
+    if (grp == 0 && c < F) {
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int g = 0; g < kWideGroups; ++g) S += lds[0][g][lc], Q += lds[1][g][lc];
+#pragma unroll
+        for (int g = 1; g < kWideGroups; ++g) gm = fmaxf(gm, ldm[0][g][lc]), xm = fmaxf(xm, ldm[1][g][lc]);
+        const float fs = (float)S, fq = (float)Q;
+        s0[c] = fs, s1[c] = fq;
+        float t = gm;
+        if (batch_stats) t += fabsf(fs) * inv_count + xm * fabsf(fq) * inv_count;
+        bnd = fabsf(w ? w[c] : 1.f) * invstd[c] * t * 1.0001f;        // (bn_bwd_bound_kernel's expression)
+    }
+    if (threadIdx.x < 64) absmax_publish(wave_absmax(bnd), slots);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kTX* kTY) void bn_act_bwd_apply_kernel(BnArgs a) {
     const int tx = threadIdx.x % kTX, ty = threadIdx.x / kTX;
@@ -766,8 +831,7 @@ int bot_bn_stats_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, f
     else if (vec == 2) hipLaunchKernelGGL((colstats_partial_kernel<2>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true, true, minmax);
     else hipLaunchKernelGGL((colstats_partial_kernel<1>), grid, dim3(kTX * kTY), 0, st, x, ldx, n, F, workspace, true, true, minmax);
     hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, x, n, F, workspace, (int)grid.y,
-                       mean, (float*)nullptr, invstd, eps, momentum, running_mean, running_var, num_batches_tracked);
-    hipLaunchKernelGGL(bn_bound_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, F, minmax, (int)grid.y, mean, invstd, weight, bias, p, bound);
+                       mean, (float*)nullptr, invstd, eps, momentum, running_mean, running_var, num_batches_tracked, minmax, weight, bias, p, bound);
     launch_halves_scale(bound, F, hscale, st);
     return hip_status("bn_stats_halves launch");
 }
@@ -787,8 +851,7 @@ int bot_bn_stats_halves_partials_f32(const float* part, const float* minmax, int
                 (double)eps, (double)momentum, (double)p);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, pivot, n, F, part, (int)nblk, mean, (float*)nullptr, invstd, eps,
-                       momentum, running_mean, running_var, num_batches_tracked);
-    hipLaunchKernelGGL(bn_bound_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, F, minmax, (int)nblk, mean, invstd, weight, bias, p, bound_workspace);
+                       momentum, running_mean, running_var, num_batches_tracked, minmax, weight, bias, p, bound_workspace);
     launch_halves_scale(bound_workspace, F, hscale, st);
     return hip_status("bn_stats_halves_partials launch");
 }
@@ -882,6 +945,17 @@ int bot_bn_act_bwd_reduce_partials_f32(const float* part, int32_t nblk, int32_t 
     BOT_REQUIRE(nblk >= 1 && F >= 1, BOT_E_RANGE, "bn_act_bwd_reduce_partials: nblk=%d F=%d", nblk, F);
     hipLaunchKernelGGL(pair_final_wide_kernel, dim3((F + kWideCols - 1) / kWideCols), dim3(kWideCols * kWideGroups), 0, (hipStream_t)stream, F, part, (int)nblk, sum_g, sum_gx);
     return hip_status("bn_act_bwd_reduce_partials launch");
+}
+
+// both second stages in one launch (no cross-rank reduction between them: the local sums are the final ones)
+int bot_bn_bwd_partials_finish_f32(const float* part, const float* pmax, int32_t nblk, int32_t F, float* sum_g, float* sum_gx, int32_t batch_stats,
+                                   double total_count, const float* weight, const float* invstd, uint32_t* absmax_slots, bot_stream_t stream) {
+    using namespace bot;
+    BOT_REQUIRE(part && pmax && sum_g && sum_gx && invstd && absmax_slots, BOT_E_NULL, "bn_bwd_partials_finish: NULL pointer");
+    BOT_REQUIRE(nblk >= 1 && F >= 1 && (!batch_stats || total_count >= 1.0), BOT_E_RANGE, "bn_bwd_partials_finish: nblk=%d F=%d total_count=%f", nblk, F, total_count);
+    hipLaunchKernelGGL(bn_bwd_finish_wide_kernel, dim3((F + kWideCols - 1) / kWideCols), dim3(kWideCols * kWideGroups), 0, (hipStream_t)stream, F, part, pmax,
+                       (int)nblk, sum_g, sum_gx, batch_stats ? (float)(1.0 / total_count) : 0.f, batch_stats != 0, weight, invstd, absmax_slots);
+    return hip_status("bn_bwd_partials_finish launch");
 }
 
 int bot_bn_bwd_bound_partials_f32(int32_t F, const float* pmax, int32_t nblk, const float* sum_g, const float* sum_gx, double total_count, const float* weight,

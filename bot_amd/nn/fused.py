@@ -226,6 +226,18 @@ def _bwd_reduce(ctx, dy, x, mean, invstd, bn_w, bn_b, drop_p, seed, want_max=Fal
     return sg, sgx, None
 
 
+def _bwd_reduce_bound(ctx, dy, x, mean, invstd, bn_w, bn_b, drop_p, seed, bn_training, total, slots):
+    """`_bwd_reduce(want_max=True)` + `_bwd_bound` for one rank (no cross-rank reduction of the sums in between): delivered partials are
+    finished in ONE launch (bot_bn_bwd_partials_finish_f32).  -> (sum_g, sum_gx), the bound folded into `slots`."""
+    link = getattr(ctx, "out_link", None)
+    st = link.claim(dy) if link is not None else None
+    if st is not None:
+        return st.finish(bn_training, total, slots)
+    sg, sgx, ws = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, want_max=True)
+    _C.bn_bwd_bound(ws, dy.shape[0], sg if bn_training else None, sgx if bn_training else None, total, bn_w, invstd, slots)
+    return sg, sgx
+
+
 def _bwd_bound(mx, n, sg, sgx, total, bn_w, invstd, slots):
     if isinstance(mx, _C.BnBwdStats):
         return mx.bound(sg, sgx, total, slots)
@@ -497,10 +509,9 @@ def _backward_direct(ctx, dy, g, h, Wcat, table, el, er, a, a_d, x, mean, invstd
     if not _C.spmm_dot_halves_fits(dx.unflatten(1, (H, D)), ft, buf, D, piece):
         return None
     DOUT_DIRECT_CALLS += 1
-    sg, sgx, ws = _bwd_reduce(ctx, dy, x, mean, invstd, bn_w, bn_b, drop_p, seed, want_max=True)
-    d_bn_w, d_bn_b = sgx, sg
     slots = _C.absmax_slots(dy.device)
-    _bwd_bound(ws, N, sg if bn_training else None, sgx if bn_training else None, total, bn_w, invstd, slots)
+    sg, sgx = _bwd_reduce_bound(ctx, dy, x, mean, invstd, bn_w, bn_b, drop_p, seed, bn_training, total, slots)      # (no sync statistics here: _dout_direct_ok)
+    d_bn_w, d_bn_b = sgx, sg
     # one scale for both big blocks: |d res| <= the BatchNorm bound, |d ft[u]| <= (row sum of the edge weights out of u) x that bound
     s1 = _C.halves_scale_from_slots(slots, mult=rowsum_bound(g, ctx.adrop[0] if ctx.adrop else 0.0))
     _C.bn_act_bwd_apply_halves(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None, sgx if bn_training else None, total,
@@ -790,7 +801,11 @@ class _GATHiddenAggFirst(torch.autograd.Function):
         if epi is None:
             dx.copy_(dy)
         else:
-            sg, sgx, ws = _bwd_reduce(ctx, dy, x, mean, invstd, bn_w, bn_b, drop_p, seed, want_max=direct)
+            one_rank = direct and not (bn_training and sync)
+            if one_rank:
+                sg, sgx = _bwd_reduce_bound(ctx, dy, x, mean, invstd, bn_w, bn_b, drop_p, seed, bn_training, total, slots)
+            else:
+                sg, sgx, ws = _bwd_reduce(ctx, dy, x, mean, invstd, bn_w, bn_b, drop_p, seed, want_max=direct)
             d_bn_w, d_bn_b = sgx, sg
             if bn_training and sync:
                 both = torch.stack([sg, sgx])
@@ -799,7 +814,8 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             if direct:
                 # a bound on max|dx| from the reduce pass's column maxima and the final sums -> the operand's scale -> dx written as halves
                 DP = (D + 63) // 64 * 64
-                _bwd_bound(ws, N, sg if bn_training else None, sgx if bn_training else None, total, bn_w, invstd, slots)
+                if not one_rank:
+                    _bwd_bound(ws, N, sg if bn_training else None, sgx if bn_training else None, total, bn_w, invstd, slots)
                 dscale = _C.halves_scale_from_slots(slots)
                 Dh = _C.bn_act_bwd_apply_halves(dy, x, mean, invstd, bn_w, bn_b, True, drop_p, seed, sg if bn_training else None,
                                                 sgx if bn_training else None, total, dscale, _l0_dh(dy.device, N, H, D, DP), D, DP)

@@ -602,6 +602,10 @@ int bot_gemm_halves3_nt3_f32(int64_t m, int64_t n, int64_t k, const float* scale
 int bot_bn_act_bwd_reduce_partials_f32(const float* part, int32_t nblk, int32_t F, float* sum_g, float* sum_gx, bot_stream_t stream);
 int bot_bn_bwd_bound_partials_f32(int32_t F, const float* pmax, int32_t nblk, const float* sum_g, const float* sum_gx, double total_count,
                                   const float* weight, const float* invstd, uint32_t* absmax_slots, bot_stream_t stream);
+/* both in ONE launch, for one rank (no cross-rank reduction of the sums in between): sum_g / sum_gx as _reduce_partials forms them, then the
+ * bound from them (batch_stats = 0: eval statistics, the sums do not enter it) */
+int bot_bn_bwd_partials_finish_f32(const float* part, const float* pmax, int32_t nblk, int32_t F, float* sum_g, float* sum_gx, int32_t batch_stats,
+                                   double total_count, const float* weight, const float* invstd, uint32_t* absmax_slots, bot_stream_t stream);
 /* v17: a RIGHT operand in FRAGMENT-MAJOR layout (b_layout = 1 of bot_gemm_halves3_nt2_f32; ldb / b2_off unused): the 16 bytes lane l of an
  * MFMA fragment holds - row 16 t + (l & 15), columns 32 s + 8 (l >> 4) .. + 7 - at halves ((t T + s) 64 + l) 8, T = piece / 32, h1 in the
  * first region, h2 ceil(n / 16) T 512 halves behind it: the 64 lanes of a fragment load read one contiguous KB (the NT kernel pays for the

@@ -437,6 +437,11 @@ class BnBwdStats:
         s = self.part.double().sum(0)
         return s[0].float(), s[1].float()
 
+    def finish(self, batch_stats, total_count, slots):
+        sg, sgx = self.sums()
+        self.bound(sg if batch_stats else None, sgx if batch_stats else None, total_count, slots)
+        return sg, sgx
+
     def bound(self, sum_g, sum_gx, total_count, slots):
         return bn_bwd_bound(self.pmax.max(0).values, self.n, sum_g, sum_gx, total_count, self.weight, self.invstd, slots)
 

@@ -553,6 +553,13 @@ def test_abi18_bn_bwd_partials_from_the_nt_product():
                 st.bound(sg, sgx, m, s1)
                 _C.bn_bwd_bound(rws, m, sg, sgx, m, bw, invstd, s2)
                 assert torch.equal(s1, s2) or float(_C.halves_scale_from_slots(s1)[0]) == float(_C.halves_scale_from_slots(s2)[0]), (m, K, F)
+                s3 = _C.absmax_slots(DEV)               # both second stages in one launch (bot_bn_bwd_partials_finish_f32): the same sums, the same bound
+                fg, fgx = st.finish(True, m, s3)
+                assert torch.equal(fg, sg) and torch.equal(fgx, sgx) and torch.equal(s3, s1), (m, K, F)
+                s4, s5 = _C.absmax_slots(DEV), _C.absmax_slots(DEV)
+                st.finish(False, m, s4)
+                st.bound(None, None, m, s5)
+                assert torch.equal(s4, s5)
                 if p > 0:        # the mask really is applied: the sums differ from the unmasked ones
                     st0 = _C.BnBwdStats(x, mean, invstd, bw, bb, relu, 0.0, seed)
                     _C.gemm_halves3_nt(db, B, sc, ws.scale, piece, piece, piece, bn=st0, **kw)
