@@ -570,6 +570,54 @@ def test_abi18_bn_bwd_partials_from_the_nt_product():
     assert _C._lib.bot_gemm_halves3_nt_bn_rows(96) == 0 and _C._lib.bot_gemm_halves3_nt_bn_rows(128) == 256
 
 
+def test_abi18_random_shapes():
+    """Randomised differential test of the by-product epilogue: 20 random (m, K, F even, pitch of x, dropout, ReLU, affine, weight layout,
+    second scale) - dy bit for bit the plain product, the column maxima (through the bound's slots) exactly and the sums to summation noise
+    against the reduce pass over the same dy, nothing outside the partial buffers' [blocks, 2, F] touched."""
+    import random
+    from bot_amd import gemm
+    rng = random.Random(18)
+    gen = torch.Generator(device=DEV).manual_seed(71)
+    for case in range(20):
+        m = rng.choice([1, 17, 255, 256, 257, 1000, 5001, 12345])
+        K = rng.choice([33, 64, 100, 250, 500, 750])
+        F = rng.choice([2, 6, 40, 190, 192, 250, 256, 258, 750])
+        ldx = F + rng.choice([0, 2, 4]) if F % 4 else F + rng.choice([0, 4])
+        p = rng.choice([0.0, 0.0, 0.3, 0.75])
+        relu, affine, b_frag = rng.random() < 0.7, rng.random() < 0.6, rng.random() < 0.5
+        d = torch.randn(m, K, device=DEV, generator=gen) * 10 ** rng.uniform(-2, 2)
+        w = torch.randn(F, K, device=DEV, generator=gen) * 10 ** rng.uniform(-2, 0)
+        x = torch.randn(m, ldx, device=DEV, generator=gen)[:, :F] * 3 + 1
+        mean = x.mean(0)
+        invstd = (x.var(0, unbiased=False) + 1e-5).rsqrt() if m > 1 else torch.ones(F, device=DEV)
+        bw = torch.randn(F, device=DEV, generator=gen) if affine else None
+        bb = torch.randn(F, device=DEV, generator=gen) * 0.3 if affine else None
+        ws = gemm.split(w, 1)
+        piece = ws.piece
+        B = _C.halves_split_frag(w, ws.scale, piece) if b_frag else ws.buf
+        sc = _C.halves_scale(d)
+        db = _C.halves_split(d, sc, 2, piece)
+        kw = dict(a2_off=piece, b_frag=b_frag, n=F)
+        if piece >= 128 and rng.random() < 0.4:
+            kw.update(scale_a2=torch.tensor([float(sc[0]) * 16, float(sc[1]) / 16], device=DEV), k_split=rng.choice([32, 64, piece - 32]))
+        plain = _C.gemm_halves3_nt(db, B, sc, ws.scale, piece, piece, piece, **kw)
+        st = _C.BnBwdStats(x, mean, invstd, bw, bb, relu, p, 4242 + case)
+        assert st.fits(m, F, piece), (case, m, K, F)
+        guard = torch.full((st.nblk + 2, 2, F), 7.0, device=DEV)
+        st.part, st.pmax = guard[1:-1], torch.full((st.nblk, 2, F), -1.0, device=DEV)
+        dy = _C.gemm_halves3_nt(db, B, sc, ws.scale, piece, piece, piece, bn=st, **kw)
+        assert torch.equal(dy, plain), (case, m, K, F)
+        assert bool((guard[0] == 7.0).all()) and bool((guard[-1] == 7.0).all()) and bool((st.pmax >= 0).all())
+        s1, s2 = _C.absmax_slots(DEV), _C.absmax_slots(DEV)
+        sg, sgx = st.finish(True, m, s1)
+        rg, rgx, rws = _C.bn_act_bwd_reduce(dy, x, mean, invstd, bw, bb, relu, p, 4242 + case, want_max=True)
+        xh_max = float(((x - mean) * invstd).abs().max())
+        tol = 3e-6 * float(dy.abs().sum(0).max()) * max(1.0, xh_max) + 1e-30
+        assert float((sg - rg).abs().max()) <= tol and float((sgx - rgx).abs().max()) <= tol, (case, m, K, F, p, relu)
+        _C.bn_bwd_bound(rws, m, sg, sgx, m, bw, invstd, s2)
+        assert float(_C.halves_scale_from_slots(s1)[0]) == float(_C.halves_scale_from_slots(s2)[0]), (case, m, K, F)
+
+
 def test_bcast_kernels_direct(golden):
     """spmm_bcast / spmm_dot_bcast (aggregate-before-project forms) against plain torch indexing."""
     s, d, n = golden.graph("g300")
