@@ -74,17 +74,17 @@ BN_BYPRODUCT_CALLS = 0
 
 
 class BnLink:
-    __slots__ = ("x", "mean", "invstd", "w", "b", "p", "seed", "stats", "key")
+    __slots__ = ("x", "mean", "invstd", "w", "b", "p", "seed", "relu", "stats", "key")
 
-    def __init__(self, x, mean, invstd, w, b, p, seed):
-        self.x, self.mean, self.invstd, self.w, self.b, self.p, self.seed = x, mean, invstd, w, b, p, seed
+    def __init__(self, x, mean, invstd, w, b, p, seed, relu=True):
+        self.x, self.mean, self.invstd, self.w, self.b, self.p, self.seed, self.relu = x, mean, invstd, w, b, p, seed, bool(relu)
         self.stats = self.key = None
 
     def stats_for(self, m, n, k):
         """A by-product request for the product [m, n] of piece width k, None when it cannot carry one."""
         if not BN_BYPRODUCT or self.x is None:
             return None
-        st = _C.BnBwdStats(self.x, self.mean, self.invstd, self.w, self.b, True, self.p, self.seed)
+        st = _C.BnBwdStats(self.x, self.mean, self.invstd, self.w, self.b, self.relu, self.p, self.seed)
         return st if st.fits(m, n, k) else None
 
     def deliver(self, st, dh):

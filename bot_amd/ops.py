@@ -375,6 +375,9 @@ def new_dropout_seed(p):
     return int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
 
 
+MODULAR_BN_LINK = os.environ.get("BOT_BN_LINK_MODULAR", "1") != "0"     # the modular epilogue (GCN, the edge-GAT stacks) takes part in gemm.BnLink too
+
+
 class _BNActDrop(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn, relu, p, bn_training, halves=False):
@@ -389,8 +392,12 @@ class _BNActDrop(torch.autograd.Function):
         if hscale is not None:       # the next projection's fp16 halves written by this pass (bot_amd.gemm.take picks them up)
             order = gemm.left_order(piece)
             y, buf = _C.bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed, halves=(hscale, piece, 2 if order == 2 else 3))
-            gemm.stash(y, gemm.Halves(buf, hscale, x.shape[0], x.shape[1], piece, order))
+            hv = gemm.Halves(buf, hscale, x.shape[0], x.shape[1], piece, order)
+            # the projection that takes these halves can deliver this pass's backward reduce with the gradient it sends back (gemm.BnLink)
+            hv.bn_link = ctx.out_link = gemm.BnLink(x, mean, invstd, weight, bias, p, seed, relu=relu) if (gemm.BN_BYPRODUCT and MODULAR_BN_LINK) else None
+            gemm.stash(y, hv)
         else:
+            ctx.out_link = None
             y = _C.bn_act_fwd(x, mean, invstd, weight, bias, relu, p, seed)
         ctx.save_for_backward(x, mean, invstd, weight, bias)
         ctx.cfg = (relu, p, seed, bn_training, sync, group, total)
@@ -402,7 +409,8 @@ class _BNActDrop(torch.autograd.Function):
         x, mean, invstd, weight, bias = ctx.saved_tensors
         relu, p, seed, bn_training, sync, group, total = ctx.cfg
         dy = dy.contiguous()
-        sg, sgx = _C.bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed)
+        st = ctx.out_link.claim(dy) if ctx.out_link is not None else None
+        sg, sgx = st.sums() if st is not None else _C.bn_act_bwd_reduce(dy, x, mean, invstd, weight, bias, relu, p, seed)
         dw = sgx if weight is not None and ctx.needs_input_grad[1] else None  # local sums: ranks' parameter grads are
         db = sg if bias is not None and ctx.needs_input_grad[2] else None     # summed later with all the others
         dx = None

@@ -524,6 +524,35 @@ def test_bn_bwd_byproduct_emulated(golden, cpu_backend, monkeypatch):
     PC.check_bn_bwd_byproduct_against_oracle(golden, "cpu")
 
 
+def test_bn_link_through_the_modular_epilogue(golden, cpu_backend, monkeypatch):
+    """The modular BatchNorm / ReLU / dropout epilogue (ops._BNActDrop: the edge-GAT stacks of configs 4 / 5) takes part in gemm.BnLink: the
+    projection that takes its halves (the next layer's merged Linear, the prediction head) delivers its backward's sums - every layer's
+    partials are claimed, the gradients are those of the reduce pass to summation noise."""
+    import torch.nn.functional as F
+    from bot_amd import gemm
+    from bot_amd.nn import edge_gat, fused
+    monkeypatch.setattr(fused, "FORCE", True)
+    monkeypatch.setattr(gemm, "FORCE", True)
+    g = PC.make_graph(golden, "g300", "cpu")
+    n = g.number_of_nodes()
+    torch.manual_seed(7)
+    model = edge_gat.ProductsGAT(node_feats=48, edge_feats=0, n_classes=96, n_layers=3, n_heads=3, n_hidden=64, edge_emb=0, activation=F.relu,
+                                 dropout=0.0, input_drop=0.0, attn_drop=0.0, edge_drop=0.0).train()
+    g.ndata["feat"] = torch.randn(n, 48)
+    gout = torch.randn(n, 96)
+    grads, counts = [], []
+    for on in (True, False):
+        monkeypatch.setattr(gemm, "BN_BYPRODUCT", on)
+        c0 = gemm.BN_BYPRODUCT_CALLS
+        model.zero_grad(set_to_none=True)
+        (model(g) * gout).sum().backward()
+        counts.append(gemm.BN_BYPRODUCT_CALLS - c0)
+        grads.append({k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None})
+    assert counts == [3, 0], counts
+    for k in grads[0]:
+        PC.grad_close(grads[0][k], grads[1][k].numpy())
+
+
 def test_hbm_budget_estimates():
     """bot_amd.workloads.hbm_budget (what bench.py prints, and refuses on, before allocating): at or above the measured single-GPU peaks
     of profiles/r05_hbm_peak.txt and within 1.5x of them, every config fits one 288 GB GPU, the step term shrinks with the world size."""
