@@ -929,7 +929,7 @@ class BnBwdStats:
 
     def fits(self, m, n, k) -> bool:
         """The product [m, n] of piece width k can carry the by-product: the 256 x 32 form, n = F even, 8-byte aligned x rows."""
-        return (m == self.n and n == self.F and F_even(self.F) and self.x.stride(0) % 2 == 0 and self.x.data_ptr() % 8 == 0 and
+        return (m == self.n and n == self.F and self.F % 2 == 0 and self.x.stride(0) % 2 == 0 and self.x.data_ptr() % 8 == 0 and
                 _lib.bot_gemm_halves3_nt_bn_rows(int(k)) == 256)
 
     def struct(self):
@@ -960,10 +960,6 @@ class BnBwdStats:
         _check(_lib.bot_bn_bwd_bound_partials_f32(self.F, self.pmax.data_ptr(), self.nblk, _ptr(sum_g), _ptr(sum_gx), float(total_count), _ptr(self.weight),
                                                   self.invstd.data_ptr(), slots.data_ptr(), _stream()), "bn_bwd_bound_partials")
         return slots
-
-
-def F_even(F) -> bool:
-    return F % 2 == 0
 
 
 def gemm_halves3_nt(a, b, scale_a, scale_b, piece_a, piece_b, k, out=None, mode=0, a2_off=None, scale_a2=None, k_split=0, b_frag=False, n=None, bn=None):

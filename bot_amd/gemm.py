@@ -74,11 +74,11 @@ BN_BYPRODUCT_CALLS = 0
 
 
 class BnLink:
-    __slots__ = ("x", "mean", "invstd", "w", "b", "p", "seed", "relu", "stats", "key")
+    __slots__ = ("x", "mean", "invstd", "w", "b", "p", "seed", "relu", "stats", "key", "ref")
 
     def __init__(self, x, mean, invstd, w, b, p, seed, relu=True):
         self.x, self.mean, self.invstd, self.w, self.b, self.p, self.seed, self.relu = x, mean, invstd, w, b, p, seed, bool(relu)
-        self.stats = self.key = None
+        self.stats = self.key = self.ref = None
 
     def stats_for(self, m, n, k):
         """A by-product request for the product [m, n] of piece width k, None when it cannot carry one."""
@@ -88,20 +88,18 @@ class BnLink:
         return st if st.fits(m, n, k) else None
 
     def deliver(self, st, dh):
-        self.stats, self.key = st, (dh.data_ptr(), dh._version, tuple(dh.shape), tuple(dh.stride()))
+        # (`ref` keeps the product's output alive until the claim: its address cannot be handed to another tensor in between)
+        self.stats, self.key, self.ref = st, (dh.data_ptr(), dh._version, tuple(dh.shape), tuple(dh.stride())), dh
 
     def claim(self, dy):
         """The delivered partials if `dy` is the tensor they were computed from (one use), else None."""
         st, key = self.stats, self.key
-        self.stats = self.key = None
+        self.stats = self.key = self.ref = None
         if st is not None and key == (dy.data_ptr(), dy._version, tuple(dy.shape), tuple(dy.stride())):
             global BN_BYPRODUCT_CALLS
             BN_BYPRODUCT_CALLS += 1
             return st
         return None
-
-    def drop(self):
-        self.x = self.mean = self.invstd = self.w = self.b = self.stats = self.key = None
 
 
 def left_order(piece: int) -> int:
