@@ -570,6 +570,32 @@ def test_abi18_bn_bwd_partials_from_the_nt_product():
     assert _C._lib.bot_gemm_halves3_nt_bn_rows(96) == 0 and _C._lib.bot_gemm_halves3_nt_bn_rows(128) == 256
 
 
+def test_absmax_slot_sets_are_zero_and_disjoint():
+    """_C.absmax_slots hands out sets of a block zeroed once per 512 requests: every set is zeros, no two sets overlap (also across the block
+    boundary), a producer's maximum lands in its own set only, and inside a hipGraph capture each request is its own (captured) fill."""
+    n = int(_C._lib.bot_absmax_slots())
+    sets = [_C.absmax_slots(DEV) for _ in range(600)]
+    ptrs = sorted(s.data_ptr() for s in sets)
+    assert all(b - a >= 4 * n for a, b in zip(ptrs, ptrs[1:]))
+    assert all(int(s.abs().sum()) == 0 and s.shape == (n,) and s.dtype == torch.int32 for s in sets)
+    x = torch.randn(1000, 40, device=DEV)
+    _C.absmax_into(x, sets[17])
+    assert int((sets[17] != 0).sum()) > 0 and all(int(s.abs().sum()) == 0 for i, s in enumerate(sets) if i != 17)
+    assert float(_C.halves_scale_from_slots(sets[17])[0]) == float(_C.halves_scale(x)[0])
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            s = _C.absmax_slots(DEV)
+            _C.absmax_into(x, s)
+            sc = _C.halves_scale_from_slots(s)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert float(sc[0]) == float(_C.halves_scale(x)[0])
+
+
 def test_abi18_random_shapes():
     """Randomised differential test of the by-product epilogue: 20 random (m, K, F even, pitch of x, dropout, ReLU, affine, weight layout,
     second scale) - dy bit for bit the plain product, the column maxima (through the bound's slots) exactly and the sums to summation noise
