@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOT_AMD_LIB") or os.path.join(_HERE, "lib", "libbot_gnn.so")  # override: A/B builds of the kernels
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -29,6 +29,7 @@ _SIGS = {
     "bot_abi_version": (ctypes.c_int, []),
     "bot_last_error": (c_char_p, []),
     "bot_last_kernel": (c_char_p, []),
+    "bot_debug_abort_trace": (ctypes.c_int, [c_char_p]),
     "bot_row_plan_default_chunk": (c_int32, [c_int64]),
     "bot_row_plan_size_host": (ctypes.c_int, [_P, c_int64, c_int32, _P, _P, _P]),
     "bot_row_plan_fill_host": (ctypes.c_int, [_P, c_int64, c_int32, _P, _P, _P]),
@@ -904,6 +905,12 @@ def stream_create(device, high_priority=False):
     with torch.cuda.device(device):
         _check(_lib.bot_stream_create(int(bool(high_priority)), ctypes.byref(h)), "stream_create")
     return torch.cuda.ExternalStream(h.value, device=device)
+
+
+def debug_abort_trace(path):
+    """include/bot_gnn.h bot_debug_abort_trace: a SIGABRT / std::terminate in this process leaves the aborting thread's native frames in
+    `path` (diagnostic; armed by tests/conftest.py, never by the product)."""
+    _check(_lib.bot_debug_abort_trace(os.fsencode(path)), "debug_abort_trace")
 
 
 class _BnBwdStats(ctypes.Structure):

@@ -1,7 +1,16 @@
 // Host-side pieces of libbot_gnn.so: error reporting, ABI version, row plan (integer work only).
+#include <cxxabi.h>
+#include <execinfo.h>
+#include <fcntl.h>
+#include <signal.h>
 #include <stdarg.h>
+#include <string.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <exception>
+#include <typeinfo>
 #include <vector>
 
 #include "common.h"
@@ -42,6 +51,88 @@ int bot_stream_create(int32_t high_priority, bot_stream_t* out) {
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? hi : lo);
     BOT_REQUIRE(e == hipSuccess, (int)e, "stream_create: %s", hipGetErrorString(e));
     *out = (bot_stream_t)s;
+    return 0;
+}
+
+// ---- v19 diagnostics: who called abort()? -------------------------------------------------------------------------------------
+// Round 5's GPU suite died with SIGABRT inside a hipGraph capture and left only Python frames (faulthandler): abort() is raised on the
+// CALLING thread, so a handler that prints that thread's native frames names the caller - the HIP runtime, RCCL's watchdog, libstdc++'s
+// terminate.  Async-signal-safe calls only (backtrace_symbols_fd writes straight to the descriptor); then the previous handler runs
+// (Python's faulthandler) and the default action ends the process as before.
+namespace {
+int g_trace_fd = -1;
+struct sigaction g_prev_abrt;
+std::terminate_handler g_prev_term = nullptr;
+
+void put(const char* s) { if (g_trace_fd >= 0) (void)!write(g_trace_fd, s, strlen(s)); }
+void put_num(long v) {
+    char b[24];
+    int i = 23;
+    b[i] = 0;
+    if (v == 0) b[--i] = '0';
+    for (; v > 0 && i > 0; v /= 10) b[--i] = (char)('0' + v % 10);
+    put(b + i);
+}
+void dump_frames(const char* why) {
+    void* fr[96];
+    put("\n=== libbot_gnn abort trace: ");
+    put(why);
+    put(" pid ");
+    put_num((long)getpid());
+    put(" tid ");
+    put_num((long)syscall(SYS_gettid));
+    put(" ===\n");
+    int n = backtrace(fr, 96);
+    if (g_trace_fd >= 0) backtrace_symbols_fd(fr, n, g_trace_fd);
+    put("=== end of trace ===\n");
+}
+void on_abort(int sig, siginfo_t* info, void* ctx) {
+    dump_frames("SIGABRT");
+    sigaction(SIGABRT, &g_prev_abrt, nullptr);          // hand over: faulthandler's dump, then the default action
+    if ((g_prev_abrt.sa_flags & SA_SIGINFO) && g_prev_abrt.sa_sigaction) g_prev_abrt.sa_sigaction(sig, info, ctx);
+    else if (g_prev_abrt.sa_handler != SIG_DFL && g_prev_abrt.sa_handler != SIG_IGN && g_prev_abrt.sa_handler) g_prev_abrt.sa_handler(sig);
+    signal(SIGABRT, SIG_DFL);
+    raise(SIGABRT);
+}
+void on_terminate() {
+    put("\n=== libbot_gnn: std::terminate");
+    if (std::type_info* t = abi::__cxa_current_exception_type()) {
+        put(", uncaught ");
+        put(t->name());
+        try {
+            throw;
+        } catch (const std::exception& e) {
+            put(": ");
+            put(e.what());
+        } catch (...) {
+        }
+    }
+    put(" ===\n");
+    dump_frames("std::terminate");
+    if (g_prev_term) g_prev_term();
+    abort();
+}
+}  // namespace
+
+int bot_debug_abort_trace(const char* path) {
+    using namespace bot;
+    BOT_REQUIRE(path != nullptr, BOT_E_NULL, "debug_abort_trace: NULL path");
+    int fd = open(path, O_WRONLY | O_CREAT | O_APPEND | O_CLOEXEC, 0644);
+    BOT_REQUIRE(fd >= 0, BOT_E_RANGE, "debug_abort_trace: cannot open %s", path);
+    void* warm[4];
+    backtrace(warm, 4);                                  // loads libgcc's unwinder now: dlopen inside a signal handler is not safe
+    const bool first = g_trace_fd < 0;
+    if (!first) close(g_trace_fd);
+    g_trace_fd = fd;
+    if (first) {
+        struct sigaction sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.sa_sigaction = on_abort;
+        sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+        sigemptyset(&sa.sa_mask);
+        sigaction(SIGABRT, &sa, &g_prev_abrt);
+        g_prev_term = std::set_terminate(on_terminate);
+    }
     return 0;
 }
 

@@ -202,6 +202,37 @@ def evaluate(model, graph, feat, labels, train_idx, val_idx, test_idx, *, use_la
     return accs + losses + (pred,)
 
 
+# Seconds drain_rccl_watchdog() sleeps after the device synchronisation: ProcessGroupNCCL's watchdog wakes every 100 ms
+# (kWatchdogThreadSleepMillis) and retires every completed Work in one pass, so five periods of margin.
+CAPTURE_DRAIN_S = float(os.environ.get("BOT_CAPTURE_DRAIN_S", "0.5"))
+
+
+def drain_rccl_watchdog(device=None) -> bool:
+    """Empty ProcessGroupNCCL's watchdog list before a hipGraph capture that contains collectives.  Returns whether it had to.
+
+    ROOT CAUSE of round 5's SIGABRT (native trace: profiles/r06_abort_trace.txt; mechanism pinned by tools/exp_capture_watchdog.py,
+    profiles/r06_capture_watchdog.txt): on this ROCm (HIP 7.0.51831) hipEventQuery refuses an event whose last-recorded STREAM is
+    currently inside a capture - hipErrorCapturedEvent, "operation not permitted on an event last recorded in a capturing stream" -
+    even when the record itself was EAGER and completed long before the capture began (CUDA refuses only events recorded during the
+    capture).  ProcessGroupNCCL keeps every eager collective's Work in a list that its watchdog THREAD polls every 100 ms with exactly
+    that query (WorkNCCL::isCompleted -> finishedGPUExecutionInternal -> hipEventQuery of the end event, recorded on RCCL's stream).  The
+    warm-up steps in front of a capture leave such Works behind; the first captured collective makes RCCL's stream join the capture; a
+    watchdog pass that falls between that and the join-back (the halo exchange's overlap window, a few ms per captured step) gets the error,
+    rethrows it, and std::terminate ends the process - about one capture in ten.  Works issued DURING a capture are never enqueued
+    (ProcessGroupNCCL checks the current stream's capture status), so an empty list stays empty: synchronise (every eager Work is complete)
+    and give the watchdog several periods to retire them.  `capture_error_mode="thread_local"` (below) is still needed: it covers the
+    watchdog's OTHER illegal-under-global-capture calls."""
+    import time
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or not torch.cuda.is_available():
+        return False
+    if "nccl" not in str(dist.get_backend()).lower():
+        return False
+    torch.cuda.synchronize(device)
+    time.sleep(CAPTURE_DRAIN_S)
+    return True
+
+
 class CapturedTrainStep:
     """One `train()` call (run.py:252-287: forward, loss, backward, optimizer step) captured ONCE into a hipGraph and replayed:
     ~300 launches per step cost one graph launch on the host, which is what bounds a rank once its GPU work drops to a few ms
@@ -234,10 +265,12 @@ class CapturedTrainStep:
         torch.cuda.current_stream(self.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         # With a process group alive, RCCL's watchdog THREAD polls its work events at any time; under the default "global" capture mode
-        # that poll is an illegal call during capture and aborts the process (seen once in ~10 suite runs: "operation not permitted when
-        # stream is capturing" raised from ProcessGroupNCCL's watchdog).  "thread_local" checks only the capturing thread's calls.
+        # that poll is an illegal call during capture and aborts the process ("operation not permitted when stream is capturing" raised
+        # from ProcessGroupNCCL's watchdog).  "thread_local" checks only the capturing thread's calls - and the watchdog must have NOTHING
+        # to poll while RCCL's stream is inside the capture (drain_rccl_watchdog: the round-5 abort).
         import torch.distributed as dist
         mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        self.drained = drain_rccl_watchdog(self.device)         # the warm-up's eager collectives: retired before RCCL's stream joins the capture
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss, self.pred = body()
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BOT_ABI_VERSION 18
+#define BOT_ABI_VERSION 19
 
 #define BOT_E_NULL (-1)     /* required pointer is NULL                 */
 #define BOT_E_RANGE (-2)    /* size / stride / head count out of range  */
@@ -54,6 +54,11 @@ int bot_stream_create(int32_t high_priority, bot_stream_t* out);
  * dispatched — the template instance depends on H, D and the operands' alignment.  Diagnostic only (bench.py names the
  * kernel of its roofline line from it); thread-local like bot_last_error. */
 const char* bot_last_kernel(void);
+/* v19, diagnostic only: from now on a SIGABRT / std::terminate in this PROCESS first appends the native frames of the thread that raised it
+ * (and the uncaught exception's type and what()) to the file `path_host`, then runs the handler that was installed before (Python's
+ * faulthandler) and ends the process as it would have ended.  abort() is raised on the calling thread, so the trace names the caller
+ * (HIP runtime, RCCL watchdog, libstdc++).  tests/conftest.py arms it for every GPU test process; the product never calls it. */
+int bot_debug_abort_trace(const char* path_host);
 
 /* ---------------------------------------------------------------------------------------------
  * Row plan (host side, pure integer work; built once per graph direction).

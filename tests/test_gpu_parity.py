@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def test_native_library_is_loaded():
     assert torch.cuda.is_available()
-    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 18
+    assert _C._lib.bot_abi_version() == _C.ABI_VERSION == 19
     maps = open("/proc/self/maps").read()
     assert "libbot_gnn.so" in maps
 
@@ -570,6 +570,7 @@ def test_abi18_bn_bwd_partials_from_the_nt_product():
     assert _C._lib.bot_gemm_halves3_nt_bn_rows(96) == 0 and _C._lib.bot_gemm_halves3_nt_bn_rows(128) == 256
 
 
+@pytest.mark.isolated
 def test_absmax_slot_sets_are_zero_and_disjoint():
     """_C.absmax_slots hands out sets of a block zeroed once per 512 requests: every set is zeros, no two sets overlap (also across the block
     boundary), a producer's maximum lands in its own set only, and inside a hipGraph capture each request is its own (captured) fill."""
@@ -1136,6 +1137,7 @@ def test_evaluate_inference_path_full_size():
 
 
 # ---------------------------------------------------------------------------------------------- hipGraph-captured train step
+@pytest.mark.isolated
 def test_captured_train_step_bit_identical_and_fresh_masks():
     """the whole train step (forward, loge loss, backward, RMSprop) captured into a hipGraph.  (a) With every drop
     rate 0 the replayed step is BIT-identical to the eager step from the same state (same kernels, same order, no atomics):
@@ -1548,9 +1550,10 @@ def test_bench_self_launch_chain_on_one_gpu():
 
 
 # ---------------------------------------------------------------------------------------------- replays, at length
-def _replay_case(kind, part_group=None):
+def _replay_case(kind, part_group=None, capture=True):
     """(eager step fn, captured step object, eager model, captured model) of one stack on a small graph of its BASELINE shape, every
-    drop rate 0 and a FIXED label mask, both models from the same state."""
+    drop rate 0 and a FIXED label mask, both models from the same state.  `capture=False`: no hipGraph is built (the captured step object
+    is None) - for callers that only want the eager step."""
     import copy
     import torch.nn.functional as F
     from bot_amd import nn as bnn, synth, train as T
@@ -1588,11 +1591,11 @@ def _replay_case(kind, part_group=None):
             loss, pred = bdist.forward_backward(m2, part, mask=mask, group=part_group, **kw)
             o2.step()
             return loss, pred
-        cap = T.CapturedTrainStep(body, DEV, warmup=3)
+        cap = T.CapturedTrainStep(body, DEV, warmup=3) if capture else None
     else:
         def eager():
             return T.train_step(m1, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o1, mask=mask, **kw)
-        cap = T.captured_train_step(m2, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o2, warmup=3, mask=mask, **kw)
+        cap = T.captured_train_step(m2, g, ds.feat, ds.labels, ds.train_idx, ds.val_idx, ds.test_idx, o2, warmup=3, mask=mask, **kw) if capture else None
     return eager, cap, m1, m2
 
 
@@ -1611,6 +1614,7 @@ def one_rank_rccl():
         dist.destroy_process_group()
 
 
+@pytest.mark.isolated
 @pytest.mark.parametrize("kind", ["arxiv", "cora", "reddit", "arxiv-1rank"])
 def test_captured_step_twelve_replays_bitwise(kind, request):
     """round 3 found torch's multi-workgroup reductions returning wrong sums from the FOURTH replay of a captured
@@ -1687,6 +1691,32 @@ def test_side_stream_bitwise(opt):
         side.ENABLED = was
 
 
+def test_capture_beside_a_live_rccl_watchdog():
+    """ROOT CAUSE of round 5's SIGABRT, as a test (bot_amd.train.drain_rccl_watchdog; tools/exp_capture_watchdog.py): eager collectives
+    leave Works in ProcessGroupNCCL's watchdog list; on this HIP, hipEventQuery of their (eager, completed) end events raises
+    hipErrorCapturedEvent while RCCL's stream is inside a capture, and the watchdog thread takes the process down.  The tool captures an
+    async all-reduce whose overlap window is stretched across several watchdog periods right behind three eager all-reduces, each trial in
+    its own process: with the product's drain in front of the capture every trial must finish; without it the trial is EXPECTED to die of
+    SIGABRT (printed, not asserted: a later ROCm may stop refusing such events, which only makes the drain unnecessary)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "exp_capture_watchdog.py")
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    for trial in range(3):
+        out = subprocess.run([sys.executable, tool, "--part", "pg", "--drain", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0 and "finished without an abort" in out.stdout, (trial, out.returncode, out.stderr[-3000:])
+    out = subprocess.run([sys.executable, tool, "--part", "pg", "--drain", "0"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode in (0, -6, 134), (out.returncode, out.stderr[-3000:])
+    died = out.returncode != 0
+    assert (not died) or "last recorded in a capturing stream" in out.stderr, out.stderr[-3000:]
+    print("without the drain the same capture %s" % ("died of SIGABRT in RCCL's watchdog (hipErrorCapturedEvent): the hazard is present on this stack"
+                                                      if died else "survived: this stack no longer refuses eagerly recorded events"))
+
+
+@pytest.mark.isolated
 @pytest.mark.parametrize("kind", ["arxiv", "cora", "reddit", "arxiv-1rank"])
 def test_no_multi_workgroup_torch_reduction_in_capturable_steps(kind, request, tmp_path):
     """The other half of the same ADVICE item: whatever the root cause of the wrong replayed sums is, no capturable step may contain
@@ -1696,7 +1726,7 @@ def test_no_multi_workgroup_torch_reduction_in_capturable_steps(kind, request, t
     import json
     from torch.profiler import ProfilerActivity, profile
     group = request.getfixturevalue("one_rank_rccl") if kind == "arxiv-1rank" else None
-    eager, cap, m1, m2 = _replay_case(kind, group)
+    eager, _, m1, m2 = _replay_case(kind, group, capture=False)       # (round 5 built a capture here and threw it away: VERDICT r5 #1b)
     eager()
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:

@@ -564,3 +564,15 @@ def test_hbm_budget_estimates():
         assert est < 268
         assert workloads.hbm_budget(name, 8)["step"] < workloads.hbm_budget(name, 1)["step"]
     assert workloads.hbm_budget("products", 1, scale=4.0)["total"] / 2 ** 30 > 288        # what bench.py would refuse with rc 4
+
+
+def test_drain_rccl_watchdog_only_acts_on_a_live_rccl_group():
+    """bot_amd.train.drain_rccl_watchdog (round 6: the root cause of round 5's abort) is a no-op without a process group and for gloo - it
+    must never cost the single-GPU capture half a second; the RCCL case runs on the GPU box (test_capture_beside_a_live_rccl_watchdog)."""
+    import time
+    import torch.distributed as dist
+    from bot_amd import train as T
+    assert not dist.is_initialized()
+    t0 = time.time()
+    assert T.drain_rccl_watchdog() is False and time.time() - t0 < 0.2
+    assert T.CAPTURE_DRAIN_S >= 0.3          # several of the watchdog's 100 ms periods
