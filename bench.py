@@ -60,6 +60,8 @@ def parse(argv=None):
                          "command (run.py:1023-1025), reported in config")
     ap.add_argument("--partitioner", default="contiguous", choices=["contiguous", "community"],
                     help="N > 1: contiguous id ranges, or ranges of the label-propagation community order (bot_amd/dist.py)")
+    ap.add_argument("--ignore-hbm-budget", action="store_true",
+                    help="start even if bot_amd.workloads.hbm_budget (a coarse estimate) exceeds the free HBM of some rank")
     ap.add_argument("--capture", default="off", choices=["on", "off"],
                     help="on: replay the train step as ONE hipGraph (bot_amd.train.CapturedTrainStep) instead of ~300 eager launches "
                          "(configs 1-3; works partitioned too, RCCL collectives are captured).  Default off: the roofline object "
@@ -321,7 +323,15 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(dev)
     print(f"[bench] rank {rank}: HBM budget (estimate) {budget['total'] / 2**30:.1f} GiB = whole-graph build {budget['whole_graph_build'] / 2**30:.1f} "
           f"+ step {budget['step'] / 2**30:.1f}; free {free_b / 2**30:.1f} of {total_b / 2**30:.1f} GiB", file=sys.stderr, flush=True)
-    if budget["total"] > free_b:
+    fits = budget["total"] <= free_b
+    if partitioned:         # one verdict for the whole job: a rank that left alone would strand the others in the build's collectives
+        import torch.distributed as dist
+        flag = torch.tensor([1.0 if fits else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        fits = bool(flag.item() > 0.5)
+    if not fits and args.ignore_hbm_budget:
+        print(f"[bench] rank {rank}: the estimate exceeds the free memory; --ignore-hbm-budget: starting anyway", file=sys.stderr, flush=True)
+    elif not fits:
         print(f"[bench] rank {rank}: --workload {args.workload} at scale {args.scale} on {world} rank(s) needs ~{budget['total'] / 2**30:.0f} GiB per "
               f"rank, {free_b / 2**30:.0f} GiB are free: not starting (lower --scale or raise --gpus)", file=sys.stderr, flush=True)
         sys.exit(4)

@@ -41,7 +41,8 @@ const char* bot_last_kernel(void) { return bot::g_kernel; }
 // A HIP stream of the library's OWN (v17): bot_amd.side runs the weight-gradient products on it.  PyTorch hands out its streams from a pool
 // of 32 per device round-robin: a pooled "second stream" held for the process lifetime is sooner or later the SAME stream a later
 // torch.cuda.Stream() / the graph-capture stream / the process group's collective stream gets - a fork that waits on itself, or captured
-// work interleaved with a collective's.  Non-blocking (no implicit synchronisation with the legacy default stream).
+// work interleaved with a collective's.  Non-blocking (no implicit synchronisation with the legacy default stream).  high_priority == 0 is
+// the device's LOWEST priority, deliberately below torch's default-priority streams (include/bot_gnn.h).
 int bot_stream_create(int32_t high_priority, bot_stream_t* out) {
     using namespace bot;
     BOT_REQUIRE(out != nullptr, BOT_E_NULL, "stream_create: NULL pointer");

@@ -112,7 +112,10 @@ class _MergeWeight(torch.autograd.Function):
         if side.produced(dm):
             # the merged gradient came from the side stream (bot_amd.side): its split runs there too when autograd will only STEAL the
             # results (each parameter's one contribution, no .grad yet); otherwise the main stream joins first
-            if with_fc and side.MERGE_ON_SIDE and side.usable(dm) and all(p is None or p.grad is None for p in (W, ctx.wres_ref, attn_l, attn_r)):
+            # (a tensor hook or post-accumulate-grad hook - gradient clipping, a DDP-style reducer - would touch the in-flight
+            # gradient on the main stream before the end-of-backward join: with any hook registered the main stream joins first)
+            if with_fc and side.MERGE_ON_SIDE and side.usable(dm) and all(p is None or (p.grad is None and side.unhooked(p))
+                                                                          for p in (W, ctx.wres_ref, attn_l, attn_r)):
                 dW, dWres, dal, dar = side.run(body, dm, W, attn_l, attn_r)
             else:
                 side.join()
@@ -732,7 +735,10 @@ class _GATHiddenAggFirst(torch.autograd.Function):
             # extremes): the statistics pass over the [N, H D] output is gone (ops.stats_partials_for says when the epilogue takes them)
             partials = None
             if bn is not None and h.is_cuda | FORCE:
-                partials = stats_partials_for(bn, bn_training, N, HD, h.device, gemm.epilogue_piece(HD, x) is not None)
+                # (only the 256 x 32 form of the grouped launch carries the by-product: BOT_NT_KERNEL=128x64 or an odd number of k-steps takes
+                # the statistics pass instead of failing in bot_gemm_halves3_nt_grouped2_f32)
+                carries = int(_C._lib.bot_gemm_halves3_nt_bn_rows(2 * FP)) == 256
+                partials = stats_partials_for(bn, bn_training, N, HD, h.device, carries and gemm.epilogue_piece(HD, x) is not None)
             _C.gemm_halves3_nt_grouped(A, B, xscale, wscale, KA, 2 * FP, out2, g_fwd, FP // 32, stats=partials)
             ctx.graph = graph
             keep = (h, W, Wr, A, ext if ext is not None else h, el, er, a, a_d, xscale)

@@ -24,7 +24,8 @@ import os
 import torch
 
 ENABLED = os.environ.get("BOT_SIDE_STREAM", "1") != "0"
-PRIORITY = int(os.environ.get("BOT_SIDE_PRIORITY", "0"))   # -1: the side stream's workgroups are dispatched first when both streams have some ready
+PRIORITY = int(os.environ.get("BOT_SIDE_PRIORITY", "0"))   # 0: the device's LOWEST stream priority (below torch's default-priority streams: the main
+# stream's workgroups go first when both have some ready); -1: the highest (the side stream's go first).  bot_stream_create has no "default priority" form.
 MERGE_ON_SIDE = os.environ.get("BOT_SIDE_MERGE", "1") != "0"
 MIN_OUT = int(os.environ.get("BOT_SIDE_MIN_OUT", "0"))   # weight gradients with fewer entries (piece x piece) run inline (0: all on the side stream; the output layer's narrow
 # one measured the same either way, profiles/r05_side_step_ab.txt)
@@ -74,6 +75,8 @@ def run(fn, *keep):
     _storages(keep, ts)
     dev = ts[0].device
     cur = torch.cuda.current_stream(dev)
+    if _PENDING[0] is not None and _CB[0] != torch._C._current_graph_task_id():
+        join()                          # a backward pass that died with an exception never reached its join: start clean
     s = _stream(dev)
     s.wait_stream(cur)
     with torch.cuda.stream(s):
@@ -94,6 +97,11 @@ def run(fn, *keep):
         _CB[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_on_backward_end)
     return out
+
+
+def unhooked(p) -> bool:
+    """No tensor hook and no post-accumulate-grad hook on parameter `p`: autograd's leaf accumulation will only take the gradient over."""
+    return not getattr(p, "_backward_hooks", None) and not getattr(p, "_post_accumulate_grad_hooks", None)
 
 
 def produced(t) -> bool:

@@ -91,7 +91,8 @@ def hbm_budget(name: str, world: int = 1, scale: float = 1.0) -> dict:
     first multi-GPU run that cannot fit says so instead of dying in the allocator.  Every rank builds the whole seeded
     dataset on its own device and cuts its block out of it (`build`), so the build term does not shrink with the world size; the step
     term does.  Calibrated on the measured single-GPU peaks (tools/hbm_peak.py, profiles/r05_hbm_peak.txt: 0.18 / 7.1 / 23.8 / 39.4 /
-    75.2 GiB for configs 1-5; the estimate lands within +25 % of each):
+    75.2 GiB for configs 1-5; the estimate lands within +25 % of each; bench.py treats it as a gate that ALL ranks take together and that
+    `--ignore-hbm-budget` overrides):
       build  80 B per edge (COO pairs, CSC, CSR, permutations, plans) + node features (+ 32 B per edge of edge features, config 4)
       step   GAT family: 9 B per edge, head and layer (attention weights, their dropped copy / signs) + 7.5 fp32 [rows, H D] tensors per
              wide layer (projection output, gradient operand, pre-BatchNorm state, halves, temporaries); GCN: 150 B per edge (the
@@ -108,7 +109,9 @@ def hbm_budget(name: str, world: int = 1, scale: float = 1.0) -> dict:
     if world > 1:
         build += e_loc * 80 + n_ext * max(f, 8) * 4              # the rank's block beside the whole graph it was cut from
     edge_part = e_loc * 150 if gcn else layers * e_loc * H * 9
-    node_part = max(1, layers - 1) * n_ext * H * D * 4 * 7.5
+    # (the modular edge-GAT stacks keep fewer [rows, H D] temporaries alive than the fused GAT layers: 4.5 against 7.5 tensors per wide layer,
+    # recalibrated on profiles/r05_hbm_peak.txt after ADVICE r5: S-products 75.2 GiB measured, 112.5 estimated before, 78 now)
+    node_part = max(1, layers - 1) * n_ext * H * D * 4 * (4.5 if edge else 7.5)
     step = int(1.3 * (edge_part + node_part))
     return {"whole_graph_build": int(build), "step": step, "total": int(build) + step + (1 << 28)}      # + 0.25 GiB of fixed costs
 

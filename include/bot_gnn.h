@@ -46,7 +46,9 @@ typedef void* bot_stream_t; /* hipStream_t */
 
 int bot_abi_version(void);
 const char* bot_last_error(void);
-/* v17: a HIP stream of the library's own (hipStreamNonBlocking; high_priority != 0: the device's highest priority), never destroyed -
+/* v17: a HIP stream of the library's own (hipStreamNonBlocking; high_priority != 0: the device's HIGHEST priority, 0: its LOWEST - not the
+ * default priority torch's streams have: the side stream's workgroups are dispatched behind the main stream's when both have some ready,
+ * which is what the step wants of work only the optimizer waits for, and what every A/B of bot_amd.side was measured with), never destroyed -
  * the second stream of bot_amd.side (weight-gradient products beside the sparse backward).  Not one of PyTorch's 32 pooled streams, which
  * are handed out round-robin and would sooner or later alias a capture stream or a process group's collective stream. */
 int bot_stream_create(int32_t high_priority, bot_stream_t* out);
