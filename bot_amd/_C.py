@@ -1025,16 +1025,18 @@ def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups,
     assert out.dtype == torch.float32 and out.stride(-1) == 1
     tab = _table(groups, 6)
     # (profile key: m, n, k, batch with 2 m n k batch = the fp16 MFMA flops of the valid output columns, three products each)
-    # stats = (part [tiles, 2, F], minmax [tiles, 2, F], pivot [F]): column statistics of the stored values as a by-product (tiles = ceil(m / 256)
-    # row blocks, F = the width the groups' output columns c_off + j index: bot_gemm_halves3_nt_grouped2_f32; finished by bn_stats_halves_partials)
+    # stats = (part [tiles, 2, F], minmax [tiles, 2, F], pivot [tiles, F]): column statistics of the stored values as a by-product (tiles =
+    # ceil(m / 256) row blocks, F = the width the groups' output columns c_off + j index; all three WRITTEN: the pivot of a tile is its first
+    # stored value - bot_gemm_halves3_nt_grouped2_f32; finished by bn_stats_halves_partials)
     sp = sm = sv = None
     sF = 0
     if stats is not None:
         sp, sm, sv = stats
         _dev(sp, sm, sv)
-        sF = sv.shape[0]
+        sF = sv.shape[1]
         tiles = (a.shape[0] + 255) // 256
-        assert sp.shape == (tiles, 2, sF) and sm.shape == (tiles, 2, sF) and sp.is_contiguous() and sm.is_contiguous() and sv.is_contiguous()
+        assert sp.shape == (tiles, 2, sF) and sm.shape == (tiles, 2, sF) and sv.shape == (tiles, sF)
+        assert sp.is_contiguous() and sm.is_contiguous() and sv.is_contiguous()
         assert sp.dtype == sm.dtype == sv.dtype == torch.float32
     _check(_timed("gemm_halves", (a.shape[0], sum(int(g[1]) * 96 * int(g[4]) for g in groups), 1, 1), lambda: _lib.bot_gemm_halves3_nt_grouped2_f32(
         a.shape[0], b.shape[0], scale_a.data_ptr(), scale_b.data_ptr(), a.data_ptr(), _ld(a), a2_off, b.data_ptr(), _ld(b), b2_off, out.data_ptr(),
@@ -1269,6 +1271,7 @@ def bn_stats_halves_partials(part, minmax, pivot, n, eps, momentum, running_mean
     (include/bot_gnn.h bot_bn_stats_halves_partials_f32): -> (mean, invstd, hscale)."""
     _dev(part, minmax, pivot, running_mean, running_var, weight, bias)
     nblk, _, F = part.shape
+    assert pivot.shape == (nblk, F) and minmax.shape == part.shape and part.is_contiguous() and minmax.is_contiguous() and pivot.is_contiguous()
     mean = torch.empty(F, dtype=torch.float32, device=part.device)
     invstd = torch.empty(F, dtype=torch.float32, device=part.device)
     hscale = torch.empty(2, dtype=torch.float32, device=part.device)

@@ -278,6 +278,71 @@ __global__ __launch_bounds__(kBlock) void colstats_final_kernel(const float* x, 
     if (num_batches && blockIdx.x == 0 && threadIdx.x == 0) num_batches[0] += 1;
 }
 
+// colstats_final_kernel for partials whose pivot differs PER ROW BLOCK (v19: the grouped NT launch's by-product takes each 256-row tile's
+// first value as that tile's pivot): block b holds n_b rows, pivot p_b, S_b = sum (v - p_b), Q_b = sum (v - p_b)^2 (fp32 sums of 256 well
+// centred terms).  Every block is re-based onto the first block's pivot P0 in double - S'_b = S_b + n_b d, Q'_b = Q_b + 2 d S_b + n_b d^2,
+// d = p_b - P0: exact algebra, and P0 is a value of the column, a few standard deviations from its mean whatever the mean is - then the
+// blocks are added in the fixed (group, block) order of pair_reduce and finished like the pass form: mean = P0 + S / n, m2 = Q - S^2 / n.
+__global__ __launch_bounds__(kBlock) void colstats_tiles_final_kernel(const float* pivot, int64_t n, int32_t F, const float* part, int nblk, int block_rows,
+                                                                     float* mean, float* invstd, float eps, float momentum, float* running_mean,
+                                                                     float* running_var, int64_t* num_batches, const float* minmax, const float* bw,
+                                                                     const float* bb, float bp, float* bound) {
+    __shared__ double lds[2][4][64];
+    __shared__ float ldm[2][4][64];
+    const int lc = threadIdx.x & 63, c = blockIdx.x * 64 + lc, grp = threadIdx.x >> 6;
+    float mn = INFINITY, mx = -INFINITY;
+    double s = 0.0, q = 0.0;
+    const double P0 = c < F ? (double)pivot[c] : 0.0;
+    if (c < F) {
+        int b = grp;
+        for (; b + 12 < nblk; b += 16) {        // four blocks in flight per group, added in block order
+            float vs[4], vq[4], vp[4], v0[4], v1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t o = ((int64_t)(b + 4 * j) * 2) * F + c;
+                vs[j] = part[o], vq[j] = part[o + F], vp[j] = pivot[(int64_t)(b + 4 * j) * F + c], v0[j] = minmax[o], v1[j] = minmax[o + F];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double nb = (double)min((int64_t)block_rows, n - (int64_t)(b + 4 * j) * block_rows), d = (double)vp[j] - P0;
+                s += (double)vs[j] + nb * d;
+                q += (double)vq[j] + 2.0 * d * (double)vs[j] + nb * d * d;
+                mn = fminf(mn, v0[j]), mx = fmaxf(mx, v1[j]);
+            }
+        }
+        for (; b < nblk; b += 4) {
+            const int64_t o = ((int64_t)b * 2) * F + c;
+            const double nb = (double)min((int64_t)block_rows, n - (int64_t)b * block_rows), d = (double)pivot[(int64_t)b * F + c] - P0;
+            const double sb = (double)part[o];
+            s += sb + nb * d;
+            q += (double)part[o + F] + 2.0 * d * sb + nb * d * d;
+            mn = fminf(mn, minmax[o]), mx = fmaxf(mx, minmax[o + F]);
+        }
+    }
+    lds[0][grp][lc] = s, lds[1][grp][lc] = q, ldm[0][grp][lc] = mn, ldm[1][grp][lc] = mx;
+    __syncthreads();
+    if (grp == 0 && c < F) {
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) S += lds[0][g][lc], Q += lds[1][g][lc];
+#pragma unroll
+        for (int g = 1; g < 4; ++g) mn = fminf(mn, ldm[0][g][lc]), mx = fmaxf(mx, ldm[1][g][lc]);
+        const float mu = (float)(P0 + S / (double)n);
+        const float m2 = (float)fmax(Q - S * S / (double)n, 0.0);
+        const float is = rsqrtf(m2 / (float)n + eps);
+        mean[c] = mu, invstd[c] = is;
+        if (bound) {                     // bn_bound_kernel's expression on this column's statistics
+            const float dev = fmaxf(fabsf(mx - mu), fabsf(mn - mu)) * is;
+            bound[c] = (fabsf(bw ? bw[c] : 1.f) * dev + fabsf(bb ? bb[c] : 0.f)) / (1.f - bp);
+        }
+        if (running_mean) {
+            running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mu;
+            running_var[c] = running_var[c] * (1.f - momentum) + momentum * (m2 / (float)(n > 1 ? n - 1 : 1));
+        }
+    }
+    if (num_batches && blockIdx.x == 0 && threadIdx.x == 0) num_batches[0] += 1;
+}
+
 // sum[c] = the unshifted partial sums added in double: the column SUM (a bias gradient).  Going through the pivot-shifted
 // fp32 mean instead loses ~eps * |pivot| * n — 2e-7 on gradients whose true sum is 0 at n = 2.45 M.
 __global__ __launch_bounds__(kBlock) void colsum_final_kernel(const float* part, int32_t F, int nblk, float* sum) {
@@ -838,8 +903,8 @@ int bot_bn_stats_halves_f32(const float* x, int64_t ldx, int64_t n, int32_t F, f
 
 // v17: bot_bn_stats_halves_f32 from column partials a PRODUCER of x delivered with it (the grouped NT GEMM's epilogue:
 // bot_gemm_halves3_nt_grouped2_f32 `stats_*`) instead of a pass over x:  part [nblk][2][F] = per row block the sums of (x - pivot) and
-// (x - pivot)^2, minmax [nblk][2][F] the column extremes, pivot [F] the shift the producer used (any value near the column mean; the
-// running mean serves - it is read here before this call updates it).  Same second stage as the pass form (partials added in block order).
+// (x - pivot)^2, minmax [nblk][2][F] the column extremes, pivot [nblk][F] the shift the producer used in each 256-row block (v19: the block's
+// own first value, written by the producer; colstats_tiles_final_kernel re-bases the blocks exactly).  nblk = ceil(n / 256).
 int bot_bn_stats_halves_partials_f32(const float* part, const float* minmax, int32_t nblk, const float* pivot, int64_t n, int32_t F, float eps, float momentum,
                                      float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                      const float* weight, const float* bias, float p, float* hscale, float* bound_workspace, bot_stream_t stream) {
@@ -850,8 +915,9 @@ int bot_bn_stats_halves_partials_f32(const float* part, const float* minmax, int
     BOT_REQUIRE(eps >= 0.f && momentum >= 0.f && momentum <= 1.f && p >= 0.f && p < 1.f, BOT_E_RANGE, "bn_stats_halves_partials: eps=%f momentum=%f p=%f",
                 (double)eps, (double)momentum, (double)p);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colstats_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, pivot, n, F, part, (int)nblk, mean, (float*)nullptr, invstd, eps,
-                       momentum, running_mean, running_var, num_batches_tracked, minmax, weight, bias, p, bound_workspace);
+    BOT_REQUIRE((int64_t)nblk == (n + 255) / 256, BOT_E_RANGE, "bn_stats_halves_partials: nblk=%d is not ceil(n / 256) for n=%lld", nblk, (long long)n);
+    hipLaunchKernelGGL(colstats_tiles_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, pivot, n, F, part, (int)nblk, 256, mean, invstd, eps, momentum,
+                       running_mean, running_var, num_batches_tracked, minmax, weight, bias, p, bound_workspace);
     launch_halves_scale(bound_workspace, F, hscale, st);
     return hip_status("bn_stats_halves_partials launch");
 }

@@ -59,11 +59,13 @@ struct H3Args {
     const float* scale_a2;
     int k2;                 // -1: one scale
     // optional (grouped nt64 launches): column statistics of the stored values as a by-product - per 256-row tile t and output column c
-    // stats_part[(2 t + 0) F + c] = sum of (v - pivot[c]), [(2 t + 1) F + c] = sum of squares, stats_minmax likewise min / max (the
-    // partials of dense.hip colstats_partial_kernel, one row block per tile: bot_bn_stats_halves_partials_f32 finishes them)
+    // stats_pivot[t F + c] = the tile's FIRST stored value of the column (written here: a pivot inside the data, so the squares do not
+    // cancel for columns whose mean is far from zero - ABI 19), stats_part[(2 t + 0) F + c] = sum of (v - pivot),
+    // [(2 t + 1) F + c] = sum of squares, stats_minmax likewise min / max (one row block per tile: bot_bn_stats_halves_partials_f32 combines
+    // the tiles' (count, pivot, sum, sum of squares) exactly, in double)
     float* stats_part;
     float* stats_minmax;
-    const float* stats_pivot;
+    float* stats_pivot;
     int stats_F;
     // optional (bot_gemm_halves3_nt3_f32, gemm_halves3_nt64_*_bnb_kernel): C is the gradient arriving at a fused BatchNorm / ReLU / dropout
     // epilogue (dense.hip bn_act_bwd_*) whose input was bnb_x [M, N]: the column sums of that backward's reduce pass (masked gradient g,
@@ -626,11 +628,6 @@ __device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3
     float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f}, st_mn[4], st_mx[4], piv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) st_mn[e] = INFINITY, st_mx[e] = -INFINITY;
-    if (stats) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (col + e < n_valid) piv[e] = p.stats_pivot[c0 + col + e];
-    }
     // BatchNorm-backward by-product (BNB): this lane's quad of columns is a Philox quad of the epilogue's dropout mask (c0 + col is a multiple
     // of 4), the x rows are read 8 rows x 128 bytes per instruction like the stores
     float b_s[4] = {0.f, 0.f, 0.f, 0.f}, b_q[4] = {0.f, 0.f, 0.f, 0.f}, b_gm[4] = {0.f, 0.f, 0.f, 0.f}, b_xm[4] = {0.f, 0.f, 0.f, 0.f};
@@ -706,6 +703,12 @@ __device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3
                     if (p.relu) v[e] = fmaxf(v[e], 0.f);
                 }
             }
+            if constexpr (pass == 0) {
+                if (stats && i == 0) {      // the tile's first row (always a row of the matrix) sits in lanes 0 .. 7 of this read: the pivot
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) piv[e] = __shfl(v[e], l7);
+                }
+            }
             if (stats && row < p.M) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -774,9 +777,10 @@ __device__ __forceinline__ void gemm_halves3_nt64_body(const H3Args& p, const H3
             const int64_t F = p.stats_F;
             float* ps = p.stats_part + ((int64_t)tm * 2) * F + c0 + col;
             float* pm = p.stats_minmax + ((int64_t)tm * 2) * F + c0 + col;
+            float* pp = p.stats_pivot + (int64_t)tm * F + c0 + col;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (col + e < n_valid) ps[e] = st_s[e], ps[F + e] = st_q[e], pm[e] = st_mn[e], pm[F + e] = st_mx[e];
+                if (col + e < n_valid) ps[e] = st_s[e], ps[F + e] = st_q[e], pm[e] = st_mn[e], pm[F + e] = st_mx[e], pp[e] = piv[e];
         }
     }
     if constexpr (BNB) {       // the same fold: 8 row groups per wave, fixed order
@@ -1274,7 +1278,7 @@ extern "C" int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const 
 extern "C" int bot_gemm_halves3_nt_grouped2_f32(int64_t m, int64_t b_rows, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
                                                 int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t n_groups,
                                                 const int64_t* groups, int32_t k_seg, const float* col_scale, const float* col_shift, int32_t relu,
-                                                uint32_t* absmax_slots, float* stats_part, float* stats_minmax, const float* stats_pivot, int32_t stats_F,
+                                                uint32_t* absmax_slots, float* stats_part, float* stats_minmax, float* stats_pivot, int32_t stats_F,
                                                 int32_t mode, bot_stream_t stream) {
     using namespace bot;
     BOT_REQUIRE((stats_part == nullptr) == (stats_minmax == nullptr) && (stats_part == nullptr) == (stats_pivot == nullptr) && (stats_part == nullptr || stats_F >= 1), -1,

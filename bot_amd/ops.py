@@ -343,24 +343,20 @@ def bn_batch_stats(x, bn, bn_training, halves_p=None, partials=None):
 
 
 STATS_BYPRODUCT = os.environ.get("BOT_STATS_BYPRODUCT", "1") != "0"
-_ZERO_PIVOT = {}
 
 
 def stats_partials_for(bn, bn_training, n_rows, F, device, halves_ok):
     """Buffers for a producer that can deliver BatchNorm's column partials as a by-product (the grouped NT GEMM's epilogue), or None when
-    `bn_batch_stats` would not take them (eval mode, partitioned statistics, no halves epilogue): (part, minmax, pivot).  The pivot (the
-    shift of the sums, which must exist before the producer runs) is ZERO: a state-independent choice - the running mean would make the
-    batch statistics depend, at rounding level, on the module's history.  Sums of 256 rows in fp32, tiles added in double: against the
-    pass form's first-row pivot the variance loses (mean / std)^2 ulps, far inside the parity bounds for pre-BatchNorm activations."""
+    `bn_batch_stats` would not take them (eval mode, partitioned statistics, no halves epilogue): (part, minmax, pivot), all written by the
+    producer.  The shift of a 256-row tile's sums is the tile's own FIRST value (ABI 19; round 5 shifted by zero, which lost
+    (mean / std)^2 ulps of the variance on un-centred columns): a state-independent choice inside the data; the finish re-bases
+    the tiles onto the first tile's pivot exactly, in double (csrc/dense.hip colstats_tiles_final_kernel)."""
     sync, _ = _dist_group(bn)
     if not (STATS_BYPRODUCT and bn_training and halves_ok and not sync and (bn.momentum is not None or not bn.track_running_stats)):
         return None
     tiles = (n_rows + 255) // 256
-    key = (str(device), F)
-    if key not in _ZERO_PIVOT:
-        _ZERO_PIVOT[key] = torch.zeros(F, dtype=torch.float32, device=device)
-    pivot = _ZERO_PIVOT[key]
-    return (torch.empty((tiles, 2, F), dtype=torch.float32, device=device), torch.empty((tiles, 2, F), dtype=torch.float32, device=device), pivot)
+    return (torch.empty((tiles, 2, F), dtype=torch.float32, device=device), torch.empty((tiles, 2, F), dtype=torch.float32, device=device),
+            torch.empty((tiles, F), dtype=torch.float32, device=device))
 
 
 def random_edge_keep(graph, drop):

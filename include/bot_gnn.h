@@ -644,15 +644,18 @@ int bot_gemm_halves3_nt_grouped_f32(int64_t m, int64_t b_rows, const float* scal
                                     const int64_t* groups, int32_t k_seg, const float* col_scale, const float* col_shift, int32_t relu,
                                     uint32_t* absmax_slots, int32_t mode, bot_stream_t stream);
 /* v17: nt_grouped with column statistics of the stored values as a by-product (BatchNorm's batch statistics without a pass over the
- * layer's output): per 256-row tile t and output column c = c_off + j, stats_part[(2 t + 0) stats_F + c] = sum over the tile's rows of
- * (C - stats_pivot[c]), [(2 t + 1) stats_F + c] the sum of squares, stats_minmax likewise the column minimum / maximum - ceil(m / 256) row
- * blocks in the layout of bot_bn_stats_halves_partials_f32, which turns them into mean / invstd / running statistics / the epilogue's
- * halves scale.  All three NULL: no statistics (= bot_gemm_halves3_nt_grouped_f32). */
+ * layer's output): per 256-row tile t and output column c = c_off + j, stats_pivot[t stats_F + c] = the tile's FIRST stored value of the
+ * column (v19: written by the launch - a pivot inside the data keeps the sum of squares from cancelling for columns whose mean is far
+ * from zero; v17/18 read one caller-given pivot per column), stats_part[(2 t + 0) stats_F + c] = sum over the tile's rows of
+ * (C - pivot), [(2 t + 1) stats_F + c] the sum of squares, stats_minmax likewise the column minimum / maximum - ceil(m / 256) row blocks in
+ * the layout of bot_bn_stats_halves_partials_f32, which combines the tiles exactly (in double) into mean / invstd / running statistics /
+ * the epilogue's halves scale.  All three NULL: no statistics (= bot_gemm_halves3_nt_grouped_f32). */
 int bot_gemm_halves3_nt_grouped2_f32(int64_t m, int64_t b_rows, const float* scale_a, const float* scale_b, const uint16_t* A, int64_t lda,
                                      int64_t a2_off, const uint16_t* B, int64_t ldb, int64_t b2_off, float* C, int64_t ldc, int32_t n_groups,
                                      const int64_t* groups, int32_t k_seg, const float* col_scale, const float* col_shift, int32_t relu,
-                                     uint32_t* absmax_slots, float* stats_part, float* stats_minmax, const float* stats_pivot, int32_t stats_F,
+                                     uint32_t* absmax_slots, float* stats_part, float* stats_minmax, float* stats_pivot, int32_t stats_F,
                                      int32_t mode, bot_stream_t stream);
+/* (v19) part / minmax [nblk][2][F], pivot [nblk][F], nblk = ceil(n / 256) row blocks of 256 rows (the last one shorter). */
 int bot_bn_stats_halves_partials_f32(const float* part, const float* minmax, int32_t nblk, const float* pivot, int64_t n, int32_t F, float eps, float momentum,
                                      float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                      const float* weight, const float* bias, float p, float* hscale, float* bound_workspace, bot_stream_t stream);

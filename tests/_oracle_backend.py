@@ -507,11 +507,12 @@ def gemm_halves3_nt_grouped(a, b, scale_a, scale_b, a2_off, b2_off, out, groups,
             res = torch.relu(res)
         _fold_absmax(absmax, res)
         flat.as_strided((m, n_valid), (ld, 1), c_off).copy_(res)
-        if stats is not None:           # per 256-row tile: sums of (v - pivot), (v - pivot)^2, column extremes (bot_gemm_halves3_nt_grouped2_f32)
-            part, minmax, pivot = stats
+        if stats is not None:           # per 256-row tile: its first row (the pivot), sums of (v - pivot), (v - pivot)^2, column extremes
+            part, minmax, pivot = stats     # (bot_gemm_halves3_nt_grouped2_f32, ABI 19)
             for t in range((m + 255) // 256):
                 v = res[256 * t:256 * (t + 1)].float()
-                dlt = v - pivot[c_off:c_off + n_valid]
+                pivot[t, c_off:c_off + n_valid] = v[0]
+                dlt = v - v[0]
                 part[t, 0, c_off:c_off + n_valid], part[t, 1, c_off:c_off + n_valid] = dlt.sum(0), (dlt * dlt).sum(0)
                 minmax[t, 0, c_off:c_off + n_valid], minmax[t, 1, c_off:c_off + n_valid] = v.min(0).values, v.max(0).values
     return out
@@ -613,8 +614,14 @@ def bn_stats_halves(x, eps, momentum, running_mean, running_var, num_batches_tra
 
 def bn_stats_halves_partials(part, minmax, pivot, n, eps, momentum, running_mean, running_var, num_batches_tracked, weight, bias, p):
     """include/bot_gnn.h bot_bn_stats_halves_partials_f32"""
-    S, Q = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
-    mean = (pivot.double() + S / n).float()
+    nblk = part.shape[0]
+    nb = torch.full((nblk, 1), 256.0, dtype=torch.float64)
+    nb[-1] = n - 256 * (nblk - 1)
+    P0 = pivot[0].double()
+    d = pivot.double() - P0             # every block re-based onto the first block's pivot (csrc/dense.hip colstats_tiles_final_kernel)
+    S = (part[:, 0].double() + nb * d).sum(0)
+    Q = (part[:, 1].double() + 2 * d * part[:, 0].double() + nb * d * d).sum(0)
+    mean = (P0 + S / n).float()
     m2 = (Q - S * S / n).clamp(min=0).float()
     invstd = torch.rsqrt(m2 / n + eps)
     if running_mean is not None:

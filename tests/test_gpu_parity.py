@@ -1837,10 +1837,12 @@ def test_gemm_halves3_nt_kernel():
 
 
 def test_stats_byproduct_of_grouped_nt():
-    """ABI 17: BatchNorm's column partials as a by-product of the grouped NT launch that writes the layer output
+    """ABI 17 / 19: BatchNorm's column partials as a by-product of the grouped NT launch that writes the layer output
     (bot_gemm_halves3_nt_grouped2_f32 `stats_*`) + bot_bn_stats_halves_partials_f32, against the pass form on the same output
-    (bot_bn_stats_halves_f32): the output itself bit for bit the launch without statistics, partial sums / extremes against torch on it,
-    mean / invstd / running statistics / the halves scale against the pass form; a pivot far from zero too."""
+    (bot_bn_stats_halves_f32): the output itself bit for bit the launch without statistics; per 256-row tile the pivot IS the tile's first
+    stored row, the partial sums / extremes against torch on the stored values; mean / invstd / running statistics / the halves scale
+    against the pass form and against fp64 - also for columns whose mean is 1e3 standard deviations from zero (round 5's zero
+    pivot cancelled there), produced with the launch's own column-shift epilogue."""
     from bot_amd.nn import fused
     gen = torch.Generator(device=DEV).manual_seed(37)
     for (N, H, D, Fin) in ((20011, 3, 250, 168), (700, 2, 70, 40)):
@@ -1851,18 +1853,24 @@ def test_stats_byproduct_of_grouped_nt():
         A[:, KA:] *= 0.01
         B = (torch.randn(HD, 6 * FP, device=DEV, generator=gen) * 30 + 3).half()
         sa, sb = torch.tensor([4.0, 0.25], device=DEV), torch.tensor([8.0, 0.125], device=DEV)
-        ref = torch.zeros(N, P2, device=DEV)
-        _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, ref, g_fwd, FP // 32)
         tiles = (N + 255) // 256
-        for pv in (0.0, 1e4):
+        plain = torch.zeros(N, P2, device=DEV)
+        _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, plain, g_fwd, FP // 32)
+        sd0 = float(plain[:, :HD].double().std(0).mean())
+        for far in (0.0, 1e3):              # column means `far` standard deviations away from zero
+            shift = torch.zeros(P2, device=DEV)
+            shift[:HD] = far * sd0 * (1 + torch.rand(HD, device=DEV, generator=gen))
+            ref = torch.zeros(N, P2, device=DEV)
+            _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, ref, g_fwd, FP // 32, col_shift=shift)
             part, minmax = torch.full((tiles, 2, HD), 7.0, device=DEV), torch.full((tiles, 2, HD), 7.0, device=DEV)
-            pivot = torch.full((HD,), pv, device=DEV)
+            pivot = torch.full((tiles, HD), 7.0, device=DEV)
             out = torch.zeros(N, P2, device=DEV)
-            _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, out, g_fwd, FP // 32, stats=(part, minmax, pivot))
+            _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, out, g_fwd, FP // 32, col_shift=shift, stats=(part, minmax, pivot))
             assert torch.equal(out, ref)
             x = out[:, :HD]
+            assert torch.equal(pivot, x[0::256])                # the tile's first stored row
             pad = torch.cat([x, x.new_full((tiles * 256 - N, HD), float("nan"))]).view(tiles, 256, HD)
-            d64 = (pad.double() - pv)
+            d64 = pad.double() - pivot.double().unsqueeze(1)
             s_ref, q_ref = torch.nansum(d64, 1), torch.nansum(d64 * d64, 1)
             big = q_ref.sqrt().max() * 16                      # a tile's sum of 256 terms: errors relative to the tile's 2-norm
             assert float((part[:, 0].double() - s_ref).abs().max() / big) < 1e-6
@@ -1870,20 +1878,21 @@ def test_stats_byproduct_of_grouped_nt():
             mn = torch.where(torch.isnan(pad), torch.full_like(pad, float("inf")), pad).min(1).values
             mx = torch.where(torch.isnan(pad), torch.full_like(pad, float("-inf")), pad).max(1).values
             assert torch.equal(minmax[:, 0], mn) and torch.equal(minmax[:, 1], mx)
-        # finished statistics against the pass form (zero pivot: the product's choice)
-        part, minmax, pivot = torch.empty((tiles, 2, HD), device=DEV), torch.empty((tiles, 2, HD), device=DEV), torch.zeros(HD, device=DEV)
-        out = torch.zeros(N, P2, device=DEV)
-        _C.gemm_halves3_nt_grouped(A, B, sa, sb, KA, 2 * FP, out, g_fwd, FP // 32, stats=(part, minmax, pivot))
-        x = out[:, :HD]
-        w, b = torch.randn(HD, device=DEV, generator=gen), torch.randn(HD, device=DEV, generator=gen)
-        rm1, rv1, nb1 = torch.zeros(HD, device=DEV), torch.ones(HD, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
-        rm2, rv2, nb2 = rm1.clone(), rv1.clone(), nb1.clone()
-        m1, i1, h1 = _C.bn_stats_halves(x, 1e-5, 0.1, rm1, rv1, nb1, w, b, 0.25)
-        m2, i2, h2 = _C.bn_stats_halves_partials(part, minmax, pivot, N, 1e-5, 0.1, rm2, rv2, nb2, w, b, 0.25)
-        sd = (1.0 / i1).max()
-        assert float((m1 - m2).abs().max() / sd) < 2e-6 and float(((i1 - i2) / i1).abs().max()) < 2e-5, (float((m1 - m2).abs().max()), float(((i1 - i2) / i1).abs().max()))
-        assert float((rm1 - rm2).abs().max() / sd) < 2e-6 and float(((rv1 - rv2) / rv1).abs().max()) < 2e-5 and int(nb2) == 1
-        assert torch.equal(h1, h2)
+            # finished statistics against the pass form and against fp64
+            w, b = torch.randn(HD, device=DEV, generator=gen), torch.randn(HD, device=DEV, generator=gen)
+            rm1, rv1, nb1 = torch.zeros(HD, device=DEV), torch.ones(HD, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+            rm2, rv2, nb2 = rm1.clone(), rv1.clone(), nb1.clone()
+            m1, i1, h1 = _C.bn_stats_halves(x, 1e-5, 0.1, rm1, rv1, nb1, w, b, 0.25)
+            m2, i2, h2 = _C.bn_stats_halves_partials(part, minmax, pivot, N, 1e-5, 0.1, rm2, rv2, nb2, w, b, 0.25)
+            x64 = x.double()
+            mu64, is64 = x64.mean(0), torch.rsqrt(x64.var(0, unbiased=False) + 1e-5)
+            sd = (1.0 / i1).max()
+            ulp = float(x.abs().max()) * 2.0 ** -23            # a mean cannot be closer to fp64 than the fp32 spacing at its magnitude
+            assert float((m2.double() - mu64).abs().max()) <= max(2e-6 * float(sd), ulp), (far, float((m2.double() - mu64).abs().max()), ulp)
+            assert float(((i2.double() - is64) / is64).abs().max()) < 2e-5, (far, float(((i2.double() - is64) / is64).abs().max()))
+            assert float((m1 - m2).abs().max()) <= max(2e-6 * float(sd), 2 * ulp) and float(((i1 - i2) / i1).abs().max()) < 4e-5
+            assert float((rm1 - rm2).abs().max()) <= max(2e-6 * float(sd), ulp) and float(((rv1 - rv2) / rv1).abs().max()) < 4e-5 and int(nb2) == 1
+            assert torch.equal(h1, h2), (far, h1, h2)
 
 
 def test_nt64_kernel_and_fragment_major_operand():
