@@ -283,36 +283,44 @@ __global__ __launch_bounds__(kBlock) void colstats_final_kernel(const float* x, 
 // centred terms).  Every block is re-based onto the first block's pivot P0 in double - S'_b = S_b + n_b d, Q'_b = Q_b + 2 d S_b + n_b d^2,
 // d = p_b - P0: exact algebra, and P0 is a value of the column, a few standard deviations from its mean whatever the mean is - then the
 // blocks are added in the fixed (group, block) order of pair_reduce and finished like the pass form: mean = P0 + S / n, m2 = Q - S^2 / n.
-__global__ __launch_bounds__(kBlock) void colstats_tiles_final_kernel(const float* pivot, int64_t n, int32_t F, const float* part, int nblk, int block_rows,
-                                                                     float* mean, float* invstd, float eps, float momentum, float* running_mean,
-                                                                     float* running_var, int64_t* num_batches, const float* minmax, const float* bw,
-                                                                     const float* bb, float bp, float* bound) {
-    __shared__ double lds[2][4][64];
-    __shared__ float ldm[2][4][64];
-    const int lc = threadIdx.x & 63, c = blockIdx.x * 64 + lc, grp = threadIdx.x >> 6;
+// 16 columns x 64 row-block groups per workgroup (1024 threads; F = 750: 47 workgroups - with 64 columns x 4 groups the 12 workgroups were bound
+// by what 12 CUs can pull from the L2: 146 us; a wave reads 4 blocks x 64 bytes per instruction)
+constexpr int kTileCols = 16, kTileGroups = 64;
+__global__ __launch_bounds__(kTileCols * kTileGroups) void colstats_tiles_final_kernel(const float* pivot, int64_t n, int32_t F, const float* part, int nblk,
+                                                                               int block_rows, float* mean, float* invstd, float eps, float momentum,
+                                                                               float* running_mean, float* running_var, int64_t* num_batches,
+                                                                               const float* minmax, const float* bw, const float* bb, float bp,
+                                                                               float* bound) {
+    __shared__ double lds[2][kTileGroups][kTileCols];
+    __shared__ float ldm[2][kTileGroups][kTileCols];
+    const int lc = threadIdx.x % kTileCols, c = blockIdx.x * kTileCols + lc, grp = threadIdx.x / kTileCols;
     float mn = INFINITY, mx = -INFINITY;
     double s = 0.0, q = 0.0;
-    const double P0 = c < F ? (double)pivot[c] : 0.0;
+    const float P0f = c < F ? pivot[c] : 0.f;
+    const double P0 = (double)P0f;
+    const int last = nblk - 1;
+    const double n_last = (double)(n - (int64_t)last * block_rows), n_full = (double)block_rows;
     if (c < F) {
+        constexpr int U = 4;                    // four blocks in flight per thread
         int b = grp;
-        for (; b + 12 < nblk; b += 16) {        // four blocks in flight per group, added in block order
-            float vs[4], vq[4], vp[4], v0[4], v1[4];
+        for (; b + (U - 1) * kTileGroups < nblk; b += U * kTileGroups) {
+            float vs[U], vq[U], vp[U], v0[U], v1[U];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t o = ((int64_t)(b + 4 * j) * 2) * F + c;
-                vs[j] = part[o], vq[j] = part[o + F], vp[j] = pivot[(int64_t)(b + 4 * j) * F + c], v0[j] = minmax[o], v1[j] = minmax[o + F];
+            for (int j = 0; j < U; ++j) {
+                const int64_t o = ((int64_t)(b + kTileGroups * j) * 2) * F + c;
+                vs[j] = part[o], vq[j] = part[o + F], vp[j] = pivot[(int64_t)(b + kTileGroups * j) * F + c], v0[j] = minmax[o], v1[j] = minmax[o + F];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double nb = (double)min((int64_t)block_rows, n - (int64_t)(b + 4 * j) * block_rows), d = (double)vp[j] - P0;
+            for (int j = 0; j < U; ++j) {
+                const double nb = (b + kTileGroups * j == last) ? n_last : n_full, d = (double)vp[j] - P0;
                 s += (double)vs[j] + nb * d;
                 q += (double)vq[j] + 2.0 * d * (double)vs[j] + nb * d * d;
                 mn = fminf(mn, v0[j]), mx = fmaxf(mx, v1[j]);
             }
         }
-        for (; b < nblk; b += 4) {
+        for (; b < nblk; b += kTileGroups) {
             const int64_t o = ((int64_t)b * 2) * F + c;
-            const double nb = (double)min((int64_t)block_rows, n - (int64_t)b * block_rows), d = (double)pivot[(int64_t)b * F + c] - P0;
+            const double nb = (b == last) ? n_last : n_full, d = (double)pivot[(int64_t)b * F + c] - P0;
             const double sb = (double)part[o];
             s += sb + nb * d;
             q += (double)part[o + F] + 2.0 * d * sb + nb * d * d;
@@ -324,9 +332,9 @@ __global__ __launch_bounds__(kBlock) void colstats_tiles_final_kernel(const floa
     if (grp == 0 && c < F) {
         double S = 0.0, Q = 0.0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) S += lds[0][g][lc], Q += lds[1][g][lc];
+        for (int g = 0; g < kTileGroups; ++g) S += lds[0][g][lc], Q += lds[1][g][lc];     // fixed (group, block) order: deterministic
 #pragma unroll
-        for (int g = 1; g < 4; ++g) mn = fminf(mn, ldm[0][g][lc]), mx = fmaxf(mx, ldm[1][g][lc]);
+        for (int g = 1; g < kTileGroups; ++g) mn = fminf(mn, ldm[0][g][lc]), mx = fmaxf(mx, ldm[1][g][lc]);
         const float mu = (float)(P0 + S / (double)n);
         const float m2 = (float)fmax(Q - S * S / (double)n, 0.0);
         const float is = rsqrtf(m2 / (float)n + eps);
@@ -601,7 +609,7 @@ __global__ __launch_bounds__(kBlock) void pair_final_kernel(int32_t F, const flo
 // v18: the second stage over MANY row blocks (one per 256-row GEMM tile: 662 at config 2, against <= 256 of the pass form) - 32 columns x
 // 16 block groups per workgroup; group g adds blocks g, g + 16, ... in order (eight pairs in flight), the groups are combined in order.
 // (8 KB of LDS: these launches run beside the side stream's weight-gradient product, whose workgroups leave 16 KB per CU)
-constexpr int kWideGroups = 16, kWideCols = 32;
+constexpr int kWideGroups = 16, kWideCols = 32;     // (round 6 tried 16 columns x 32 groups = 47 workgroups: 91 -> 183 us per step beside the side stream's weight-gradient workgroups)
 __global__ __launch_bounds__(kWideCols * kWideGroups) void pair_final_wide_kernel(int32_t F, const float* part, int nblk, float* s0, float* s1) {
     __shared__ double lds[2][kWideGroups][kWideCols];
     const int lc = threadIdx.x % kWideCols, c = blockIdx.x * kWideCols + lc, grp = threadIdx.x / kWideCols;
@@ -669,7 +677,7 @@ __global__ __launch_bounds__(kWideCols * kWideGroups) void bn_bwd_finish_wide_ke
     float gm = 0.f, xm = 0.f;
     if (c < F) {
         int b = grp;
-        for (; b + 3 * kWideGroups < nblk; b += 4 * kWideGroups) {
+        for (; b + 3 * kWideGroups < nblk; b += 4 * kWideGroups) {      // (eight in flight instead of four: 41 -> 78 us beside a weight-gradient workgroup, round 6)
             float vs[4], vq[4], vg[4], vx[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -916,7 +924,7 @@ int bot_bn_stats_halves_partials_f32(const float* part, const float* minmax, int
                 (double)eps, (double)momentum, (double)p);
     hipStream_t st = (hipStream_t)stream;
     BOT_REQUIRE((int64_t)nblk == (n + 255) / 256, BOT_E_RANGE, "bn_stats_halves_partials: nblk=%d is not ceil(n / 256) for n=%lld", nblk, (long long)n);
-    hipLaunchKernelGGL(colstats_tiles_final_kernel, dim3((F + 63) / 64), dim3(kBlock), 0, st, pivot, n, F, part, (int)nblk, 256, mean, invstd, eps, momentum,
+    hipLaunchKernelGGL(colstats_tiles_final_kernel, dim3((F + kTileCols - 1) / kTileCols), dim3(kTileCols * kTileGroups), 0, st, pivot, n, F, part, (int)nblk, 256, mean, invstd, eps, momentum,
                        running_mean, running_var, num_batches_tracked, minmax, weight, bias, p, bound_workspace);
     launch_halves_scale(bound_workspace, F, hscale, st);
     return hip_status("bn_stats_halves_partials launch");
@@ -1103,7 +1111,7 @@ static int bn_act_bwd_apply_impl(const float* dy, int64_t lddy, const float* x, 
     bool quad;
     const int vec = bn_vec(F, {ldx, lddy, lddx}, {x, dy, dx}, &quad);
     a.wx = !quad || rows16(x, ldx), a.wdy = !quad || rows16(dy, lddy), a.wdx = !quad || rows16(dx, lddx);
-    const dim3 grid = bn_grid(F, vec, n);
+    const dim3 grid = bn_grid(F, vec, n);       // (round 6: 384 ... 1024 row blocks instead of 256 change nothing, alone or beside the side stream)
     hipStream_t st = (hipStream_t)stream;
     if (vec == 4) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<4>), grid, dim3(kTX * kTY), 0, st, a);
     else if (vec == 2) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<2>), grid, dim3(kTX * kTY), 0, st, a);
