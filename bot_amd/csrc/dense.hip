@@ -1112,6 +1112,9 @@ static int bn_act_bwd_apply_impl(const float* dy, int64_t lddy, const float* x, 
     const int vec = bn_vec(F, {ldx, lddy, lddx}, {x, dy, dx}, &quad);
     a.wx = !quad || rows16(x, ldx), a.wdy = !quad || rows16(dy, lddy), a.wdx = !quad || rows16(dx, lddx);
     const dim3 grid = bn_grid(F, vec, n);       // (round 6: 384 ... 1024 row blocks instead of 256 change nothing, alone or beside the side stream)
+    // (round 6, profiles/r06_apply_beside_tn.txt: beside the side stream's weight-gradient product this pass takes as long as that product -
+    // 0.40 -> 0.95 ms - and the PAIR ends 40-90 us after the product alone would: s_setprio 3 for this pass's waves gave 0.74 ms here and
+    // +60 us on the product, and nothing in the step, 10.52 vs 10.54 ms: the time moves to the kernels behind it)
     hipStream_t st = (hipStream_t)stream;
     if (vec == 4) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<4>), grid, dim3(kTX * kTY), 0, st, a);
     else if (vec == 2) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<2>), grid, dim3(kTX * kTY), 0, st, a);
