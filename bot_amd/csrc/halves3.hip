@@ -1350,6 +1350,8 @@ namespace {
 // grouped: as many whole rounds of 8 splits (one per XCD) as keep an XCD's workgroups (splits / 8 x tiles) within its 32 CUs, each
 // split >= 1024 rows
 int tn_grouped_splits(int64_t n_rows, int n_tiles) {
+    // (round 6: config 2's 12-tile launch runs 16 splits = 192 workgroups, 24 of an XCD's 32 CUs; 4 / 5 / 8 splits per XCD - 96 % / 94 % /
+    // 100 % of the slots in two or three rounds - gave 10.57 / 10.55 / 10.55 ms per step against 10.49: more partial tiles, shorter splits)
     const int per_xcd = std::max(1, 32 / n_tiles);
     return (int)std::max<int64_t>(1, std::min<int64_t>(8 * per_xcd, n_rows / 1024));
 }
