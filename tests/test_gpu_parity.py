@@ -1708,12 +1708,13 @@ def test_capture_beside_a_live_rccl_watchdog():
     for trial in range(3):
         out = subprocess.run([sys.executable, tool, "--part", "pg", "--drain", "1"], capture_output=True, text=True, timeout=600, cwd=root)
         assert out.returncode == 0 and "finished without an abort" in out.stdout, (trial, out.returncode, out.stderr[-3000:])
+    # the leg without the remedy is information, not a criterion (whatever it does, the product never runs it)
     out = subprocess.run([sys.executable, tool, "--part", "pg", "--drain", "0"], capture_output=True, text=True, timeout=600, cwd=root)
-    assert out.returncode in (0, -6, 134), (out.returncode, out.stderr[-3000:])
-    died = out.returncode != 0
-    assert (not died) or "last recorded in a capturing stream" in out.stderr, out.stderr[-3000:]
-    print("without the drain the same capture %s" % ("died of SIGABRT in RCCL's watchdog (hipErrorCapturedEvent): the hazard is present on this stack"
-                                                      if died else "survived: this stack no longer refuses eagerly recorded events"))
+    if out.returncode == 0:
+        print("without the drain the same capture survived: this stack no longer refuses eagerly recorded events")
+    else:
+        print("without the drain the same capture ended with rc %d (%s)" % (out.returncode, "hipErrorCapturedEvent in RCCL's watchdog: the hazard is present "
+              "on this stack" if "last recorded in a capturing stream" in out.stderr else "another reason: " + out.stderr[-300:]))
 
 
 @pytest.mark.isolated
