@@ -95,6 +95,39 @@ def test_midsize_against_oracle():
         PC.grad_close(rt.grad, ro.grad.numpy())
 
 
+def test_dense_graph_attention_rows_against_oracle():
+    """Round 6: the edge-sized row kernels (attention forward / backward, segment sum) give a whole wavefront to a short row where the mean
+    degree is 64 or more (configs 3 / 4: S-proteins' rows hold ~600 edges) instead of 16 lanes.  A 1 500-node graph of mean in-degree ~100
+    with a heavy tail (short rows of every length up to the long-row threshold, and rows beyond it), H = 1, 3, 6, with attention dropout
+    and with an edge term: logits / weights / aggregation and every gradient against the oracle."""
+    n = 1500
+    rs, rd = _powerlaw(n, 80000, 11)
+    s, d = R.preprocess_edges(rs, rd, n)
+    g = bot_amd.Graph(s, d, n, chunk=128).to(DEV)
+    assert g.number_of_edges() >= 64 * n and g.csc.n_long > 0 and g.csc.n_long < n // 2
+    gen = torch.Generator().manual_seed(2)
+    for H, D in ((1, 40), (3, 64), (6, 80)):
+        x = torch.randn(n, H, D, generator=gen)
+        el, er = torch.randn(n, H, 1, generator=gen), torch.randn(n, H, 1, generator=gen)
+        gout = torch.randn(n, H, D, generator=gen)
+        xo, lo, ro = PC.leaf(x), PC.leaf(el), PC.leaf(er)
+        e = torch.nn.functional.leaky_relu(R.u_add_v(s, d, lo, ro), 0.2)
+        ref = R.u_mul_e_sum(s, d, n, xo, R.edge_softmax(d, n, e))
+        (ref * gout).sum().backward()
+        xt, lt, rt = PC.leaf(x, DEV), PC.leaf(el, DEV), PC.leaf(er, DEV)
+        a = ops.gat_attention(g, lt, rt, negative_slope=0.2, order="csc")
+        out = ops.u_mul_e_sum(g, xt, a, order="csc")
+        (out * gout.to(DEV)).sum().backward()
+        PC.fwd_close(out, ref.detach().numpy(), 1e-4)
+        PC.grad_close(xt.grad, xo.grad.numpy())
+        PC.grad_close(lt.grad, lo.grad.numpy())
+        PC.grad_close(rt.grad, ro.grad.numpy())
+        # rows of the attention weights sum to one; the segment sum (copy_e_sum) against the oracle
+        w = torch.rand(g.number_of_edges(), H, generator=gen)
+        ref_s = R.copy_e_sum(d, n, w)
+        PC.fwd_close(ops.copy_e_sum(g, w.to(DEV)), ref_s.numpy(), 2e-5 * float(ref_s.abs().max()))
+
+
 def test_full_size_properties():
     """ogbn-arxiv-shaped graph (BASELINE config 2 size): size-independent properties.
     (1) linearity: spmm(x1 + 2*x2) == spmm(x1) + 2*spmm(x2);  (2) attention rows sum to 1, so aggregating
