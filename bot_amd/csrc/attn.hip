@@ -14,6 +14,10 @@
 
 namespace bot {
 
+// (round 6 tried a whole wavefront per short row where the mean degree is 64 or more - S-proteins: attention forward 3.70 -> 3.53 ms, backward
+// 1.99 -> 1.87, step 287.6 -> 285.5 ms - and withdrew it: the other summation order moved config 4's badly conditioned gradients from
+// 53 / 10 / 1 (within 1e-4 of fp64 / only through the 2x clause / farther than the fp32 oracle) to 52 / 12 / 0, over the count the
+// full-size test bounds; 0.7 % of one config does not buy a looser bound)
 constexpr int kRowLanes = 16;
 
 template <int LANES>
@@ -334,10 +338,7 @@ __device__ __forceinline__ void attn_bwd_row(const AttnArgs& p, const Ctx& ctx, 
 // start first: they are the longest pieces of work), the others take 16 short rows each (a 16-lane group per row).  As two
 // launches the long-row kernel (a few hundred small workgroups, latency-bound by the longest row) ran alone on an empty chip
 // behind the short-row kernel: 73 + 47 us per forward at S-arxiv; merged they overlap.
-// RL = lanes per short row: 16 (four rows per wavefront) for the sparse graphs this was built for (mean in-degree ~15), 64 (a wavefront per
-// row) where the mean degree is 64 or more (round 6: S-proteins' rows hold ~600 edges, half of them below the long-row threshold of 512 -
-// 16 lanes walked them 32 edges deep, one 24-byte record per lane in flight).
-template <int HT, bool BWD, int RL>
+template <int HT, bool BWD>
 __global__ __launch_bounds__(kBlock) void attn_kernel(AttnArgs p, int n_long) {
     __shared__ float lds[(kBlock / 64) * 8];
     if ((int)blockIdx.x < n_long) {  // workgroup-uniform
@@ -348,32 +349,25 @@ __global__ __launch_bounds__(kBlock) void attn_kernel(AttnArgs p, int n_long) {
         else attn_fwd_row<HT>(p, ctx, row, beg, end);
         return;
     }
-    const int64_t row = ((int64_t)(blockIdx.x - n_long) * kBlock + threadIdx.x) / RL;
+    const int64_t row = ((int64_t)(blockIdx.x - n_long) * kBlock + threadIdx.x) / kRowLanes;
     if (row >= p.n_rows) return;
     const int beg = p.indptr[row], end = p.indptr[row + 1];
     if (end - beg > p.chunk) return;  // a long row: owned by one of the first workgroups
-    GroupCtx<RL> ctx{(int)(threadIdx.x % RL)};
+    GroupCtx<kRowLanes> ctx{(int)(threadIdx.x % kRowLanes)};
     if constexpr (BWD) attn_bwd_row<HT>(p, ctx, (int)row, beg, end);
     else attn_fwd_row<HT>(p, ctx, (int)row, beg, end);
 }
 
-// lanes per short row of the edge-sized row kernels: a wavefront per row from a mean degree of 64 on
-static int row_lanes(int64_t n_rows, int64_t nnz) { return nnz >= 64 * n_rows ? 64 : kRowLanes; }
-
 template <bool BWD>
-static int launch_attn(AttnArgs p, int64_t n_long, int64_t nnz, hipStream_t st) {
-    const int rl = row_lanes(p.n_rows, nnz);
-    const int64_t blocks = (p.n_rows * rl + kBlock - 1) / kBlock;
+static int launch_attn(AttnArgs p, int64_t n_long, hipStream_t st) {
+    const int64_t blocks = (p.n_rows * kRowLanes + kBlock - 1) / kBlock;
     p.wide = p.H <= 8 && aligned(p.el, 16) && aligned(p.ee, 16) && aligned(p.a, 16) && aligned(p.da, 16) && aligned(p.dz, 16) &&
              aligned(p.a_drop, 16);
     for (int h0 = 0; h0 < p.H;) {  // heads in register tiles of up to 8 (one sweep over the edges for H <= 8)
         const int ht = p.H - h0 >= 8 ? 8 : p.H - h0;
         p.h0 = h0;
-#define BOT_LAUNCH_ATTN(HT)                                                                                                                   \
-    do {                                                                                                                                      \
-        if (rl == 64) hipLaunchKernelGGL((attn_kernel<HT, BWD, 64>), dim3((unsigned)(blocks + n_long)), dim3(kBlock), 0, st, p, (int)n_long); \
-        else hipLaunchKernelGGL((attn_kernel<HT, BWD, kRowLanes>), dim3((unsigned)(blocks + n_long)), dim3(kBlock), 0, st, p, (int)n_long);   \
-    } while (0)
+#define BOT_LAUNCH_ATTN(HT) \
+    hipLaunchKernelGGL((attn_kernel<HT, BWD>), dim3((unsigned)(blocks + n_long)), dim3(kBlock), 0, st, p, (int)n_long)
         switch (ht) {
             case 8: BOT_LAUNCH_ATTN(8); break;
             case 7: BOT_LAUNCH_ATTN(7); break;
@@ -423,7 +417,7 @@ __device__ __forceinline__ void seg_row(const SegArgs& p, const Ctx& ctx, int ro
     }
 }
 
-template <int WT, int RL>
+template <int WT>
 __global__ __launch_bounds__(kBlock) void seg_kernel(SegArgs p, int n_long) {  // long rows first, as in attn_kernel
     __shared__ float lds[(kBlock / 64) * 8];
     if ((int)blockIdx.x < n_long) {
@@ -432,11 +426,11 @@ __global__ __launch_bounds__(kBlock) void seg_kernel(SegArgs p, int n_long) {  /
         seg_row<WT>(p, ctx, row, p.indptr[row], p.indptr[row + 1]);
         return;
     }
-    const int64_t row = ((int64_t)(blockIdx.x - n_long) * kBlock + threadIdx.x) / RL;
+    const int64_t row = ((int64_t)(blockIdx.x - n_long) * kBlock + threadIdx.x) / kRowLanes;
     if (row >= p.n_rows) return;
     const int beg = p.indptr[row], end = p.indptr[row + 1];
     if (end - beg > p.chunk) return;
-    GroupCtx<RL> ctx{(int)(threadIdx.x % RL)};
+    GroupCtx<kRowLanes> ctx{(int)(threadIdx.x % kRowLanes)};
     seg_row<WT>(p, ctx, (int)row, beg, end);
 }
 
@@ -475,7 +469,7 @@ int bot_gat_attn_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t 
     BOT_REQUIRE((attn_drop > 0.f) == (a_drop != nullptr), BOT_E_NULL, "gat_attn_fwd: a_drop goes with attn_drop > 0");
     AttnArgs p{indptr, indices, n_rows, long_rows, chunk, el, er, ee, eperm, keep, slope, H, 0, a, nullptr, aperm, nullptr,
                nullptr, nullptr, false, zsign, attn_drop, drop_seed, seed_offset, a_drop};
-    return launch_attn<false>(p, n_long, nnz, (hipStream_t)stream);
+    return launch_attn<false>(p, n_long, (hipStream_t)stream);
 }
 
 int bot_gat_attn_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t nnz,
@@ -492,7 +486,7 @@ int bot_gat_attn_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t 
     BOT_REQUIRE(attn_drop >= 0.f && attn_drop < 1.f, BOT_E_RANGE, "gat_attn_bwd: attn_drop=%f must be in [0,1)", (double)attn_drop);
     AttnArgs p{indptr, indices, n_rows, long_rows, chunk, el, er, ee, eperm, nullptr, slope, H, 0, const_cast<float*>(a), da,
                aperm, dz, zperm, der, false, const_cast<uint8_t*>(zsign), attn_drop, drop_seed, seed_offset, nullptr};
-    return launch_attn<true>(p, n_long, nnz, (hipStream_t)stream);
+    return launch_attn<true>(p, n_long, (hipStream_t)stream);
 }
 
 int bot_segment_sum_f32(const int32_t* indptr, int64_t n_rows, int64_t nnz, const int32_t* long_rows, int64_t n_long,
@@ -506,16 +500,11 @@ int bot_segment_sum_f32(const int32_t* indptr, int64_t n_rows, int64_t nnz, cons
     BOT_REQUIRE(n_long == 0 || long_rows, BOT_E_NULL, "segment_sum: long_rows is NULL");
     hipStream_t st = (hipStream_t)stream;
     SegArgs p{indptr, n_rows, long_rows, chunk, vals, perm, W, 0, out, W <= 8 && aligned(vals, 16)};
-    const int rl = row_lanes(n_rows, nnz);
-    const int64_t blocks = (n_rows * rl + kBlock - 1) / kBlock;
+    const int64_t blocks = (n_rows * kRowLanes + kBlock - 1) / kBlock;
     for (int w0 = 0; w0 < W;) {  // record columns in register tiles of up to 8 (one sweep for W <= 8)
         const int wt = W - w0 >= 8 ? 8 : W - w0;
         p.w0 = w0;
-#define BOT_LAUNCH_SEG(WT)                                                                                                              \
-    do {                                                                                                                                \
-        if (rl == 64) hipLaunchKernelGGL((seg_kernel<WT, 64>), dim3((unsigned)(blocks + n_long)), dim3(kBlock), 0, st, p, (int)n_long); \
-        else hipLaunchKernelGGL((seg_kernel<WT, kRowLanes>), dim3((unsigned)(blocks + n_long)), dim3(kBlock), 0, st, p, (int)n_long);   \
-    } while (0)
+#define BOT_LAUNCH_SEG(WT) hipLaunchKernelGGL((seg_kernel<WT>), dim3((unsigned)(blocks + n_long)), dim3(kBlock), 0, st, p, (int)n_long)
         switch (wt) {
             case 8: BOT_LAUNCH_SEG(8); break;
             case 7: BOT_LAUNCH_SEG(7); break;

@@ -96,10 +96,10 @@ def test_midsize_against_oracle():
 
 
 def test_dense_graph_attention_rows_against_oracle():
-    """Round 6: the edge-sized row kernels (attention forward / backward, segment sum) give a whole wavefront to a short row where the mean
-    degree is 64 or more (configs 3 / 4: S-proteins' rows hold ~600 edges) instead of 16 lanes.  A 1 500-node graph of mean in-degree ~100
-    with a heavy tail (short rows of every length up to the long-row threshold, and rows beyond it), H = 1, 3, 6, with attention dropout
-    and with an edge term: logits / weights / aggregation and every gradient against the oracle."""
+    """Round 6: the edge-sized row kernels (attention forward / backward, segment sum) on a DENSE graph at mid size - a 1 500-node graph
+    of mean in-degree ~95 with a heavy tail (short rows of every length up to the long-row threshold, 16 lanes walking up to 8 edges deep,
+    and rows beyond it: a path the sparse mid-size test does not reach and the full-size tests reach only inside whole steps), H = 1, 3, 6:
+    logits / weights / aggregation and every gradient against the oracle, and the segment sum."""
     n = 1500
     rs, rd = _powerlaw(n, 80000, 11)
     s, d = R.preprocess_edges(rs, rd, n)
