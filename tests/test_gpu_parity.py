@@ -1657,6 +1657,7 @@ def test_captured_step_twelve_replays_bitwise(kind, request):
     buffers at the end: any reduction (or anything else) that goes wrong under replay shows up as the first differing tensor."""
     group = request.getfixturevalue("one_rank_rccl") if kind == "arxiv-1rank" else None
     eager, cap, m1, m2 = _replay_case(kind, group)
+    assert cap.drained is (kind == "arxiv-1rank")       # a live RCCL group: the watchdog's list was emptied before the capture (DESIGN section 8)
     for _ in range(3):                    # the capture ran 3 warm-up steps on m2 (the capture pass itself does not execute)
         eager()
     for it in range(12):
