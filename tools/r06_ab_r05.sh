@@ -1,6 +1,8 @@
 #!/bin/bash
 # Same-box alternating A/B of the headline step: this tree against the round-5 tree (ab_r05/: `git archive 74337a3` built in place; not
 # committed).   tools/r06_ab_r05.sh <rounds> [extra bench args]
+# Recreate ab_r05/ first (in the authoring container):  mkdir ab_r05 && git archive 74337a3 | tar -x -C ab_r05 && make -C ab_r05/bot_amd/csrc -j4 &&
+#   make -C ab_r05/oracle/csrc && mkdir -p ab_r05/profiles && git show 74337a3:profiles/spmm_traffic.json > ab_r05/profiles/spmm_traffic.json
 R=${1:-3}; shift
 O=$GRAFT_REPO_ROOT/gpurun_out/r06; mkdir -p $O
 for i in $(seq 1 $R); do
