@@ -203,8 +203,9 @@ def evaluate(model, graph, feat, labels, train_idx, val_idx, test_idx, *, use_la
 
 
 # Seconds drain_rccl_watchdog() sleeps after the device synchronisation: ProcessGroupNCCL's watchdog wakes every 100 ms
-# (kWatchdogThreadSleepMillis) and retires every completed Work in one pass, so five periods of margin.
-CAPTURE_DRAIN_S = float(os.environ.get("BOT_CAPTURE_DRAIN_S", "0.5"))
+# (kWatchdogThreadSleepMillis) and retires every completed Work in one pass: ten periods of margin (a capture happens once per run; the
+# experiments of profiles/r06_capture_watchdog.txt ran with five).
+CAPTURE_DRAIN_S = float(os.environ.get("BOT_CAPTURE_DRAIN_S", "1.0"))
 
 
 def drain_rccl_watchdog(device=None) -> bool:
@@ -220,7 +221,7 @@ def drain_rccl_watchdog(device=None) -> bool:
     watchdog pass that falls between that and the join-back (the halo exchange's overlap window, a few ms per captured step) gets the error,
     rethrows it, and std::terminate ends the process - about one capture in ten.  Works issued DURING a capture are never enqueued
     (ProcessGroupNCCL checks the current stream's capture status), so an empty list stays empty: synchronise (every eager Work is complete)
-    and give the watchdog several periods to retire them.  `capture_error_mode="thread_local"` (below) is still needed: it covers the
+    and give the watchdog ten of its periods to retire them.  `capture_error_mode="thread_local"` (below) is still needed: it covers the
     watchdog's OTHER illegal-under-global-capture calls."""
     import time
     import torch.distributed as dist
