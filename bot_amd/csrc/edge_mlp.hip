@@ -88,41 +88,71 @@ __global__ __launch_bounds__(kBlock) void edge_mlp_bwd_kernel(const float* __res
     for (int h = 0; h < 8; ++h) w2[h] = h < H ? W2[h * kJ + j] : 0.f;
     const float bj = b1[j];
     f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // One MFMA step folds 4 edges; a wave takes U steps (16 edges) per trip with all their loads issued before the first
-    // MFMA — with one step per trip a wave had a single round of loads in flight (6.0 ms per call at E = 77.7 M,
-    // latency-bound).
+    // One MFMA step folds 4 edges; a wave takes U steps (16 edges) per trip.  Round 6: the 16 edges' records (16 x 32 B of features, 16 x 4H B
+    // of dz: both contiguous in CSC order) are fetched ONCE per wave - lanes 0..31 one 16-byte chunk of the features each, lanes 32.. one
+    // 16-byte chunk of the dz span - one trip ahead, and handed to the (unit j, edge slot k) lanes through 1 KB of LDS per wave.  Before,
+    // the 16 lanes of an edge slot each loaded the slot's whole record: 64 unique bytes per load instruction, the launch bound by the
+    // address path (3.0 ms per call at E = 79 M, 4.4 GB); the MFMA sequence and the lane -> edge mapping are unchanged (bitwise the same sums).
     constexpr int U = 4;
-    for (int64_t base = wave * (4 * U); base < E; base += n_waves * (4 * U)) {
+    __shared__ __attribute__((aligned(16))) float stage[kBlock / 64][256];
+    float* sf = stage[threadIdx.x >> 6];        // [16 edges][8] features
+    float* sz = sf + 128;                       // [16 edges][H] dz records, linear
+    const int zt = lane - 32;                   // lanes 32..: floats [4 zt, 4 zt + 4) of the trip's 16 H dz floats
+    const int64_t EH = E * H;
+    auto fetch = [&](int64_t base) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < 32) {
+            const int64_t e = base + (lane >> 1);
+            if (e < E) v = *reinterpret_cast<const float4*>(ef + e * kI + (lane & 1) * 4);
+        } else if (4 * zt < 16 * H) {
+            const int64_t o = base * H + 4 * zt;        // (base is a multiple of 16: the span starts 64 H bytes into dz - 16-byte aligned with dz)
+            if (wide && o + 3 < EH) {
+                v = *reinterpret_cast<const float4*>(dz + o);
+            } else {
+                if (o < EH) v.x = dz[o];
+                if (o + 1 < EH) v.y = dz[o + 1];
+                if (o + 2 < EH) v.z = dz[o + 2];
+                if (o + 3 < EH) v.w = dz[o + 3];
+            }
+        }
+        return v;
+    };
+    const int64_t stride = n_waves * (4 * U);
+    // (one trip ahead: 2.14 ms per call; three ahead: 2.34 - the launch is a balance of vector issue, LDS and MFMA, not latency-bound)
+    float4 cur = fetch(wave * (4 * U));
+    for (int64_t base = wave * (4 * U); base < E; base += stride) {
+        const float4 nxt = base + stride < E ? fetch(base + stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < 32) *reinterpret_cast<float4*>(sf + lane * 4) = cur;
+        else if (4 * zt < 16 * H) *reinterpret_cast<float4*>(sz + zt * 4) = cur;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // lanes read each other's chunks below
         float f[U][kI], dzv[U][8], bz[U], bf[U];
         bool live[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t e = base + u * 4 + k;
-            live[u] = e < E;
-            const int64_t ec = live[u] ? e : E - 1;  // tail: re-read a valid edge, contributions zeroed below
-            vload<4>(*reinterpret_cast<float(*)[4]>(&f[u][0]), ef + ec * kI);
-            vload<4>(*reinterpret_cast<float(*)[4]>(&f[u][4]), ef + ec * kI + 4);
-            // the H-float record of dz as 8- / 16-byte vectors where H allows (every 4-byte load touches the record's line again)
+            const int slot = u * 4 + k;
+            live[u] = base + slot < E;          // (a tail slot holds zeros: its contributions are zeroed below as before)
+            const float4 f0 = *reinterpret_cast<const float4*>(sf + slot * kI), f1 = *reinterpret_cast<const float4*>(sf + slot * kI + 4);
+            f[u][0] = f0.x, f[u][1] = f0.y, f[u][2] = f0.z, f[u][3] = f0.w, f[u][4] = f1.x, f[u][5] = f1.y, f[u][6] = f1.z, f[u][7] = f1.w;
 #pragma unroll
             for (int h = 0; h < 8; ++h) dzv[u][h] = 0.f;
-            const float* q = dz + ec * H;
-            if (wide && H % 4 == 0) {
+            if constexpr (H % 4 == 0) {         // the slot's 4 H-byte record as 16- / 8-byte LDS reads where H allows
 #pragma unroll
-                for (int h = 0; h + 3 < H; h += 4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(q + h);
+                for (int h = 0; h < H; h += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(sz + slot * H + h);
                     dzv[u][h] = t4.x, dzv[u][h + 1] = t4.y, dzv[u][h + 2] = t4.z, dzv[u][h + 3] = t4.w;
                 }
-            } else if (wide && H % 2 == 0) {
+            } else if constexpr (H % 2 == 0) {
 #pragma unroll
-                for (int h = 0; h + 1 < H; h += 2) {
-                    const float2 t2 = *reinterpret_cast<const float2*>(q + h);
+                for (int h = 0; h < H; h += 2) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(sz + slot * H + h);
                     dzv[u][h] = t2.x, dzv[u][h + 1] = t2.y;
                 }
             } else {
 #pragma unroll
-                for (int h = 0; h < H; ++h) dzv[u][h] = q[h];
+                for (int h = 0; h < H; ++h) dzv[u][h] = sz[slot * H + h];
             }
-            // B operands: column n = lane & 15 of this lane's edge slot — picked out of the registers just loaded
+            // B operands: column n = lane & 15 of this lane's edge slot — picked out of the registers just loaded (one more LDS read each
+            // instead of the select chains: 2.14 -> 2.23 ms per call, the LDS is as busy as the vector pipe here)
             float zb = 0.f, fb = j == kI ? 1.f : 0.f;
 #pragma unroll
             for (int h = 0; h < H; ++h) zb = j == h ? dzv[u][h] : zb;
@@ -131,18 +161,20 @@ __global__ __launch_bounds__(kBlock) void edge_mlp_bwd_kernel(const float* __res
             bz[u] = zb;
             bf[u] = fb;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // every read of this trip's chunks is done before the next trip overwrites them
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float pre = bj, t = 0.f;
 #pragma unroll
             for (int i = 0; i < kI; ++i) pre = fmaf(w1[i], f[u][i], pre);
 #pragma unroll
-            for (int h = 0; h < 8; ++h) t = fmaf(dzv[u][h], w2[h], t);
+            for (int h = 0; h < 8; ++h) t = fmaf(dzv[u][h], w2[h], t);      // (heads beyond H: 0 x 0, kept so that the sums stay bitwise what they were)
             const float r = live[u] ? fmaxf(pre, 0.f) : 0.f;
             const float du = (live[u] && pre > 0.f) ? t : 0.f;
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, bz[u], acc2, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(du, bf[u], acc1, 0, 0, 0);
         }
+        cur = nxt;
     }
     // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
     float* p = part + wave * 512;
