@@ -18,6 +18,9 @@ namespace bot {
 // 1.99 -> 1.87, step 287.6 -> 285.5 ms - and withdrew it: the other summation order moved config 4's badly conditioned gradients from
 // 53 / 10 / 1 (within 1e-4 of fp64 / only through the 2x clause / farther than the fp32 oracle) to 52 / 12 / 0, over the count the
 // full-size test bounds; 0.7 % of one config does not buy a looser bound)
+// (round 6 also grouped the row loop's optional index loads into branch-free straight-line code - five dependent memory round trips per edge
+// became three - and measured nothing: S-products 3.35 -> 3.42 ms, S-proteins 3.70 -> 3.71 ms.  These launches are bound by the random
+// 128-byte lines their el[src] gathers pull through the fabric (S-products: 126 M lines = 16 GB per forward), not by latency; reverted.)
 constexpr int kRowLanes = 16;
 
 template <int LANES>
