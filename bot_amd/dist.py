@@ -22,6 +22,8 @@ BASELINE.json's north star adds for graphs that outgrow one GPU.  Design (SURVEY
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 
 import torch
@@ -303,11 +305,12 @@ def all_reduce_grads(model: nn.Module, group=None):
             p.grad = torch.zeros_like(p)
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat, group=group)
-    off = 0
+    off, views = 0, []
     for p in params:
         n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p))
+        views.append(flat[off:off + n].view_as(p))
         off += n
+    torch._foreach_copy_([p.grad for p in params], views)       # one multi-tensor launch (a copy per parameter was 27 launches a step)
 
 
 def seed_rank_streams(base_seed: int, rank: int):
@@ -330,6 +333,17 @@ def forward_backward(model, part: Partition, *, use_labels=True, mask_rate=0.5, 
     """Partitioned counterpart of `bot_amd.train.forward_backward` (run.py:252-284): same step, the loss is the
     mean over the prediction nodes of ALL ranks, parameter gradients are summed over ranks."""
     tr = part.train_idx
+    if (T.FUSED_STEP and n_label_iters == 0 and part.feat.dtype == torch.float32 and loss in ("logit", "loge", "savage")
+            and os.environ.get("BOT_DIST_FUSED_STEP", "1") != "0"):
+        # the single-GPU step's glue (label split, input assembly + input dropout, per-node loss with its gradient: four launches for ~45
+        # tensor ops, bot_amd.train) with the prediction-node COUNT summed over the ranks before the loss reads it (round 6: at one rank
+        # the partitioned step paid 0.2 ms and ~40 launches for the tensor-op form, profiles/r06_partitioned_1rank_kernel_diff.txt)
+        local, pred, _ = T._fused_forward_backward(model, part.graph, part.feat, part.labels, tr, use_labels=use_labels, mask_rate=mask_rate, loss=loss,
+                                                   n_classes=n_classes, mask=mask, count_reduce=lambda c: dist.all_reduce(c, group=group))
+        all_reduce_grads(model, group)
+        total = local.detach().clone()
+        dist.all_reduce(total, group=group)
+        return total, pred
     if mask is None:
         mask = torch.rand(tr.shape, device=tr.device) < mask_rate
     # Fixed shapes throughout (no `tr[mask]`: boolean indexing makes the host wait for the device twice per step, which is

@@ -53,7 +53,10 @@ class _NodeLoss(torch.autograd.Function):
         return dx * g, None, None, None, None
 
 
-def _fused_forward_backward(model, graph, feat, labels, train_idx, *, use_labels, mask_rate, loss, n_classes, mask):
+def _fused_forward_backward(model, graph, feat, labels, train_idx, *, use_labels, mask_rate, loss, n_classes, mask, count_reduce=None):
+    """`count_reduce(count)`: called on the device word that holds the number of prediction nodes before the loss reads it - the
+    partitioned step (bot_amd.dist) all-reduces it there, which makes the local loss this rank's additive share of the GLOBAL mean and
+    scales its gradient accordingly."""
     from . import _C
     from .nn import fused
     from .ops import new_dropout_seed
@@ -61,6 +64,8 @@ def _fused_forward_backward(model, graph, feat, labels, train_idx, *, use_labels
     code, wn = _split_buffers(train_idx, n)
     count = _C.label_split(train_idx, labels, mask, mask_rate, new_dropout_seed(1.0) if mask is None else 0, use_labels,
                            code if use_labels else None, wn)
+    if count_reduce is not None:
+        count_reduce(count)
     from . import nn as bnn
     # only stacks known to honour `input_already_dropped` hand their input dropout over; any other model keeps its own
     drop = getattr(model, "input_drop", None) if isinstance(model, (bnn.GAT, bnn.GCN)) else None

@@ -284,7 +284,7 @@ def test_partitioned_label_reuse_evaluate_and_partitioner(partitioner, world, tm
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
-SCALES = {"cora": 0.3, "arxiv": 0.004, "reddit": 0.00002, "proteins": 0.00004, "products": 0.00003}
+SCALES = {"cora": 0.3, "arxiv": 0.004, "reddit": 0.0001, "proteins": 0.00004, "products": 0.00003}     # (reddit: 23 nodes - at 8 nodes a step whose random split leaves NO prediction node has a NaN mean, as in the reference)
 
 
 def _worker_workloads(rank, world, port, tmp):
