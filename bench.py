@@ -150,10 +150,17 @@ def launch_ranks(args, argv) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool: RCCL's intra-node transport needs it
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
-    print("bench.py: launching " + " ".join(cmd), file=sys.stderr)
-    return relay_child(cmd, env=env, timeout=args.launch_timeout)
+    rc = 1
+    for attempt in range(3):      # (a port found free by bind(0) + close can be taken again before the launcher listens on it: a fast failure is retried)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+        print("bench.py: launching " + " ".join(cmd), file=sys.stderr)
+        t0 = time.time()
+        rc = relay_child(cmd, env=env, timeout=args.launch_timeout)
+        if rc in (0, 2, 4, 124) or time.time() - t0 > 20.0:
+            break
+        print(f"bench.py: the launch ended with rc {rc} after {time.time() - t0:.1f} s; trying another port", file=sys.stderr)
+    return rc
 
 
 class Watchdog:

@@ -1632,15 +1632,32 @@ def _replay_case(kind, part_group=None, capture=True):
     return eager, cap, m1, m2
 
 
-@pytest.fixture
-def one_rank_rccl():
+def init_one_rank_rccl():
+    """A 1-rank RCCL process group over a TCP store on a free local port.  A port found free by bind(0) + close can be taken again before
+    init_process_group listens on it (EADDRINUSE once in 32 tight-loop runs, round 6): retried on another port.  (A file store avoids the
+    port but made the same tests take 50 - 180 s instead of 4: FileStore polls.)"""
     import socket
     import torch.distributed as dist
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    last = None
+    for _ in range(5):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            return
+        except Exception as e:      # DistNetworkError (a RuntimeError): address already in use
+            if "in use" not in str(e).lower() and "EADDRINUSE" not in str(e):
+                raise
+            last = e
+    raise last
+
+
+@pytest.fixture
+def one_rank_rccl():
+    import torch.distributed as dist
+    init_one_rank_rccl()
     try:
         yield None
     finally:

@@ -18,6 +18,27 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def init_one_rank():
+    """1-rank RCCL group over a TCP store on a free local port; a port lost between bind(0) + close and the listen is retried."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    last = None
+    for _ in range(5):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            return
+        except Exception as e:
+            if "in use" not in str(e).lower() and "EADDRINUSE" not in str(e):
+                raise
+            last = e
+    raise last
+
+
 def part_hip():
     import torch
     x = torch.zeros(1 << 20, device="cuda")
@@ -56,14 +77,9 @@ def part_hip():
 
 
 def part_pg(drain, hold, eager):
-    import socket
     import torch
     import torch.distributed as dist
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    init_one_rank()
     t = torch.ones(1 << 16, device="cuda")
     dist.all_reduce(t)
     torch.cuda.synchronize()
@@ -97,15 +113,10 @@ def part_pg(drain, hold, eager):
 def part_step(captures):
     """The suite's own case: the 1-rank partitioned config-2 step (halo all-to-alls with async_op=True, gradient / BatchNorm / loss all-reduces),
     `captures` times {CapturedTrainStep (3 eager warm-up steps, then the capture), eager steps, replays}."""
-    import socket
     import torch
     import torch.distributed as dist
     from tests.test_gpu_parity import _replay_case
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    init_one_rank()
     for c in range(captures):
         eager, cap, m1, m2 = _replay_case("arxiv-1rank", None)
         for _ in range(4):
